@@ -1,0 +1,311 @@
+"""ctypes binding of libcpecan_hip.so (include/cpecan_hip.h) and a host-side mirror of the reference's
+operator interface for the hot path.
+
+Names follow the reference (inc/pairwiseAligner.h, inc/stateMachine.h): ``stateMachine5_construct``,
+``pairwiseAlignmentBandingParameters_construct``, ``getAlignedPairsUsingAnchors`` ... so the parity tests read
+like tests/pairwiseAlignerTest.c.  All DP work happens in the HIP library; if it is missing or no GPU is
+present every compute call raises -- there is no CPU fallback here.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcpecan_hip.so")
+
+fiveState, fiveStateAsymmetric, threeState, threeStateAsymmetric = 0, 1, 2, 3  # inc/stateMachine.h:28-33
+EMIT_MATCH, EMIT_INDEL, EMIT_EXPECT = 0, 1, 2
+PAIR_ALIGNMENT_PROB_1 = 10000000  # inc/pairwiseAligner.h:26
+
+
+class CpecanError(RuntimeError):
+    pass
+
+
+class StateMachine(C.Structure):
+    """cpecan_model: the flattened StateMachine5/StateMachine3 (impl/stateMachine.c:377-399, 631-646)."""
+    _fields_ = [
+        ("type", C.c_int32), ("reserved", C.c_int32),
+        ("matchContinue", C.c_double),
+        ("matchFromShortGapX", C.c_double), ("matchFromShortGapY", C.c_double),
+        ("matchFromLongGapX", C.c_double), ("matchFromLongGapY", C.c_double),
+        ("gapShortOpenX", C.c_double), ("gapShortOpenY", C.c_double),
+        ("gapShortExtendX", C.c_double), ("gapShortExtendY", C.c_double),
+        ("gapShortSwitchToX", C.c_double), ("gapShortSwitchToY", C.c_double),
+        ("gapLongOpenX", C.c_double), ("gapLongOpenY", C.c_double),
+        ("gapLongExtendX", C.c_double), ("gapLongExtendY", C.c_double),
+        ("gapLongSwitchToX", C.c_double), ("gapLongSwitchToY", C.c_double),
+        ("emissionMatch", C.c_double * 16), ("emissionGapX", C.c_double * 4), ("emissionGapY", C.c_double * 4),
+    ]
+
+    @property
+    def stateNumber(self):
+        return 5 if self.type in (fiveState, fiveStateAsymmetric) else 3
+
+
+class Hmm(C.Structure):
+    """cpecan_hmm (inc/stateMachine.h:61-67)."""
+    _fields_ = [("type", C.c_int32), ("stateNumber", C.c_int32), ("transitions", C.c_double * 25),
+                ("emissions", C.c_double * 80), ("likelihood", C.c_double)]
+
+
+class PairwiseAlignmentParameters(C.Structure):
+    """cpecan_params: the fields of PairwiseAlignmentParameters the DP reads (inc/pairwiseAligner.h:28-41)."""
+    _fields_ = [
+        ("threshold", C.c_double),
+        ("minDiagsBetweenTraceBack", C.c_int64),
+        ("traceBackDiagonals", C.c_int64),
+        ("diagonalExpansion", C.c_int64),
+        ("splitMatrixBiggerThanThis", C.c_int64),
+        ("dynamicAnchorExpansion", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class Stats(C.Structure):
+    _fields_ = [
+        ("problems", C.c_int64), ("regions", C.c_int64), ("cells", C.c_int64), ("diagonals", C.c_int64),
+        ("pairs", C.c_int64), ("deviceBytes", C.c_int64),
+        ("kernelMs", C.c_double), ("h2dMs", C.c_double), ("d2hMs", C.c_double),
+        ("launches", C.c_int32), ("wavesPerLaunch", C.c_int32),
+    ]
+
+
+# Every symbol include/cpecan_hip.h declares (checked by tests/test_abi.py).
+EXPORTS = [
+    "cpecan_model_default", "cpecan_model_from_hmm", "cpecan_hmm_init", "cpecan_hmm_normalise", "cpecan_hmm_write",
+    "cpecan_hmm_load", "cpecan_params_default", "cpecan_band", "cpecan_split_points", "cpecan_device_count",
+    "cpecan_last_error", "cpecan_batch_create", "cpecan_batch_destroy", "cpecan_batch_add", "cpecan_batch_upload",
+    "cpecan_batch_run", "cpecan_batch_download", "cpecan_batch_result", "cpecan_batch_expectations",
+    "cpecan_batch_stats", "cpecan_batch_set_debug", "cpecan_batch_debug_fetch",
+    "cpecan_get_aligned_pairs_using_anchors", "cpecan_free",
+]
+
+_lib = None
+
+
+def lib():
+    """Loads the HIP library; raises if it has not been built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CpecanError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` or "
+                          "`make -C cpecan_amd/csrc`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    i64p, i32p, dp = C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_double)
+    vp = C.c_void_p
+    L.cpecan_model_default.argtypes = [C.POINTER(StateMachine), C.c_int32]
+    L.cpecan_model_from_hmm.argtypes = [C.POINTER(StateMachine), C.POINTER(Hmm)]
+    L.cpecan_hmm_init.argtypes = [C.POINTER(Hmm), C.c_int32, C.c_double]
+    L.cpecan_hmm_normalise.argtypes = [C.POINTER(Hmm)]
+    L.cpecan_hmm_write.argtypes = [C.POINTER(Hmm), C.c_char_p]
+    L.cpecan_hmm_load.argtypes = [C.POINTER(Hmm), C.c_char_p]
+    L.cpecan_params_default.argtypes = [C.POINTER(PairwiseAlignmentParameters)]
+    L.cpecan_band.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, i64p]
+    L.cpecan_split_points.restype = C.c_int64
+    L.cpecan_split_points.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, i64p]
+    L.cpecan_device_count.restype = C.c_int
+    L.cpecan_last_error.restype = C.c_char_p
+    L.cpecan_batch_create.argtypes = [C.POINTER(vp), C.POINTER(StateMachine), C.POINTER(PairwiseAlignmentParameters),
+                                      C.c_int, C.c_int]
+    L.cpecan_batch_destroy.argtypes = [vp]
+    L.cpecan_batch_destroy.restype = None
+    L.cpecan_batch_add.restype = C.c_int64
+    L.cpecan_batch_add.argtypes = [vp, C.c_char_p, C.c_int64, C.c_char_p, C.c_int64, i64p, C.c_int64, C.c_int, C.c_int]
+    L.cpecan_batch_upload.argtypes = [vp]
+    L.cpecan_batch_run.argtypes = [vp, vp]
+    L.cpecan_batch_download.argtypes = [vp]
+    L.cpecan_batch_result.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(i32p), i64p]
+    L.cpecan_batch_expectations.argtypes = [vp, C.POINTER(Hmm)]
+    L.cpecan_batch_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.cpecan_batch_set_debug.argtypes = [vp, C.c_int]
+    L.cpecan_batch_debug_fetch.argtypes = [vp, C.c_int64, dp, C.c_int64, dp, C.c_int64]
+    L.cpecan_get_aligned_pairs_using_anchors.argtypes = [
+        C.POINTER(StateMachine), C.c_char_p, C.c_char_p, i64p, C.c_int64, C.POINTER(PairwiseAlignmentParameters),
+        C.c_int, C.c_int, C.POINTER(i32p), i64p]
+    L.cpecan_free.argtypes = [vp]
+    L.cpecan_free.restype = None
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc < 0:
+        msg = lib().cpecan_last_error()
+        raise CpecanError("%s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+    return rc
+
+
+def _bytes(s):
+    return s.encode() if isinstance(s, str) else bytes(s)
+
+
+def _anchor_array(anchorPairs):
+    """anchorPairs: sequence of (x, y) or (x, y, expansion) -- the stIntTuple list of the reference -- or int64[n,3]."""
+    if isinstance(anchorPairs, np.ndarray):
+        a = np.ascontiguousarray(anchorPairs, dtype=np.int64).reshape(-1, 3)
+    else:
+        rows = [(int(t[0]), int(t[1]), int(t[2]) if len(t) > 2 else 0) for t in anchorPairs]
+        a = np.array(rows, dtype=np.int64).reshape(-1, 3)
+    n = a.shape[0]
+    if n == 0:
+        a = np.zeros((1, 3), dtype=np.int64)
+    return a, a.ctypes.data_as(C.POINTER(C.c_int64)), n
+
+
+# ---- model / parameter constructors, named as in the reference ----
+def stateMachine5_construct(type=fiveState):  # impl/stateMachine.c:482
+    m = StateMachine()
+    _check(lib().cpecan_model_default(C.byref(m), type), "stateMachine5_construct")
+    if m.stateNumber != 5:
+        raise CpecanError("Wrong type for five state %i" % type)
+    return m
+
+
+def stateMachine3_construct(type=threeState):  # impl/stateMachine.c:716
+    m = StateMachine()
+    _check(lib().cpecan_model_default(C.byref(m), type), "stateMachine3_construct")
+    if m.stateNumber != 3:
+        raise CpecanError("Tried to create a three state state-machine with the wrong type")
+    return m
+
+
+def hmm_constructEmpty(pseudoExpectation, type):  # impl/stateMachine.c:23
+    h = Hmm()
+    _check(lib().cpecan_hmm_init(C.byref(h), type, pseudoExpectation), "hmm_constructEmpty")
+    return h
+
+
+def hmm_normalise(hmm):  # impl/stateMachine.c:88
+    _check(lib().cpecan_hmm_normalise(C.byref(hmm)), "hmm_normalise")
+
+
+def hmm_getStateMachine(hmm):  # impl/stateMachine.c:797
+    m = StateMachine()
+    _check(lib().cpecan_model_from_hmm(C.byref(m), C.byref(hmm)), "hmm_getStateMachine")
+    return m
+
+
+def hmm_write(hmm, path):  # impl/stateMachine.c:133
+    _check(lib().cpecan_hmm_write(C.byref(hmm), _bytes(path)), "hmm_write")
+
+
+def hmm_loadFromFile(path):  # impl/stateMachine.c:145
+    h = Hmm()
+    _check(lib().cpecan_hmm_load(C.byref(h), _bytes(path)), "hmm_loadFromFile")
+    return h
+
+
+def pairwiseAlignmentBandingParameters_construct(**overrides):  # impl/pairwiseAligner.c:1334
+    p = PairwiseAlignmentParameters()
+    _check(lib().cpecan_params_default(C.byref(p)), "pairwiseAlignmentBandingParameters_construct")
+    for k, v in overrides.items():
+        if not hasattr(p, k):
+            raise AttributeError(k)
+        setattr(p, k, v)
+    return p
+
+
+def band_construct(anchorPairs, lX, lY, expansion, dynamic=False):  # impl/pairwiseAligner.c:128-234
+    a, ptr, n = _anchor_array(anchorPairs)
+    out = np.zeros(3 * (lX + lY + 1), dtype=np.int64)
+    _check(lib().cpecan_band(ptr, n, lX, lY, expansion, int(dynamic), out.ctypes.data_as(C.POINTER(C.c_int64))),
+           "band_construct")
+    return [tuple(int(v) for v in out[3 * i:3 * i + 3]) for i in range(lX + lY + 1)]
+
+
+def getSplitPoints(anchorPairs, lX, lY, maxMatrixSize, raggedLeft, raggedRight):  # impl/pairwiseAligner.c:1230
+    a, ptr, n = _anchor_array(anchorPairs)
+    out = np.zeros(4 * (n + 2), dtype=np.int64)
+    cnt = _check(lib().cpecan_split_points(ptr, n, lX, lY, maxMatrixSize, int(raggedLeft), int(raggedRight),
+                                           out.ctypes.data_as(C.POINTER(C.c_int64))), "getSplitPoints")
+    return [tuple(int(v) for v in out[4 * i:4 * i + 4]) for i in range(cnt)]
+
+
+def device_count():
+    return lib().cpecan_device_count()
+
+
+class Batch:
+    """N independent alignment problems on one GPU (cpecan_batch_*)."""
+
+    def __init__(self, sM, p=None, emit=EMIT_MATCH, device=0, debug=False):
+        self._h = C.c_void_p()
+        self._p = p or pairwiseAlignmentBandingParameters_construct()
+        self._sM = sM
+        _check(lib().cpecan_batch_create(C.byref(self._h), C.byref(sM), C.byref(self._p), emit, device),
+               "cpecan_batch_create")
+        if debug:
+            _check(lib().cpecan_batch_set_debug(self._h, 1), "cpecan_batch_set_debug")
+        self.n = 0
+
+    def close(self):
+        if self._h:
+            lib().cpecan_batch_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def add(self, sX, sY, anchorPairs=(), raggedLeft=False, raggedRight=False):
+        sx, sy = _bytes(sX), _bytes(sY)
+        a, ptr, n = _anchor_array(anchorPairs)
+        idx = _check(lib().cpecan_batch_add(self._h, sx, len(sx), sy, len(sy), ptr, n, int(raggedLeft),
+                                            int(raggedRight)), "cpecan_batch_add")
+        self.n += 1
+        return idx
+
+    def upload(self):
+        _check(lib().cpecan_batch_upload(self._h), "cpecan_batch_upload")
+
+    def run(self, stream=None):
+        _check(lib().cpecan_batch_run(self._h, C.c_void_p(stream or 0)), "cpecan_batch_run")
+
+    def download(self):
+        _check(lib().cpecan_batch_download(self._h), "cpecan_batch_download")
+
+    def result(self, problem, which=0):
+        ptr = C.POINTER(C.c_int32)()
+        n = C.c_int64()
+        _check(lib().cpecan_batch_result(self._h, problem, which, C.byref(ptr), C.byref(n)), "cpecan_batch_result")
+        if n.value == 0:
+            return np.zeros((0, 3), dtype=np.int32)
+        return np.ctypeslib.as_array(ptr, shape=(n.value * 3,)).copy().reshape(n.value, 3)
+
+    def stats(self):
+        s = Stats()
+        _check(lib().cpecan_batch_stats(self._h, C.byref(s)), "cpecan_batch_stats")
+        return s
+
+    def debug_fetch(self, problem, cells, diagonals):
+        fb = np.zeros(cells, dtype=np.float64)
+        tot = np.zeros(diagonals, dtype=np.float64)
+        dp = C.POINTER(C.c_double)
+        _check(lib().cpecan_batch_debug_fetch(self._h, problem, fb.ctypes.data_as(dp), cells, tot.ctypes.data_as(dp),
+                                              diagonals), "cpecan_batch_debug_fetch")
+        return fb, tot
+
+
+def getAlignedPairsUsingAnchors(sM, sX, sY, anchorPairs, p, alignmentHasRaggedLeftEnd=False,
+                                alignmentHasRaggedRightEnd=False):
+    """impl/pairwiseAligner.c:1431: list of (score, x, y), in the reference's list order."""
+    a, ptr, n = _anchor_array(anchorPairs)
+    out = C.POINTER(C.c_int32)()
+    cnt = C.c_int64()
+    _check(lib().cpecan_get_aligned_pairs_using_anchors(C.byref(sM), _bytes(sX), _bytes(sY), ptr, n, C.byref(p),
+                                                        int(alignmentHasRaggedLeftEnd), int(alignmentHasRaggedRightEnd),
+                                                        C.byref(out), C.byref(cnt)), "getAlignedPairsUsingAnchors")
+    res = np.ctypeslib.as_array(out, shape=(max(cnt.value, 1) * 3,))[:cnt.value * 3].copy().reshape(cnt.value, 3)
+    lib().cpecan_free(C.cast(out, C.c_void_p))
+    return res

@@ -1,0 +1,1014 @@
+/*
+ * cpecan_host.c -- host side (plain C99) of libcpecan_hip.so.
+ *
+ * Everything that is integer bookkeeping in the reference stays on the host, in C, as the north star asks:
+ * the band (impl/pairwiseAligner.c:94-234), the split into regions (:1206-1326), the traceback schedule
+ * (:791-810), packing of problems into flat arrays for the GPU and re-assembly of the returned triples into
+ * the reference's list order (:1411-1418).  All floating-point DP work happens in cpecan_kernels.hip; there is
+ * no CPU implementation of it in this library.
+ */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "cpecan_internal.h"
+
+/* ------------------------------------------------------------------------------------------------
+ * models: impl/stateMachine.c
+ * ---------------------------------------------------------------------------------------------- */
+enum { kMatch = 0, kShortX = 1, kShortY = 2, kLongX = 3, kLongY = 4 }; /* stateMachine.c:261-263 */
+
+static int is_five(int32_t type) { return type == CPECAN_FIVE_STATE || type == CPECAN_FIVE_STATE_ASYM; }
+static int is_three(int32_t type) { return type == CPECAN_THREE_STATE || type == CPECAN_THREE_STATE_ASYM; }
+
+int cpecan_model_default(cpecan_model *m, int32_t type) {
+    if (!m || !(is_five(type) || is_three(type))) return CPECAN_EINVAL;
+    memset(m, 0, sizeof *m);
+    m->type = type;
+    /* emissions: stateMachine.c:269-292 */
+    const double eMatch = -2.1149196655034745, eTransversion = -4.5691014376830479, eTransition = -3.9833860032220842;
+    for (int x = 0; x < 4; x++) {
+        for (int y = 0; y < 4; y++) {
+            m->emissionMatch[x * 4 + y] = x == y ? eMatch : (((x ^ y) == 2) ? eTransition : eTransversion);
+        }
+        m->emissionGapX[x] = m->emissionGapY[x] = -1.6094379124341003;
+    }
+    m->matchContinue = -0.030064059121770816;
+    m->matchFromShortGapX = m->matchFromShortGapY = -1.272871422049609;
+    m->gapShortExtendX = m->gapShortExtendY = -0.3388262689231553;
+    m->gapShortSwitchToX = m->gapShortSwitchToY = -4.910694825551255;
+    if (is_five(type)) { /* stateMachine.c:484-501 */
+        m->matchFromLongGapX = m->matchFromLongGapY = -5.673280173170473;
+        m->gapShortOpenX = m->gapShortOpenY = -4.34381910900448;
+        m->gapLongOpenX = m->gapLongOpenY = -6.30810595366929;
+        m->gapLongExtendX = m->gapLongExtendY = -0.003442492794189331;
+        m->gapLongSwitchToX = m->gapLongSwitchToY = -6.30810595366929;
+    } else { /* stateMachine.c:718-726 */
+        m->gapShortOpenX = m->gapShortOpenY = -4.21256642;
+    }
+    return CPECAN_OK;
+}
+
+int cpecan_hmm_init(cpecan_hmm *h, int32_t type, double pseudo) { /* stateMachine.c:23-48 */
+    if (!h || !(is_five(type) || is_three(type))) return CPECAN_EINVAL;
+    h->type = type;
+    h->stateNumber = is_five(type) ? 5 : 3;
+    for (int i = 0; i < 25; i++) h->transitions[i] = pseudo;
+    for (int i = 0; i < 80; i++) h->emissions[i] = pseudo;
+    h->likelihood = 0.0;
+    return CPECAN_OK;
+}
+
+int cpecan_hmm_normalise(cpecan_hmm *h) { /* stateMachine.c:88-112 */
+    if (!h) return CPECAN_EINVAL;
+    const int S = h->stateNumber;
+    for (int from = 0; from < S; from++) {
+        double sum = 0.0;
+        for (int to = 0; to < S; to++) sum += h->transitions[from * S + to];
+        for (int to = 0; to < S; to++) h->transitions[from * S + to] /= sum;
+    }
+    for (int s = 0; s < S; s++) {
+        double sum = 0.0;
+        for (int i = 0; i < 16; i++) sum += h->emissions[s * 16 + i];
+        for (int i = 0; i < 16; i++) h->emissions[s * 16 + i] /= sum;
+    }
+    return CPECAN_OK;
+}
+
+int cpecan_hmm_write(const cpecan_hmm *h, const char *path) { /* stateMachine.c:133-143 */
+    FILE *f = fopen(path, "w");
+    if (!f) return CPECAN_EINVAL;
+    const int S = h->stateNumber;
+    fprintf(f, "%i\t", h->type);
+    for (int i = 0; i < S * S; i++) fprintf(f, "%f\t", h->transitions[i]);
+    fprintf(f, "%f\n", h->likelihood);
+    for (int i = 0; i < S * 16; i++) fprintf(f, "%f\t", h->emissions[i]);
+    fprintf(f, "\n");
+    fclose(f);
+    return CPECAN_OK;
+}
+
+int cpecan_hmm_load(cpecan_hmm *h, const char *path) { /* stateMachine.c:145-202 */
+    FILE *f = fopen(path, "r");
+    if (!f) return CPECAN_EINVAL;
+    int type = -1, rc = CPECAN_EINVAL;
+    if (fscanf(f, "%i", &type) == 1 && cpecan_hmm_init(h, type, 0.0) == CPECAN_OK) {
+        const int S = h->stateNumber;
+        int ok = 1;
+        for (int i = 0; i < S * S && ok; i++) ok = fscanf(f, "%lf", &h->transitions[i]) == 1;
+        ok = ok && fscanf(f, "%lf", &h->likelihood) == 1;
+        for (int i = 0; i < S * 16 && ok; i++) ok = fscanf(f, "%lf", &h->emissions[i]) == 1;
+        if (ok) rc = CPECAN_OK;
+    }
+    fclose(f);
+    return rc;
+}
+
+static double tr(const cpecan_hmm *h, int from, int to) { return h->transitions[from * h->stateNumber + to]; }
+static double emi(const cpecan_hmm *h, int s, int x, int y) { return h->emissions[s * 16 + x * 4 + y]; }
+
+/* emissions_loadGapProbs, stateMachine.c:327-349: collapse gap-state emission matrices onto one sequence */
+static void gap_emissions(const cpecan_hmm *h, double *out, const int *xs, int nx, const int *ys, int ny) {
+    double acc[4] = {0, 0, 0, 0}, sum = 0.0;
+    for (int i = 0; i < nx; i++)
+        for (int x = 0; x < 4; x++)
+            for (int y = 0; y < 4; y++) acc[x] += emi(h, xs[i], x, y);
+    for (int i = 0; i < ny; i++)
+        for (int x = 0; x < 4; x++)
+            for (int y = 0; y < 4; y++) acc[y] += emi(h, ys[i], x, y);
+    for (int i = 0; i < 4; i++) sum += acc[i];
+    for (int i = 0; i < 4; i++) out[i] = log(acc[i] / sum);
+}
+
+static void exchange(double *a, double *b) {
+    double t = *a;
+    *a = *b;
+    *b = t;
+}
+
+/* keep "long" the state with the larger extend probability, stateMachine.c:544-550 */
+static void order_short_long(double *extS, double *extL, double *fromS, double *fromL, double *openS, double *openL,
+                             double *swS, double *swL) {
+    if (*extS > *extL) {
+        exchange(extS, extL);
+        exchange(fromS, fromL);
+        exchange(openS, openL);
+        exchange(swS, swL);
+    }
+}
+
+int cpecan_model_from_hmm(cpecan_model *m, const cpecan_hmm *h) { /* stateMachine.c:529-620, 747-819 */
+    if (!m || !h) return CPECAN_EINVAL;
+    if (cpecan_model_default(m, h->type) != CPECAN_OK) return CPECAN_EINVAL;
+    const int sym = (h->type == CPECAN_FIVE_STATE || h->type == CPECAN_THREE_STATE);
+    const int xs5[2] = {kShortX, kLongX}, ys5[2] = {kShortY, kLongY}, xs3[1] = {kShortX}, ys3[1] = {kShortY};
+    m->matchContinue = log(tr(h, kMatch, kMatch));
+    /* match emissions: stateMachine.c:298-317 */
+    for (int x = 0; x < 4; x++) {
+        for (int y = 0; y < 4; y++) {
+            m->emissionMatch[x * 4 + y] =
+                (!sym || x == y) ? log(emi(h, kMatch, x, y)) : log((emi(h, kMatch, x < y ? x : y, x < y ? y : x) +
+                                                                    emi(h, kMatch, x < y ? y : x, x < y ? x : y)) / 2.0);
+        }
+    }
+    if (h->type == CPECAN_FIVE_STATE) {
+        m->matchFromShortGapX = log((tr(h, kShortX, kMatch) + tr(h, kShortY, kMatch)) / 2);
+        m->matchFromLongGapX = log((tr(h, kLongX, kMatch) + tr(h, kLongY, kMatch)) / 2);
+        m->gapShortOpenX = log((tr(h, kMatch, kShortX) + tr(h, kMatch, kShortY)) / 2);
+        m->gapShortExtendX = log((tr(h, kShortX, kShortX) + tr(h, kShortY, kShortY)) / 2);
+        m->gapShortSwitchToX = log((tr(h, kShortX, kShortY) + tr(h, kShortY, kShortX)) / 2);
+        m->gapLongOpenX = log((tr(h, kMatch, kLongX) + tr(h, kMatch, kLongY)) / 2);
+        m->gapLongExtendX = log((tr(h, kLongX, kLongX) + tr(h, kLongY, kLongY)) / 2);
+        m->gapLongSwitchToX = log((tr(h, kLongX, kLongY) + tr(h, kLongY, kLongX)) / 2);
+        order_short_long(&m->gapShortExtendX, &m->gapLongExtendX, &m->matchFromShortGapX, &m->matchFromLongGapX,
+                         &m->gapShortOpenX, &m->gapLongOpenX, &m->gapShortSwitchToX, &m->gapLongSwitchToX);
+        m->matchFromShortGapY = m->matchFromShortGapX;
+        m->matchFromLongGapY = m->matchFromLongGapX;
+        m->gapShortOpenY = m->gapShortOpenX;
+        m->gapShortExtendY = m->gapShortExtendX;
+        m->gapShortSwitchToY = m->gapShortSwitchToX;
+        m->gapLongOpenY = m->gapLongOpenX;
+        m->gapLongExtendY = m->gapLongExtendX;
+        m->gapLongSwitchToY = m->gapLongSwitchToX;
+        gap_emissions(h, m->emissionGapX, xs5, 2, ys5, 2);
+        gap_emissions(h, m->emissionGapY, xs5, 2, ys5, 2);
+    } else if (h->type == CPECAN_FIVE_STATE_ASYM) {
+        m->matchFromShortGapX = log(tr(h, kShortX, kMatch));
+        m->matchFromLongGapX = log(tr(h, kLongX, kMatch));
+        m->gapShortOpenX = log(tr(h, kMatch, kShortX));
+        m->gapShortExtendX = log(tr(h, kShortX, kShortX));
+        m->gapShortSwitchToX = log(tr(h, kShortY, kShortX));
+        m->gapLongOpenX = log(tr(h, kMatch, kLongX));
+        m->gapLongExtendX = log(tr(h, kLongX, kLongX));
+        m->gapLongSwitchToX = log(tr(h, kLongY, kLongX));
+        order_short_long(&m->gapShortExtendX, &m->gapLongExtendX, &m->matchFromShortGapX, &m->matchFromLongGapX,
+                         &m->gapShortOpenX, &m->gapLongOpenX, &m->gapShortSwitchToX, &m->gapLongSwitchToX);
+        m->matchFromShortGapY = log(tr(h, kShortY, kMatch));
+        m->matchFromLongGapY = log(tr(h, kLongY, kMatch));
+        m->gapShortOpenY = log(tr(h, kMatch, kShortY));
+        m->gapShortExtendY = log(tr(h, kShortY, kShortY));
+        m->gapShortSwitchToY = log(tr(h, kShortX, kShortY));
+        m->gapLongOpenY = log(tr(h, kMatch, kLongY));
+        m->gapLongExtendY = log(tr(h, kLongY, kLongY));
+        m->gapLongSwitchToY = log(tr(h, kLongX, kLongY));
+        order_short_long(&m->gapShortExtendY, &m->gapLongExtendY, &m->matchFromShortGapY, &m->matchFromLongGapY,
+                         &m->gapShortOpenY, &m->gapLongOpenY, &m->gapShortSwitchToY, &m->gapLongSwitchToY);
+        gap_emissions(h, m->emissionGapX, xs5, 2, NULL, 0);
+        gap_emissions(h, m->emissionGapY, NULL, 0, ys5, 2);
+    } else if (h->type == CPECAN_THREE_STATE) {
+        m->matchFromShortGapX = m->matchFromShortGapY = log((tr(h, kShortX, kMatch) + tr(h, kShortY, kMatch)) / 2.0);
+        m->gapShortOpenX = m->gapShortOpenY = log((tr(h, kMatch, kShortX) + tr(h, kMatch, kShortY)) / 2.0);
+        m->gapShortExtendX = m->gapShortExtendY = log((tr(h, kShortX, kShortX) + tr(h, kShortY, kShortY)) / 2.0);
+        m->gapShortSwitchToX = m->gapShortSwitchToY = log((tr(h, kShortY, kShortX) + tr(h, kShortX, kShortY)) / 2.0);
+        gap_emissions(h, m->emissionGapX, xs3, 1, ys3, 1);
+        gap_emissions(h, m->emissionGapY, xs3, 1, ys3, 1);
+    } else {
+        m->matchFromShortGapX = log(tr(h, kShortX, kMatch));
+        m->matchFromShortGapY = log(tr(h, kShortY, kMatch));
+        m->gapShortOpenX = log(tr(h, kMatch, kShortX));
+        m->gapShortOpenY = log(tr(h, kMatch, kShortY));
+        m->gapShortExtendX = log(tr(h, kShortX, kShortX));
+        m->gapShortExtendY = log(tr(h, kShortY, kShortY));
+        m->gapShortSwitchToX = log(tr(h, kShortY, kShortX));
+        m->gapShortSwitchToY = log(tr(h, kShortX, kShortY));
+        gap_emissions(h, m->emissionGapX, xs3, 1, NULL, 0);
+        gap_emissions(h, m->emissionGapY, NULL, 0, ys3, 1);
+    }
+    return CPECAN_OK;
+}
+
+int cpecan_params_default(cpecan_params *p) { /* pairwiseAligner.c:1334-1348 */
+    if (!p) return CPECAN_EINVAL;
+    memset(p, 0, sizeof *p);
+    p->threshold = 0.01;
+    p->minDiagsBetweenTraceBack = 1000;
+    p->traceBackDiagonals = 40;
+    p->diagonalExpansion = 20;
+    p->splitMatrixBiggerThanThis = (int64_t)3000 * 3000;
+    p->dynamicAnchorExpansion = 0;
+    return CPECAN_OK;
+}
+
+/* Kernel-side view of the model: priors (stateMachine.c:401-448, 648-687) and N-padded emissions (:351-366). */
+static void kernel_model(const cpecan_model *m, double threshold, CpkModel *k) {
+    const double ninf = -INFINITY;
+    memset(k, 0, sizeof *k);
+    k->type = m->type;
+    k->nStates = is_five(m->type) ? 5 : 3;
+    k->threshold = threshold;
+    for (int s = 0; s < CPK_MAX_STATES; s++) k->start[s] = k->raggedStart[s] = k->end[s] = k->raggedEnd[s] = ninf;
+    k->start[kMatch] = 0.0;
+    k->end[kMatch] = m->matchContinue;
+    k->end[kShortX] = m->matchFromShortGapX;
+    k->end[kShortY] = m->matchFromShortGapY;
+    if (k->nStates == 5) {
+        k->raggedStart[kLongX] = k->raggedStart[kLongY] = 0.0;
+        k->end[kLongX] = m->matchFromLongGapX;
+        k->end[kLongY] = m->matchFromLongGapY;
+        k->raggedEnd[kMatch] = m->gapLongOpenX;
+        k->raggedEnd[kShortX] = m->gapLongOpenX;
+        k->raggedEnd[kShortY] = m->gapLongOpenY;
+        k->raggedEnd[kLongX] = m->gapLongExtendX;
+        k->raggedEnd[kLongY] = m->gapLongExtendY;
+    } else {
+        k->raggedStart[kShortX] = k->raggedStart[kShortY] = 0.0;
+        k->raggedEnd[kMatch] = (m->gapShortOpenX + m->gapShortOpenY) / 2.0;
+        k->raggedEnd[kShortX] = m->gapShortExtendX;
+        k->raggedEnd[kShortY] = m->gapShortExtendY;
+    }
+    k->matchContinue = m->matchContinue;
+    k->matchFromShortX = m->matchFromShortGapX;
+    k->matchFromShortY = m->matchFromShortGapY;
+    k->matchFromLongX = m->matchFromLongGapX;
+    k->matchFromLongY = m->matchFromLongGapY;
+    k->shortOpenX = m->gapShortOpenX;
+    k->shortOpenY = m->gapShortOpenY;
+    k->shortExtendX = m->gapShortExtendX;
+    k->shortExtendY = m->gapShortExtendY;
+    k->shortSwitchToX = m->gapShortSwitchToX;
+    k->shortSwitchToY = m->gapShortSwitchToY;
+    k->longOpenX = m->gapLongOpenX;
+    k->longOpenY = m->gapLongOpenY;
+    k->longExtendX = m->gapLongExtendX;
+    k->longExtendY = m->gapLongExtendY;
+    for (int x = 0; x < 5; x++) {
+        k->gapXEm[x] = x == CPK_SYM_N ? -1.386294361 : m->emissionGapX[x];
+        k->gapYEm[x] = x == CPK_SYM_N ? -1.386294361 : m->emissionGapY[x];
+        for (int y = 0; y < 5; y++)
+            k->matchEm[x * 5 + y] = (x == CPK_SYM_N || y == CPK_SYM_N) ? -2.772588722 : m->emissionMatch[x * 4 + y];
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * band and split geometry (integers only)
+ * ---------------------------------------------------------------------------------------------- */
+static int64_t clamp_to(int64_t v, int64_t hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+static int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
+static int64_t imin(int64_t a, int64_t b) { return a < b ? a : b; }
+
+/* Band of one region.  For consecutive anchors P and Q (matrix coordinates, virtual first (0,0) and last
+ * (lX,lY)) the band between their anti-diagonals is the rectangle [Px-e/2, Qx+e/2] x [Py-e/2, Qy+e/2]
+ * clipped to the matrix (pairwiseAligner.c:173-176, 226-229); a diagonal's cells are the lattice points of the
+ * rectangle on it, i.e. x in [max(xLo, d - yHi), min(xHi, d - yLo)] -- the closed form of :104-122.
+ * Writes xmyL/xmyR per diagonal.  Returns CPECAN_EINVAL where the reference would assert or throw. */
+static int build_band(const int64_t *anchors, int64_t n, int64_t lX, int64_t lY, int64_t expansion, int dynamic,
+                      int64_t *xmyL, int64_t *xmyR) {
+    if (lX < 0 || lY < 0) return CPECAN_EINVAL;
+    if (!dynamic && (expansion < 0 || expansion % 2 != 0)) return CPECAN_EINVAL;
+    int64_t used = 0;
+    int64_t pX = 0, pY = 0;           /* previous anchor */
+    int64_t qSum = 0;                 /* anti-diagonal of the next anchor */
+    int64_t qX = 0, qY = 0;
+    int64_t xLo = 0, xHi = 0, yLo = 0, yHi = 0;
+    int64_t e = dynamic ? 0 : expansion;
+    for (int64_t d = 0; d <= lX + lY; d++) {
+        const int64_t lo = imax(xLo, d - yHi), hi = imin(xHi, d - yLo);
+        if (lo > hi) return CPECAN_EINVAL; /* diagonal_construct would throw, pairwiseAligner.c:31 */
+        xmyL[d] = 2 * lo - d;
+        xmyR[d] = 2 * hi - d;
+        if (qSum != d) continue;
+        pX = qX;
+        pY = qY;
+        qX = lX;
+        qY = lY;
+        if (used < n) {
+            qX = anchors[3 * used] + 1;
+            qY = anchors[3 * used + 1] + 1;
+            if (dynamic) e = anchors[3 * used + 2];
+            used++;
+            if (qX <= pX || qY <= pY || qX > lX || qY > lY || e < 0 || e % 2 != 0) return CPECAN_EINVAL; /* :159-166 */
+        }
+        qSum = qX + qY;
+        xLo = clamp_to(pX - e / 2, lX);
+        yHi = clamp_to(qY + e / 2, lY);
+        xHi = clamp_to(qX + e / 2, lX);
+        yLo = clamp_to(pY - e / 2, lY);
+    }
+    return CPECAN_OK;
+}
+
+int cpecan_band(const int64_t *anchors, int64_t nAnchors, int64_t lX, int64_t lY, int64_t expansion, int dynamic,
+                int64_t *out) {
+    const int64_t n = lX + lY + 1;
+    if (n <= 0 || !out) return CPECAN_EINVAL;
+    int64_t *lo = malloc(sizeof(int64_t) * (size_t)n * 2), *hi = lo + n;
+    if (!lo) return CPECAN_ENOMEM;
+    int rc = build_band(anchors, nAnchors, lX, lY, expansion, dynamic, lo, hi);
+    if (rc == CPECAN_OK) {
+        for (int64_t d = 0; d < n; d++) {
+            out[3 * d] = d;
+            out[3 * d + 1] = lo[d];
+            out[3 * d + 2] = hi[d];
+        }
+    }
+    free(lo);
+    return rc;
+}
+
+/* getSplitPoints, pairwiseAligner.c:1206-1257.  A gap between consecutive anchors whose matrix exceeds
+ * maxMatrixSize closes the current rectangle half-way into the gap (at most sqrt(max) deep) and opens the
+ * next one the same distance before the following anchor. */
+typedef struct {
+    int64_t x1, y1; /* start of the rectangle being grown */
+    int64_t *out;
+    int64_t count;
+    int64_t limit, depth;
+} SplitState;
+
+static int cut_if_large(SplitState *s, int64_t fromX, int64_t fromY, int64_t toX, int64_t toY, int suppress) {
+    const int64_t gx = toX - fromX, gy = toY - fromY;
+    if (gx * gy <= s->limit) return 0;
+    const int64_t hx = imin(gx / 2, s->depth), hy = imin(gy / 2, s->depth);
+    if (!suppress) {
+        int64_t *r = s->out + 4 * s->count++;
+        r[0] = s->x1;
+        r[1] = s->y1;
+        r[2] = fromX + hx;
+        r[3] = fromY + hy;
+    }
+    s->x1 = toX - hx;
+    s->y1 = toY - hy;
+    return 1;
+}
+
+int64_t cpecan_split_points(const int64_t *anchors, int64_t nAnchors, int64_t lX, int64_t lY, int64_t maxMatrixSize,
+                            int raggedLeft, int raggedRight, int64_t *out) {
+    if (lX < 0 || lY < 0 || nAnchors < 0 || !out) return CPECAN_EINVAL;
+    SplitState s = {0, 0, out, 0, maxMatrixSize, (int64_t)sqrt((double)maxMatrixSize)};
+    int64_t fromX = 0, fromY = 0;
+    for (int64_t i = 0; i < nAnchors; i++) {
+        const int64_t ax = anchors[3 * i], ay = anchors[3 * i + 1];
+        if (ax < fromX || ay < fromY || ax >= lX || ay >= lY) return CPECAN_EINVAL; /* :1240-1243 */
+        cut_if_large(&s, fromX, fromY, ax, ay, raggedLeft && i == 0);
+        fromX = ax + 1;
+        fromY = ay + 1;
+    }
+    const int cutAtEnd = cut_if_large(&s, fromX, fromY, lX, lY, raggedLeft && nAnchors == 0);
+    if (!cutAtEnd || !raggedRight) {
+        int64_t *r = out + 4 * s.count++;
+        r[0] = s.x1;
+        r[1] = s.y1;
+        r[2] = lX;
+        r[3] = lY;
+    }
+    return s.count;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * the batch object
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    int64_t problem;   /* owning problem */
+    int64_t x1, y1;    /* offset of the region inside the problem (coordinate correction, :1411-1418) */
+    int64_t lX, lY;
+    int64_t seqXOff, seqYOff; /* into the symbol blob */
+    int64_t anchorOff, nAnchors;
+    int raggedLeft, raggedRight;
+    /* filled by upload */
+    int64_t cells;
+    int64_t devIndex; /* position in the cost-sorted device array */
+} HostRegion;
+
+typedef struct {
+    int64_t firstRegion, nRegions;
+    int32_t *triples[3];
+    int64_t nTriples[3];
+} HostProblem;
+
+struct cpecan_batch {
+    cpecan_model model;
+    cpecan_params params;
+    int emit, device, debug;
+    int frozen, ran, downloaded;
+    HostProblem *problems;
+    int64_t nProblems, capProblems;
+    HostRegion *regions;
+    int64_t nRegions, capRegions;
+    uint8_t *symbols;
+    int64_t nSymbols, capSymbols;
+    int64_t *anchors;
+    int64_t nAnchorVals, capAnchorVals;
+    /* frozen state */
+    CpkRegion *devRegions; /* cost-sorted */
+    int64_t *devToHost;    /* devRegions[i] describes regions[devToHost[i]] */
+    CpkSegment *segs;
+    int64_t nSegs;
+    int64_t nDiags;
+    CpkGeometry geo;
+    int64_t outTriples; /* per list */
+    int nLists;
+    int64_t dbgCells, dbgDiags;
+    CpkDevice *dev;
+    cpecan_stats stats;
+};
+
+static int grow(void **p, int64_t *cap, int64_t need, size_t elem) {
+    if (need <= *cap) return 0;
+    int64_t c = *cap ? *cap : 16;
+    while (c < need) c *= 2;
+    void *q = realloc(*p, (size_t)c * elem);
+    if (!q) return -1;
+    *p = q;
+    *cap = c;
+    return 0;
+}
+
+int cpecan_device_count(void) { return cpk_device_count(); }
+const char *cpecan_last_error(void) { return cpk_last_error(); }
+
+int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpecan_params *params, int emit,
+                        int device) {
+    if (!out || !model || !params) return CPECAN_EINVAL;
+    if (!(is_five(model->type) || is_three(model->type))) return CPECAN_EINVAL;
+    if (emit != CPECAN_EMIT_MATCH) {
+        cpk_set_error("emitter %d is not implemented on the HIP path yet (only CPECAN_EMIT_MATCH)", emit);
+        return CPECAN_EINVAL;
+    }
+    /* preconditions of getPosteriorProbsWithBanding, pairwiseAligner.c:761-765 */
+    if (params->traceBackDiagonals < 1 || params->diagonalExpansion < 0 || params->diagonalExpansion % 2 != 0 ||
+        params->minDiagsBetweenTraceBack < 2 || params->traceBackDiagonals + 1 >= params->minDiagsBetweenTraceBack ||
+        !(params->threshold >= 0.0 && params->threshold <= 1.0)) {
+        cpk_set_error("invalid banding parameters");
+        return CPECAN_EINVAL;
+    }
+    /* The GPU is bound at upload time: adding problems and planning (bands, schedules) are host-only integer work. */
+    cpecan_batch *b = calloc(1, sizeof *b);
+    if (!b) return CPECAN_ENOMEM;
+    b->model = *model;
+    b->params = *params;
+    b->emit = emit;
+    b->device = device;
+    b->dev = NULL;
+    b->nLists = emit == CPECAN_EMIT_INDEL ? 3 : 1;
+    *out = b;
+    return CPECAN_OK;
+}
+
+static void free_results(cpecan_batch *b) {
+    for (int64_t i = 0; i < b->nProblems; i++)
+        for (int l = 0; l < 3; l++) {
+            free(b->problems[i].triples[l]);
+            b->problems[i].triples[l] = NULL;
+            b->problems[i].nTriples[l] = 0;
+        }
+}
+
+void cpecan_batch_destroy(cpecan_batch *b) {
+    if (!b) return;
+    free_results(b);
+    cpk_device_destroy(b->dev);
+    free(b->problems);
+    free(b->regions);
+    free(b->symbols);
+    free(b->anchors);
+    free(b->devRegions);
+    free(b->devToHost);
+    free(b->segs);
+    free(b);
+}
+
+int cpecan_batch_set_debug(cpecan_batch *b, int on) {
+    if (!b || b->frozen) return CPECAN_ESTATE;
+    b->debug = on != 0;
+    return CPECAN_OK;
+}
+
+static uint8_t to_symbol(char c) { /* symbol_convertCharToSymbol, pairwiseAligner.c:317-334 */
+    switch (c) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    default: return CPK_SYM_N;
+    }
+}
+
+/* Appends N + symbols + N (so that index x addresses base x-1 and x = 0 / x = l+1 read as N). */
+static int64_t append_symbols(cpecan_batch *b, const char *s, int64_t l) {
+    if (grow((void **)&b->symbols, &b->capSymbols, b->nSymbols + l + 2, 1)) return -1;
+    const int64_t off = b->nSymbols;
+    uint8_t *dst = b->symbols + off;
+    dst[0] = CPK_SYM_N;
+    for (int64_t i = 0; i < l; i++) dst[i + 1] = to_symbol(s[i]);
+    dst[l + 1] = CPK_SYM_N;
+    b->nSymbols += l + 2;
+    return off;
+}
+
+int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char *sY, int64_t lY,
+                         const int64_t *anchors, int64_t nAnchors, int raggedLeft, int raggedRight) {
+    if (!b || b->frozen) return CPECAN_ESTATE;
+    if (lX < 0 || lY < 0 || nAnchors < 0 || (lX > 0 && !sX) || (lY > 0 && !sY) || (nAnchors > 0 && !anchors))
+        return CPECAN_EINVAL;
+    if (lX + lY >= (int64_t)1 << 30) return CPECAN_EINVAL;
+    /* anchors must be strictly increasing in both coordinates (pairwiseAligner.c:159-164) */
+    for (int64_t i = 0; i < nAnchors; i++) {
+        const int64_t x = anchors[3 * i], y = anchors[3 * i + 1];
+        if (x < 0 || y < 0 || x >= lX || y >= lY) return CPECAN_EINVAL;
+        if (i > 0 && (x <= anchors[3 * (i - 1)] || y <= anchors[3 * (i - 1) + 1])) return CPECAN_EINVAL;
+    }
+    int64_t *rects = malloc(sizeof(int64_t) * 4 * (size_t)(nAnchors + 2));
+    if (!rects) return CPECAN_ENOMEM;
+    const int64_t nRects = cpecan_split_points(anchors, nAnchors, lX, lY, b->params.splitMatrixBiggerThanThis,
+                                               raggedLeft, raggedRight, rects);
+    if (nRects < 0) {
+        free(rects);
+        return CPECAN_EINVAL;
+    }
+    if (grow((void **)&b->problems, &b->capProblems, b->nProblems + 1, sizeof(HostProblem)) ||
+        grow((void **)&b->regions, &b->capRegions, b->nRegions + nRects, sizeof(HostRegion)) ||
+        grow((void **)&b->anchors, &b->capAnchorVals, b->nAnchorVals + 3 * nAnchors, sizeof(int64_t))) {
+        free(rects);
+        return CPECAN_ENOMEM;
+    }
+    HostProblem *pr = &b->problems[b->nProblems];
+    memset(pr, 0, sizeof *pr);
+    pr->firstRegion = b->nRegions;
+    pr->nRegions = nRects;
+    int64_t next = 0; /* anchors are handed to regions in order, pairwiseAligner.c:1296-1308 */
+    for (int64_t i = 0; i < nRects; i++) {
+        const int64_t x1 = rects[4 * i], y1 = rects[4 * i + 1], x2 = rects[4 * i + 2], y2 = rects[4 * i + 3];
+        HostRegion *r = &b->regions[b->nRegions++];
+        memset(r, 0, sizeof *r);
+        r->problem = b->nProblems;
+        r->x1 = x1;
+        r->y1 = y1;
+        r->lX = x2 - x1;
+        r->lY = y2 - y1;
+        r->raggedLeft = raggedLeft || i > 0;
+        r->raggedRight = raggedRight || i < nRects - 1;
+        r->seqXOff = append_symbols(b, sX + x1, r->lX);
+        r->seqYOff = append_symbols(b, sY + y1, r->lY);
+        if (r->seqXOff < 0 || r->seqYOff < 0) {
+            free(rects);
+            return CPECAN_ENOMEM;
+        }
+        r->anchorOff = b->nAnchorVals / 3;
+        while (next < nAnchors && anchors[3 * next] + anchors[3 * next + 1] < x2 + y2) {
+            int64_t *a = b->anchors + b->nAnchorVals;
+            a[0] = anchors[3 * next] - x1;
+            a[1] = anchors[3 * next + 1] - y1;
+            a[2] = anchors[3 * next + 2];
+            b->nAnchorVals += 3;
+            r->nAnchors++;
+            next++;
+        }
+    }
+    free(rects);
+    return b->nProblems++;
+}
+
+typedef struct {
+    int64_t cells;
+    int64_t index;
+} CostKey;
+
+static int by_cost_desc(const void *a, const void *b) {
+    const CostKey *p = a, *q = b;
+    if (p->cells != q->cells) return p->cells > q->cells ? -1 : 1;
+    return p->index < q->index ? -1 : (p->index > q->index);
+}
+
+static int64_t default_out_cap(const cpecan_batch *b, const HostRegion *r) {
+    int64_t cap = 6 * (r->lX + r->lY) + 64;
+    if (b->params.threshold <= 0.0 || cap > r->cells) cap = r->cells;
+    return cap < 1 ? 1 : cap;
+}
+
+int cpecan_batch_upload(cpecan_batch *b) {
+    if (!b || b->frozen) return CPECAN_ESTATE;
+    if (b->nRegions == 0) {
+        if (cpk_device_count() < 1) {
+            cpk_set_error("no usable HIP device: the HIP path has no CPU fallback");
+            return CPECAN_ENODEVICE;
+        }
+        b->frozen = 1;
+        return CPECAN_OK;
+    }
+    const cpecan_params *p = &b->params;
+    const int S = is_five(b->model.type) ? 5 : 3;
+    int rc = CPECAN_OK;
+
+    /* pass 1: bands -> per-region cell counts, total diagonals */
+    int64_t totalDiags = 0;
+    for (int64_t i = 0; i < b->nRegions; i++) totalDiags += b->regions[i].lX + b->regions[i].lY + 1;
+    CpkDiag *diags = malloc(sizeof(CpkDiag) * (size_t)totalDiags);
+    int64_t *diagStart = malloc(sizeof(int64_t) * (size_t)b->nRegions);
+    CostKey *keys = malloc(sizeof(CostKey) * (size_t)b->nRegions);
+    int64_t maxN = 0;
+    for (int64_t i = 0; i < b->nRegions; i++) maxN = imax(maxN, b->regions[i].lX + b->regions[i].lY);
+    int64_t *lo = malloc(sizeof(int64_t) * (size_t)(maxN + 1) * 2), *hi = lo ? lo + maxN + 1 : NULL;
+    if (!diags || !diagStart || !keys || !lo) {
+        rc = CPECAN_ENOMEM;
+        goto fail1;
+    }
+    {
+        int64_t at = 0;
+        for (int64_t i = 0; i < b->nRegions; i++) {
+            HostRegion *r = &b->regions[i];
+            const int64_t N = r->lX + r->lY;
+            rc = build_band(b->anchors + 3 * r->anchorOff, r->nAnchors, r->lX, r->lY, p->diagonalExpansion,
+                            p->dynamicAnchorExpansion, lo, hi);
+            if (rc != CPECAN_OK) {
+                cpk_set_error("region %lld of problem %lld: anchors do not define a valid band", (long long)i,
+                              (long long)r->problem);
+                goto fail1;
+            }
+            diagStart[i] = at;
+            int64_t cells = 0;
+            for (int64_t d = 0; d <= N; d++) {
+                const int64_t w = (hi[d] - lo[d]) / 2 + 1;
+                if (cells + w >= (int64_t)1 << 31) {
+                    rc = CPECAN_EINVAL;
+                    cpk_set_error("region too large for 32-bit cell offsets");
+                    goto fail1;
+                }
+                diags[at + d].xmyL = (int32_t)lo[d];
+                diags[at + d].width = (int32_t)w;
+                diags[at + d].cellOff = (int32_t)cells;
+                diags[at + d].ringOff = 0;
+                cells += w;
+            }
+            r->cells = cells;
+            keys[i].cells = N > 0 ? cells : 0;
+            keys[i].index = i;
+            at += N + 1;
+        }
+    }
+    qsort(keys, (size_t)b->nRegions, sizeof(CostKey), by_cost_desc); /* longest first: the work queue is LPT */
+
+    /* pass 2: traceback schedule per region (pairwiseAligner.c:791-810), forward ring layout, scratch sizes */
+    int64_t nSegs = 0, capSegs = 0;
+    CpkSegment *segs = NULL;
+    b->devRegions = calloc((size_t)b->nRegions, sizeof(CpkRegion));
+    b->devToHost = malloc(sizeof(int64_t) * (size_t)b->nRegions);
+    if (!b->devRegions || !b->devToHost) {
+        rc = CPECAN_ENOMEM;
+        goto fail2;
+    }
+    CpkGeometry geo;
+    memset(&geo, 0, sizeof geo);
+    geo.nRegions = (int32_t)b->nRegions;
+    geo.nStates = S;
+    geo.emit = b->emit;
+    geo.debug = b->debug;
+    int64_t outAt = 0, dbgCells = 0, dbgDiags = 0, totalCells = 0;
+    for (int64_t di = 0; di < b->nRegions; di++) {
+        const int64_t hiRegion = keys[di].index;
+        HostRegion *r = &b->regions[hiRegion];
+        r->devIndex = di;
+        b->devToHost[di] = hiRegion;
+        CpkRegion *g = &b->devRegions[di];
+        CpkDiag *dg = diags + diagStart[hiRegion];
+        const int64_t N = r->lX + r->lY;
+        g->seqXOff = r->seqXOff;
+        g->seqYOff = r->seqYOff;
+        g->diagOff = diagStart[hiRegion];
+        g->segOff = nSegs;
+        g->lX = (int32_t)r->lX;
+        g->lY = (int32_t)r->lY;
+        g->raggedLeft = r->raggedLeft;
+        g->raggedRight = r->raggedRight;
+        g->dbgCellOff = dbgCells;
+        g->dbgDiagOff = dbgDiags;
+        if (b->debug) {
+            dbgCells += r->cells;
+            dbgDiags += N + 1;
+        }
+        totalCells += r->cells;
+        int32_t maxW = 0;
+        for (int64_t d = 0; d <= N; d++) maxW = dg[d].width > maxW ? dg[d].width : maxW;
+        g->maxWidth = maxW;
+        geo.maxWidth = maxW > geo.maxWidth ? maxW : geo.maxWidth;
+        /* segments */
+        int64_t tracedBackTo = 0, liveMax = 0, fbMax = 0;
+        int32_t refreshMax = 0;
+        for (int64_t d = 1; d <= N; d++) {
+            const int atEnd = d == N;
+            const int tracebackPoint =
+                d >= tracedBackTo + p->minDiagsBetweenTraceBack && dg[d].width <= p->diagonalExpansion * 2 + 1;
+            if (!atEnd && !tracebackPoint) continue;
+            if (grow((void **)&segs, &capSegs, nSegs + 1, sizeof(CpkSegment))) {
+                rc = CPECAN_ENOMEM;
+                goto fail2;
+            }
+            CpkSegment *sg = &segs[nSegs++];
+            memset(sg, 0, sizeof *sg);
+            sg->tbPrev = (int32_t)tracedBackTo;
+            sg->dTop = (int32_t)d;
+            sg->tbFrom = (int32_t)(d - (atEnd ? 0 : p->traceBackDiagonals + 1));
+            sg->atEnd = atEnd;
+            sg->nRefresh = (int32_t)((sg->tbFrom - (sg->tbPrev + 1)) / CPK_REFRESH_PERIOD + 1);
+            refreshMax = sg->nRefresh > refreshMax ? sg->nRefresh : refreshMax;
+            /* forward diagonals tbPrev..dTop are live during this traceback */
+            const int64_t live = (int64_t)dg[d].cellOff + dg[d].width - dg[tracedBackTo].cellOff;
+            liveMax = imax(liveMax, live);
+            const int64_t fbCells = (int64_t)dg[sg->tbFrom].cellOff + dg[sg->tbFrom].width - dg[sg->tbPrev + 1].cellOff;
+            fbMax = imax(fbMax, fbCells);
+            g->nSeg++;
+            tracedBackTo = sg->tbFrom;
+        }
+        /* ring: diagonals are laid down one after another and never straddle the end of the ring */
+        const int64_t ringCells = liveMax + maxW;
+        int64_t pos = 0;
+        for (int64_t d = 0; d <= N; d++) {
+            if (pos + dg[d].width > ringCells) pos = 0;
+            dg[d].ringOff = (int32_t)pos;
+            pos += dg[d].width;
+        }
+        geo.ringCells = imax(geo.ringCells, ringCells);
+        geo.fbCells = imax(geo.fbCells, fbMax);
+        geo.maxRefresh = refreshMax > geo.maxRefresh ? refreshMax : geo.maxRefresh;
+        g->outCap = (int32_t)default_out_cap(b, r);
+        g->outOff = outAt;
+        outAt += g->outCap;
+    }
+    if (geo.maxRefresh < 1) geo.maxRefresh = 1;
+    if (geo.ringCells < 1) geo.ringCells = 1;
+    if (geo.fbCells < 1) geo.fbCells = 1;
+    geo.rollStride = geo.maxWidth + 2;
+    geo.refreshCells = (int64_t)geo.maxWidth * geo.maxRefresh;
+    if (geo.refreshCells < 1) geo.refreshCells = 1;
+    geo.rollDoubles = (int64_t)3 * S * geo.rollStride;
+    /* LDS budget: leave room for several waves per CU; beyond 64 KiB per wave the rolling buffers go to HBM */
+    geo.useGlobalRoll = (sizeof(double) * (size_t)(40 + geo.rollDoubles) > 64 * 1024);
+    b->geo = geo;
+    b->segs = segs;
+    b->nSegs = nSegs;
+    b->nDiags = totalDiags;
+    b->outTriples = outAt < 1 ? 1 : outAt;
+    b->dbgCells = dbgCells < 1 ? 1 : dbgCells;
+    b->dbgDiags = dbgDiags < 1 ? 1 : dbgDiags;
+
+    b->stats.problems = b->nProblems;
+    b->stats.regions = b->nRegions;
+    b->stats.cells = totalCells;
+    b->stats.diagonals = totalDiags;
+    CpkModel km;
+    kernel_model(&b->model, p->threshold, &km);
+    if (!b->dev) {
+        rc = cpk_device_create(&b->dev, b->device); /* fails with CPECAN_ENODEVICE when there is no GPU */
+        if (rc != CPECAN_OK) goto fail2;
+    }
+    rc = cpk_device_upload(b->dev, &geo, &km, b->devRegions, diags, totalDiags, segs, nSegs, b->symbols, b->nSymbols,
+                           b->outTriples, b->nLists, b->dbgCells, b->dbgDiags, &b->stats.h2dMs);
+    if (rc != CPECAN_OK) goto fail2;
+    b->stats.deviceBytes = cpk_device_bytes(b->dev);
+    b->stats.wavesPerLaunch = cpk_device_waves(b->dev);
+    b->frozen = 1;
+    free(diags);
+    free(diagStart);
+    free(keys);
+    free(lo);
+    return CPECAN_OK;
+
+fail2:
+    free(segs);
+    free(b->devRegions);
+    free(b->devToHost);
+    b->devRegions = NULL;
+    b->devToHost = NULL;
+    b->segs = NULL;
+    b->nSegs = 0;
+fail1:
+    free(diags);
+    free(diagStart);
+    free(keys);
+    free(lo);
+    return rc;
+}
+
+int cpecan_batch_run(cpecan_batch *b, void *stream) {
+    if (!b || !b->frozen) return CPECAN_ESTATE;
+    b->downloaded = 0;
+    if (b->nRegions == 0) {
+        b->ran = 1;
+        return CPECAN_OK;
+    }
+    int rc = cpk_device_run(b->dev, stream);
+    if (rc == CPECAN_OK) {
+        b->ran = 1;
+        b->stats.launches = 1;
+    }
+    return rc;
+}
+
+/* Re-assembles one problem's list: regions in order; inside a region the reference pops its sub-list from the
+ * back (pairwiseAligner.c:1415-1417), which yields traceback segments in descending order, each already in the
+ * order the kernel wrote it (diagonal ascending, x-y descending). */
+static int assemble_problem(cpecan_batch *b, int64_t pi, const int32_t *counts, const int32_t *segStarts,
+                            const int32_t *triples) {
+    HostProblem *pr = &b->problems[pi];
+    for (int l = 0; l < b->nLists; l++) {
+        const int32_t *cnt = counts + (size_t)l * b->nRegions;
+        const int32_t *ss = segStarts + (size_t)l * b->nSegs;
+        const int32_t *tr3 = triples + (size_t)l * b->outTriples * 3;
+        int64_t total = 0;
+        for (int64_t i = 0; i < pr->nRegions; i++) total += cnt[b->regions[pr->firstRegion + i].devIndex];
+        int32_t *dst = malloc(sizeof(int32_t) * 3 * (size_t)(total ? total : 1));
+        if (!dst) return CPECAN_ENOMEM;
+        int64_t at = 0;
+        for (int64_t i = 0; i < pr->nRegions; i++) {
+            const HostRegion *r = &b->regions[pr->firstRegion + i];
+            const CpkRegion *g = &b->devRegions[r->devIndex];
+            const int32_t n = cnt[r->devIndex];
+            for (int s = g->nSeg - 1; s >= 0; s--) {
+                const int32_t from = ss[g->segOff + s];
+                const int32_t to = s + 1 < g->nSeg ? ss[g->segOff + s + 1] : n;
+                const int32_t *src = tr3 + 3 * (g->outOff + from);
+                for (int32_t k = 0; k < to - from; k++) {
+                    dst[3 * at] = src[3 * k];
+                    dst[3 * at + 1] = src[3 * k + 1] + (int32_t)r->x1;
+                    dst[3 * at + 2] = src[3 * k + 2] + (int32_t)r->y1;
+                    at++;
+                }
+            }
+        }
+        pr->triples[l] = dst;
+        pr->nTriples[l] = total;
+        b->stats.pairs += total;
+    }
+    return CPECAN_OK;
+}
+
+int cpecan_batch_download(cpecan_batch *b) {
+    if (!b || !b->ran) return CPECAN_ESTATE;
+    free_results(b);
+    b->stats.pairs = 0;
+    if (b->nRegions == 0) {
+        b->downloaded = 1;
+        return CPECAN_OK;
+    }
+    int rc = CPECAN_OK;
+    int32_t *counts = NULL, *segStarts = NULL, *triples = NULL;
+    for (int attempt = 0; attempt < 3; attempt++) {
+        free(counts);
+        free(segStarts);
+        free(triples);
+        counts = malloc(sizeof(int32_t) * (size_t)b->nLists * b->nRegions);
+        segStarts = malloc(sizeof(int32_t) * (size_t)b->nLists * (b->nSegs ? b->nSegs : 1));
+        triples = malloc(sizeof(int32_t) * 3 * (size_t)b->nLists * b->outTriples);
+        if (!counts || !segStarts || !triples) {
+            rc = CPECAN_ENOMEM;
+            break;
+        }
+        rc = cpk_device_download(b->dev, counts, segStarts, triples, NULL, &b->stats.kernelMs, &b->stats.d2hMs);
+        if (rc != CPECAN_OK) break;
+        /* did any region overflow its output slice?  If so enlarge exactly and run once more. */
+        int overflow = 0;
+        int64_t outAt = 0;
+        for (int64_t di = 0; di < b->nRegions; di++) {
+            int32_t need = 0;
+            for (int l = 0; l < b->nLists; l++) {
+                const int32_t c = counts[(size_t)l * b->nRegions + di];
+                need = c > need ? c : need;
+            }
+            CpkRegion *g = &b->devRegions[di];
+            if (need > g->outCap) {
+                overflow = 1;
+                g->outCap = need;
+            }
+            g->outOff = outAt;
+            outAt += g->outCap;
+        }
+        if (!overflow) break;
+        b->outTriples = outAt;
+        rc = cpk_device_update_regions(b->dev, b->devRegions, b->outTriples);
+        if (rc != CPECAN_OK) break;
+        rc = cpk_device_run(b->dev, NULL);
+        if (rc != CPECAN_OK) break;
+        b->stats.launches++;
+        if (attempt == 2) {
+            cpk_set_error("output overflow persisted after re-running");
+            rc = CPECAN_ESTATE;
+        }
+    }
+    if (rc == CPECAN_OK) {
+        for (int64_t i = 0; i < b->nProblems && rc == CPECAN_OK; i++) rc = assemble_problem(b, i, counts, segStarts, triples);
+        if (rc == CPECAN_OK) b->downloaded = 1;
+    }
+    free(counts);
+    free(segStarts);
+    free(triples);
+    return rc;
+}
+
+int cpecan_batch_result(const cpecan_batch *b, int64_t problem, int which, const int32_t **triples, int64_t *n) {
+    if (!b || !b->downloaded) return CPECAN_ESTATE;
+    if (problem < 0 || problem >= b->nProblems || which < 0 || which >= b->nLists) return CPECAN_EINVAL;
+    *triples = b->problems[problem].triples[which];
+    *n = b->problems[problem].nTriples[which];
+    return CPECAN_OK;
+}
+
+int cpecan_batch_expectations(const cpecan_batch *b, cpecan_hmm *acc) {
+    (void)b;
+    (void)acc;
+    cpk_set_error("expectation emitter is not implemented on the HIP path yet");
+    return CPECAN_EINVAL;
+}
+
+int cpecan_batch_stats(const cpecan_batch *b, cpecan_stats *s) {
+    if (!b || !s) return CPECAN_EINVAL;
+    *s = b->stats;
+    return CPECAN_OK;
+}
+
+int cpecan_batch_debug_fetch(const cpecan_batch *b, int64_t problem, double *fbMatch, int64_t cells, double *totalUsed,
+                             int64_t diagonals) {
+    if (!b || !b->downloaded || !b->debug) return CPECAN_ESTATE;
+    if (problem < 0 || problem >= b->nProblems || b->problems[problem].nRegions != 1) return CPECAN_EINVAL;
+    const HostRegion *r = &b->regions[b->problems[problem].firstRegion];
+    const CpkRegion *g = &b->devRegions[r->devIndex];
+    if (cells != r->cells || diagonals != r->lX + r->lY + 1) return CPECAN_EINVAL;
+    double *fbAll = malloc(sizeof(double) * (size_t)b->dbgCells), *totAll = malloc(sizeof(double) * (size_t)b->dbgDiags);
+    if (!fbAll || !totAll) {
+        free(fbAll);
+        free(totAll);
+        return CPECAN_ENOMEM;
+    }
+    int rc = cpk_device_debug_fetch(b->dev, fbAll, b->dbgCells, totAll, b->dbgDiags);
+    if (rc == CPECAN_OK) {
+        memcpy(fbMatch, fbAll + g->dbgCellOff, sizeof(double) * (size_t)cells);
+        memcpy(totalUsed, totAll + g->dbgDiagOff, sizeof(double) * (size_t)diagonals);
+    }
+    free(fbAll);
+    free(totAll);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * single-problem convenience
+ * ---------------------------------------------------------------------------------------------- */
+void cpecan_free(void *p) { free(p); }
+
+int cpecan_get_aligned_pairs_using_anchors(const cpecan_model *m, const char *sX, const char *sY,
+                                           const int64_t *anchors, int64_t nAnchors, const cpecan_params *p,
+                                           int raggedLeft, int raggedRight, int32_t **triples, int64_t *n) {
+    if (!m || !sX || !sY || !p || !triples || !n) return CPECAN_EINVAL;
+    cpecan_batch *b = NULL;
+    int rc = cpecan_batch_create(&b, m, p, CPECAN_EMIT_MATCH, 0);
+    if (rc != CPECAN_OK) return rc;
+    int64_t idx = cpecan_batch_add(b, sX, (int64_t)strlen(sX), sY, (int64_t)strlen(sY), anchors, nAnchors, raggedLeft,
+                                   raggedRight);
+    rc = idx < 0 ? (int)idx : CPECAN_OK;
+    if (rc == CPECAN_OK) rc = cpecan_batch_upload(b);
+    if (rc == CPECAN_OK) rc = cpecan_batch_run(b, NULL);
+    if (rc == CPECAN_OK) rc = cpecan_batch_download(b);
+    if (rc == CPECAN_OK) {
+        const int32_t *src;
+        int64_t cnt;
+        rc = cpecan_batch_result(b, 0, 0, &src, &cnt);
+        if (rc == CPECAN_OK) {
+            *triples = malloc(sizeof(int32_t) * 3 * (size_t)(cnt ? cnt : 1));
+            if (!*triples) rc = CPECAN_ENOMEM;
+            else {
+                memcpy(*triples, src, sizeof(int32_t) * 3 * (size_t)cnt);
+                *n = cnt;
+            }
+        }
+    }
+    cpecan_batch_destroy(b);
+    return rc;
+}

@@ -1,0 +1,117 @@
+/*
+ * cpecan_internal.h -- structures shared by the C host code (cpecan_host.c) and the HIP
+ * translation unit (cpecan_kernels.hip).  Not part of the public ABI.
+ */
+#ifndef CPECAN_INTERNAL_H_
+#define CPECAN_INTERNAL_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "cpecan_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPK_MAX_STATES 5
+#define CPK_SYM_N 4
+#define CPK_WAVE 64
+#define CPK_REFRESH_PERIOD 10 /* total probability is refreshed every 10th emitted diagonal, pairwiseAligner.c:830 */
+
+/* One anti-diagonal of a region's band, as the kernels read it (one 16-byte scalar load). */
+typedef struct {
+    int32_t xmyL;    /* smallest x-y on the diagonal */
+    int32_t width;   /* number of cells */
+    int32_t ringOff; /* first cell of this diagonal inside the region's forward ring (in cells) */
+    int32_t cellOff; /* number of band cells on earlier diagonals of the region */
+} CpkDiag;
+
+/* One traceback segment (pairwiseAligner.c:791-862): the forward sweep runs up to dTop, then the
+ * backward sweep runs from dTop down to tbPrev+1 and diagonals tbPrev+1..tbFrom are emitted. */
+typedef struct {
+    int32_t tbPrev;   /* tracedBackTo on entry */
+    int32_t dTop;     /* diagonal the traceback starts from */
+    int32_t tbFrom;   /* tracedBackFrom: highest emitted diagonal */
+    int32_t atEnd;    /* dTop == lX+lY */
+    int32_t nRefresh; /* number of total-probability refresh points in the segment */
+    int32_t pad[3];
+} CpkSegment;
+
+/* One DP region (a whole problem, or one rectangle of getSplitPoints). */
+typedef struct {
+    int64_t seqXOff, seqYOff; /* byte offsets of the padded symbol strings (symbol[0] = N, symbol[i] = base i-1) */
+    int64_t diagOff;          /* index of the region's first CpkDiag */
+    int64_t segOff;           /* index of the region's first CpkSegment */
+    int64_t outOff;           /* first output triple slot of the region (per output list) */
+    int64_t dbgCellOff;       /* debug: first cell in the debug fb array */
+    int64_t dbgDiagOff;       /* debug: first diagonal in the debug total array */
+    int32_t lX, lY;
+    int32_t nSeg;
+    int32_t outCap;           /* capacity in triples (per output list) */
+    int32_t raggedLeft, raggedRight;
+    int32_t maxWidth;
+    int32_t pad;
+} CpkRegion;
+
+/* Model constants as the kernels use them: per-state priors, named transitions and padded emissions. */
+typedef struct {
+    int32_t nStates;
+    int32_t type;
+    double start[CPK_MAX_STATES], raggedStart[CPK_MAX_STATES];
+    double end[CPK_MAX_STATES], raggedEnd[CPK_MAX_STATES];
+    /* transitions, log space */
+    double matchContinue;
+    double matchFromShortX, matchFromShortY, matchFromLongX, matchFromLongY;
+    double shortOpenX, shortOpenY, shortExtendX, shortExtendY, shortSwitchToX, shortSwitchToY;
+    double longOpenX, longOpenY, longExtendX, longExtendY;
+    /* emissions with the N row/column filled in (stateMachine.c:351-366) */
+    double matchEm[25]; /* [cX*5+cY] */
+    double gapXEm[5], gapYEm[5];
+    double threshold;
+} CpkModel;
+
+/* Per-launch geometry computed on the host. */
+typedef struct {
+    int32_t nRegions;
+    int32_t nStates;
+    int32_t emit;
+    int32_t maxWidth;     /* widest diagonal in the batch */
+    int32_t rollStride;   /* doubles per state row of a rolling LDS buffer (maxWidth + 2 guards) */
+    int32_t maxRefresh;   /* most refresh points in any segment */
+    int32_t useGlobalRoll;/* rolling buffers do not fit in LDS: keep them in global memory */
+    int32_t debug;
+    int64_t ringCells;    /* forward ring capacity per slot, in cells */
+    int64_t fbCells;      /* fb scratch per slot, in cells */
+    int64_t refreshCells; /* c/m scratch per slot = maxWidth * maxRefresh (each) */
+    int64_t rollDoubles;  /* global rolling buffer per slot, doubles (only when useGlobalRoll) */
+} CpkGeometry;
+
+/* Device-side mirror of a frozen batch; owned by the HIP TU. */
+typedef struct CpkDevice CpkDevice;
+
+/* ---- implemented in cpecan_kernels.hip ---- */
+int cpk_device_count(void);
+const char *cpk_last_error(void);
+int cpk_device_create(CpkDevice **out, int device);
+void cpk_device_destroy(CpkDevice *dev);
+/* Copies the packed inputs to the GPU and sizes every scratch buffer. */
+int cpk_device_upload(CpkDevice *dev, const CpkGeometry *geo, const CpkModel *model, const CpkRegion *regions,
+                      const CpkDiag *diags, int64_t nDiags, const CpkSegment *segs, int64_t nSegs,
+                      const uint8_t *symbols, int64_t nSymbolBytes, int64_t outTriplesPerList, int nLists,
+                      int64_t dbgCells, int64_t dbgDiags, double *h2dMs);
+int cpk_device_update_regions(CpkDevice *dev, const CpkRegion *regions, int64_t outTriplesPerList);
+int cpk_device_run(CpkDevice *dev, void *stream);
+/* Blocks until the run is complete and copies back counts/triples (and expectation sums). */
+int cpk_device_download(CpkDevice *dev, int32_t *counts /* [nLists][nRegions] */,
+                        int32_t *segStarts /* [nLists][nSegsTotal] */, int32_t *triples /* [nLists][outTriples*3] */,
+                        double *expect /* [106] */, double *kernelMs, double *d2hMs);
+int cpk_device_debug_fetch(CpkDevice *dev, double *fb, int64_t cells, double *totals, int64_t diags);
+int64_t cpk_device_bytes(const CpkDevice *dev);
+int cpk_device_waves(const CpkDevice *dev);
+void cpk_set_error(const char *fmt, ...);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,174 @@
+/*
+ * cpecan_hip.h -- C ABI of libcpecan_hip.so: the MI355X-native replacement for cPecan's banded
+ * pair-HMM forward/backward/posterior path (reference: impl/pairwiseAligner.c:756-949 driven
+ * through :1273-1513, model in impl/stateMachine.c:255-823).
+ *
+ * Plain pointers and sizes only.  Two layers:
+ *
+ *  1. the BATCH API (cpecan_batch_*): N independent alignment problems are packed, shipped to one
+ *     GPU, run by hand-written HIP kernels, and returned as packed (score,x,y) int32 triples in the
+ *     reference's list order.  This is what a batched caller (cPecanRealign-style loop,
+ *     cPecanRealign.c:509-537) should use; it is additive to the reference API.
+ *
+ *  2. single-problem entry points (cpecan_get_aligned_pairs_using_anchors, ...): one call == a batch
+ *     of one; they take the same arguments as the reference functions they replace with stList /
+ *     StateMachine flattened to arrays / PODs.  include/cpecan_dropin.h layers the reference's own
+ *     symbol names (getAlignedPairsUsingAnchors, stateMachine5_construct, ...) on top of these.
+ *
+ * Every function returns 0 on success or a negative CPECAN_E* code; nothing here falls back to a
+ * CPU implementation: without a usable GPU the calls fail with CPECAN_ENODEVICE.
+ */
+#ifndef CPECAN_HIP_H_
+#define CPECAN_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CPECAN_PROB_1 10000000 /* PAIR_ALIGNMENT_PROB_1, inc/pairwiseAligner.h:26 */
+
+enum {
+    CPECAN_OK = 0,
+    CPECAN_EINVAL = -1,    /* bad argument (the reference would assert or stThrow, pairwiseAligner.c:31,761-765) */
+    CPECAN_ENODEVICE = -2, /* no HIP device / kernels unavailable */
+    CPECAN_EHIP = -3,      /* a HIP runtime call failed; see cpecan_last_error() */
+    CPECAN_ENOMEM = -4,
+    CPECAN_ESTATE = -5     /* call sequence error (e.g. results requested before run) */
+};
+
+/* StateMachineType, inc/stateMachine.h:28-33 */
+enum { CPECAN_FIVE_STATE = 0, CPECAN_FIVE_STATE_ASYM = 1, CPECAN_THREE_STATE = 2, CPECAN_THREE_STATE_ASYM = 3 };
+
+/* What the traceback emits per diagonal (the reference passes a callback, inc/pairwiseAligner.h:245-248):
+ * MATCH  = diagonalCalculationPosteriorMatchProbs  (impl/pairwiseAligner.c:666)
+ * INDEL  = diagonalCalculationPosteriorProbs       (impl/pairwiseAligner.c:691)
+ * EXPECT = diagonalCalculationExpectations         (impl/pairwiseAligner.c:735) */
+enum { CPECAN_EMIT_MATCH = 0, CPECAN_EMIT_INDEL = 1, CPECAN_EMIT_EXPECT = 2 };
+
+/* Flattened StateMachine5 / StateMachine3 (impl/stateMachine.c:377-399, 631-646): log-space
+ * transition and emission parameters. Three-state models use the "short" fields and ignore "long". */
+typedef struct cpecan_model {
+    int32_t type; /* CPECAN_FIVE_STATE ... */
+    int32_t reserved;
+    double matchContinue;
+    double matchFromShortGapX, matchFromShortGapY, matchFromLongGapX, matchFromLongGapY;
+    double gapShortOpenX, gapShortOpenY, gapShortExtendX, gapShortExtendY, gapShortSwitchToX, gapShortSwitchToY;
+    double gapLongOpenX, gapLongOpenY, gapLongExtendX, gapLongExtendY, gapLongSwitchToX, gapLongSwitchToY;
+    double emissionMatch[16]; /* [x*4+y] */
+    double emissionGapX[4];
+    double emissionGapY[4];
+} cpecan_model;
+
+/* Hmm, inc/stateMachine.h:61-67, with fixed-size arrays. */
+typedef struct cpecan_hmm {
+    int32_t type;
+    int32_t stateNumber;
+    double transitions[25]; /* [from*stateNumber+to] */
+    double emissions[80];   /* [state*16+x*4+y] */
+    double likelihood;
+} cpecan_hmm;
+
+/* The fields of PairwiseAlignmentParameters the DP reads (inc/pairwiseAligner.h:28-41). */
+typedef struct cpecan_params {
+    double threshold;
+    int64_t minDiagsBetweenTraceBack;
+    int64_t traceBackDiagonals;
+    int64_t diagonalExpansion;
+    int64_t splitMatrixBiggerThanThis;
+    int32_t dynamicAnchorExpansion;
+    int32_t reserved;
+} cpecan_params;
+
+typedef struct cpecan_batch cpecan_batch;
+
+/* Per-run statistics (for bench.py and the roofline line). */
+typedef struct cpecan_stats {
+    int64_t problems;      /* alignment problems added */
+    int64_t regions;       /* DP sub-problems after splitting by large gaps */
+    int64_t cells;         /* sum of band widths over all regions == the metric's unit */
+    int64_t diagonals;     /* sum of (lX+lY+1) over regions */
+    int64_t pairs;         /* triples emitted (after the last run) */
+    int64_t deviceBytes;   /* device memory held by the batch */
+    double kernelMs;       /* HIP-event time of the last run's DP kernel launch(es) */
+    double h2dMs, d2hMs;   /* last upload / download */
+    int32_t launches;      /* kernel launches in the last run (1 unless output overflow forced a re-run) */
+    int32_t wavesPerLaunch;
+} cpecan_stats;
+
+/* ---- model / parameter helpers (stateMachine.c / pairwiseAligner.c defaults) ---- */
+int cpecan_model_default(cpecan_model *m, int32_t type);          /* stateMachine5/3_construct, stateMachine.c:482,716 */
+int cpecan_model_from_hmm(cpecan_model *m, const cpecan_hmm *h);  /* hmm_getStateMachine, stateMachine.c:797 */
+int cpecan_hmm_init(cpecan_hmm *h, int32_t type, double pseudoExpectation); /* hmm_constructEmpty :23 */
+int cpecan_hmm_normalise(cpecan_hmm *h);                          /* hmm_normalise :88 */
+int cpecan_hmm_write(const cpecan_hmm *h, const char *path);      /* hmm_write :133 */
+int cpecan_hmm_load(cpecan_hmm *h, const char *path);             /* hmm_loadFromFile :145 */
+int cpecan_params_default(cpecan_params *p);                      /* pairwiseAlignmentBandingParameters_construct :1334 */
+
+/* ---- integer geometry, exported because the reference exports and unit-tests it ---- */
+/* band_construct / band_constructDynamic (pairwiseAligner.c:128-234): out[3*d..] = xay,xmyL,xmyR for d in 0..lX+lY. */
+int cpecan_band(const int64_t *anchors, int64_t nAnchors, int64_t lX, int64_t lY, int64_t expansion, int dynamic,
+                int64_t *out);
+/* getSplitPoints (pairwiseAligner.c:1230): out holds 4*(nAnchors+2) values; returns the count (>=0) or <0. */
+int64_t cpecan_split_points(const int64_t *anchors, int64_t nAnchors, int64_t lX, int64_t lY, int64_t maxMatrixSize,
+                            int raggedLeft, int raggedRight, int64_t *out);
+
+/* ---- device ---- */
+int cpecan_device_count(void);
+const char *cpecan_last_error(void);
+
+/* ---- batch API ---- */
+/* Creates an empty batch bound to HIP device `device`. `emit` selects the emitter for every problem. */
+int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpecan_params *params, int emit,
+                        int device);
+void cpecan_batch_destroy(cpecan_batch *b);
+
+/* Adds one alignment problem: same inputs as getAlignedPairsUsingAnchors (pairwiseAligner.c:1431):
+ * sequences (need not be NUL-terminated; any byte that is not ACGTacgt is N), anchors as nAnchors
+ * triples (x, y, expansion) strictly increasing in x and y, and the two ragged-end flags.
+ * The problem is cut into DP regions exactly as pairwiseAligner.c:1273-1326 does. Returns the problem index. */
+int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char *sY, int64_t lY,
+                         const int64_t *anchors, int64_t nAnchors, int raggedLeft, int raggedRight);
+
+/* Freezes the batch: builds band tables and traceback schedules on the host, allocates device
+ * memory and copies the packed inputs to the GPU. */
+int cpecan_batch_upload(cpecan_batch *b);
+
+/* Launches the DP on `stream` (a hipStream_t passed as void*, NULL = the null stream) with inputs
+ * already resident; asynchronous. May be called repeatedly (bench). */
+int cpecan_batch_run(cpecan_batch *b, void *stream);
+
+/* Waits for the run, copies results to the host and orders them as the reference's lists. */
+int cpecan_batch_download(cpecan_batch *b);
+
+/* Results for problem i after download. Triples are (score, x, y) int32 in the reference's list order
+ * (per region: traceback segments descending, diagonals ascending, x-y descending).
+ * which: 0 = aligned pairs, 1 = gapX pairs, 2 = gapY pairs (1,2 only for CPECAN_EMIT_INDEL). */
+int cpecan_batch_result(const cpecan_batch *b, int64_t problem, int which, const int32_t **triples, int64_t *n);
+
+/* For CPECAN_EMIT_EXPECT: adds the batch's expectation counts into *acc (transitions, emissions, likelihood),
+ * like getExpectationsUsingAnchors (pairwiseAligner.c:1500) called once per problem on the same Hmm. */
+int cpecan_batch_expectations(const cpecan_batch *b, cpecan_hmm *acc);
+
+int cpecan_batch_stats(const cpecan_batch *b, cpecan_stats *s);
+
+/* Debug / test hook: for single-region problem i, copies the per-cell forward+backward match sums
+ * (fb[cell] = F.match + B.match at emit time) and the total log-probability used for each diagonal.
+ * Buffers must hold `cells` and `diagonals` doubles; needs the batch to have been created with
+ * cpecan_batch_set_debug(b,1) before upload. */
+int cpecan_batch_set_debug(cpecan_batch *b, int on);
+int cpecan_batch_debug_fetch(const cpecan_batch *b, int64_t problem, double *fbMatch, int64_t cells,
+                             double *totalUsed, int64_t diagonals);
+
+/* ---- single-problem convenience (a batch of one) ---- */
+/* getAlignedPairsUsingAnchors (pairwiseAligner.c:1431): *triples is malloc'd (free with cpecan_free). */
+int cpecan_get_aligned_pairs_using_anchors(const cpecan_model *m, const char *sX, const char *sY,
+                                           const int64_t *anchors, int64_t nAnchors, const cpecan_params *p,
+                                           int raggedLeft, int raggedRight, int32_t **triples, int64_t *n);
+void cpecan_free(void *p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CPECAN_HIP_H_ */

@@ -1,0 +1,200 @@
+"""CPU-side checks of the product library: it loads, exports every symbol include/cpecan_hip.h declares,
+its integer host logic (band, split points, models, hmm I/O) agrees with the reference fixtures and with the
+oracle, and compute calls fail loudly without a GPU (no CPU fallback)."""
+import ctypes as C
+import json
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from cpecan_amd import api
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = json.load(open(os.path.join(ROOT, "tests", "golden", "reference_fixtures.json")))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "cpecan_hip.h")).read()
+    declared = set(re.findall(r"\b(cpecan_[a-z_0-9]+)\s*\(", header))
+    L = api.lib()
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert declared == set(api.EXPORTS)
+
+
+def test_band_golden_and_vs_oracle():
+    g = GOLD["test_bands"]
+    assert api.band_construct(g["anchors"], g["lX"], g["lY"], g["expansion"]) == [tuple(d) for d in g["diagonals"]]
+    rng = random.Random(1)
+    for _ in range(300):
+        lX, lY = rng.randrange(0, 120), rng.randrange(0, 120)
+        anchors, x, y = [], -1, -1
+        while True:
+            x += rng.randrange(1, 20)
+            y += rng.randrange(1, 20)
+            if x >= lX or y >= lY:
+                break
+            anchors.append((x, y, 2 * rng.randrange(0, 6)))
+        e = 2 * rng.randrange(0, 11)
+        for dyn in (False, True):
+            assert api.band_construct(anchors, lX, lY, e, dyn) == ob.band(anchors, lX, lY, e, dyn)
+
+
+def test_band_rejects_bad_anchors():
+    with pytest.raises(api.CpecanError):
+        api.band_construct([(3, 3, 0), (2, 5, 0)], 10, 10, 2)
+    with pytest.raises(api.CpecanError):
+        api.band_construct([(3, 3, 0)], 10, 10, 3)  # odd expansion, pairwiseAligner.c:187
+
+
+def test_split_points_golden_and_vs_oracle():
+    g = GOLD["test_getSplitPoints"]
+    for case in g["cases"]:
+        got = api.getSplitPoints(case["anchors"], case["lX"], case["lY"], g["matrixSize"], case["raggedLeft"],
+                                 case["raggedRight"])
+        assert got == [tuple(r) for r in case["expect"]]
+    rng = random.Random(2)
+    for _ in range(200):
+        lX, lY = rng.randrange(1, 5000), rng.randrange(1, 5000)
+        anchors, x, y = [], -1, -1
+        while True:
+            x += rng.randrange(1, 700)
+            y += rng.randrange(1, 700)
+            if x >= lX or y >= lY:
+                break
+            anchors.append((x, y, 0))
+        mx = rng.choice([10, 1000, 250000])
+        for rl in (0, 1):
+            for rr in (0, 1):
+                assert api.getSplitPoints(anchors, lX, lY, mx, rl, rr) == ob.split_points(anchors, lX, lY, mx, rl, rr)
+
+
+def _oracle_model_as_dict(m):
+    return {(t.block, t.frm, t.to): t.tP for t in list(m.tr)[:m.nTransitions]}
+
+
+def test_default_models_match_oracle_constants():
+    for t in (api.fiveState, api.threeState):
+        pm = api.stateMachine5_construct(t) if t == api.fiveState else api.stateMachine3_construct(t)
+        om = ob.model(t)
+        tr = _oracle_model_as_dict(om)
+        assert tr[(1, 0, 0)] == pm.matchContinue
+        assert tr[(0, 0, 1)] == pm.gapShortOpenX and tr[(0, 1, 1)] == pm.gapShortExtendX
+        assert tr[(2, 0, 2)] == pm.gapShortOpenY and tr[(2, 2, 2)] == pm.gapShortExtendY
+        assert tr[(1, 1, 0)] == pm.matchFromShortGapX and tr[(1, 2, 0)] == pm.matchFromShortGapY
+        if t == api.fiveState:
+            assert tr[(0, 0, 3)] == pm.gapLongOpenX and tr[(0, 3, 3)] == pm.gapLongExtendX
+            assert tr[(1, 3, 0)] == pm.matchFromLongGapX and tr[(1, 4, 0)] == pm.matchFromLongGapY
+        else:
+            assert tr[(0, 2, 1)] == pm.gapShortSwitchToX and tr[(2, 1, 2)] == pm.gapShortSwitchToY
+        for x in range(4):
+            assert om.gapXEm[x] == pm.emissionGapX[x] and om.gapYEm[x] == pm.emissionGapY[x]
+            for y in range(4):
+                assert om.matchEm[x * 5 + y] == pm.emissionMatch[x * 4 + y]
+
+
+@pytest.mark.parametrize("mtype", [0, 1, 2, 3])
+def test_model_from_hmm_matches_oracle(mtype):
+    rng = random.Random(40 + mtype)
+    for _ in range(20):
+        ph, oh = api.hmm_constructEmpty(0.0, mtype), ob.hmm(mtype, 0.0)
+        S = ph.stateNumber
+        for i in range(S * S):
+            ph.transitions[i] = oh.T[i] = rng.random()
+        for i in range(S * 16):
+            ph.emissions[i] = oh.E[i] = rng.random()
+        api.hmm_normalise(ph)
+        ob.lib().orc_hmm_normalise(oh)
+        assert list(ph.transitions)[:S * S] == list(oh.T)[:S * S]
+        pm, om = api.hmm_getStateMachine(ph), ob.model_from_hmm(oh)
+        tr = _oracle_model_as_dict(om)
+        assert tr[(1, 0, 0)] == pm.matchContinue
+        assert tr[(0, 0, 1)] == pm.gapShortOpenX and tr[(2, 0, 2)] == pm.gapShortOpenY
+        assert tr[(0, 1, 1)] == pm.gapShortExtendX and tr[(2, 2, 2)] == pm.gapShortExtendY
+        assert tr[(1, 1, 0)] == pm.matchFromShortGapX and tr[(1, 2, 0)] == pm.matchFromShortGapY
+        if S == 5:
+            assert tr[(0, 0, 3)] == pm.gapLongOpenX and tr[(2, 0, 4)] == pm.gapLongOpenY
+            assert tr[(0, 3, 3)] == pm.gapLongExtendX and tr[(2, 4, 4)] == pm.gapLongExtendY
+            assert tr[(1, 3, 0)] == pm.matchFromLongGapX and tr[(1, 4, 0)] == pm.matchFromLongGapY
+        else:
+            assert tr[(0, 2, 1)] == pm.gapShortSwitchToX and tr[(2, 1, 2)] == pm.gapShortSwitchToY
+        for x in range(4):
+            assert om.gapXEm[x] == pm.emissionGapX[x] and om.gapYEm[x] == pm.emissionGapY[x]
+            for y in range(4):
+                assert om.matchEm[x * 5 + y] == pm.emissionMatch[x * 4 + y]
+
+
+@pytest.mark.parametrize("mtype", [0, 1, 2, 3])
+def test_hmm_write_load_normalise(tmp_path, mtype):
+    # tests/pairwiseAlignerTest.c:997-1073
+    h = api.hmm_constructEmpty(0.0, mtype)
+    S = h.stateNumber
+    for i in range(S * S):
+        h.transitions[i] += i
+    for i in range(S * 16):
+        h.emissions[i] += i
+    path = str(tmp_path / "t.hmm")
+    api.hmm_write(h, path)
+    g = api.hmm_loadFromFile(path)
+    assert g.type == mtype and g.stateNumber == S
+    assert list(g.transitions)[:S * S] == [float(i) for i in range(S * S)]
+    assert list(g.emissions)[:S * 16] == [float(i) for i in range(S * 16)]
+    api.hmm_normalise(g)
+    for f in range(S):
+        z = f * S * S + (S * (S - 1)) // 2
+        for to in range(S):
+            assert g.transitions[f * S + to] == (f * S + to) / z
+
+
+def test_parameter_defaults():
+    p = api.pairwiseAlignmentBandingParameters_construct()
+    assert (p.threshold, p.minDiagsBetweenTraceBack, p.traceBackDiagonals, p.diagonalExpansion,
+            p.splitMatrixBiggerThanThis, p.dynamicAnchorExpansion) == (0.01, 1000, 40, 20, 9000000, 0)
+
+
+def test_compute_fails_loudly_without_gpu():
+    if api.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(api.CpecanError):
+        api.getAlignedPairsUsingAnchors(api.stateMachine5_construct(), "ACGT", "ACGT", (),
+                                        api.pairwiseAlignmentBandingParameters_construct())
+    # adding problems and planning are host-only; binding the GPU (upload) is where it must fail
+    b = api.Batch(api.stateMachine5_construct())
+    b.add("ACGT", "ACGT")
+    with pytest.raises(api.CpecanError, match="no usable HIP device"):
+        b.upload()
+    with pytest.raises(api.CpecanError):
+        b.run()
+    e = api.Batch(api.stateMachine5_construct())
+    with pytest.raises(api.CpecanError):
+        e.upload()  # even an empty batch refuses to pretend it ran
+
+
+def test_planning_cell_counts_match_oracle_band():
+    """Host planning (bands, split regions) runs without a GPU; its cell counts equal the oracle's."""
+    from cpecan_amd.workload import make_batch
+    probs = make_batch(3, 6, 700, 30)
+    kw = dict(diagonalExpansion=30, splitMatrixBiggerThanThis=2000)
+    b = api.Batch(api.stateMachine5_construct(), api.pairwiseAlignmentBandingParameters_construct(**kw))
+    for sx, sy, a in probs:
+        b.add(sx, sy, a, True, False)
+    try:
+        b.upload()
+    except api.CpecanError:
+        pass  # no GPU here: planning has run, the device step refused
+    st = b.stats()
+    want = sum(ob.band_cells(sx, sy, a, ob.params(**kw), True, False) for sx, sy, a in probs)
+    assert st.cells == want and st.problems == 6 and st.regions >= 6
+
+
+def test_product_never_touches_the_oracle():
+    pkg = os.path.join(ROOT, "cpecan_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle_binding" not in text and "liboracle" not in text and "cpecan_oracle" not in text, f

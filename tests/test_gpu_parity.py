@@ -1,0 +1,196 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+Run on the MI355X box with `pytest -m gpu`."""
+import random
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from cpecan_amd import api
+from cpecan_amd.workload import make_batch, make_pair
+from parity import assert_pairs_match
+
+pytestmark = pytest.mark.gpu
+
+_ALPHABET = "AaCcGgTt" * 11 + "N"
+
+
+def _rand_seq(rng, n):
+    return "".join(rng.choice(_ALPHABET) for _ in range(n))
+
+
+def _evolve(rng, s):
+    s = "".join(rng.choice(_ALPHABET) if rng.random() > 0.8 else ch for ch in s)
+    while rng.random() > 0.2:
+        s = s.replace(_rand_seq(rng, rng.randrange(2, 4)), _rand_seq(rng, rng.randrange(0, 10)))
+    return s
+
+
+def _rand_anchors(rng, lX, lY):
+    out, x, y = [], -1, -1
+    while True:
+        x += rng.randrange(1, 20)
+        y += rng.randrange(1, 20)
+        if x >= lX or y >= lY:
+            return out
+        out.append((x, y, 2 * rng.randrange(0, 5)))
+
+
+def _sm(mtype):
+    return api.stateMachine5_construct(mtype) if mtype in (0, 1) else api.stateMachine3_construct(mtype)
+
+
+def _run_batch(mtype, problems, raggeds=None, **pkw):
+    p = api.pairwiseAlignmentBandingParameters_construct(**pkw)
+    with api.Batch(_sm(mtype), p) as b:
+        for i, (sx, sy, a) in enumerate(problems):
+            rl, rr = raggeds[i] if raggeds else (False, False)
+            b.add(sx, sy, a, rl, rr)
+        b.upload()
+        b.run()
+        b.download()
+        return [b.result(i) for i in range(len(problems))], b.stats()
+
+
+def _check_batch(mtype, problems, raggeds=None, **pkw):
+    got, st = _run_batch(mtype, problems, raggeds, **pkw)
+    om, op = ob.model(mtype), ob.params(**pkw)
+    worst = 0.0
+    for i, (sx, sy, a) in enumerate(problems):
+        rl, rr = raggeds[i] if raggeds else (False, False)
+        want = ob.aligned_pairs(om, sx, sy, a, op, rl, rr)
+        worst = max(worst, assert_pairs_match(got[i], want, threshold=op.threshold))
+    return worst, st
+
+
+def test_known_answer_pairs():
+    # tests/pairwiseAlignerTest.c:242-324 + SURVEY 8c scores
+    p = api.pairwiseAlignmentBandingParameters_construct(threshold=0.2)
+    got = api.getAlignedPairsUsingAnchors(api.stateMachine5_construct(), "AGCG", "AGTTCG", (), p)
+    assert got.tolist() == [[9944673, 0, 0], [9259684, 1, 1], [8665179, 2, 4], [9893294, 3, 5]]
+
+
+@pytest.mark.parametrize("mtype", [0, 2])
+def test_config1_plumbing_full_dp(mtype):
+    # BASELINE configs[0]: ~200 bp, no anchors -> full (unbanded) DP
+    sx, sy, _ = make_pair(1, 0, 200, 0)
+    _check_batch(mtype, [(sx, sy, ())])
+
+
+def test_empty_and_degenerate_inputs():
+    probs = [("", "", ()), ("ACGT", "", ()), ("", "ACGTN", ()), ("A", "A", ()), ("N", "T", ()), ("ACGTACGT", "ACG", ())]
+    got, _ = _run_batch(0, probs)
+    assert len(got[0]) == 0 and len(got[1]) == 0 and len(got[2]) == 0
+    _check_batch(0, probs)
+    _check_batch(2, probs)
+
+
+def test_random_banded_property_like_reference():
+    # tests/pairwiseAlignerTest.c:403-438: random anchors, random traceback parameters, random expansions
+    rng = random.Random(21)
+    for _ in range(25):
+        sx = _rand_seq(rng, rng.randrange(0, 100))
+        sy = _evolve(rng, sx)
+        tbd = rng.randrange(1, 10)
+        kw = dict(traceBackDiagonals=tbd, minDiagsBetweenTraceBack=tbd + rng.randrange(2, 10),
+                  diagonalExpansion=2 * rng.randrange(0, 10), dynamicAnchorExpansion=int(rng.random() > 0.5),
+                  splitMatrixBiggerThanThis=10 ** 12)
+        _check_batch(0, [(sx, sy, _rand_anchors(rng, len(sx), len(sy)))], **kw)
+
+
+@pytest.mark.parametrize("mtype", [0, 2])
+def test_ragged_ends_all_combinations(mtype):
+    rng = random.Random(31 + mtype)
+    core = _rand_seq(rng, 100)
+    sy = _rand_seq(rng, 60) + core + _rand_seq(rng, 60)
+    probs = [(core, sy, ())] * 4
+    raggeds = [(False, False), (True, False), (False, True), (True, True)]
+    _check_batch(mtype, probs, raggeds)
+
+
+def test_multi_segment_tracebacks_default_schedule():
+    # N > 2*minDiagsBetweenTraceBack so intermediate tracebacks fire with the default 1000/40 schedule
+    problems = make_batch(3, 3, 2000, 100)
+    worst, st = _check_batch(0, problems, diagonalExpansion=100)
+    assert st.cells > 3 * 400000
+
+
+def test_short_traceback_schedule_and_threshold_zero():
+    sx, sy, a = make_pair(5, 0, 400, 10)
+    _check_batch(0, [(sx, sy, a)], diagonalExpansion=10, minDiagsBetweenTraceBack=30, traceBackDiagonals=5)
+    _check_batch(2, [(sx, sy, a)], diagonalExpansion=10, minDiagsBetweenTraceBack=12, traceBackDiagonals=1,
+                 threshold=0.0)
+
+
+def test_split_by_large_gaps_regions():
+    # cPecanRealign-style: tiny split threshold, small expansion, ragged ends (cPecanRealign.c:355-357,537)
+    rng = random.Random(41)
+    sx = _rand_seq(rng, 500)
+    sy = _evolve(rng, sx)
+    n = min(len(sx), len(sy))
+    anchors = [(i, i, 4) for i in range(5, n - 5, 29)]
+    _check_batch(0, [(sx, sy, anchors)], [(True, True)], diagonalExpansion=4, splitMatrixBiggerThanThis=10)
+    _check_batch(0, [(sx, sy, anchors)], [(False, False)], diagonalExpansion=4, splitMatrixBiggerThanThis=400)
+
+
+def test_hmm_loaded_models():
+    rng = random.Random(51)
+    for mtype in (0, 1, 2, 3):
+        ph, oh = api.hmm_constructEmpty(0.0, mtype), ob.hmm(mtype, 0.0)
+        S = ph.stateNumber
+        for i in range(S * S):
+            ph.transitions[i] = oh.T[i] = 0.05 + rng.random()
+        for i in range(S * 16):
+            ph.emissions[i] = oh.E[i] = 0.05 + rng.random()
+        api.hmm_normalise(ph)
+        ob.lib().orc_hmm_normalise(oh)
+        sx = _rand_seq(rng, 150)
+        sy = _evolve(rng, sx)
+        p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=30)
+        got = api.getAlignedPairsUsingAnchors(api.hmm_getStateMachine(ph), sx, sy, (), p)
+        want = ob.aligned_pairs(ob.model_from_hmm(oh), sx, sy, (), ob.params(diagonalExpansion=30))
+        assert_pairs_match(got, want, threshold=p.threshold)
+
+
+def test_config_A_sample_three_state_band50():
+    # BASELINE configs[1] shape (1 kb x 1 kb, stateMachine3, band 50) on a 24-pair sample
+    problems = make_batch(2, 24, 1000, 50)
+    worst, st = _check_batch(2, problems, diagonalExpansion=50)
+    assert st.regions == 24
+
+
+def test_config_B_sample_five_state_band100():
+    # BASELINE configs[2] shape (2 kb x 2 kb, stateMachine5, band 100) on a 12-pair sample
+    problems = make_batch(3, 12, 2000, 100, first=100)
+    _check_batch(0, problems, diagonalExpansion=100)
+
+
+def test_wide_band_uses_global_rolling_buffers():
+    # 1500 x 1500 without anchors: diagonals up to 1501 cells -> rolling buffers exceed the LDS budget
+    sx, sy, _ = make_pair(7, 0, 1500, 0)
+    _check_batch(0, [(sx, sy, ())], diagonalExpansion=20)
+
+
+def test_output_overflow_triggers_exact_rerun():
+    sx, sy, a = make_pair(8, 0, 300, 40)
+    got, st = _run_batch(0, [(sx, sy, a)], diagonalExpansion=40, threshold=1e-9)
+    want = ob.aligned_pairs(ob.model(0), sx, sy, a, ob.params(diagonalExpansion=40, threshold=1e-9))
+    assert_pairs_match(got[0], want, threshold=1e-9)
+
+
+def test_full_size_properties_config_B_slice():
+    """Size-independent properties at BASELINE's full per-pair size: scores in (0, 1e7], coordinates unique and
+    in range, per-row posterior mass <= 1 (+ logAdd slack), and results independent of batch composition."""
+    problems = make_batch(3, 64, 2000, 100, first=500)
+    got, st = _run_batch(0, problems, diagonalExpansion=100)
+    for (sx, sy, a), tri in zip(problems, got):
+        assert len(tri) > 0.9 * min(len(sx), len(sy))
+        assert tri[:, 0].min() > 0 and tri[:, 0].max() <= api.PAIR_ALIGNMENT_PROB_1
+        assert tri[:, 1].min() >= 0 and tri[:, 1].max() < len(sx)
+        assert tri[:, 2].min() >= 0 and tri[:, 2].max() < len(sy)
+        assert len({(int(x), int(y)) for _, x, y in tri}) == len(tri)
+        rowmass = np.bincount(tri[:, 1], weights=tri[:, 0], minlength=len(sx))
+        assert rowmass.max() <= 1.01 * api.PAIR_ALIGNMENT_PROB_1
+    again, _ = _run_batch(0, problems[10:20], diagonalExpansion=100)
+    for t1, t2 in zip(got[10:20], again):
+        assert np.array_equal(t1, t2)
