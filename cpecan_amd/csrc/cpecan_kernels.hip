@@ -651,8 +651,21 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (d->ldsBytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->ldsBytes));
     }
-    int perCU = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCU, (const void *)fn, CPK_WAVE, d->ldsBytes));
+    // Resident single-wave workgroups per CU.  hipOccupancyMaxActiveBlocksPerMultiprocessor answers 3 for this
+    // 64-thread kernel (it reports waves per SIMD), so the bound is computed from the register file and LDS
+    // directly (MI355X_MICROARCH.md: 512 VGPRs per lane per SIMD in granules of 8, 4 SIMDs, 32 waves, 160 KiB LDS).
+    // Over-estimating is harmless: surplus workgroups simply queue, every wave exits when the work queue is empty.
+    hipFuncAttributes attr;
+    HIP_TRY(hipFuncGetAttributes(&attr, (const void *)fn));
+    const int vgprAlloc = ((attr.numRegs > 0 ? attr.numRegs : 128) + 7) / 8 * 8;
+    int wavesPerSimd = 512 / vgprAlloc;
+    if (wavesPerSimd > 8) wavesPerSimd = 8;
+    if (wavesPerSimd < 1) wavesPerSimd = 1;
+    int perCU = 4 * wavesPerSimd;
+    const size_t ldsTotal = d->ldsBytes + (size_t)attr.sharedSizeBytes;
+    const int byLds = (int)((160 * 1024) / (ldsTotal ? ldsTotal : 1));
+    if (byLds < perCU) perCU = byLds;
+    if (perCU > 32) perCU = 32;
     if (perCU < 1) {
         cpk_set_error("kernel does not fit on a CU (LDS %zu bytes)", d->ldsBytes);
         return CPECAN_EHIP;
