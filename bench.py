@@ -147,7 +147,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "cpecan_pairhmm_sweep<%d,false>" % S,
+                "kernel": "cpecan_pairhmm_sweep<%d, true>" % S,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

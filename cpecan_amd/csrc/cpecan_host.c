@@ -767,12 +767,17 @@ int cpecan_batch_upload(cpecan_batch *b) {
     if (geo.maxRefresh < 1) geo.maxRefresh = 1;
     if (geo.ringCells < 1) geo.ringCells = 1;
     if (geo.fbCells < 1) geo.fbCells = 1;
-    geo.rollStride = geo.maxWidth + 2;
+    geo.rollStride = geo.maxWidth + 1;
+    {
+        int64_t seqMax = 0;
+        for (int64_t i = 0; i < b->nRegions; i++) seqMax = imax(seqMax, b->regions[i].lX + b->regions[i].lY + 4);
+        geo.seqLdsBytes = (int32_t)imin(seqMax, (int64_t)1 << 30);
+    }
     geo.refreshCells = (int64_t)geo.maxWidth * geo.maxRefresh;
     if (geo.refreshCells < 1) geo.refreshCells = 1;
     geo.rollDoubles = (int64_t)3 * S * geo.rollStride;
-    /* LDS budget: leave room for several waves per CU; beyond 64 KiB per wave the rolling buffers go to HBM */
-    geo.useGlobalRoll = (sizeof(double) * (size_t)(40 + geo.rollDoubles) > 64 * 1024);
+    /* LDS budget: beyond 64 KiB per wave (rolling buffers + symbol strings) the batch takes the global-memory path */
+    geo.useGlobalRoll = (sizeof(double) * (size_t)(40 + geo.rollDoubles) + (size_t)geo.seqLdsBytes + 16 > 64 * 1024);
     b->geo = geo;
     b->segs = segs;
     b->nSegs = nSegs;

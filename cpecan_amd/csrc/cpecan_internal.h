@@ -77,12 +77,13 @@ typedef struct {
     int32_t nStates;
     int32_t emit;
     int32_t maxWidth;     /* widest diagonal in the batch */
-    int32_t rollStride;   /* doubles per state row of a rolling LDS buffer (maxWidth + 2 guards) */
+    int32_t rollStride;   /* doubles per state row of a rolling buffer (maxWidth + the -inf guard at position 0) */
     int32_t maxRefresh;   /* most refresh points in any segment */
-    int32_t useGlobalRoll;/* rolling buffers do not fit in LDS: keep them in global memory */
+    int32_t useGlobalRoll;/* slow path: rolling buffers and symbol strings stay in global memory (too big for LDS) */
+    int32_t seqLdsBytes;  /* fast path: bytes of LDS for the two padded symbol strings of the largest region */
     int32_t debug;
     int64_t ringCells;    /* forward ring capacity per slot, in cells */
-    int64_t fbCells;      /* fb scratch per slot, in cells */
+    int64_t fbCells;      /* posterior-candidate scratch per slot, in cells (most emitted cells of one segment) */
     int64_t refreshCells; /* c/m scratch per slot = maxWidth * maxRefresh (each) */
     int64_t rollDoubles;  /* global rolling buffer per slot, doubles (only when useGlobalRoll) */
 } CpkGeometry;

@@ -59,19 +59,35 @@ extern "C" const char *cpk_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------------
 // device code
 // ------------------------------------------------------------------------------------------------
+struct Candidate {  // a cell that may pass the posterior threshold once the total probability is known
+    double fb;      // F.match + B.match
+    int32_t x, y;   // matrix coordinates
+};
+
+// Transition log-probabilities and the threshold travel BY VALUE in the kernel arguments: kernarg loads are scalar
+// (s_load), so the hot loops never wait on vector memory for a model constant.
+struct KConsts {
+    double matchContinue;
+    double matchFromShortX, matchFromShortY, matchFromLongX, matchFromLongY;
+    double shortOpenX, shortOpenY, shortExtendX, shortExtendY, shortSwitchToX, shortSwitchToY;
+    double longOpenX, longOpenY, longExtendX, longExtendY;
+    double threshold;
+};
+
 struct KArgs {
+    KConsts kc;
     const CpkRegion *regions;
     const CpkDiag *diags;
     const CpkSegment *segs;
     const uint8_t *symbols;
     const CpkModel *model;
     CpkGeometry geo;
-    double *ring;    // [slots][ringCells*S]
-    double *fb;      // [slots][fbCells]
-    double *cbuf;    // [slots][refreshCells]
-    double *mbuf;    // [slots][refreshCells]
-    double *totals;  // [slots][maxRefresh]
-    double *groll;   // [slots][rollDoubles]   (only when geo.useGlobalRoll)
+    double *ring;      // [slots][ringCells*S]   forward values of the live traceback segment
+    Candidate *cand;   // [slots][candCells]     posterior candidates of the segment being traced back
+    double *cbuf;      // [slots][refreshCells]  per-cell F.B dot products on refresh diagonals, [k][j]
+    double *mbuf;      // [slots][refreshCells]  per-cell "match straddling the diagonal" terms, [k][j]
+    double *totals;    // [slots][maxRefresh]
+    double *groll;     // [slots][rollDoubles]   rolling buffers when they do not fit in LDS
     int32_t *outCounts;  // [nLists][nRegions]
     int32_t *segStarts;  // [nLists][nSegsTotal]
     int32_t *triples;    // [nLists][outTriplesPerList*3]
@@ -109,14 +125,11 @@ __device__ __forceinline__ double logadd(double x, double y) {
     return (d < 7.5) ? r : hi;
 }
 
-// v_med3_i32: clamps a neighbour's dense index onto [-1, hi]; -1 and hi address the -inf guard cells of its row
-__device__ __forceinline__ int med3(int a, int b, int c) {
-    int r;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
-    return r;
-}
+// Row position of neighbour cell i of a diagonal that has `w` cells (w = 0: the diagonal does not exist):
+// cells sit at positions 1..w, position 0 of every row is a permanent -inf guard.
+__device__ __forceinline__ int guard_pos(int i, int w) { return ((unsigned)i < (unsigned)w) ? i + 1 : 0; }
 
-__device__ __forceinline__ int wave_max(int v) {
+__device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         const int o = __shfl_xor(v, off);
@@ -125,9 +138,15 @@ __device__ __forceinline__ int wave_max(int v) {
     return v;
 }
 
-template <bool GROLL>
+__device__ __forceinline__ float wave_max_f32(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+template <bool GLOBAL_ROLL>
 __device__ __forceinline__ void roll_fence() {
-    if (GROLL) {
+    if (GLOBAL_ROLL) {
         __syncthreads();  // workgroup-scope release/acquire on global memory (single-wave workgroup)
     } else {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -135,54 +154,92 @@ __device__ __forceinline__ void roll_fence() {
     }
 }
 
+// data this wave wrote earlier in the same launch: always a vector load, never the scalar cache
 __device__ __forceinline__ double ld_self(const double *p) {
-    // data this wave wrote earlier in the same launch: always a vector load, never the scalar cache
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
 }
 
-template <int S, bool GROLL>
+// 64 consecutive entries of the region's diagonal table, one per lane, handed out with v_readlane: the sweeps
+// touch the table once per diagonal and must not wait on a memory load for it.
+struct DiagCache {
+    const CpkDiag *table;
+    int last;  // highest valid diagonal (N)
+    int base;  // diagonal held by lane 0
+    int lane;
+    int eXmyL, eWidth, eRing, eCell;
+
+    __device__ __forceinline__ void load(int b) {
+        base = b;
+        int i = b + lane;
+        i = i < 0 ? 0 : (i > last ? last : i);
+        const int4 e = *reinterpret_cast<const int4 *>(table + i);
+        eXmyL = e.x;
+        eWidth = e.y;
+        eRing = e.z;
+        eCell = e.w;
+        // consume the loaded registers here so the s_waitcnt for this load sits inside the (rare) refill branch;
+        // otherwise hipcc puts a vmcnt(0) at the branch merge and every diagonal waits for its ring stores
+        asm volatile("" ::"v"(eXmyL), "v"(eWidth), "v"(eRing), "v"(eCell));
+    }
+    // descending = the caller walks towards lower diagonals (refill so that d is the LAST lane of the chunk)
+    __device__ __forceinline__ CpkDiag get(int d, bool descending) {
+        if (d < base || d >= base + CPK_WAVE) load(descending ? d - (CPK_WAVE - 1) : d);
+        const int l = __builtin_amdgcn_readfirstlane(d - base);
+        CpkDiag g;
+        g.xmyL = __builtin_amdgcn_readlane(eXmyL, l);
+        g.width = __builtin_amdgcn_readlane(eWidth, l);
+        g.ringOff = __builtin_amdgcn_readlane(eRing, l);
+        g.cellOff = __builtin_amdgcn_readlane(eCell, l);
+        return g;
+    }
+};
+
+constexpr int kPrefetch = 3;  // passes (of 64 cells) of F.match prefetched one diagonal ahead in the traceback
+constexpr float kCandMargin = 3.0f;  // log-space slack of the candidate filter (see DESIGN.md "candidate filter")
+
+// FAST: rolling diagonals and the two symbol strings live in LDS.  !FAST: both stay in global memory (bands wider
+// than the LDS budget, or sequences too long for it); same arithmetic, workgroup-scope fences.
+template <int S, bool FAST>
 struct Sweep {
-    // wave-uniform context
     const KArgs &a;
-    const CpkModel &m;
-    const CpkDiag *dg;   // region's diagonal table
-    const uint8_t *sxp;  // padded symbols: sxp[x] = symbol of base x-1, sxp[0] = N
+    const KConsts &m;  // kernarg-resident constants
+    DiagCache dc;
+    const uint8_t *sxp;  // padded symbols: sxp[x] = symbol of base x-1, sxp[0] = sxp[lX+1] = N
     const uint8_t *syp;
-    double *roll;        // 3 rolling buffers [3][S][stride]
+    double *roll;        // 3 rolling buffers [3][S][stride]; position 0 of each row = -inf guard
     const double *em;    // LDS emissions: [0..24] match, [25..29] gapX, [30..34] gapY
-    double *ring, *fb, *cbuf, *mbuf, *totals;
+    double *ring;
+    Candidate *cand;
+    double *cbuf, *mbuf, *totals;
     int stride;
     int lane;
     int N;
+    // forward sweep state: the two previous diagonals' table entries
+    CpkDiag f1, f2;
 
     __device__ __forceinline__ double *rbuf(int d) const { return roll + (size_t)((d + 3) % 3) * S * stride; }
     __device__ __forceinline__ double *ringAt(const CpkDiag &g) const { return ring + (size_t)g.ringOff * S; }
 
     // ---- forward: impl/pairwiseAligner.c:609-629 with stateMachine{5,3}_cellCalculate as the per-cell body ----
     __device__ void forward(int d) {
-        const CpkDiag g = dg[d];
-        const CpkDiag g1 = dg[d - 1];
+        const CpkDiag g = dc.get(d, false);
         const int W = g.width;
-        const int dl = (g.xmyL - 1 - g1.xmyL) >> 1;  // lower neighbour (d-1, xmy-1) sits at k + dl, upper at k + dl + 1
-        const int hi1 = g1.width;
-        int dm = 0, hi2 = -1;
-        if (d >= 2) {
-            const CpkDiag g2 = dg[d - 2];
-            dm = (g.xmyL - g2.xmyL) >> 1;  // middle neighbour (d-2, xmy) sits at k + dm
-            hi2 = g2.width;
-        }
+        const int dl = (g.xmyL - 1 - f1.xmyL) >> 1;  // lower neighbour (d-1, xmy-1) is cell k+dl, upper is k+dl+1
+        const int w1 = f1.width;
+        const int dm = (g.xmyL - f2.xmyL) >> 1;      // middle neighbour (d-2, xmy) is cell k+dm
+        const int w2 = d >= 2 ? f2.width : 0;
         double *cur = rbuf(d);
         const double *p1 = rbuf(d - 1);
         const double *p2 = rbuf(d - 2);
         double *out = ringAt(g);
+        const int xlo = (d + g.xmyL) >> 1;
         for (int k = lane; k < W; k += CPK_WAVE) {
-            const int xmy = g.xmyL + 2 * k;
-            const int x = (d + xmy) >> 1, y = d - x;
+            const int x = xlo + k, y = d - x;
             const int cX = sxp[x], cY = syp[y];
             const double eX = em[25 + cX], eM = em[cX * 5 + cY], eY = em[30 + cY];
-            const int iL = med3(k + dl, -1, hi1) + 1;
-            const int iU = med3(k + dl + 1, -1, hi1) + 1;
-            const int iM = med3(k + dm, -1, hi2) + 1;
+            const int iL = guard_pos(k + dl, w1);
+            const int iU = guard_pos(k + dl + 1, w1);
+            const int iM = guard_pos(k + dm, w2);
             double v[S];
             if (S == 5) {
                 // states: 0 match, 1 shortGapX, 2 shortGapY, 3 longGapX, 4 longGapY (stateMachine.c:261-263)
@@ -227,13 +284,13 @@ struct Sweep {
                 out[(size_t)s * W + k] = v[s];
             }
         }
-        if (lane < S) cur[lane * stride + W + 1] = NEG_INF;  // end guard of every state row
-        roll_fence<GROLL>();
+        roll_fence<!FAST>();
+        f2 = f1;
+        f1 = g;
     }
 
     // Puts diagonal d of the forward ring back into its rolling buffer (after a traceback used the buffers).
-    __device__ void reloadForward(int d) {
-        const CpkDiag g = dg[d];
+    __device__ void reloadForward(const CpkDiag &g, int d) {
         const int W = g.width;
         double *cur = rbuf(d);
         const double *src = ringAt(g);
@@ -241,159 +298,214 @@ struct Sweep {
 #pragma unroll
             for (int s = 0; s < S; s++) cur[s * stride + k + 1] = ld_self(src + (size_t)s * W + k);
         }
-        if (lane < S) cur[lane * stride + W + 1] = NEG_INF;
-        roll_fence<GROLL>();
+        roll_fence<!FAST>();
     }
 
-    // Seeds a traceback: every cell of diagonal d gets the end-state prior (pairwiseAligner.c:798-799).
-    __device__ void seedBackward(int d, const double *prior) {
-        const int W = dg[d].width;
-        double *cur = rbuf(d);
-        for (int k = lane; k < W; k += CPK_WAVE) {
-#pragma unroll
-            for (int s = 0; s < S; s++) cur[s * stride + k + 1] = prior[s];
-        }
-        if (lane < S) cur[lane * stride + W + 1] = NEG_INF;
-        roll_fence<GROLL>();
-    }
-
-    // ---- backward: the reference scatters from diagonal d2+1 / d2+2 into d2 (pairwiseAligner.c:392-395,
-    // 631-634); this gathers the same terms in the same order.
-    // Also forms fb = F.match + B.match for emitted diagonals and, on refresh diagonals, the two
-    // per-cell series whose sequential logAdd folds give the total probability (:636-653).
-    __device__ void backward(int d2, const CpkSegment &sg, bool seeded, int64_t fbBase) {
-        const CpkDiag g = dg[d2];
-        const int W = g.width;
-        const bool emit = d2 <= sg.tbFrom;
-        const bool refresh = emit && ((sg.tbFrom - d2) % CPK_REFRESH_PERIOD == 0);
-        const int jr = (sg.tbFrom - d2) / CPK_REFRESH_PERIOD;
+    // ---- traceback of one segment (pairwiseAligner.c:796-862).
+    // The reference scatters from diagonal d2+1 / d2+2 into d2 (:392-395, :631-634); this gathers the same terms in
+    // the same order.  Per emitted diagonal it forms fb = F.match + B.match and keeps
+    // the cells that can still reach the threshold once the total is known; on refresh diagonals it also writes the
+    // two per-cell series whose sequential logAdd folds give the total probability (:636-653).
+    // Returns the number of candidates appended (in visit order: diagonal descending, x-y ascending).
+    __device__ int traceback(const CpkSegment &sg, const double *endPrior, double *dbgFb) {
         const int J = sg.nRefresh;
-        double *cur = rbuf(d2);
-        int db = 0, hiB = -1, da = 0, hiA = -1;
-        const double *pb = rbuf(d2 + 1);
-        const double *pa = rbuf(d2 + 2);
-        if (!seeded) {
-            const CpkDiag gb = dg[d2 + 1];
-            db = (g.xmyL - 1 - gb.xmyL) >> 1;  // source (d2+1, xmy-1) at k + db, source (d2+1, xmy+1) at k + db + 1
-            hiB = gb.width;
-            if (d2 + 2 <= sg.dTop) {
-                const CpkDiag ga = dg[d2 + 2];
-                da = (g.xmyL - ga.xmyL) >> 1;  // source (d2+2, xmy) at k + da
-                hiA = ga.width;
+        const float logThr = (float)log(m.threshold);  // -inf for threshold 0: every match cell is a candidate
+        int nCand = 0;
+        float lastMax = -__builtin_huge_valf();
+        CpkDiag gb{}, ga{};  // table entries of d2+1 and d2+2
+        CpkDiag g = dc.get(sg.dTop, true);
+        // F.match of the first emitted diagonal, prefetched
+        double fmCur[kPrefetch] = {0.0, 0.0, 0.0};
+        if (sg.dTop <= sg.tbFrom) {
+            const double *src = ringAt(g);
+#pragma unroll
+            for (int q = 0; q < kPrefetch; q++) {
+                const int k = q * CPK_WAVE + lane;
+                fmCur[q] = k < g.width ? ld_self(src + k) : 0.0;
             }
         }
-        const double *fsrc = ringAt(g);
-        for (int k = lane; k < W; k += CPK_WAVE) {
-            double v[S];
-            if (seeded) {
+        for (int d2 = sg.dTop; d2 > sg.tbPrev; d2--) {
+            const bool seeded = d2 == sg.dTop;
+            const int W = g.width;
+            const bool emit = d2 <= sg.tbFrom;
+            const bool refresh = emit && ((sg.tbFrom - d2) % CPK_REFRESH_PERIOD == 0);
+            const int jr = (sg.tbFrom - d2) / CPK_REFRESH_PERIOD;
+            // prefetch F.match of the next diagonal down while this one is computed
+            CpkDiag gnext{};
+            double fmNext[kPrefetch] = {0.0, 0.0, 0.0};
+            const bool nextEmit = d2 - 1 > sg.tbPrev && d2 - 1 <= sg.tbFrom;
+            if (d2 - 1 >= 0) gnext = dc.get(d2 - 1, true);
+            if (nextEmit) {
+                const double *src = ringAt(gnext);
 #pragma unroll
-                for (int s = 0; s < S; s++) v[s] = cur[s * stride + k + 1];
-            } else {
-                const int xmy = g.xmyL + 2 * k;
-                const int x = (d2 + xmy) >> 1, y = d2 - x;
-                const int cX1 = sxp[x + 1], cY1 = syp[y + 1];  // symbols of the source cells (x+1,.) and (.,y+1)
-                const double eX = em[25 + cX1], eM = em[cX1 * 5 + cY1], eY = em[30 + cY1];
-                const int iU = med3(k + db, -1, hiB) + 1;      // cell (x, y+1): its "upper" neighbour is the target
-                const int iL = med3(k + db + 1, -1, hiB) + 1;  // cell (x+1, y): its "lower" neighbour is the target
-                const int iA = med3(k + da, -1, hiA) + 1;      // cell (x+1, y+1): its "middle" neighbour is the target
-                const double aM = pa[0 * stride + iA];
-                if (S == 5) {
-                    const double uSY = pb[2 * stride + iU], uLY = pb[4 * stride + iU];
-                    const double lSX = pb[1 * stride + iL], lLX = pb[3 * stride + iL];
-                    double t = aM + (eM + m.matchContinue);
-                    t = logadd(t, uSY + (eY + m.shortOpenY));
-                    t = logadd(t, uLY + (eY + m.longOpenY));
-                    t = logadd(t, lSX + (eX + m.shortOpenX));
-                    t = logadd(t, lLX + (eX + m.longOpenX));
-                    v[0] = t;
-                    v[1] = logadd(aM + (eM + m.matchFromShortX), lSX + (eX + m.shortExtendX));
-                    v[2] = logadd(aM + (eM + m.matchFromShortY), uSY + (eY + m.shortExtendY));
-                    v[3] = logadd(aM + (eM + m.matchFromLongX), lLX + (eX + m.longExtendX));
-                    v[4] = logadd(aM + (eM + m.matchFromLongY), uLY + (eY + m.longExtendY));
+                for (int q = 0; q < kPrefetch; q++) {
+                    const int k = q * CPK_WAVE + lane;
+                    fmNext[q] = k < gnext.width ? ld_self(src + k) : 0.0;
+                }
+            }
+            double *cur = rbuf(d2);
+            const double *pb = rbuf(d2 + 1);
+            const double *pa = rbuf(d2 + 2);
+            const int db = (g.xmyL - 1 - gb.xmyL) >> 1;  // source (d2+1, xmy-1) is cell k+db, source (d2+1, xmy+1) is k+db+1
+            const int wB = seeded ? 0 : gb.width;
+            const int da = (g.xmyL - ga.xmyL) >> 1;      // source (d2+2, xmy) is cell k+da
+            const int wA = (!seeded && d2 + 2 <= sg.dTop) ? ga.width : 0;
+            const double *fsrc = ringAt(g);
+            const int xlo = (d2 + g.xmyL) >> 1;
+            int pass = 0;
+            for (int k = lane; k < W; k += CPK_WAVE, pass++) {
+                const int x = xlo + k, y = d2 - x;
+                double v[S];
+                if (seeded) {
+                    // every cell of the top diagonal gets the end-state prior (:798-799)
+#pragma unroll
+                    for (int s = 0; s < S; s++) v[s] = endPrior[s];
                 } else {
-                    const double uGY = pb[2 * stride + iU];
-                    const double lGX = pb[1 * stride + iL];
-                    double t = aM + (eM + m.matchContinue);
-                    t = logadd(t, uGY + (eY + m.shortOpenY));
-                    t = logadd(t, lGX + (eX + m.shortOpenX));
-                    v[0] = t;
-                    t = aM + (eM + m.matchFromShortX);
-                    t = logadd(t, uGY + (eY + m.shortSwitchToY));
-                    t = logadd(t, lGX + (eX + m.shortExtendX));
-                    v[1] = t;
-                    t = aM + (eM + m.matchFromShortY);
-                    t = logadd(t, uGY + (eY + m.shortExtendY));
-                    t = logadd(t, lGX + (eX + m.shortSwitchToX));
-                    v[2] = t;
+                    const int cX1 = sxp[x + 1], cY1 = syp[y + 1];  // symbols of the source cells (x+1,.) and (.,y+1)
+                    const double eX = em[25 + cX1], eM = em[cX1 * 5 + cY1], eY = em[30 + cY1];
+                    const int iU = guard_pos(k + db, wB);      // cell (x, y+1): its "upper" neighbour is the target
+                    const int iL = guard_pos(k + db + 1, wB);  // cell (x+1, y): its "lower" neighbour is the target
+                    const int iA = guard_pos(k + da, wA);      // cell (x+1, y+1): its "middle" neighbour is the target
+                    const double aM = pa[0 * stride + iA];
+                    if (S == 5) {
+                        const double uSY = pb[2 * stride + iU], uLY = pb[4 * stride + iU];
+                        const double lSX = pb[1 * stride + iL], lLX = pb[3 * stride + iL];
+                        double t = aM + (eM + m.matchContinue);
+                        t = logadd(t, uSY + (eY + m.shortOpenY));
+                        t = logadd(t, uLY + (eY + m.longOpenY));
+                        t = logadd(t, lSX + (eX + m.shortOpenX));
+                        t = logadd(t, lLX + (eX + m.longOpenX));
+                        v[0] = t;
+                        v[1] = logadd(aM + (eM + m.matchFromShortX), lSX + (eX + m.shortExtendX));
+                        v[2] = logadd(aM + (eM + m.matchFromShortY), uSY + (eY + m.shortExtendY));
+                        v[3] = logadd(aM + (eM + m.matchFromLongX), lLX + (eX + m.longExtendX));
+                        v[4] = logadd(aM + (eM + m.matchFromLongY), uLY + (eY + m.longExtendY));
+                    } else {
+                        const double uGY = pb[2 * stride + iU];
+                        const double lGX = pb[1 * stride + iL];
+                        double t = aM + (eM + m.matchContinue);
+                        t = logadd(t, uGY + (eY + m.shortOpenY));
+                        t = logadd(t, lGX + (eX + m.shortOpenX));
+                        v[0] = t;
+                        t = aM + (eM + m.matchFromShortX);
+                        t = logadd(t, uGY + (eY + m.shortSwitchToY));
+                        t = logadd(t, lGX + (eX + m.shortExtendX));
+                        v[1] = t;
+                        t = aM + (eM + m.matchFromShortY);
+                        t = logadd(t, uGY + (eY + m.shortExtendY));
+                        t = logadd(t, lGX + (eX + m.shortSwitchToX));
+                        v[2] = t;
+                    }
                 }
 #pragma unroll
                 for (int s = 0; s < S; s++) cur[s * stride + k + 1] = v[s];
+                if (emit) {
+                    double f0;
+                    if (pass == 0) f0 = fmCur[0];
+                    else if (pass == 1) f0 = fmCur[1];
+                    else if (pass == 2) f0 = fmCur[2];
+                    else f0 = ld_self(fsrc + k);
+                    const double fbv = f0 + v[0];
+                    if (dbgFb) dbgFb[g.cellOff + k] = fbv;
+                    if (refresh) {
+                        // cell_dotProduct over states, pairwiseAligner.c:402-408
+                        double t = fbv;
+#pragma unroll
+                        for (int s = 1; s < S; s++) t = logadd(t, ld_self(fsrc + (size_t)s * W + k) + v[s]);
+                        cbuf[(size_t)k * J + jr] = t;
+                    }
+                }
             }
+            // candidate filter (wave-uniform control flow: every lane takes part in the max and the ballot)
             if (emit) {
-                const double f0 = ld_self(fsrc + k);
-                const double fbv = f0 + v[0];
-                fb[(size_t)(g.cellOff - fbBase) + k] = fbv;
-                if (refresh) {
-                    // cell_dotProduct over states, pairwiseAligner.c:402-408
-                    double t = fbv;
-#pragma unroll
-                    for (int s = 1; s < S; s++) t = logadd(t, ld_self(fsrc + (size_t)s * W + k) + v[s]);
-                    cbuf[(size_t)k * J + jr] = t;
+                pass = 0;
+                for (int kb = 0; kb < W; kb += CPK_WAVE, pass++) {
+                    const int k = kb + lane;
+                    const int x = xlo + k, y = d2 - x;
+                    const bool valid = k < W && x > 0 && y > 0;  // match cells only (pairwiseAligner.c:680)
+                    double fbv = NEG_INF;
+                    if (valid) {
+                        double f0;
+                        if (pass == 0) f0 = fmCur[0];
+                        else if (pass == 1) f0 = fmCur[1];
+                        else if (pass == 2) f0 = fmCur[2];
+                        else f0 = ld_self(fsrc + k);
+                        fbv = f0 + cur[0 * stride + k + 1];
+                    }
+                    const float fbf = (float)fbv;
+                    const float pmax = wave_max_f32(fbf);
+                    lastMax = fmaxf(lastMax, pmax);
+                    const bool keep = valid && fbf >= lastMax + logThr - kCandMargin;
+                    const unsigned long long mask = __ballot(keep);
+                    if (keep) {
+                        const int rank =
+                            __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                        Candidate c;
+                        c.fb = fbv;
+                        c.x = x;
+                        c.y = y;
+                        cand[nCand + rank] = c;
+                    }
+                    nCand += __popcll(mask);
                 }
             }
-        }
-        if (!seeded && lane < S) cur[lane * stride + W + 1] = NEG_INF;
-        roll_fence<GROLL>();
-        if (refresh && d2 + 1 <= sg.dTop) {
-            // matches straddling d2: middle-block forward step from F[d2-1] into the cells of d2+1, times B[d2+1]
-            // (pairwiseAligner.c:643-651).  Non-match states of the temporary stay -inf and drop out exactly.
-            const CpkDiag gn = dg[d2 + 1];
-            const CpkDiag gp = dg[d2 - 1];
-            const int Wn = gn.width, Wp = gp.width;
-            const int dmm = (gn.xmyL - gp.xmyL) >> 1;
-            const double *fprev = ringAt(gp);
-            const double *bn = rbuf(d2 + 1);
-            for (int k = lane; k < Wn; k += CPK_WAVE) {
-                const int xmy = gn.xmyL + 2 * k;
-                const int x = (d2 + 1 + xmy) >> 1, y = d2 + 1 - x;
-                const double eM = em[sxp[x] * 5 + syp[y]];
-                const int kp = k + dmm;
-                const bool ok = kp >= 0 && kp < Wp;
-                const int kq = ok ? kp : 0;
-                double f[S];
+            roll_fence<!FAST>();
+            if (refresh && d2 + 1 <= sg.dTop) {
+                // matches straddling d2: middle-block forward step from F[d2-1] into the cells of d2+1, times B[d2+1]
+                // (pairwiseAligner.c:643-651).  Non-match states of the temporary stay -inf and drop out exactly.
+                const int Wn = gb.width, Wp = gnext.width;
+                const int dmm = (gb.xmyL - gnext.xmyL) >> 1;
+                const double *fprev = ringAt(gnext);
+                const double *bn = rbuf(d2 + 1);
+                const int xlon = (d2 + 1 + gb.xmyL) >> 1;
+                for (int k = lane; k < Wn; k += CPK_WAVE) {
+                    const int x = xlon + k, y = d2 + 1 - x;
+                    const double eM = em[sxp[x] * 5 + syp[y]];
+                    const int kp = k + dmm;
+                    const bool ok = kp >= 0 && kp < Wp;
+                    const int kq = ok ? kp : 0;
+                    double f[S];
 #pragma unroll
-                for (int s = 0; s < S; s++) {
-                    const double val = ld_self(fprev + (size_t)s * Wp + kq);
-                    f[s] = ok ? val : NEG_INF;
+                    for (int s = 0; s < S; s++) {
+                        const double val = ld_self(fprev + (size_t)s * Wp + kq);
+                        f[s] = ok ? val : NEG_INF;
+                    }
+                    double t = f[0] + (eM + m.matchContinue);
+                    t = logadd(t, f[1] + (eM + m.matchFromShortX));
+                    t = logadd(t, f[2] + (eM + m.matchFromShortY));
+                    if (S == 5) {
+                        t = logadd(t, f[3] + (eM + m.matchFromLongX));
+                        t = logadd(t, f[4] + (eM + m.matchFromLongY));
+                    }
+                    mbuf[(size_t)k * J + jr] = t + bn[0 * stride + k + 1];
                 }
-                double t = f[0] + (eM + m.matchContinue);
-                t = logadd(t, f[1] + (eM + m.matchFromShortX));
-                t = logadd(t, f[2] + (eM + m.matchFromShortY));
-                if (S == 5) {
-                    t = logadd(t, f[3] + (eM + m.matchFromLongX));
-                    t = logadd(t, f[4] + (eM + m.matchFromLongY));
-                }
-                mbuf[(size_t)k * J + jr] = t + bn[0 * stride + k + 1];
             }
+            // slide the window of table entries and prefetched F.match down one diagonal
+            ga = gb;
+            gb = g;
+            g = gnext;
+#pragma unroll
+            for (int q = 0; q < kPrefetch; q++) fmCur[q] = fmNext[q];
         }
+        return nCand;
     }
 
     // ---- total probability at every refresh point of the segment: one lane per refresh point, each doing the
     // reference's sequential folds (dpDiagonal_dotProduct :513-523, then the straddle term :649).
-    __device__ void foldTotals(const CpkSegment &sg) {
+    __device__ void foldTotals(const CpkSegment &sg, const CpkDiag *table) {
         const int J = sg.nRefresh;
         for (int j0 = 0; j0 < J; j0 += CPK_WAVE) {
             const int j = j0 + lane;
             const bool on = j < J;
             const int r = sg.tbFrom - CPK_REFRESH_PERIOD * (on ? j : 0);
-            const int Wc = on ? dg[r].width : 0;
-            const int Wm = (on && r + 1 <= sg.dTop) ? dg[r + 1].width : 0;
+            const int Wc = on ? table[r].width : 0;
+            const int Wm = (on && r + 1 <= sg.dTop) ? table[r + 1].width : 0;
             double total = NEG_INF, straddle = NEG_INF;
-            const int Wc_max = wave_max(Wc), Wm_max = wave_max(Wm);
-            for (int k = 0; k < Wc_max; k++) {
+            const int WcMax = wave_max_i32(Wc), WmMax = wave_max_i32(Wm);
+            for (int k = 0; k < WcMax; k++) {
                 if (k < Wc) total = logadd(total, ld_self(cbuf + (size_t)k * J + j));
             }
-            for (int k = 0; k < Wm_max; k++) {
+            for (int k = 0; k < WmMax; k++) {
                 if (k < Wm) straddle = logadd(straddle, ld_self(mbuf + (size_t)k * J + j));
             }
             if (on) {
@@ -404,70 +516,59 @@ struct Sweep {
         roll_fence<true>();
     }
 
-    // ---- thresholded posteriors in list order (diagonal ascending, x-y descending), pairwiseAligner.c:655-689
-    __device__ int emitMatches(const CpkSegment &sg, int32_t *out, int outCap, int count, int64_t fbBase,
-                               double *dbgTot, double *dbgFb) {
+    // ---- thresholded posteriors (pairwiseAligner.c:655-689) from the candidate list, walked backwards so that the
+    // output is in the reference's list order (diagonal ascending, x-y descending).
+    __device__ int emitMatches(const CpkSegment &sg, int nCand, int32_t *out, int outCap, int count) {
         const double thr = m.threshold;
-        const double logThrLo = log(thr) - 1e-6;
-        for (int d2 = sg.tbPrev + 1; d2 <= sg.tbFrom; d2++) {
-            const CpkDiag g = dg[d2];
-            const int W = g.width;
-            const double total = ld_self(totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
-            if (dbgTot) dbgTot[d2] = total;  // every lane stores the same value: no lane test next to the ballots below
-            for (int base = ((W - 1) / CPK_WAVE) * CPK_WAVE; base >= 0; base -= CPK_WAVE) {
-                const int k = base + (CPK_WAVE - 1 - lane);
-                const bool in = k < W;
-                double z = NEG_INF;
-                int x = 0, y = 0;
-                bool valid = false;  // only cells with x > 0 and y > 0 are match cells (pairwiseAligner.c:680)
-                if (in) {
-                    const int xmy = g.xmyL + 2 * k;
-                    x = (d2 + xmy) >> 1;
-                    y = d2 - x;
-                    const double fbv = ld_self(fb + (size_t)(g.cellOff - fbBase) + k);
-                    if (dbgFb) dbgFb[g.cellOff + k] = fbv;
-                    valid = x > 0 && y > 0;
-                    if (valid) z = fbv - total;
-                }
-                const bool cand = valid && z >= logThrLo;
-                if (__ballot(cand) == 0ull) continue;
-                double p = exp(z);
-                const bool keep = cand && p >= thr;
-                const unsigned long long mask = __ballot(keep);
-                if (mask == 0ull) continue;
-                if (keep) {
-                    if (p > 1.0) p = 1.0;
-                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                    const int pos = count + rank;
-                    if (pos < outCap) {
-                        out[3 * (size_t)pos + 0] = (int32_t)floor(p * (double)CPECAN_PROB_1);
-                        out[3 * (size_t)pos + 1] = x - 1;
-                        out[3 * (size_t)pos + 2] = y - 1;
-                    }
-                }
-                count += __popcll(mask);
+        for (int top = nCand; top > 0; top -= CPK_WAVE) {
+            const int i = top - 1 - lane;
+            const bool valid = i >= 0;
+            double p = 0.0;
+            int x = 0, y = 0;
+            if (valid) {
+                const double fbv = ld_self(&cand[i].fb);
+                const long long xy = __hip_atomic_load(reinterpret_cast<const long long *>(&cand[i].x), __ATOMIC_RELAXED,
+                                                       __HIP_MEMORY_SCOPE_WAVEFRONT);
+                x = (int)(xy & 0xffffffffll);
+                y = (int)(xy >> 32);
+                const double total = ld_self(totals + (sg.tbFrom - (x + y)) / CPK_REFRESH_PERIOD);
+                p = exp(fbv - total);
             }
+            const bool keep = valid && p >= thr;
+            const unsigned long long mask = __ballot(keep);
+            if (keep) {
+                if (p > 1.0) p = 1.0;
+                const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                const int pos = count + rank;
+                if (pos < outCap) {
+                    out[3 * (size_t)pos + 0] = (int32_t)floor(p * (double)CPECAN_PROB_1);
+                    out[3 * (size_t)pos + 1] = x - 1;
+                    out[3 * (size_t)pos + 2] = y - 1;
+                }
+            }
+            count += __popcll(mask);
         }
         return count;
     }
 };
 
-template <int S, bool GROLL>
+template <int S, bool FAST>
 __global__ void __launch_bounds__(CPK_WAVE) cpecan_pairhmm_sweep(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const CpkModel &m = *a.model;
     const int stride = a.geo.rollStride;
 
-    // emission tables -> LDS (per-lane indexed reads)
+    // LDS: [0,40) emission tables | rolling buffers (FAST) | symbol strings (FAST)
     double *em = lds;
     if (lane < 25) em[lane] = m.matchEm[lane];
     if (lane < 5) {
         em[25 + lane] = m.gapXEm[lane];
         em[30 + lane] = m.gapYEm[lane];
     }
-    double *roll = GROLL ? (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles) : (lds + 40);
-    // every rolling cell starts as -inf so that guards (position 0 of each row) are valid forever
+    double *roll = FAST ? (lds + 40) : (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles);
+    uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + 40 + (size_t)3 * S * stride);
+    // every rolling cell starts as -inf; position 0 of each row is never written again (the guard)
     for (int i = lane; i < 3 * S * stride; i += CPK_WAVE) roll[i] = NEG_INF;
     __syncthreads();
 
@@ -481,56 +582,72 @@ __global__ void __launch_bounds__(CPK_WAVE) cpecan_pairhmm_sweep(const KArgs a) 
         if (r >= a.geo.nRegions) break;
 
         const CpkRegion &rg = a.regions[r];
-        Sweep<S, GROLL> sw{a,
-                           m,
-                           a.diags + rg.diagOff,
-                           a.symbols + rg.seqXOff,
-                           a.symbols + rg.seqYOff,
-                           roll,
-                           em,
-                           a.ring + slot * (size_t)a.geo.ringCells * S,
-                           a.fb + slot * (size_t)a.geo.fbCells,
-                           a.cbuf + slot * (size_t)a.geo.refreshCells,
-                           a.mbuf + slot * (size_t)a.geo.refreshCells,
-                           a.totals + slot * (size_t)a.geo.maxRefresh,
-                           stride,
-                           lane,
-                           rg.lX + rg.lY};
-        const int N = sw.N;
+        const int lX = rg.lX, lY = rg.lY, N = lX + lY;
+        const uint8_t *gx = a.symbols + rg.seqXOff, *gy = a.symbols + rg.seqYOff;
+        if (FAST) {
+            // stage N + bases + N of both strings into LDS (byte reads per cell come from here)
+            for (int i = lane; i < lX + 2; i += CPK_WAVE) seqLds[i] = gx[i];
+            for (int i = lane; i < lY + 2; i += CPK_WAVE) seqLds[lX + 2 + i] = gy[i];
+            roll_fence<false>();
+        }
+        const CpkDiag *table = a.diags + rg.diagOff;
+        Sweep<S, FAST> sw{a,
+                          a.kc,
+                          DiagCache{table, N, 0, lane, 0, 0, 0, 0},
+                          FAST ? seqLds : gx,
+                          FAST ? seqLds + lX + 2 : gy,
+                          roll,
+                          em,
+                          a.ring + slot * (size_t)a.geo.ringCells * S,
+                          a.cand + slot * (size_t)a.geo.fbCells,
+                          a.cbuf + slot * (size_t)a.geo.refreshCells,
+                          a.mbuf + slot * (size_t)a.geo.refreshCells,
+                          a.totals + slot * (size_t)a.geo.maxRefresh,
+                          stride,
+                          lane,
+                          N,
+                          CpkDiag{},
+                          CpkDiag{}};
         int32_t *out = a.triples + 3 * rg.outOff;
         int count = 0;
         if (N > 0) {
+            sw.dc.load(0);
             // diagonal 0: the single cell (0,0) holds the start prior (pairwiseAligner.c:776-777)
             const double *startPrior = rg.raggedLeft ? m.raggedStart : m.start;
             {
+                const CpkDiag g0 = sw.dc.get(0, false);
                 double *cur = sw.rbuf(0);
-                double *o0 = sw.ringAt(sw.dg[0]);
+                double *o0 = sw.ringAt(g0);
                 if (lane < S) {
                     cur[lane * stride + 1] = startPrior[lane];
-                    cur[lane * stride + 2] = NEG_INF;
                     o0[lane] = startPrior[lane];
                 }
-                roll_fence<GROLL>();
+                roll_fence<!FAST>();
+                sw.f1 = g0;
+                sw.f2 = g0;
             }
             int d = 1;
             for (int si = 0; si < rg.nSeg; si++) {
                 const CpkSegment sg = a.segs[rg.segOff + si];
                 for (; d <= sg.dTop; d++) sw.forward(d);
-                // traceback (pairwiseAligner.c:796-862)
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
-                const int64_t fbBase = sw.dg[sg.tbPrev + 1].cellOff;
-                sw.seedBackward(sg.dTop, endPrior);
-                sw.backward(sg.dTop, sg, true, fbBase);
-                for (int d2 = sg.dTop - 1; d2 > sg.tbPrev; d2--) sw.backward(d2, sg, false, fbBase);
-                roll_fence<true>();  // fb / cbuf / mbuf stores of all lanes are complete before they are re-read
-                sw.foldTotals(sg);
+                const int nCand = sw.traceback(sg, endPrior, a.geo.debug ? a.dbgFb + rg.dbgCellOff : nullptr);
+                roll_fence<true>();  // candidate / cbuf / mbuf stores of all lanes are complete before they are re-read
+                sw.foldTotals(sg, table);
+                if (a.geo.debug) {
+                    for (int d2 = sg.tbPrev + 1 + lane; d2 <= sg.tbFrom; d2 += CPK_WAVE)
+                        a.dbgTotals[rg.dbgDiagOff + d2] = ld_self(sw.totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
+                }
                 if (lane == 0) a.segStarts[rg.segOff + si] = count;
-                count = sw.emitMatches(sg, out, rg.outCap, count, fbBase,
-                                       a.geo.debug ? a.dbgTotals + rg.dbgDiagOff : nullptr,
-                                       a.geo.debug ? a.dbgFb + rg.dbgCellOff : nullptr);
+                count = sw.emitMatches(sg, nCand, out, rg.outCap, count);
                 if (!sg.atEnd) {
-                    sw.reloadForward(sg.dTop - 1);
-                    sw.reloadForward(sg.dTop);
+                    // the traceback reused the rolling buffers: restore F[dTop-1], F[dTop] for the forward sweep
+                    const CpkDiag gTopM1 = sw.dc.get(sg.dTop - 1, false);
+                    const CpkDiag gTop = sw.dc.get(sg.dTop, false);
+                    sw.reloadForward(gTopM1, sg.dTop - 1);
+                    sw.reloadForward(gTop, sg.dTop);
+                    sw.f2 = gTopM1;
+                    sw.f1 = gTop;
                 }
             }
         }
@@ -545,6 +662,7 @@ struct CpkDevice {
     int device = 0;
     int numCUs = 0;
     CpkGeometry geo{};
+    KConsts kc{};
     int nLists = 1;
     int64_t nSegs = 0, nDiags = 0;
     int64_t outTriplesPerList = 0;
@@ -557,7 +675,7 @@ struct CpkDevice {
     CpkSegment *dSegs = nullptr;
     uint8_t *dSymbols = nullptr;
     CpkModel *dModel = nullptr;
-    double *dRing = nullptr, *dFb = nullptr, *dC = nullptr, *dM = nullptr, *dTotals = nullptr, *dGroll = nullptr;
+    double *dRing = nullptr; Candidate *dCand = nullptr; double *dC = nullptr, *dM = nullptr, *dTotals = nullptr, *dGroll = nullptr;
     int32_t *dCounts = nullptr, *dSegStarts = nullptr, *dTriples = nullptr;
     unsigned int *dQueue = nullptr;
     double *dDbgFb = nullptr, *dDbgTotals = nullptr;
@@ -592,12 +710,13 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
 }
 
 static void free_all(CpkDevice *d) {
-    void *ptrs[] = {d->dRegions, d->dDiags, d->dSegs, d->dSymbols, d->dModel, d->dRing, d->dFb, d->dC, d->dM,
+    void *ptrs[] = {d->dRegions, d->dDiags, d->dSegs, d->dSymbols, d->dModel, d->dRing, d->dCand, d->dC, d->dM,
                     d->dTotals, d->dGroll, d->dCounts, d->dSegStarts, d->dTriples, d->dQueue, d->dDbgFb, d->dDbgTotals};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     d->dRegions = nullptr; d->dDiags = nullptr; d->dSegs = nullptr; d->dSymbols = nullptr; d->dModel = nullptr;
-    d->dRing = d->dFb = d->dC = d->dM = d->dTotals = d->dGroll = nullptr;
+    d->dRing = d->dC = d->dM = d->dTotals = d->dGroll = nullptr;
+    d->dCand = nullptr;
     d->dCounts = d->dSegStarts = d->dTriples = nullptr;
     d->dQueue = nullptr;
     d->dDbgFb = d->dDbgTotals = nullptr;
@@ -625,8 +744,9 @@ static int dev_alloc(CpkDevice *d, T **p, size_t count) {
 using KernelFn = void (*)(const KArgs);
 
 static KernelFn pick_kernel(const CpkGeometry &g) {
-    if (g.nStates == 5) return g.useGlobalRoll ? cpecan_pairhmm_sweep<5, true> : cpecan_pairhmm_sweep<5, false>;
-    return g.useGlobalRoll ? cpecan_pairhmm_sweep<3, true> : cpecan_pairhmm_sweep<3, false>;
+    const bool fast = !g.useGlobalRoll;  // second template argument = FAST (LDS rolling buffers + LDS symbol strings)
+    if (g.nStates == 5) return fast ? cpecan_pairhmm_sweep<5, true> : cpecan_pairhmm_sweep<5, false>;
+    return fast ? cpecan_pairhmm_sweep<3, true> : cpecan_pairhmm_sweep<3, false>;
 }
 
 extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const CpkModel *model, const CpkRegion *regions,
@@ -636,6 +756,10 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     HIP_TRY(hipSetDevice(d->device));
     free_all(d);
     d->geo = *geo;
+    d->kc = KConsts{model->matchContinue, model->matchFromShortX, model->matchFromShortY, model->matchFromLongX,
+                    model->matchFromLongY, model->shortOpenX, model->shortOpenY, model->shortExtendX,
+                    model->shortExtendY, model->shortSwitchToX, model->shortSwitchToY, model->longOpenX,
+                    model->longOpenY, model->longExtendX, model->longExtendY, model->threshold};
     d->nLists = nLists;
     d->nSegs = nSegs;
     d->nDiags = nDiags;
@@ -645,8 +769,10 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     d->ran = false;
     const int S = geo->nStates;
 
-    // LDS: 40 doubles of emission tables + three rolling buffers (unless they live in global memory)
-    d->ldsBytes = sizeof(double) * (40 + (geo->useGlobalRoll ? 0 : (size_t)3 * S * geo->rollStride));
+    // LDS: 40 doubles of emission tables + (fast path) three rolling buffers + both padded symbol strings
+    d->ldsBytes = sizeof(double) * 40;
+    if (!geo->useGlobalRoll)
+        d->ldsBytes += sizeof(double) * (size_t)3 * S * geo->rollStride + (size_t)((geo->seqLdsBytes + 15) / 16 * 16);
     KernelFn fn = pick_kernel(*geo);
     if (d->ldsBytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->ldsBytes));
@@ -681,7 +807,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (int rc = dev_alloc(d, &d->dSymbols, (size_t)nSymbolBytes)) return rc;
     if (int rc = dev_alloc(d, &d->dModel, 1)) return rc;
     if (int rc = dev_alloc(d, &d->dRing, (size_t)slots * geo->ringCells * S)) return rc;
-    if (int rc = dev_alloc(d, &d->dFb, (size_t)slots * geo->fbCells)) return rc;
+    if (int rc = dev_alloc(d, &d->dCand, (size_t)slots * geo->fbCells)) return rc;
     if (int rc = dev_alloc(d, &d->dC, (size_t)slots * geo->refreshCells)) return rc;
     if (int rc = dev_alloc(d, &d->dM, (size_t)slots * geo->refreshCells)) return rc;
     if (int rc = dev_alloc(d, &d->dTotals, (size_t)slots * geo->maxRefresh)) return rc;
@@ -736,6 +862,7 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     HIP_TRY(hipSetDevice(d->device));
     hipStream_t st = (hipStream_t)stream;
     KArgs a{};
+    a.kc = d->kc;
     a.regions = d->dRegions;
     a.diags = d->dDiags;
     a.segs = d->dSegs;
@@ -743,7 +870,7 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.model = d->dModel;
     a.geo = d->geo;
     a.ring = d->dRing;
-    a.fb = d->dFb;
+    a.cand = d->dCand;
     a.cbuf = d->dC;
     a.mbuf = d->dM;
     a.totals = d->dTotals;

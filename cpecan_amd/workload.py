@@ -2,8 +2,10 @@
 
 Counter-based splitmix64, so every pair's sequences depend only on (seed, pair index):
 any rank can regenerate exactly its shard.  X is uniform ACGT; Y is X with 5 % substitutions,
-2 % single-base deletions and 2 % single-base insertions; anchors are every 50th aligned
-column of the true alignment whose two bases are equal, as (x, y, expansion) triples.
+2 % single-base deletions and 2 % single-base insertions; anchors are, for every 50th aligned
+column of the true alignment, the first aligned column at or after it whose two bases are equal
+(so anchors stay ~50 apart and the band is 101-~155 cells wide at expansion 100, the geometry
+BASELINE.md quotes), as (x, y, expansion) triples.
 """
 import numpy as np
 
@@ -51,8 +53,14 @@ def make_pair(seed, index, length, expansion, anchor_every=50, sub=0.05, dele=0.
     y[ypos[keep]] = yb[keep]
     # anchors
     cols = np.nonzero(keep)[0]
-    pick = cols[anchor_every // 2::anchor_every]
-    pick = pick[xb[pick] == yb[pick]]
+    same = xb[cols] == yb[cols]
+    # for each slot (every anchor_every-th aligned column) take the first equal-base column at or after it
+    nxt = np.where(same, np.arange(len(cols)), len(cols))
+    nxt = np.minimum.accumulate(nxt[::-1])[::-1]
+    slots = np.arange(anchor_every // 2, len(cols), anchor_every)
+    chosen = np.unique(nxt[slots])
+    chosen = chosen[chosen < len(cols)]
+    pick = cols[chosen]
     anchors = np.stack([pick, ypos[pick], np.full_like(pick, expansion)], axis=1).astype(np.int64)
     return _BASES[xb].tobytes(), _BASES[y].tobytes(), anchors
 
