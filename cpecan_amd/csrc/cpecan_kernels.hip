@@ -27,6 +27,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -102,27 +103,73 @@ struct KArgs {
 // lo == -inf or d >= 7.5, else lo + P(d).  d is +inf when only lo is -inf and NaN when both are, and
 // both fail (d < 7.5), so one comparison covers the reference's two tests.  The cubic's coefficients are
 // float literals in the reference, i.e. float32 values widened to double; Horner with separate mul/add.
-__device__ __forceinline__ double logadd(double x, double y) {
+// The four cubics live in a 128-byte LDS table [segment][c3,c2,c1,c0] read with two ds_read_b128: selecting
+// four 64-bit coefficients with v_cndmask cost 24 VALU instructions per logAdd (47 % of the forward loop).
+struct __attribute__((aligned(16))) Cubic {
+    double c3, c2, c1, c0;
+};
+
+__device__ __forceinline__ void fill_cubics(double *t) {
+    const float c[16] = {-0.009350833524763f, 0.130659527668286f, 0.498799810682272f, 0.693203116424741f,
+                         -0.014532321752540f, 0.139942324101744f, 0.495635523139337f, 0.692140569840976f,
+                         -0.004605031767994f, 0.063427417320019f, 0.695956496475118f, 0.514272634594009f,
+                         -0.000458661602210f, 0.009695946122598f, 0.930734667215156f, 0.168037164329057f};
+    const int l = threadIdx.x;
+    if (l < 16) {
+        float v = c[0];
+#pragma unroll
+        for (int i = 1; i < 16; i++) v = l == i ? c[i] : v;
+        t[l] = (double)v;
+    }
+}
+
+__device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
     const double hi = __builtin_fmax(x, y);
     const double lo = __builtin_fmin(x, y);
     const double d = hi - lo;
-    const bool s0 = d <= 1.0, s1 = d <= 2.5, s2 = d <= 4.5;
-    const double c3 = s0 ? (double)-0.009350833524763f
-                         : (s1 ? (double)-0.014532321752540f : (s2 ? (double)-0.004605031767994f : (double)-0.000458661602210f));
-    const double c2 = s0 ? (double)0.130659527668286f
-                         : (s1 ? (double)0.139942324101744f : (s2 ? (double)0.063427417320019f : (double)0.009695946122598f));
-    const double c1 = s0 ? (double)0.498799810682272f
-                         : (s1 ? (double)0.495635523139337f : (s2 ? (double)0.695956496475118f : (double)0.930734667215156f));
-    const double c0 = s0 ? (double)0.693203116424741f
-                         : (s1 ? (double)0.692140569840976f : (s2 ? (double)0.514272634594009f : (double)0.168037164329057f));
-    double r = c3 * d;
-    r = r + c2;
+    const int seg = (d > 1.0) + (d > 2.5) + (d > 4.5);  // NaN -> 0, +inf -> 3: any row will do, the result is hi
+    const Cubic q = tab[seg];
+    double r = q.c3 * d;
+    r = r + q.c2;
     r = r * d;
-    r = r + c1;
+    r = r + q.c1;
     r = r * d;
-    r = r + c0;
+    r = r + q.c0;
     r = r + lo;
     return (d < 7.5) ? r : hi;
+}
+
+// N independent logAdds advanced in lock-step stages (compare/select -> table fetch -> Horner) so that the N LDS
+// table fetches are in flight together instead of one fetch + wait per logAdd.  acc[i] = logAdd(acc[i], t[i]).
+template <int N>
+__device__ __forceinline__ void logadd_n(const Cubic *tab, double (&acc)[N], const double (&t)[N]) {
+    double hi[N], lo[N], d[N];
+    Cubic q[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        hi[i] = __builtin_fmax(acc[i], t[i]);
+        lo[i] = __builtin_fmin(acc[i], t[i]);
+        d[i] = hi[i] - lo[i];
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) q[i] = tab[(d[i] > 1.0) + (d[i] > 2.5) + (d[i] > 4.5)];
+    double r[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = q[i].c3 * d[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = r[i] + q[i].c2;
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = r[i] * d[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = r[i] + q[i].c1;
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = r[i] * d[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = r[i] + q[i].c0;
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = r[i] + lo[i];
+#pragma unroll
+    for (int i = 0; i < N; i++) acc[i] = (d[i] < 7.5) ? r[i] : hi[i];
 }
 
 // Row position of neighbour cell i of a diagonal that has `w` cells (w = 0: the diagonal does not exist):
@@ -194,6 +241,7 @@ struct DiagCache {
     }
 };
 
+constexpr int kLdsHeader = 56;  // doubles of LDS in front of the rolling buffers: 16 (cubics) + 40 (emissions)
 constexpr int kPrefetch = 3;  // passes (of 64 cells) of F.match prefetched one diagonal ahead in the traceback
 constexpr float kCandMargin = 3.0f;  // log-space slack of the candidate filter (see DESIGN.md "candidate filter")
 
@@ -208,6 +256,7 @@ struct Sweep {
     const uint8_t *syp;
     double *roll;        // 3 rolling buffers [3][S][stride]; position 0 of each row = -inf guard
     const double *em;    // LDS emissions: [0..24] match, [25..29] gapX, [30..34] gapY
+    const Cubic *lg;     // LDS logAdd cubics
     double *ring;
     Candidate *cand;
     double *cbuf, *mbuf, *totals;
@@ -221,67 +270,118 @@ struct Sweep {
     __device__ __forceinline__ double *ringAt(const CpkDiag &g) const { return ring + (size_t)g.ringOff * S; }
 
     // ---- forward: impl/pairwiseAligner.c:609-629 with stateMachine{5,3}_cellCalculate as the per-cell body ----
-    __device__ void forward(int d) {
-        const CpkDiag g = dc.get(d, false);
-        const int W = g.width;
-        const int dl = (g.xmyL - 1 - f1.xmyL) >> 1;  // lower neighbour (d-1, xmy-1) is cell k+dl, upper is k+dl+1
-        const int w1 = f1.width;
-        const int dm = (g.xmyL - f2.xmyL) >> 1;      // middle neighbour (d-2, xmy) is cell k+dm
-        const int w2 = d >= 2 ? f2.width : 0;
-        double *cur = rbuf(d);
-        const double *p1 = rbuf(d - 1);
-        const double *p2 = rbuf(d - 2);
-        double *out = ringAt(g);
-        const int xlo = (d + g.xmyL) >> 1;
-        for (int k = lane; k < W; k += CPK_WAVE) {
-            const int x = xlo + k, y = d - x;
-            const int cX = sxp[x], cY = syp[y];
-            const double eX = em[25 + cX], eM = em[cX * 5 + cY], eY = em[30 + cY];
-            const int iL = guard_pos(k + dl, w1);
-            const int iU = guard_pos(k + dl + 1, w1);
-            const int iM = guard_pos(k + dm, w2);
-            double v[S];
-            if (S == 5) {
-                // states: 0 match, 1 shortGapX, 2 shortGapY, 3 longGapX, 4 longGapY (stateMachine.c:261-263)
+    struct FwdCtx {
+        int d, xlo, dl, w1, dm, w2;
+        const double *p1, *p2;
+    };
+
+    // NC cells (NC = 1 or 2, 64 lanes apart on the same diagonal) computed together.  Fold order per state is the
+    // reference's transition-list order; independent folds advance in lock-step (logadd_n).
+    template <int NC>
+    __device__ __forceinline__ void fwdCells(const FwdCtx &c, const int (&k)[NC], double (&v)[NC][S]) const {
+        int cX[NC], cY[NC];
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            const int x = c.xlo + k[q], y = c.d - x;
+            cX[q] = sxp[x];
+            cY[q] = syp[y];
+        }
+        const double *p1 = c.p1, *p2 = c.p2;
+        if (S == 5) {
+            // states: 0 match, 1 shortGapX, 2 shortGapY, 3 longGapX, 4 longGapY (stateMachine.c:261-263)
+            double acc[NC * 5], t[NC * 5], m2[NC], m3[NC], m4[NC];
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                const double eX = em[25 + cX[q]], eM = em[cX[q] * 5 + cY[q]], eY = em[30 + cY[q]];
+                const int iL = guard_pos(k[q] + c.dl, c.w1);
+                const int iU = guard_pos(k[q] + c.dl + 1, c.w1);
+                const int iM = guard_pos(k[q] + c.dm, c.w2);
                 const double lM = p1[0 * stride + iL], lSX = p1[1 * stride + iL], lLX = p1[3 * stride + iL];
                 const double uM = p1[0 * stride + iU], uSY = p1[2 * stride + iU], uLY = p1[4 * stride + iU];
                 const double mM = p2[0 * stride + iM], mSX = p2[1 * stride + iM], mSY = p2[2 * stride + iM],
                              mLX = p2[3 * stride + iM], mLY = p2[4 * stride + iM];
-                // lower block, stateMachine.c:454-462
-                v[1] = logadd(lM + (eX + m.shortOpenX), lSX + (eX + m.shortExtendX));
-                v[3] = logadd(lM + (eX + m.longOpenX), lLX + (eX + m.longExtendX));
-                // middle block, :463-470
-                double t = mM + (eM + m.matchContinue);
-                t = logadd(t, mSX + (eM + m.matchFromShortX));
-                t = logadd(t, mSY + (eM + m.matchFromShortY));
-                t = logadd(t, mLX + (eM + m.matchFromLongX));
-                t = logadd(t, mLY + (eM + m.matchFromLongY));
-                v[0] = t;
-                // upper block, :471-479
-                v[2] = logadd(uM + (eY + m.shortOpenY), uSY + (eY + m.shortExtendY));
-                v[4] = logadd(uM + (eY + m.longOpenY), uLY + (eY + m.longExtendY));
-            } else {
-                // states: 0 match, 1 gapX, 2 gapY; stateMachine.c:695-713
+                // first two terms of every state's fold: lower block :454-462, middle :463-470, upper :471-479
+                acc[q * 5 + 0] = mM + (eM + m.matchContinue);
+                t[q * 5 + 0] = mSX + (eM + m.matchFromShortX);
+                acc[q * 5 + 1] = lM + (eX + m.shortOpenX);
+                t[q * 5 + 1] = lSX + (eX + m.shortExtendX);
+                acc[q * 5 + 2] = uM + (eY + m.shortOpenY);
+                t[q * 5 + 2] = uSY + (eY + m.shortExtendY);
+                acc[q * 5 + 3] = lM + (eX + m.longOpenX);
+                t[q * 5 + 3] = lLX + (eX + m.longExtendX);
+                acc[q * 5 + 4] = uM + (eY + m.longOpenY);
+                t[q * 5 + 4] = uLY + (eY + m.longExtendY);
+                m2[q] = mSY + (eM + m.matchFromShortY);
+                m3[q] = mLX + (eM + m.matchFromLongX);
+                m4[q] = mLY + (eM + m.matchFromLongY);
+            }
+            logadd_n<NC * 5>(lg, acc, t);
+            // the match state folds three more terms, in order
+            double am[NC];
+#pragma unroll
+            for (int q = 0; q < NC; q++) am[q] = acc[q * 5 + 0];
+            logadd_n<NC>(lg, am, m2);
+            logadd_n<NC>(lg, am, m3);
+            logadd_n<NC>(lg, am, m4);
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                v[q][0] = am[q];
+#pragma unroll
+                for (int s2 = 1; s2 < 5; s2++) v[q][s2] = acc[q * 5 + s2];
+            }
+        } else {
+            // states: 0 match, 1 gapX, 2 gapY; stateMachine.c:695-713
+            double acc[NC * 3], t[NC * 3], u[NC * 3];
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                const double eX = em[25 + cX[q]], eM = em[cX[q] * 5 + cY[q]], eY = em[30 + cY[q]];
+                const int iL = guard_pos(k[q] + c.dl, c.w1);
+                const int iU = guard_pos(k[q] + c.dl + 1, c.w1);
+                const int iM = guard_pos(k[q] + c.dm, c.w2);
                 const double lM = p1[0 * stride + iL], lGX = p1[1 * stride + iL], lGY = p1[2 * stride + iL];
                 const double uM = p1[0 * stride + iU], uGX = p1[1 * stride + iU], uGY = p1[2 * stride + iU];
                 const double mM = p2[0 * stride + iM], mGX = p2[1 * stride + iM], mGY = p2[2 * stride + iM];
-                double t = lM + (eX + m.shortOpenX);
-                t = logadd(t, lGX + (eX + m.shortExtendX));
-                t = logadd(t, lGY + (eX + m.shortSwitchToX));
-                v[1] = t;
-                t = mM + (eM + m.matchContinue);
-                t = logadd(t, mGX + (eM + m.matchFromShortX));
-                t = logadd(t, mGY + (eM + m.matchFromShortY));
-                v[0] = t;
-                t = uM + (eY + m.shortOpenY);
-                t = logadd(t, uGY + (eY + m.shortExtendY));
-                t = logadd(t, uGX + (eY + m.shortSwitchToY));
-                v[2] = t;
+                acc[q * 3 + 0] = mM + (eM + m.matchContinue);
+                t[q * 3 + 0] = mGX + (eM + m.matchFromShortX);
+                u[q * 3 + 0] = mGY + (eM + m.matchFromShortY);
+                acc[q * 3 + 1] = lM + (eX + m.shortOpenX);
+                t[q * 3 + 1] = lGX + (eX + m.shortExtendX);
+                u[q * 3 + 1] = lGY + (eX + m.shortSwitchToX);
+                acc[q * 3 + 2] = uM + (eY + m.shortOpenY);
+                t[q * 3 + 2] = uGY + (eY + m.shortExtendY);
+                u[q * 3 + 2] = uGX + (eY + m.shortSwitchToY);
             }
+            logadd_n<NC * 3>(lg, acc, t);
+            logadd_n<NC * 3>(lg, acc, u);
+#pragma unroll
+            for (int q = 0; q < NC; q++)
+#pragma unroll
+                for (int s2 = 0; s2 < 3; s2++) v[q][s2] = acc[q * 3 + s2];
+        }
+    }
+
+    __device__ void forward(int d) {
+        const CpkDiag g = dc.get(d, false);
+        const int W = g.width;
+        FwdCtx c;
+        c.d = d;
+        c.xlo = (d + g.xmyL) >> 1;
+        c.dl = (g.xmyL - 1 - f1.xmyL) >> 1;  // lower neighbour (d-1, xmy-1) is cell k+dl, upper is k+dl+1
+        c.w1 = f1.width;
+        c.dm = (g.xmyL - f2.xmyL) >> 1;      // middle neighbour (d-2, xmy) is cell k+dm
+        c.w2 = d >= 2 ? f2.width : 0;
+        c.p1 = rbuf(d - 1);
+        c.p2 = rbuf(d - 2);
+        double *cur = rbuf(d);
+        double *out = ringAt(g);
+        for (int k0 = lane; k0 < W; k0 += CPK_WAVE) {
+            const int kk[1] = {k0};
+            double v[1][S];
+            fwdCells<1>(c, kk, v);
 #pragma unroll
             for (int s = 0; s < S; s++) {
-                cur[s * stride + k + 1] = v[s];
-                out[(size_t)s * W + k] = v[s];
+                cur[s * stride + k0 + 1] = v[0][s];
+                out[(size_t)s * W + k0] = v[0][s];
             }
         }
         roll_fence<!FAST>();
@@ -299,6 +399,100 @@ struct Sweep {
             for (int s = 0; s < S; s++) cur[s * stride + k + 1] = ld_self(src + (size_t)s * W + k);
         }
         roll_fence<!FAST>();
+    }
+
+    struct BwdCtx {
+        int d2, xlo, db, wB, da, wA;
+        const double *pb, *pa;
+        bool seeded;
+        const double *endPrior;
+    };
+    // B[d2][k] gathered from B[d2+1], B[d2+2] in the reference's scatter order, NC cells at a time
+    template <int NC>
+    __device__ __forceinline__ void bwdCells(const BwdCtx &c, const int (&k)[NC], double (&v)[NC][S]) const {
+        if (c.seeded) {
+            // every cell of the top diagonal gets the end-state prior (pairwiseAligner.c:798-799)
+#pragma unroll
+            for (int q = 0; q < NC; q++)
+#pragma unroll
+                for (int s = 0; s < S; s++) v[q][s] = c.endPrior[s];
+            return;
+        }
+        int cX1[NC], cY1[NC];
+#pragma unroll
+        for (int q = 0; q < NC; q++) {
+            const int x = c.xlo + k[q], y = c.d2 - x;
+            cX1[q] = sxp[x + 1];  // symbols of the source cells (x+1,.) and (.,y+1)
+            cY1[q] = syp[y + 1];
+        }
+        const double *pb = c.pb, *pa = c.pa;
+        if (S == 5) {
+            double acc[NC * 5], t[NC * 5], m2[NC], m3[NC], m4[NC];
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                const double eX = em[25 + cX1[q]], eM = em[cX1[q] * 5 + cY1[q]], eY = em[30 + cY1[q]];
+                const int iU = guard_pos(k[q] + c.db, c.wB);      // cell (x, y+1): its "upper" neighbour is the target
+                const int iL = guard_pos(k[q] + c.db + 1, c.wB);  // cell (x+1, y): its "lower" neighbour is the target
+                const int iA = guard_pos(k[q] + c.da, c.wA);      // cell (x+1, y+1): its "middle" neighbour is the target
+                const double aM = pa[0 * stride + iA];
+                const double uSY = pb[2 * stride + iU], uLY = pb[4 * stride + iU];
+                const double lSX = pb[1 * stride + iL], lLX = pb[3 * stride + iL];
+                // per target state: (1) middle term from d2+2, (2) upper-block terms, (3) lower-block terms
+                acc[q * 5 + 0] = aM + (eM + m.matchContinue);
+                t[q * 5 + 0] = uSY + (eY + m.shortOpenY);
+                m2[q] = uLY + (eY + m.longOpenY);
+                m3[q] = lSX + (eX + m.shortOpenX);
+                m4[q] = lLX + (eX + m.longOpenX);
+                acc[q * 5 + 1] = aM + (eM + m.matchFromShortX);
+                t[q * 5 + 1] = lSX + (eX + m.shortExtendX);
+                acc[q * 5 + 2] = aM + (eM + m.matchFromShortY);
+                t[q * 5 + 2] = uSY + (eY + m.shortExtendY);
+                acc[q * 5 + 3] = aM + (eM + m.matchFromLongX);
+                t[q * 5 + 3] = lLX + (eX + m.longExtendX);
+                acc[q * 5 + 4] = aM + (eM + m.matchFromLongY);
+                t[q * 5 + 4] = uLY + (eY + m.longExtendY);
+            }
+            logadd_n<NC * 5>(lg, acc, t);
+            double am[NC];
+#pragma unroll
+            for (int q = 0; q < NC; q++) am[q] = acc[q * 5 + 0];
+            logadd_n<NC>(lg, am, m2);
+            logadd_n<NC>(lg, am, m3);
+            logadd_n<NC>(lg, am, m4);
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                v[q][0] = am[q];
+#pragma unroll
+                for (int s2 = 1; s2 < 5; s2++) v[q][s2] = acc[q * 5 + s2];
+            }
+        } else {
+            double acc[NC * 3], t[NC * 3], u[NC * 3];
+#pragma unroll
+            for (int q = 0; q < NC; q++) {
+                const double eX = em[25 + cX1[q]], eM = em[cX1[q] * 5 + cY1[q]], eY = em[30 + cY1[q]];
+                const int iU = guard_pos(k[q] + c.db, c.wB);
+                const int iL = guard_pos(k[q] + c.db + 1, c.wB);
+                const int iA = guard_pos(k[q] + c.da, c.wA);
+                const double aM = pa[0 * stride + iA];
+                const double uGY = pb[2 * stride + iU];
+                const double lGX = pb[1 * stride + iL];
+                acc[q * 3 + 0] = aM + (eM + m.matchContinue);
+                t[q * 3 + 0] = uGY + (eY + m.shortOpenY);
+                u[q * 3 + 0] = lGX + (eX + m.shortOpenX);
+                acc[q * 3 + 1] = aM + (eM + m.matchFromShortX);
+                t[q * 3 + 1] = uGY + (eY + m.shortSwitchToY);
+                u[q * 3 + 1] = lGX + (eX + m.shortExtendX);
+                acc[q * 3 + 2] = aM + (eM + m.matchFromShortY);
+                t[q * 3 + 2] = uGY + (eY + m.shortExtendY);
+                u[q * 3 + 2] = lGX + (eX + m.shortSwitchToX);
+            }
+            logadd_n<NC * 3>(lg, acc, t);
+            logadd_n<NC * 3>(lg, acc, u);
+#pragma unroll
+            for (int q = 0; q < NC; q++)
+#pragma unroll
+                for (int s2 = 0; s2 < 3; s2++) v[q][s2] = acc[q * 3 + s2];
+        }
     }
 
     // ---- traceback of one segment (pairwiseAligner.c:796-862).
@@ -352,102 +546,84 @@ struct Sweep {
             const int wA = (!seeded && d2 + 2 <= sg.dTop) ? ga.width : 0;
             const double *fsrc = ringAt(g);
             const int xlo = (d2 + g.xmyL) >> 1;
+            BwdCtx c;
+            c.d2 = d2;
+            c.xlo = xlo;
+            c.db = db;
+            c.wB = wB;
+            c.da = da;
+            c.wA = wA;
+            c.pb = pb;
+            c.pa = pa;
+            c.seeded = seeded;
+            c.endPrior = endPrior;
+            const float keepFrom = lastMax + logThr - kCandMargin;  // wave-uniform
+            // Wave-uniform loop (the candidate count must stay identical in every lane): lanes past the end of the
+            // diagonal recompute its last cell and have their stores masked.
             int pass = 0;
-            for (int k = lane; k < W; k += CPK_WAVE, pass++) {
-                const int x = xlo + k, y = d2 - x;
-                double v[S];
-                if (seeded) {
-                    // every cell of the top diagonal gets the end-state prior (:798-799)
+            for (int kb = 0; kb < W; kb += CPK_WAVE, pass++) {
+                const int k0 = kb + lane;
+                const bool on = k0 < W;
+                const int kk[1] = {on ? k0 : W - 1};
+                double v[1][S];
+                bwdCells<1>(c, kk, v);
+                if (on) {
 #pragma unroll
-                    for (int s = 0; s < S; s++) v[s] = endPrior[s];
-                } else {
-                    const int cX1 = sxp[x + 1], cY1 = syp[y + 1];  // symbols of the source cells (x+1,.) and (.,y+1)
-                    const double eX = em[25 + cX1], eM = em[cX1 * 5 + cY1], eY = em[30 + cY1];
-                    const int iU = guard_pos(k + db, wB);      // cell (x, y+1): its "upper" neighbour is the target
-                    const int iL = guard_pos(k + db + 1, wB);  // cell (x+1, y): its "lower" neighbour is the target
-                    const int iA = guard_pos(k + da, wA);      // cell (x+1, y+1): its "middle" neighbour is the target
-                    const double aM = pa[0 * stride + iA];
-                    if (S == 5) {
-                        const double uSY = pb[2 * stride + iU], uLY = pb[4 * stride + iU];
-                        const double lSX = pb[1 * stride + iL], lLX = pb[3 * stride + iL];
-                        double t = aM + (eM + m.matchContinue);
-                        t = logadd(t, uSY + (eY + m.shortOpenY));
-                        t = logadd(t, uLY + (eY + m.longOpenY));
-                        t = logadd(t, lSX + (eX + m.shortOpenX));
-                        t = logadd(t, lLX + (eX + m.longOpenX));
-                        v[0] = t;
-                        v[1] = logadd(aM + (eM + m.matchFromShortX), lSX + (eX + m.shortExtendX));
-                        v[2] = logadd(aM + (eM + m.matchFromShortY), uSY + (eY + m.shortExtendY));
-                        v[3] = logadd(aM + (eM + m.matchFromLongX), lLX + (eX + m.longExtendX));
-                        v[4] = logadd(aM + (eM + m.matchFromLongY), uLY + (eY + m.longExtendY));
-                    } else {
-                        const double uGY = pb[2 * stride + iU];
-                        const double lGX = pb[1 * stride + iL];
-                        double t = aM + (eM + m.matchContinue);
-                        t = logadd(t, uGY + (eY + m.shortOpenY));
-                        t = logadd(t, lGX + (eX + m.shortOpenX));
-                        v[0] = t;
-                        t = aM + (eM + m.matchFromShortX);
-                        t = logadd(t, uGY + (eY + m.shortSwitchToY));
-                        t = logadd(t, lGX + (eX + m.shortExtendX));
-                        v[1] = t;
-                        t = aM + (eM + m.matchFromShortY);
-                        t = logadd(t, uGY + (eY + m.shortExtendY));
-                        t = logadd(t, lGX + (eX + m.shortSwitchToX));
-                        v[2] = t;
-                    }
+                    for (int s = 0; s < S; s++) cur[s * stride + k0 + 1] = v[0][s];
                 }
-#pragma unroll
-                for (int s = 0; s < S; s++) cur[s * stride + k + 1] = v[s];
                 if (emit) {
                     double f0;
                     if (pass == 0) f0 = fmCur[0];
                     else if (pass == 1) f0 = fmCur[1];
                     else if (pass == 2) f0 = fmCur[2];
-                    else f0 = ld_self(fsrc + k);
-                    const double fbv = f0 + v[0];
-                    if (dbgFb) dbgFb[g.cellOff + k] = fbv;
-                    if (refresh) {
+                    else f0 = on ? ld_self(fsrc + k0) : 0.0;
+                    const double fbv = f0 + v[0][0];
+                    if (on && dbgFb) dbgFb[g.cellOff + k0] = fbv;
+                    if (refresh && on) {
                         // cell_dotProduct over states, pairwiseAligner.c:402-408
                         double t = fbv;
 #pragma unroll
-                        for (int s = 1; s < S; s++) t = logadd(t, ld_self(fsrc + (size_t)s * W + k) + v[s]);
-                        cbuf[(size_t)k * J + jr] = t;
+                        for (int s = 1; s < S; s++) t = logadd(lg, t, ld_self(fsrc + (size_t)s * W + k0) + v[0][s]);
+                        cbuf[(size_t)k0 * J + jr] = t;
                     }
+                    // candidate filter: a match cell (x > 0, y > 0; pairwiseAligner.c:680) survives when it is within
+                    // log(threshold) - margin of the bound on the total probability (DESIGN.md "candidate filter").
+                    const int x = xlo + k0, y = d2 - x;
+                    const bool keep = on && x > 0 && y > 0 && (float)fbv >= keepFrom;
+                    const unsigned long long mask = __ballot(keep);
+                    if (keep) {
+                        const int rank =
+                            __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                        Candidate cd;
+                        cd.fb = fbv;
+                        cd.x = x;
+                        cd.y = y;
+                        cand[nCand + rank] = cd;
+                    }
+                    nCand += __popcll(mask);
                 }
             }
-            // candidate filter (wave-uniform control flow: every lane takes part in the max and the ballot)
-            if (emit) {
+            // The bound is renewed on refresh diagonals only (every 10th): max(this diagonal's maximum, old bound - 1).
+            // The reference itself asserts that consecutive totals differ by less than 1.0 (pairwiseAligner.c:834), so
+            // the decayed old bound stays below the current total.  Wave-uniform loop: all lanes join the shuffles.
+            if (refresh) {
+                float diagMax = -__builtin_huge_valf();
                 pass = 0;
                 for (int kb = 0; kb < W; kb += CPK_WAVE, pass++) {
                     const int k = kb + lane;
                     const int x = xlo + k, y = d2 - x;
-                    const bool valid = k < W && x > 0 && y > 0;  // match cells only (pairwiseAligner.c:680)
-                    double fbv = NEG_INF;
-                    if (valid) {
+                    float fbf = -__builtin_huge_valf();
+                    if (k < W && x > 0 && y > 0) {
                         double f0;
                         if (pass == 0) f0 = fmCur[0];
                         else if (pass == 1) f0 = fmCur[1];
                         else if (pass == 2) f0 = fmCur[2];
                         else f0 = ld_self(fsrc + k);
-                        fbv = f0 + cur[0 * stride + k + 1];
+                        fbf = (float)(f0 + cur[0 * stride + k + 1]);
                     }
-                    const float fbf = (float)fbv;
-                    const float pmax = wave_max_f32(fbf);
-                    lastMax = fmaxf(lastMax, pmax);
-                    const bool keep = valid && fbf >= lastMax + logThr - kCandMargin;
-                    const unsigned long long mask = __ballot(keep);
-                    if (keep) {
-                        const int rank =
-                            __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                        Candidate c;
-                        c.fb = fbv;
-                        c.x = x;
-                        c.y = y;
-                        cand[nCand + rank] = c;
-                    }
-                    nCand += __popcll(mask);
+                    diagMax = fmaxf(diagMax, wave_max_f32(fbf));
                 }
+                lastMax = fmaxf(diagMax, lastMax - 1.0f);
             }
             roll_fence<!FAST>();
             if (refresh && d2 + 1 <= sg.dTop) {
@@ -471,11 +647,11 @@ struct Sweep {
                         f[s] = ok ? val : NEG_INF;
                     }
                     double t = f[0] + (eM + m.matchContinue);
-                    t = logadd(t, f[1] + (eM + m.matchFromShortX));
-                    t = logadd(t, f[2] + (eM + m.matchFromShortY));
+                    t = logadd(lg, t, f[1] + (eM + m.matchFromShortX));
+                    t = logadd(lg, t, f[2] + (eM + m.matchFromShortY));
                     if (S == 5) {
-                        t = logadd(t, f[3] + (eM + m.matchFromLongX));
-                        t = logadd(t, f[4] + (eM + m.matchFromLongY));
+                        t = logadd(lg, t, f[3] + (eM + m.matchFromLongX));
+                        t = logadd(lg, t, f[4] + (eM + m.matchFromLongY));
                     }
                     mbuf[(size_t)k * J + jr] = t + bn[0 * stride + k + 1];
                 }
@@ -503,13 +679,13 @@ struct Sweep {
             double total = NEG_INF, straddle = NEG_INF;
             const int WcMax = wave_max_i32(Wc), WmMax = wave_max_i32(Wm);
             for (int k = 0; k < WcMax; k++) {
-                if (k < Wc) total = logadd(total, ld_self(cbuf + (size_t)k * J + j));
+                if (k < Wc) total = logadd(lg, total, ld_self(cbuf + (size_t)k * J + j));
             }
             for (int k = 0; k < WmMax; k++) {
-                if (k < Wm) straddle = logadd(straddle, ld_self(mbuf + (size_t)k * J + j));
+                if (k < Wm) straddle = logadd(lg, straddle, ld_self(mbuf + (size_t)k * J + j));
             }
             if (on) {
-                if (r + 1 <= sg.dTop) total = logadd(total, straddle);
+                if (r + 1 <= sg.dTop) total = logadd(lg, total, straddle);
                 totals[j] = total;
             }
         }
@@ -553,21 +729,24 @@ struct Sweep {
 };
 
 template <int S, bool FAST>
-__global__ void __launch_bounds__(CPK_WAVE) cpecan_pairhmm_sweep(const KArgs a) {
+__global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(1, 2)))
+cpecan_pairhmm_sweep(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const CpkModel &m = *a.model;
     const int stride = a.geo.rollStride;
 
-    // LDS: [0,40) emission tables | rolling buffers (FAST) | symbol strings (FAST)
-    double *em = lds;
+    // LDS (doubles): [0,16) logAdd cubics | [16,56) emission tables | rolling buffers (FAST) | symbol strings (FAST)
+    fill_cubics(lds);
+    const Cubic *lg = reinterpret_cast<const Cubic *>(lds);
+    double *em = lds + 16;
     if (lane < 25) em[lane] = m.matchEm[lane];
     if (lane < 5) {
         em[25 + lane] = m.gapXEm[lane];
         em[30 + lane] = m.gapYEm[lane];
     }
-    double *roll = FAST ? (lds + 40) : (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles);
-    uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + 40 + (size_t)3 * S * stride);
+    double *roll = FAST ? (lds + kLdsHeader) : (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles);
+    uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + kLdsHeader + (size_t)3 * S * stride);
     // every rolling cell starts as -inf; position 0 of each row is never written again (the guard)
     for (int i = lane; i < 3 * S * stride; i += CPK_WAVE) roll[i] = NEG_INF;
     __syncthreads();
@@ -598,6 +777,7 @@ __global__ void __launch_bounds__(CPK_WAVE) cpecan_pairhmm_sweep(const KArgs a) 
                           FAST ? seqLds + lX + 2 : gy,
                           roll,
                           em,
+                          lg,
                           a.ring + slot * (size_t)a.geo.ringCells * S,
                           a.cand + slot * (size_t)a.geo.fbCells,
                           a.cbuf + slot * (size_t)a.geo.refreshCells,
@@ -630,11 +810,12 @@ __global__ void __launch_bounds__(CPK_WAVE) cpecan_pairhmm_sweep(const KArgs a) 
             for (int si = 0; si < rg.nSeg; si++) {
                 const CpkSegment sg = a.segs[rg.segOff + si];
                 for (; d <= sg.dTop; d++) sw.forward(d);
+                if (a.geo.debug & 2) continue;  // diagnostic: time the forward sweep alone (no traceback, no output)
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
-                const int nCand = sw.traceback(sg, endPrior, a.geo.debug ? a.dbgFb + rg.dbgCellOff : nullptr);
+                const int nCand = sw.traceback(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr);
                 roll_fence<true>();  // candidate / cbuf / mbuf stores of all lanes are complete before they are re-read
                 sw.foldTotals(sg, table);
-                if (a.geo.debug) {
+                if (a.geo.debug & 1) {
                     for (int d2 = sg.tbPrev + 1 + lane; d2 <= sg.tbFrom; d2 += CPK_WAVE)
                         a.dbgTotals[rg.dbgDiagOff + d2] = ld_self(sw.totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
                 }
@@ -770,7 +951,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     const int S = geo->nStates;
 
     // LDS: 40 doubles of emission tables + (fast path) three rolling buffers + both padded symbol strings
-    d->ldsBytes = sizeof(double) * 40;
+    d->ldsBytes = sizeof(double) * kLdsHeader;
     if (!geo->useGlobalRoll)
         d->ldsBytes += sizeof(double) * (size_t)3 * S * geo->rollStride + (size_t)((geo->seqLdsBytes + 15) / 16 * 16);
     KernelFn fn = pick_kernel(*geo);
@@ -792,6 +973,10 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     const int byLds = (int)((160 * 1024) / (ldsTotal ? ldsTotal : 1));
     if (byLds < perCU) perCU = byLds;
     if (perCU > 32) perCU = 32;
+    if (const char *cap = getenv("CPECAN_MAX_WAVES_PER_CU")) {  // tuning/diagnostic knob
+        const int c = atoi(cap);
+        if (c >= 1 && c < perCU) perCU = c;
+    }
     if (perCU < 1) {
         cpk_set_error("kernel does not fit on a CU (LDS %zu bytes)", d->ldsBytes);
         return CPECAN_EHIP;
@@ -869,6 +1054,7 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.symbols = d->dSymbols;
     a.model = d->dModel;
     a.geo = d->geo;
+    if (const char *skip = getenv("CPECAN_DEBUG_SKIP")) a.geo.debug |= (atoi(skip) & 6);  // diagnostic phase bisection
     a.ring = d->dRing;
     a.cand = d->dCand;
     a.cbuf = d->dC;
