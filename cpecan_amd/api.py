@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcpecan_hip.so")
 
 fiveState, fiveStateAsymmetric, threeState, threeStateAsymmetric = 0, 1, 2, 3  # inc/stateMachine.h:28-33
-EMIT_MATCH, EMIT_INDEL, EMIT_EXPECT = 0, 1, 2
+EMIT_MATCH, EMIT_INDEL, EMIT_EXPECT, EMIT_FORWARD = 0, 1, 2, 3
 PAIR_ALIGNMENT_PROB_1 = 10000000  # inc/pairwiseAligner.h:26
 
 
@@ -78,8 +78,9 @@ EXPORTS = [
     "cpecan_hmm_load", "cpecan_params_default", "cpecan_band", "cpecan_split_points", "cpecan_device_count",
     "cpecan_last_error", "cpecan_batch_create", "cpecan_batch_destroy", "cpecan_batch_add", "cpecan_batch_upload",
     "cpecan_batch_run", "cpecan_batch_download", "cpecan_batch_result", "cpecan_batch_expectations",
-    "cpecan_batch_stats", "cpecan_batch_set_debug", "cpecan_batch_debug_fetch",
-    "cpecan_get_aligned_pairs_using_anchors", "cpecan_free",
+    "cpecan_batch_stats", "cpecan_batch_set_debug", "cpecan_batch_debug_fetch", "cpecan_batch_forward_prob",
+    "cpecan_get_aligned_pairs_using_anchors", "cpecan_get_aligned_pairs_with_indels_using_anchors",
+    "cpecan_compute_forward_probability", "cpecan_free",
 ]
 
 _lib = None
@@ -125,6 +126,13 @@ def lib():
     L.cpecan_get_aligned_pairs_using_anchors.argtypes = [
         C.POINTER(StateMachine), C.c_char_p, C.c_char_p, i64p, C.c_int64, C.POINTER(PairwiseAlignmentParameters),
         C.c_int, C.c_int, C.POINTER(i32p), i64p]
+    L.cpecan_batch_forward_prob.argtypes = [vp, C.c_int64, dp]
+    L.cpecan_get_aligned_pairs_with_indels_using_anchors.argtypes = [
+        C.POINTER(StateMachine), C.c_char_p, C.c_char_p, i64p, C.c_int64, C.POINTER(PairwiseAlignmentParameters),
+        C.c_int, C.c_int, C.POINTER(i32p), i64p, C.POINTER(i32p), i64p, C.POINTER(i32p), i64p]
+    L.cpecan_compute_forward_probability.argtypes = [
+        C.POINTER(StateMachine), C.c_char_p, C.c_char_p, i64p, C.c_int64, C.POINTER(PairwiseAlignmentParameters),
+        C.c_int, C.c_int, dp]
     L.cpecan_free.argtypes = [vp]
     L.cpecan_free.restype = None
     _lib = L
@@ -283,6 +291,11 @@ class Batch:
             return np.zeros((0, 3), dtype=np.int32)
         return np.ctypeslib.as_array(ptr, shape=(n.value * 3,)).copy().reshape(n.value, 3)
 
+    def forward_prob(self, problem):
+        v = C.c_double()
+        _check(lib().cpecan_batch_forward_prob(self._h, problem, C.byref(v)), "cpecan_batch_forward_prob")
+        return v.value
+
     def stats(self):
         s = Stats()
         _check(lib().cpecan_batch_stats(self._h, C.byref(s)), "cpecan_batch_stats")
@@ -309,3 +322,33 @@ def getAlignedPairsUsingAnchors(sM, sX, sY, anchorPairs, p, alignmentHasRaggedLe
     res = np.ctypeslib.as_array(out, shape=(max(cnt.value, 1) * 3,))[:cnt.value * 3].copy().reshape(cnt.value, 3)
     lib().cpecan_free(C.cast(out, C.c_void_p))
     return res
+
+
+def _take_list(ptr, n):
+    res = np.ctypeslib.as_array(ptr, shape=(max(n, 1) * 3,))[:n * 3].copy().reshape(n, 3)
+    lib().cpecan_free(C.cast(ptr, C.c_void_p))
+    return res
+
+
+def getAlignedPairsWithIndelsUsingAnchors(sM, sX, sY, anchorPairs, p, alignmentHasRaggedLeftEnd=False,
+                                          alignmentHasRaggedRightEnd=False):
+    """impl/pairwiseAligner.c:1451: (alignedPairs, gapXPairs, gapYPairs), each int32[n,3] of (score, x, y)."""
+    a, ptr, n = _anchor_array(anchorPairs)
+    outs = [C.POINTER(C.c_int32)() for _ in range(3)]
+    cnts = [C.c_int64() for _ in range(3)]
+    _check(lib().cpecan_get_aligned_pairs_with_indels_using_anchors(
+        C.byref(sM), _bytes(sX), _bytes(sY), ptr, n, C.byref(p), int(alignmentHasRaggedLeftEnd),
+        int(alignmentHasRaggedRightEnd), C.byref(outs[0]), C.byref(cnts[0]), C.byref(outs[1]), C.byref(cnts[1]),
+        C.byref(outs[2]), C.byref(cnts[2])), "getAlignedPairsWithIndelsUsingAnchors")
+    return tuple(_take_list(o, c.value) for o, c in zip(outs, cnts))
+
+
+def computeForwardProbability(seqX, seqY, anchorPairs, p, sM, alignmentHasRaggedLeftEnd=False,
+                              alignmentHasRaggedRightEnd=False):
+    """impl/pairwiseAligner.c:936 (argument order as in the reference)."""
+    a, ptr, n = _anchor_array(anchorPairs)
+    v = C.c_double()
+    _check(lib().cpecan_compute_forward_probability(C.byref(sM), _bytes(seqX), _bytes(seqY), ptr, n, C.byref(p),
+                                                    int(alignmentHasRaggedLeftEnd), int(alignmentHasRaggedRightEnd),
+                                                    C.byref(v)), "computeForwardProbability")
+    return v.value

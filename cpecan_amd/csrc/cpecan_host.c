@@ -440,6 +440,7 @@ struct cpecan_batch {
     int nLists;
     int64_t dbgCells, dbgDiags;
     CpkDevice *dev;
+    double *forward; /* [nRegions] in device order, FORWARD emitter */
     cpecan_stats stats;
 };
 
@@ -461,8 +462,8 @@ int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpe
                         int device) {
     if (!out || !model || !params) return CPECAN_EINVAL;
     if (!(is_five(model->type) || is_three(model->type))) return CPECAN_EINVAL;
-    if (emit != CPECAN_EMIT_MATCH) {
-        cpk_set_error("emitter %d is not implemented on the HIP path yet (only CPECAN_EMIT_MATCH)", emit);
+    if (emit != CPECAN_EMIT_MATCH && emit != CPECAN_EMIT_INDEL && emit != CPECAN_EMIT_FORWARD) {
+        cpk_set_error("emitter %d is not implemented on the HIP path yet", emit);
         return CPECAN_EINVAL;
     }
     /* preconditions of getPosteriorProbsWithBanding, pairwiseAligner.c:761-765 */
@@ -505,6 +506,7 @@ void cpecan_batch_destroy(cpecan_batch *b) {
     free(b->devRegions);
     free(b->devToHost);
     free(b->segs);
+    free(b->forward);
     free(b);
 }
 
@@ -550,8 +552,17 @@ int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char
     }
     int64_t *rects = malloc(sizeof(int64_t) * 4 * (size_t)(nAnchors + 2));
     if (!rects) return CPECAN_ENOMEM;
-    const int64_t nRects = cpecan_split_points(anchors, nAnchors, lX, lY, b->params.splitMatrixBiggerThanThis,
-                                               raggedLeft, raggedRight, rects);
+    int64_t nRects;
+    if (b->emit == CPECAN_EMIT_FORWARD) { /* computeForwardProbability never splits (pairwiseAligner.c:936-949) */
+        nRects = 1;
+        rects[0] = 0;
+        rects[1] = 0;
+        rects[2] = lX;
+        rects[3] = lY;
+    } else {
+        nRects = cpecan_split_points(anchors, nAnchors, lX, lY, b->params.splitMatrixBiggerThanThis, raggedLeft,
+                                     raggedRight, rects);
+    }
     if (nRects < 0) {
         free(rects);
         return CPECAN_EINVAL;
@@ -576,8 +587,8 @@ int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char
         r->y1 = y1;
         r->lX = x2 - x1;
         r->lY = y2 - y1;
-        r->raggedLeft = raggedLeft || i > 0;
-        r->raggedRight = raggedRight || i < nRects - 1;
+        r->raggedLeft = (raggedLeft || i > 0) ? 1 : 0;
+        r->raggedRight = (raggedRight || i < nRects - 1) ? 1 : 0;
         r->seqXOff = append_symbols(b, sX + x1, r->lX);
         r->seqYOff = append_symbols(b, sY + y1, r->lY);
         if (r->seqXOff < 0 || r->seqYOff < 0) {
@@ -648,8 +659,9 @@ int cpecan_batch_upload(cpecan_batch *b) {
         for (int64_t i = 0; i < b->nRegions; i++) {
             HostRegion *r = &b->regions[i];
             const int64_t N = r->lX + r->lY;
+            /* the forward-probability path always uses the static band (pairwiseAligner.c:894) */
             rc = build_band(b->anchors + 3 * r->anchorOff, r->nAnchors, r->lX, r->lY, p->diagonalExpansion,
-                            p->dynamicAnchorExpansion, lo, hi);
+                            b->emit == CPECAN_EMIT_FORWARD ? 0 : p->dynamicAnchorExpansion, lo, hi);
             if (rc != CPECAN_OK) {
                 cpk_set_error("region %lld of problem %lld: anchors do not define a valid band", (long long)i,
                               (long long)r->problem);
@@ -763,6 +775,10 @@ int cpecan_batch_upload(cpecan_batch *b) {
         g->outCap = (int32_t)default_out_cap(b, r);
         g->outOff = outAt;
         outAt += g->outCap;
+    }
+    if (b->emit == CPECAN_EMIT_FORWARD) { /* no traceback: nothing is kept of the forward matrix */
+        geo.ringCells = 1;
+        geo.fbCells = 1;
     }
     if (geo.maxRefresh < 1) geo.maxRefresh = 1;
     if (geo.ringCells < 1) geo.ringCells = 1;
@@ -898,8 +914,16 @@ int cpecan_batch_download(cpecan_batch *b) {
             rc = CPECAN_ENOMEM;
             break;
         }
-        rc = cpk_device_download(b->dev, counts, segStarts, triples, NULL, &b->stats.kernelMs, &b->stats.d2hMs);
+        if (b->emit == CPECAN_EMIT_FORWARD && !b->forward) {
+            b->forward = malloc(sizeof(double) * (size_t)b->nRegions);
+            if (!b->forward) {
+                rc = CPECAN_ENOMEM;
+                break;
+            }
+        }
+        rc = cpk_device_download(b->dev, counts, segStarts, triples, b->forward, &b->stats.kernelMs, &b->stats.d2hMs);
         if (rc != CPECAN_OK) break;
+        if (b->emit == CPECAN_EMIT_FORWARD) break; /* no lists in this mode: the kernel wrote one double per region */
         /* did any region overflow its output slice?  If so enlarge exactly and run once more. */
         int overflow = 0;
         int64_t outAt = 0;
@@ -929,10 +953,10 @@ int cpecan_batch_download(cpecan_batch *b) {
             rc = CPECAN_ESTATE;
         }
     }
-    if (rc == CPECAN_OK) {
+    if (rc == CPECAN_OK && b->emit != CPECAN_EMIT_FORWARD) {
         for (int64_t i = 0; i < b->nProblems && rc == CPECAN_OK; i++) rc = assemble_problem(b, i, counts, segStarts, triples);
-        if (rc == CPECAN_OK) b->downloaded = 1;
     }
+    if (rc == CPECAN_OK) b->downloaded = 1;
     free(counts);
     free(segStarts);
     free(triples);
@@ -944,6 +968,13 @@ int cpecan_batch_result(const cpecan_batch *b, int64_t problem, int which, const
     if (problem < 0 || problem >= b->nProblems || which < 0 || which >= b->nLists) return CPECAN_EINVAL;
     *triples = b->problems[problem].triples[which];
     *n = b->problems[problem].nTriples[which];
+    return CPECAN_OK;
+}
+
+int cpecan_batch_forward_prob(const cpecan_batch *b, int64_t problem, double *logProb) {
+    if (!b || !b->downloaded || b->emit != CPECAN_EMIT_FORWARD) return CPECAN_ESTATE;
+    if (problem < 0 || problem >= b->nProblems || !logProb) return CPECAN_EINVAL;
+    *logProb = b->forward[b->regions[b->problems[problem].firstRegion].devIndex];
     return CPECAN_OK;
 }
 
@@ -988,12 +1019,12 @@ int cpecan_batch_debug_fetch(const cpecan_batch *b, int64_t problem, double *fbM
  * ---------------------------------------------------------------------------------------------- */
 void cpecan_free(void *p) { free(p); }
 
-int cpecan_get_aligned_pairs_using_anchors(const cpecan_model *m, const char *sX, const char *sY,
-                                           const int64_t *anchors, int64_t nAnchors, const cpecan_params *p,
-                                           int raggedLeft, int raggedRight, int32_t **triples, int64_t *n) {
-    if (!m || !sX || !sY || !p || !triples || !n) return CPECAN_EINVAL;
+/* one problem through a batch of one: create, add, upload, run, download */
+static int run_single(cpecan_batch **out, const cpecan_model *m, const char *sX, const char *sY, const int64_t *anchors,
+                      int64_t nAnchors, const cpecan_params *p, int raggedLeft, int raggedRight, int emit) {
+    if (!m || !sX || !sY || !p) return CPECAN_EINVAL;
     cpecan_batch *b = NULL;
-    int rc = cpecan_batch_create(&b, m, p, CPECAN_EMIT_MATCH, 0);
+    int rc = cpecan_batch_create(&b, m, p, emit, 0);
     if (rc != CPECAN_OK) return rc;
     int64_t idx = cpecan_batch_add(b, sX, (int64_t)strlen(sX), sY, (int64_t)strlen(sY), anchors, nAnchors, raggedLeft,
                                    raggedRight);
@@ -1001,19 +1032,67 @@ int cpecan_get_aligned_pairs_using_anchors(const cpecan_model *m, const char *sX
     if (rc == CPECAN_OK) rc = cpecan_batch_upload(b);
     if (rc == CPECAN_OK) rc = cpecan_batch_run(b, NULL);
     if (rc == CPECAN_OK) rc = cpecan_batch_download(b);
-    if (rc == CPECAN_OK) {
-        const int32_t *src;
-        int64_t cnt;
-        rc = cpecan_batch_result(b, 0, 0, &src, &cnt);
-        if (rc == CPECAN_OK) {
-            *triples = malloc(sizeof(int32_t) * 3 * (size_t)(cnt ? cnt : 1));
-            if (!*triples) rc = CPECAN_ENOMEM;
-            else {
-                memcpy(*triples, src, sizeof(int32_t) * 3 * (size_t)cnt);
-                *n = cnt;
-            }
-        }
+    if (rc != CPECAN_OK) {
+        cpecan_batch_destroy(b);
+        return rc;
     }
+    *out = b;
+    return CPECAN_OK;
+}
+
+static int copy_list(const cpecan_batch *b, int which, int32_t **triples, int64_t *n) {
+    const int32_t *src;
+    int64_t cnt;
+    int rc = cpecan_batch_result(b, 0, which, &src, &cnt);
+    if (rc != CPECAN_OK) return rc;
+    *triples = malloc(sizeof(int32_t) * 3 * (size_t)(cnt ? cnt : 1));
+    if (!*triples) return CPECAN_ENOMEM;
+    memcpy(*triples, src, sizeof(int32_t) * 3 * (size_t)cnt);
+    *n = cnt;
+    return CPECAN_OK;
+}
+
+int cpecan_get_aligned_pairs_using_anchors(const cpecan_model *m, const char *sX, const char *sY,
+                                           const int64_t *anchors, int64_t nAnchors, const cpecan_params *p,
+                                           int raggedLeft, int raggedRight, int32_t **triples, int64_t *n) {
+    if (!triples || !n) return CPECAN_EINVAL;
+    cpecan_batch *b = NULL;
+    int rc = run_single(&b, m, sX, sY, anchors, nAnchors, p, raggedLeft, raggedRight, CPECAN_EMIT_MATCH);
+    if (rc != CPECAN_OK) return rc;
+    rc = copy_list(b, 0, triples, n);
+    cpecan_batch_destroy(b);
+    return rc;
+}
+
+int cpecan_get_aligned_pairs_with_indels_using_anchors(const cpecan_model *m, const char *sX, const char *sY,
+                                                       const int64_t *anchors, int64_t nAnchors, const cpecan_params *p,
+                                                       int raggedLeft, int raggedRight, int32_t **match, int64_t *nMatch,
+                                                       int32_t **gapX, int64_t *nGapX, int32_t **gapY, int64_t *nGapY) {
+    if (!match || !nMatch || !gapX || !nGapX || !gapY || !nGapY) return CPECAN_EINVAL;
+    cpecan_batch *b = NULL;
+    int rc = run_single(&b, m, sX, sY, anchors, nAnchors, p, raggedLeft, raggedRight, CPECAN_EMIT_INDEL);
+    if (rc != CPECAN_OK) return rc;
+    *match = *gapX = *gapY = NULL;
+    rc = copy_list(b, 0, match, nMatch);
+    if (rc == CPECAN_OK) rc = copy_list(b, 1, gapX, nGapX);
+    if (rc == CPECAN_OK) rc = copy_list(b, 2, gapY, nGapY);
+    if (rc != CPECAN_OK) {
+        free(*match);
+        free(*gapX);
+        free(*gapY);
+    }
+    cpecan_batch_destroy(b);
+    return rc;
+}
+
+int cpecan_compute_forward_probability(const cpecan_model *m, const char *sX, const char *sY, const int64_t *anchors,
+                                       int64_t nAnchors, const cpecan_params *p, int raggedLeft, int raggedRight,
+                                       double *logProb) {
+    if (!logProb) return CPECAN_EINVAL;
+    cpecan_batch *b = NULL;
+    int rc = run_single(&b, m, sX, sY, anchors, nAnchors, p, raggedLeft, raggedRight, CPECAN_EMIT_FORWARD);
+    if (rc != CPECAN_OK) return rc;
+    rc = cpecan_batch_forward_prob(b, 0, logProb);
     cpecan_batch_destroy(b);
     return rc;
 }

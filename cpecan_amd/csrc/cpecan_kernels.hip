@@ -95,6 +95,7 @@ struct KArgs {
     int64_t outTriplesPerList;
     int64_t nSegsTotal;
     unsigned int *queue;
+    double *forwardOut;  // [nRegions] total forward log-probability (forward mode)
     double *dbgFb;
     double *dbgTotals;
 };
@@ -265,6 +266,7 @@ struct Sweep {
     int N;
     // forward sweep state: the two previous diagonals' table entries
     CpkDiag f1, f2;
+    bool storeRing = true;  // false for the forward-probability mode: nothing reads the forward values back
 
     __device__ __forceinline__ double *rbuf(int d) const { return roll + (size_t)((d + 3) % 3) * S * stride; }
     __device__ __forceinline__ double *ringAt(const CpkDiag &g) const { return ring + (size_t)g.ringOff * S; }
@@ -379,9 +381,10 @@ struct Sweep {
             double v[1][S];
             fwdCells<1>(c, kk, v);
 #pragma unroll
-            for (int s = 0; s < S; s++) {
-                cur[s * stride + k0 + 1] = v[0][s];
-                out[(size_t)s * W + k0] = v[0][s];
+            for (int s = 0; s < S; s++) cur[s * stride + k0 + 1] = v[0][s];
+            if (storeRing) {
+#pragma unroll
+                for (int s = 0; s < S; s++) out[(size_t)s * W + k0] = v[0][s];
             }
         }
         roll_fence<!FAST>();
@@ -497,26 +500,35 @@ struct Sweep {
 
     // ---- traceback of one segment (pairwiseAligner.c:796-862).
     // The reference scatters from diagonal d2+1 / d2+2 into d2 (:392-395, :631-634); this gathers the same terms in
-    // the same order.  Per emitted diagonal it forms fb = F.match + B.match and keeps
-    // the cells that can still reach the threshold once the total is known; on refresh diagonals it also writes the
-    // two per-cell series whose sequential logAdd folds give the total probability (:636-653).
-    // Returns the number of candidates appended (in visit order: diagonal descending, x-y ascending).
-    __device__ int traceback(const CpkSegment &sg, const double *endPrior, double *dbgFb) {
+    // the same order.  Per emitted diagonal it forms fb = F.s + B.s for the NL emitted
+    // states (match; plus gapX, gapY for the indel emitter, :691-733) and keeps the cells that can still reach the
+    // threshold once the total is known; on refresh diagonals it also writes the two per-cell series whose sequential
+    // logAdd folds give the total probability (:636-653).
+    // nCand[l] receives the number of candidates appended to list l (visit order: diagonal descending, x-y ascending).
+    template <int NL>
+    __device__ void traceback(const CpkSegment &sg, const double *endPrior, double *dbgFb, int (&nCand)[NL]) {
         const int J = sg.nRefresh;
-        const float logThr = (float)log(m.threshold);  // -inf for threshold 0: every match cell is a candidate
-        int nCand = 0;
+        const float logThr = (float)log(m.threshold);  // -inf for threshold 0: every cell is a candidate
+#pragma unroll
+        for (int l = 0; l < NL; l++) nCand[l] = 0;
         float lastMax = -__builtin_huge_valf();
         CpkDiag gb{}, ga{};  // table entries of d2+1 and d2+2
         CpkDiag g = dc.get(sg.dTop, true);
-        // F.match of the first emitted diagonal, prefetched
-        double fmCur[kPrefetch] = {0.0, 0.0, 0.0};
+        // F rows of the emitted states for the first emitted diagonal, prefetched (list l emits state l)
+        double fmCur[NL][kPrefetch];
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+#pragma unroll
+            for (int q = 0; q < kPrefetch; q++) fmCur[l][q] = 0.0;
         if (sg.dTop <= sg.tbFrom) {
             const double *src = ringAt(g);
 #pragma unroll
-            for (int q = 0; q < kPrefetch; q++) {
-                const int k = q * CPK_WAVE + lane;
-                fmCur[q] = k < g.width ? ld_self(src + k) : 0.0;
-            }
+            for (int l = 0; l < NL; l++)
+#pragma unroll
+                for (int q = 0; q < kPrefetch; q++) {
+                    const int k = q * CPK_WAVE + lane;
+                    fmCur[l][q] = k < g.width ? ld_self(src + (size_t)l * g.width + k) : 0.0;
+                }
         }
         for (int d2 = sg.dTop; d2 > sg.tbPrev; d2--) {
             const bool seeded = d2 == sg.dTop;
@@ -524,41 +536,41 @@ struct Sweep {
             const bool emit = d2 <= sg.tbFrom;
             const bool refresh = emit && ((sg.tbFrom - d2) % CPK_REFRESH_PERIOD == 0);
             const int jr = (sg.tbFrom - d2) / CPK_REFRESH_PERIOD;
-            // prefetch F.match of the next diagonal down while this one is computed
+            // prefetch the F rows of the next diagonal down while this one is computed
             CpkDiag gnext{};
-            double fmNext[kPrefetch] = {0.0, 0.0, 0.0};
+            double fmNext[NL][kPrefetch];
+#pragma unroll
+            for (int l = 0; l < NL; l++)
+#pragma unroll
+                for (int q = 0; q < kPrefetch; q++) fmNext[l][q] = 0.0;
             const bool nextEmit = d2 - 1 > sg.tbPrev && d2 - 1 <= sg.tbFrom;
             if (d2 - 1 >= 0) gnext = dc.get(d2 - 1, true);
             if (nextEmit) {
                 const double *src = ringAt(gnext);
 #pragma unroll
-                for (int q = 0; q < kPrefetch; q++) {
-                    const int k = q * CPK_WAVE + lane;
-                    fmNext[q] = k < gnext.width ? ld_self(src + k) : 0.0;
-                }
+                for (int l = 0; l < NL; l++)
+#pragma unroll
+                    for (int q = 0; q < kPrefetch; q++) {
+                        const int k = q * CPK_WAVE + lane;
+                        fmNext[l][q] = k < gnext.width ? ld_self(src + (size_t)l * gnext.width + k) : 0.0;
+                    }
             }
             double *cur = rbuf(d2);
-            const double *pb = rbuf(d2 + 1);
-            const double *pa = rbuf(d2 + 2);
-            const int db = (g.xmyL - 1 - gb.xmyL) >> 1;  // source (d2+1, xmy-1) is cell k+db, source (d2+1, xmy+1) is k+db+1
-            const int wB = seeded ? 0 : gb.width;
-            const int da = (g.xmyL - ga.xmyL) >> 1;      // source (d2+2, xmy) is cell k+da
-            const int wA = (!seeded && d2 + 2 <= sg.dTop) ? ga.width : 0;
             const double *fsrc = ringAt(g);
             const int xlo = (d2 + g.xmyL) >> 1;
             BwdCtx c;
             c.d2 = d2;
             c.xlo = xlo;
-            c.db = db;
-            c.wB = wB;
-            c.da = da;
-            c.wA = wA;
-            c.pb = pb;
-            c.pa = pa;
+            c.db = (g.xmyL - 1 - gb.xmyL) >> 1;  // source (d2+1, xmy-1) is cell k+db, source (d2+1, xmy+1) is k+db+1
+            c.wB = seeded ? 0 : gb.width;
+            c.da = (g.xmyL - ga.xmyL) >> 1;      // source (d2+2, xmy) is cell k+da
+            c.wA = (!seeded && d2 + 2 <= sg.dTop) ? ga.width : 0;
+            c.pb = rbuf(d2 + 1);
+            c.pa = rbuf(d2 + 2);
             c.seeded = seeded;
             c.endPrior = endPrior;
             const float keepFrom = lastMax + logThr - kCandMargin;  // wave-uniform
-            // Wave-uniform loop (the candidate count must stay identical in every lane): lanes past the end of the
+            // Wave-uniform loop (the candidate counts must stay identical in every lane): lanes past the end of the
             // diagonal recompute its last cell and have their stores masked.
             int pass = 0;
             for (int kb = 0; kb < W; kb += CPK_WAVE, pass++) {
@@ -572,35 +584,47 @@ struct Sweep {
                     for (int s = 0; s < S; s++) cur[s * stride + k0 + 1] = v[0][s];
                 }
                 if (emit) {
-                    double f0;
-                    if (pass == 0) f0 = fmCur[0];
-                    else if (pass == 1) f0 = fmCur[1];
-                    else if (pass == 2) f0 = fmCur[2];
-                    else f0 = on ? ld_self(fsrc + k0) : 0.0;
-                    const double fbv = f0 + v[0][0];
-                    if (on && dbgFb) dbgFb[g.cellOff + k0] = fbv;
+                    const int x = xlo + k0, y = d2 - x;
+                    double fbv[NL];
+#pragma unroll
+                    for (int l = 0; l < NL; l++) {
+                        double f0;
+                        if (pass == 0) f0 = fmCur[l][0];
+                        else if (pass == 1) f0 = fmCur[l][1];
+                        else if (pass == 2) f0 = fmCur[l][2];
+                        else f0 = on ? ld_self(fsrc + (size_t)l * W + k0) : 0.0;
+                        fbv[l] = f0 + v[0][l];
+                    }
+                    if (on && dbgFb) dbgFb[g.cellOff + k0] = fbv[0];
                     if (refresh && on) {
                         // cell_dotProduct over states, pairwiseAligner.c:402-408
-                        double t = fbv;
+                        double t = fbv[0];
 #pragma unroll
-                        for (int s = 1; s < S; s++) t = logadd(lg, t, ld_self(fsrc + (size_t)s * W + k0) + v[0][s]);
+                        for (int s = 1; s < S; s++) {
+                            const double fs = s < NL ? fbv[s] : ld_self(fsrc + (size_t)s * W + k0) + v[0][s];
+                            t = logadd(lg, t, fs);
+                        }
                         cbuf[(size_t)k0 * J + jr] = t;
                     }
-                    // candidate filter: a match cell (x > 0, y > 0; pairwiseAligner.c:680) survives when it is within
-                    // log(threshold) - margin of the bound on the total probability (DESIGN.md "candidate filter").
-                    const int x = xlo + k0, y = d2 - x;
-                    const bool keep = on && x > 0 && y > 0 && (float)fbv >= keepFrom;
-                    const unsigned long long mask = __ballot(keep);
-                    if (keep) {
-                        const int rank =
-                            __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                        Candidate cd;
-                        cd.fb = fbv;
-                        cd.x = x;
-                        cd.y = y;
-                        cand[nCand + rank] = cd;
+                    // candidate filter: a cell survives when it is within log(threshold) - margin of the bound on the
+                    // total probability (DESIGN.md "candidate filter").  Match cells need x > 0 and y > 0, gapX cells
+                    // x > 0, gapY cells y > 0 (pairwiseAligner.c:680, :719, :725).
+#pragma unroll
+                    for (int l = 0; l < NL; l++) {
+                        const bool cell = l == 0 ? (x > 0 && y > 0) : (l == 1 ? x > 0 : y > 0);
+                        const bool keep = on && cell && (float)fbv[l] >= keepFrom;
+                        const unsigned long long mask = __ballot(keep);
+                        if (keep) {
+                            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                            Candidate cd;
+                            cd.fb = fbv[l];
+                            cd.x = x;
+                            cd.y = y;
+                            cand[(size_t)l * a.geo.fbCells + nCand[l] + rank] = cd;
+                        }
+                        nCand[l] += __popcll(mask);
                     }
-                    nCand += __popcll(mask);
                 }
             }
             // The bound is renewed on refresh diagonals only (every 10th): max(this diagonal's maximum, old bound - 1).
@@ -615,9 +639,9 @@ struct Sweep {
                     float fbf = -__builtin_huge_valf();
                     if (k < W && x > 0 && y > 0) {
                         double f0;
-                        if (pass == 0) f0 = fmCur[0];
-                        else if (pass == 1) f0 = fmCur[1];
-                        else if (pass == 2) f0 = fmCur[2];
+                        if (pass == 0) f0 = fmCur[0][0];
+                        else if (pass == 1) f0 = fmCur[0][1];
+                        else if (pass == 2) f0 = fmCur[0][2];
                         else f0 = ld_self(fsrc + k);
                         fbf = (float)(f0 + cur[0 * stride + k + 1]);
                     }
@@ -656,14 +680,15 @@ struct Sweep {
                     mbuf[(size_t)k * J + jr] = t + bn[0 * stride + k + 1];
                 }
             }
-            // slide the window of table entries and prefetched F.match down one diagonal
+            // slide the window of table entries and prefetched F rows down one diagonal
             ga = gb;
             gb = g;
             g = gnext;
 #pragma unroll
-            for (int q = 0; q < kPrefetch; q++) fmCur[q] = fmNext[q];
+            for (int l = 0; l < NL; l++)
+#pragma unroll
+                for (int q = 0; q < kPrefetch; q++) fmCur[l][q] = fmNext[l][q];
         }
-        return nCand;
     }
 
     // ---- total probability at every refresh point of the segment: one lane per refresh point, each doing the
@@ -694,7 +719,8 @@ struct Sweep {
 
     // ---- thresholded posteriors (pairwiseAligner.c:655-689) from the candidate list, walked backwards so that the
     // output is in the reference's list order (diagonal ascending, x-y descending).
-    __device__ int emitMatches(const CpkSegment &sg, int nCand, int32_t *out, int outCap, int count) {
+    __device__ int emitMatches(const CpkSegment &sg, const Candidate *cand, int nCand, int32_t *out, int outCap,
+                               int count) {
         const double thr = m.threshold;
         for (int top = nCand; top > 0; top -= CPK_WAVE) {
             const int i = top - 1 - lane;
@@ -728,7 +754,10 @@ struct Sweep {
     }
 };
 
-template <int S, bool FAST>
+// EMIT: CPECAN_EMIT_MATCH (0), CPECAN_EMIT_INDEL (1) or kEmitForward (3: forward sweep only, total probability out)
+constexpr int kEmitForward = 3;
+
+template <int S, bool FAST, int EMIT>
 __global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(1, 2)))
 cpecan_pairhmm_sweep(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -779,7 +808,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                           em,
                           lg,
                           a.ring + slot * (size_t)a.geo.ringCells * S,
-                          a.cand + slot * (size_t)a.geo.fbCells,
+                          a.cand + slot * (size_t)a.geo.fbCells * (EMIT == CPECAN_EMIT_INDEL ? 3 : 1),
                           a.cbuf + slot * (size_t)a.geo.refreshCells,
                           a.mbuf + slot * (size_t)a.geo.refreshCells,
                           a.totals + slot * (size_t)a.geo.maxRefresh,
@@ -788,8 +817,39 @@ cpecan_pairhmm_sweep(const KArgs a) {
                           N,
                           CpkDiag{},
                           CpkDiag{}};
-        int32_t *out = a.triples + 3 * rg.outOff;
-        int count = 0;
+        constexpr int NL = EMIT == CPECAN_EMIT_INDEL ? 3 : 1;
+        int count[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) count[l] = 0;
+        sw.storeRing = EMIT != kEmitForward;
+        if (EMIT == kEmitForward) {
+            // getForwardProbWithBanding (pairwiseAligner.c:879-931): forward sweep over the whole matrix, then the
+            // total probability of the last diagonal against the end prior; no traceback.
+            double total = 0.0;  // LOG_ONE for two empty sequences (:889-891)
+            if (N > 0) {
+                sw.dc.load(0);
+                const double *startPrior = rg.raggedLeft ? m.raggedStart : m.start;
+                const CpkDiag g0 = sw.dc.get(0, false);
+                double *cur0 = sw.rbuf(0);
+                if (lane < S) cur0[lane * stride + 1] = startPrior[lane];
+                roll_fence<!FAST>();
+                sw.f1 = g0;
+                sw.f2 = g0;
+                for (int d = 1; d <= N; d++) sw.forward(d);
+                const double *endPrior = rg.raggedRight ? m.raggedEnd : m.end;
+                const double *last = sw.rbuf(N);
+                const int W = sw.f1.width;
+                total = NEG_INF;  // dpDiagonal_dotProduct (:513-523) over the cells of diagonal N, every lane alike
+                for (int k = 0; k < W; k++) {
+                    double t = last[0 * stride + k + 1] + endPrior[0];
+#pragma unroll
+                    for (int s = 1; s < S; s++) t = logadd(lg, t, last[s * stride + k + 1] + endPrior[s]);
+                    total = logadd(lg, total, t);
+                }
+            }
+            if (lane == 0) a.forwardOut[r] = total;
+            continue;
+        }
         if (N > 0) {
             sw.dc.load(0);
             // diagonal 0: the single cell (0,0) holds the start prior (pairwiseAligner.c:776-777)
@@ -812,15 +872,21 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 for (; d <= sg.dTop; d++) sw.forward(d);
                 if (a.geo.debug & 2) continue;  // diagnostic: time the forward sweep alone (no traceback, no output)
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
-                const int nCand = sw.traceback(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr);
+                int nCand[NL];
+                sw.template traceback<NL>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
                 roll_fence<true>();  // candidate / cbuf / mbuf stores of all lanes are complete before they are re-read
                 sw.foldTotals(sg, table);
                 if (a.geo.debug & 1) {
                     for (int d2 = sg.tbPrev + 1 + lane; d2 <= sg.tbFrom; d2 += CPK_WAVE)
                         a.dbgTotals[rg.dbgDiagOff + d2] = ld_self(sw.totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
                 }
-                if (lane == 0) a.segStarts[rg.segOff + si] = count;
-                count = sw.emitMatches(sg, nCand, out, rg.outCap, count);
+#pragma unroll
+                for (int l = 0; l < NL; l++) {
+                    if (lane == 0) a.segStarts[(size_t)l * a.nSegsTotal + rg.segOff + si] = count[l];
+                    count[l] = sw.emitMatches(sg, sw.cand + (size_t)l * a.geo.fbCells, nCand[l],
+                                              a.triples + 3 * ((size_t)l * a.outTriplesPerList + rg.outOff), rg.outCap,
+                                              count[l]);
+                }
                 if (!sg.atEnd) {
                     // the traceback reused the rolling buffers: restore F[dTop-1], F[dTop] for the forward sweep
                     const CpkDiag gTopM1 = sw.dc.get(sg.dTop - 1, false);
@@ -832,7 +898,9 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 }
             }
         }
-        if (lane == 0) a.outCounts[r] = count;
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+            if (lane == 0) a.outCounts[(size_t)l * a.geo.nRegions + r] = count[l];
     }
 }
 
@@ -856,7 +924,7 @@ struct CpkDevice {
     CpkSegment *dSegs = nullptr;
     uint8_t *dSymbols = nullptr;
     CpkModel *dModel = nullptr;
-    double *dRing = nullptr; Candidate *dCand = nullptr; double *dC = nullptr, *dM = nullptr, *dTotals = nullptr, *dGroll = nullptr;
+    double *dRing = nullptr; Candidate *dCand = nullptr; double *dForward = nullptr; double *dC = nullptr, *dM = nullptr, *dTotals = nullptr, *dGroll = nullptr;
     int32_t *dCounts = nullptr, *dSegStarts = nullptr, *dTriples = nullptr;
     unsigned int *dQueue = nullptr;
     double *dDbgFb = nullptr, *dDbgTotals = nullptr;
@@ -892,12 +960,13 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
 
 static void free_all(CpkDevice *d) {
     void *ptrs[] = {d->dRegions, d->dDiags, d->dSegs, d->dSymbols, d->dModel, d->dRing, d->dCand, d->dC, d->dM,
-                    d->dTotals, d->dGroll, d->dCounts, d->dSegStarts, d->dTriples, d->dQueue, d->dDbgFb, d->dDbgTotals};
+                    d->dTotals, d->dGroll, d->dCounts, d->dSegStarts, d->dTriples, d->dQueue, d->dDbgFb, d->dDbgTotals, d->dForward};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     d->dRegions = nullptr; d->dDiags = nullptr; d->dSegs = nullptr; d->dSymbols = nullptr; d->dModel = nullptr;
     d->dRing = d->dC = d->dM = d->dTotals = d->dGroll = nullptr;
     d->dCand = nullptr;
+    d->dForward = nullptr;
     d->dCounts = d->dSegStarts = d->dTriples = nullptr;
     d->dQueue = nullptr;
     d->dDbgFb = d->dDbgTotals = nullptr;
@@ -926,8 +995,16 @@ using KernelFn = void (*)(const KArgs);
 
 static KernelFn pick_kernel(const CpkGeometry &g) {
     const bool fast = !g.useGlobalRoll;  // second template argument = FAST (LDS rolling buffers + LDS symbol strings)
-    if (g.nStates == 5) return fast ? cpecan_pairhmm_sweep<5, true> : cpecan_pairhmm_sweep<5, false>;
-    return fast ? cpecan_pairhmm_sweep<3, true> : cpecan_pairhmm_sweep<3, false>;
+#define CPK_PICK(E)                                                                                          \
+    if (g.emit == (E)) {                                                                                     \
+        if (g.nStates == 5) return fast ? cpecan_pairhmm_sweep<5, true, (E)> : cpecan_pairhmm_sweep<5, false, (E)>; \
+        return fast ? cpecan_pairhmm_sweep<3, true, (E)> : cpecan_pairhmm_sweep<3, false, (E)>;              \
+    }
+    CPK_PICK(CPECAN_EMIT_MATCH)
+    CPK_PICK(CPECAN_EMIT_INDEL)
+    CPK_PICK(kEmitForward)
+#undef CPK_PICK
+    return nullptr;
 }
 
 extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const CpkModel *model, const CpkRegion *regions,
@@ -955,6 +1032,10 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (!geo->useGlobalRoll)
         d->ldsBytes += sizeof(double) * (size_t)3 * S * geo->rollStride + (size_t)((geo->seqLdsBytes + 15) / 16 * 16);
     KernelFn fn = pick_kernel(*geo);
+    if (!fn) {
+        cpk_set_error("no kernel for emitter %d", geo->emit);
+        return CPECAN_EINVAL;
+    }
     if (d->ldsBytes > 64 * 1024) {
         HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->ldsBytes));
     }
@@ -992,7 +1073,8 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (int rc = dev_alloc(d, &d->dSymbols, (size_t)nSymbolBytes)) return rc;
     if (int rc = dev_alloc(d, &d->dModel, 1)) return rc;
     if (int rc = dev_alloc(d, &d->dRing, (size_t)slots * geo->ringCells * S)) return rc;
-    if (int rc = dev_alloc(d, &d->dCand, (size_t)slots * geo->fbCells)) return rc;
+    if (int rc = dev_alloc(d, &d->dCand, (size_t)slots * geo->fbCells * (geo->emit == CPECAN_EMIT_INDEL ? 3 : 1))) return rc;
+    if (int rc = dev_alloc(d, &d->dForward, (size_t)geo->nRegions)) return rc;
     if (int rc = dev_alloc(d, &d->dC, (size_t)slots * geo->refreshCells)) return rc;
     if (int rc = dev_alloc(d, &d->dM, (size_t)slots * geo->refreshCells)) return rc;
     if (int rc = dev_alloc(d, &d->dTotals, (size_t)slots * geo->maxRefresh)) return rc;
@@ -1067,6 +1149,7 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.outTriplesPerList = d->outTriplesPerList;
     a.nSegsTotal = d->nSegs;
     a.queue = d->dQueue;
+    a.forwardOut = d->dForward;
     a.dbgFb = d->dDbgFb;
     a.dbgTotals = d->dDbgTotals;
     HIP_TRY(hipMemsetAsync(d->dQueue, 0, sizeof(unsigned int), st));
@@ -1105,7 +1188,8 @@ extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segSt
     if (d2hMs) *d2hMs = ms;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    (void)expect;
+    if (expect && d->geo.emit == kEmitForward)
+        HIP_TRY(hipMemcpy(expect, d->dForward, sizeof(double) * (size_t)d->geo.nRegions, hipMemcpyDeviceToHost));
     return CPECAN_OK;
 }
 

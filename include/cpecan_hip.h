@@ -44,8 +44,9 @@ enum { CPECAN_FIVE_STATE = 0, CPECAN_FIVE_STATE_ASYM = 1, CPECAN_THREE_STATE = 2
 /* What the traceback emits per diagonal (the reference passes a callback, inc/pairwiseAligner.h:245-248):
  * MATCH  = diagonalCalculationPosteriorMatchProbs  (impl/pairwiseAligner.c:666)
  * INDEL  = diagonalCalculationPosteriorProbs       (impl/pairwiseAligner.c:691)
- * EXPECT = diagonalCalculationExpectations         (impl/pairwiseAligner.c:735) */
-enum { CPECAN_EMIT_MATCH = 0, CPECAN_EMIT_INDEL = 1, CPECAN_EMIT_EXPECT = 2 };
+ * EXPECT = diagonalCalculationExpectations         (impl/pairwiseAligner.c:735)
+ * FORWARD = no traceback: getForwardProbWithBanding     (impl/pairwiseAligner.c:879) */
+enum { CPECAN_EMIT_MATCH = 0, CPECAN_EMIT_INDEL = 1, CPECAN_EMIT_EXPECT = 2, CPECAN_EMIT_FORWARD = 3 };
 
 /* Flattened StateMachine5 / StateMachine3 (impl/stateMachine.c:377-399, 631-646): log-space
  * transition and emission parameters. Three-state models use the "short" fields and ignore "long". */
@@ -151,6 +152,10 @@ int cpecan_batch_result(const cpecan_batch *b, int64_t problem, int which, const
  * like getExpectationsUsingAnchors (pairwiseAligner.c:1500) called once per problem on the same Hmm. */
 int cpecan_batch_expectations(const cpecan_batch *b, cpecan_hmm *acc);
 
+/* For CPECAN_EMIT_FORWARD: total forward log-probability of problem i (computeForwardProbability, pairwiseAligner.c:936).
+ * Problems of a FORWARD batch are never split into regions and always use the static band (:894). */
+int cpecan_batch_forward_prob(const cpecan_batch *b, int64_t problem, double *logProb);
+
 int cpecan_batch_stats(const cpecan_batch *b, cpecan_stats *s);
 
 /* Debug / test hook: for single-region problem i, copies the per-cell forward+backward match sums
@@ -166,6 +171,16 @@ int cpecan_batch_debug_fetch(const cpecan_batch *b, int64_t problem, double *fbM
 int cpecan_get_aligned_pairs_using_anchors(const cpecan_model *m, const char *sX, const char *sY,
                                            const int64_t *anchors, int64_t nAnchors, const cpecan_params *p,
                                            int raggedLeft, int raggedRight, int32_t **triples, int64_t *n);
+/* getAlignedPairsWithIndelsUsingAnchors (pairwiseAligner.c:1451): three malloc'd triple lists; gap lists may hold -1
+ * as the coordinate of the sequence that is gapped. */
+int cpecan_get_aligned_pairs_with_indels_using_anchors(const cpecan_model *m, const char *sX, const char *sY,
+                                                       const int64_t *anchors, int64_t nAnchors, const cpecan_params *p,
+                                                       int raggedLeft, int raggedRight, int32_t **match, int64_t *nMatch,
+                                                       int32_t **gapX, int64_t *nGapX, int32_t **gapY, int64_t *nGapY);
+/* computeForwardProbability (pairwiseAligner.c:936). */
+int cpecan_compute_forward_probability(const cpecan_model *m, const char *sX, const char *sY, const int64_t *anchors,
+                                       int64_t nAnchors, const cpecan_params *p, int raggedLeft, int raggedRight,
+                                       double *logProb);
 void cpecan_free(void *p);
 
 #ifdef __cplusplus

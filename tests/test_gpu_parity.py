@@ -194,3 +194,78 @@ def test_full_size_properties_config_B_slice():
     again, _ = _run_batch(0, problems[10:20], diagonalExpansion=100)
     for t1, t2 in zip(got[10:20], again):
         assert np.array_equal(t1, t2)
+
+
+# ---- indel emitter (diagonalCalculationPosteriorProbs, pairwiseAligner.c:691-733) ----
+
+def _check_indels(mtype, sx, sy, anchors, rl=False, rr=False, **pkw):
+    p = api.pairwiseAlignmentBandingParameters_construct(**pkw)
+    got = api.getAlignedPairsWithIndelsUsingAnchors(_sm(mtype), sx, sy, anchors, p, rl, rr)
+    want = ob.aligned_pairs_with_indels(ob.model(mtype), sx, sy, anchors, ob.params(**pkw), rl, rr)
+    for g, w in zip(got, want):
+        assert_pairs_match(g, w, threshold=p.threshold)
+    return got
+
+
+@pytest.mark.parametrize("mtype", [0, 2])
+def test_indel_emitter_matches_oracle(mtype):
+    # tests/pairwiseAlignerTest.c:867-942 uses stateMachine3; both models here
+    rng = random.Random(61 + mtype)
+    for _ in range(6):
+        sx = _rand_seq(rng, rng.randrange(1, 120))
+        sy = _evolve(rng, sx)
+        match, gapx, gapy = _check_indels(mtype, sx, sy, (), bool(rng.random() > 0.5), bool(rng.random() > 0.5))
+        if len(gapx):
+            assert gapx[:, 1].min() >= 0 and gapx[:, 2].min() >= -1
+        if len(gapy):
+            assert gapy[:, 1].min() >= -1 and gapy[:, 2].min() >= 0
+    sx, sy, a = make_pair(9, 0, 1200, 30)
+    _check_indels(mtype, sx, sy, a, diagonalExpansion=30)  # multi-segment
+
+
+def test_indel_emitter_match_list_equals_match_emitter():
+    sx, sy, a = make_pair(9, 1, 500, 20)
+    p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=20)
+    m1 = api.getAlignedPairsUsingAnchors(_sm(0), sx, sy, a, p)
+    m2, _, _ = api.getAlignedPairsWithIndelsUsingAnchors(_sm(0), sx, sy, a, p)
+    assert np.array_equal(m1, m2)
+
+
+# ---- forward probability (computeForwardProbability, pairwiseAligner.c:936) ----
+
+def test_forward_probability_known_answers():
+    # SURVEY 8c known answers from the reference
+    p = api.pairwiseAlignmentBandingParameters_construct()
+    assert abs(api.computeForwardProbability("AGCG", "AGTTCG", (), p, api.stateMachine5_construct()) + 17.519321161239) < 1e-11
+    assert abs(api.computeForwardProbability("AGCG", "AGTTCG", (), p, api.stateMachine3_construct()) + 17.381039440328) < 1e-11
+    assert abs(api.computeForwardProbability("AGCG", "AGTTCG", (), p, api.stateMachine3_construct(), True, True)
+               + 20.651524037167) < 1e-11
+    assert api.computeForwardProbability("", "", (), p, api.stateMachine3_construct()) == 0.0
+
+
+def test_forward_probability_matches_oracle_and_reference_properties():
+    # tests/pairwiseAlignerTest.c:1157-1188
+    rng = random.Random(71)
+    sm, om = api.stateMachine3_construct(), ob.model(2)
+    p, op = api.pairwiseAlignmentBandingParameters_construct(), ob.params()
+    with api.Batch(sm, p, emit=api.EMIT_FORWARD) as b:
+        cases = []
+        for _ in range(40):
+            sx = _rand_seq(rng, rng.randrange(10, 100))
+            sy = _evolve(rng, sx)
+            rl, rr = rng.random() > 0.5, rng.random() > 0.5
+            cases.append((sx, sy, rl, rr))
+            b.add(sx, sy, (), rl, rr)
+            b.add(sx, sx, (), rl, rr)
+        b.upload()
+        b.run()
+        b.download()
+        for i, (sx, sy, rl, rr) in enumerate(cases):
+            lp, lpi = b.forward_prob(2 * i), b.forward_prob(2 * i + 1)
+            assert lp == ob.forward_prob(om, sx, sy, (), op, rl, rr)  # pure logAdd arithmetic: bit-identical
+            assert lpi == ob.forward_prob(om, sx, sx, (), op, rl, rr)
+            assert float("-inf") < lp <= 0.0 and lp <= lpi
+    sx, sy, a = make_pair(10, 0, 1500, 40)
+    p5 = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=40, dynamicAnchorExpansion=1)
+    got = api.computeForwardProbability(sx, sy, a, p5, api.stateMachine5_construct())
+    assert got == ob.forward_prob(ob.model(0), sx, sy, a, ob.params(diagonalExpansion=40, dynamicAnchorExpansion=1))
