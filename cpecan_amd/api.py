@@ -291,6 +291,11 @@ class Batch:
             return np.zeros((0, 3), dtype=np.int32)
         return np.ctypeslib.as_array(ptr, shape=(n.value * 3,)).copy().reshape(n.value, 3)
 
+    def expectations(self, hmm):
+        """Adds the batch's expectation counts into hmm (EMIT_EXPECT), like getExpectationsUsingAnchors on each problem."""
+        _check(lib().cpecan_batch_expectations(self._h, C.byref(hmm)), "cpecan_batch_expectations")
+        return hmm
+
     def forward_prob(self, problem):
         v = C.c_double()
         _check(lib().cpecan_batch_forward_prob(self._h, problem, C.byref(v)), "cpecan_batch_forward_prob")
@@ -352,3 +357,15 @@ def computeForwardProbability(seqX, seqY, anchorPairs, p, sM, alignmentHasRagged
                                                     int(alignmentHasRaggedLeftEnd), int(alignmentHasRaggedRightEnd),
                                                     C.byref(v)), "computeForwardProbability")
     return v.value
+
+
+def getExpectationsUsingAnchors(sM, hmmExpectations, sX, sY, anchorPairs, p, alignmentHasRaggedLeftEnd=False,
+                                alignmentHasRaggedRightEnd=False):
+    """impl/pairwiseAligner.c:1500: accumulates into hmmExpectations (+=), likelihood included."""
+    with Batch(sM, p, emit=EMIT_EXPECT) as b:
+        b.add(sX, sY, anchorPairs, alignmentHasRaggedLeftEnd, alignmentHasRaggedRightEnd)
+        b.upload()
+        b.run()
+        b.download()
+        b.expectations(hmmExpectations)
+    return hmmExpectations

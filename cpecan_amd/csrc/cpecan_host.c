@@ -462,8 +462,8 @@ int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpe
                         int device) {
     if (!out || !model || !params) return CPECAN_EINVAL;
     if (!(is_five(model->type) || is_three(model->type))) return CPECAN_EINVAL;
-    if (emit != CPECAN_EMIT_MATCH && emit != CPECAN_EMIT_INDEL && emit != CPECAN_EMIT_FORWARD) {
-        cpk_set_error("emitter %d is not implemented on the HIP path yet", emit);
+    if (emit != CPECAN_EMIT_MATCH && emit != CPECAN_EMIT_INDEL && emit != CPECAN_EMIT_FORWARD && emit != CPECAN_EMIT_EXPECT) {
+        cpk_set_error("unknown emitter %d", emit);
         return CPECAN_EINVAL;
     }
     /* preconditions of getPosteriorProbsWithBanding, pairwiseAligner.c:761-765 */
@@ -793,7 +793,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
     if (geo.refreshCells < 1) geo.refreshCells = 1;
     geo.rollDoubles = (int64_t)3 * S * geo.rollStride;
     /* LDS budget: beyond 64 KiB per wave (rolling buffers + symbol strings) the batch takes the global-memory path */
-    geo.useGlobalRoll = (sizeof(double) * (size_t)(56 + geo.rollDoubles) + (size_t)geo.seqLdsBytes + 16 > 64 * 1024);
+    geo.useGlobalRoll = (sizeof(double) * (size_t)(136 + geo.rollDoubles) + (size_t)geo.seqLdsBytes + 16 > 64 * 1024);
     b->geo = geo;
     b->segs = segs;
     b->nSegs = nSegs;
@@ -914,8 +914,8 @@ int cpecan_batch_download(cpecan_batch *b) {
             rc = CPECAN_ENOMEM;
             break;
         }
-        if (b->emit == CPECAN_EMIT_FORWARD && !b->forward) {
-            b->forward = malloc(sizeof(double) * (size_t)b->nRegions);
+        if ((b->emit == CPECAN_EMIT_FORWARD || b->emit == CPECAN_EMIT_EXPECT) && !b->forward) {
+            b->forward = malloc(sizeof(double) * (size_t)(b->nRegions > 106 ? b->nRegions : 106));
             if (!b->forward) {
                 rc = CPECAN_ENOMEM;
                 break;
@@ -923,7 +923,7 @@ int cpecan_batch_download(cpecan_batch *b) {
         }
         rc = cpk_device_download(b->dev, counts, segStarts, triples, b->forward, &b->stats.kernelMs, &b->stats.d2hMs);
         if (rc != CPECAN_OK) break;
-        if (b->emit == CPECAN_EMIT_FORWARD) break; /* no lists in this mode: the kernel wrote one double per region */
+        if (b->emit == CPECAN_EMIT_FORWARD || b->emit == CPECAN_EMIT_EXPECT) break; /* these emitters produce no lists */
         /* did any region overflow its output slice?  If so enlarge exactly and run once more. */
         int overflow = 0;
         int64_t outAt = 0;
@@ -953,7 +953,7 @@ int cpecan_batch_download(cpecan_batch *b) {
             rc = CPECAN_ESTATE;
         }
     }
-    if (rc == CPECAN_OK && b->emit != CPECAN_EMIT_FORWARD) {
+    if (rc == CPECAN_OK && b->emit != CPECAN_EMIT_FORWARD && b->emit != CPECAN_EMIT_EXPECT) {
         for (int64_t i = 0; i < b->nProblems && rc == CPECAN_OK; i++) rc = assemble_problem(b, i, counts, segStarts, triples);
     }
     if (rc == CPECAN_OK) b->downloaded = 1;
@@ -979,10 +979,15 @@ int cpecan_batch_forward_prob(const cpecan_batch *b, int64_t problem, double *lo
 }
 
 int cpecan_batch_expectations(const cpecan_batch *b, cpecan_hmm *acc) {
-    (void)b;
-    (void)acc;
-    cpk_set_error("expectation emitter is not implemented on the HIP path yet");
-    return CPECAN_EINVAL;
+    if (!b || !b->downloaded || b->emit != CPECAN_EMIT_EXPECT) return CPECAN_ESTATE;
+    const int S = is_five(b->model.type) ? 5 : 3;
+    if (!acc || acc->stateNumber != S) return CPECAN_EINVAL;
+    if (b->nRegions == 0) return CPECAN_OK;
+    /* b->forward holds the batch sums: [0,25) transitions [from*S+to], [25,105) emissions, [105] likelihood */
+    for (int i = 0; i < S * S; i++) acc->transitions[i] += b->forward[i];
+    for (int i = 0; i < S * 16; i++) acc->emissions[i] += b->forward[25 + i];
+    acc->likelihood += b->forward[105];
+    return CPECAN_OK;
 }
 
 int cpecan_batch_stats(const cpecan_batch *b, cpecan_stats *s) {

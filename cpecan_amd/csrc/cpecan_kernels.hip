@@ -96,6 +96,7 @@ struct KArgs {
     int64_t nSegsTotal;
     unsigned int *queue;
     double *forwardOut;  // [nRegions] total forward log-probability (forward mode)
+    double *expectOut;   // [slots][128] per-wave expectation partial sums (expectation mode)
     double *dbgFb;
     double *dbgTotals;
 };
@@ -242,7 +243,7 @@ struct DiagCache {
     }
 };
 
-constexpr int kLdsHeader = 56;  // doubles of LDS in front of the rolling buffers: 16 (cubics) + 40 (emissions)
+constexpr int kLdsHeader = 136;  // doubles of LDS in front of the rolling buffers: 16 cubics + 40 emissions + 80 expectation sums
 constexpr int kPrefetch = 3;  // passes (of 64 cells) of F.match prefetched one diagonal ahead in the traceback
 constexpr float kCandMargin = 3.0f;  // log-space slack of the candidate filter (see DESIGN.md "candidate filter")
 
@@ -505,7 +506,7 @@ struct Sweep {
     // threshold once the total is known; on refresh diagonals it also writes the two per-cell series whose sequential
     // logAdd folds give the total probability (:636-653).
     // nCand[l] receives the number of candidates appended to list l (visit order: diagonal descending, x-y ascending).
-    template <int NL>
+    template <int NL, bool CANDS>
     __device__ void traceback(const CpkSegment &sg, const double *endPrior, double *dbgFb, int (&nCand)[NL]) {
         const int J = sg.nRefresh;
         const float logThr = (float)log(m.threshold);  // -inf for threshold 0: every cell is a candidate
@@ -610,7 +611,7 @@ struct Sweep {
                     // total probability (DESIGN.md "candidate filter").  Match cells need x > 0 and y > 0, gapX cells
                     // x > 0, gapY cells y > 0 (pairwiseAligner.c:680, :719, :725).
 #pragma unroll
-                    for (int l = 0; l < NL; l++) {
+                    for (int l = 0; l < (CANDS ? NL : 0); l++) {
                         const bool cell = l == 0 ? (x > 0 && y > 0) : (l == 1 ? x > 0 : y > 0);
                         const bool keep = on && cell && (float)fbv[l] >= keepFrom;
                         const unsigned long long mask = __ballot(keep);
@@ -630,7 +631,7 @@ struct Sweep {
             // The bound is renewed on refresh diagonals only (every 10th): max(this diagonal's maximum, old bound - 1).
             // The reference itself asserts that consecutive totals differ by less than 1.0 (pairwiseAligner.c:834), so
             // the decayed old bound stays below the current total.  Wave-uniform loop: all lanes join the shuffles.
-            if (refresh) {
+            if (refresh && CANDS) {
                 float diagMax = -__builtin_huge_valf();
                 pass = 0;
                 for (int kb = 0; kb < W; kb += CPK_WAVE, pass++) {
@@ -688,6 +689,115 @@ struct Sweep {
             for (int l = 0; l < NL; l++)
 #pragma unroll
                 for (int q = 0; q < kPrefetch; q++) fmCur[l][q] = fmNext[l][q];
+        }
+    }
+
+    // ---- expectation step (diagonalCalculationExpectations, pairwiseAligner.c:735-746; updateExpectations :418-432).
+    // Second backward sweep of the segment, run once the totals are known.  For every emitted diagonal d2, every cell
+    // of B[d2] and every transition into it: p = exp(F_nbr[from] + B[to] + (eP + tP) - total) with the neighbours
+    // taken from F[d2-1] / F[d2-2]; T[from][to] += p, and E[to][cX][cY] += p when neither symbol is N.
+    // The reference has already freed F[d2-2] at the lowest diagonal of a segment (:843-845), so the middle block
+    // contributes nothing there; reproduced.  Sums are linear-space fp64: order-insensitive at the 1e-5 gate.
+    // tAcc: per-lane sums, one per transition in list order; eLds: [state*16 + cX*4 + cY] in LDS (fp64 LDS atomics).
+    static constexpr int kNT = S == 5 ? 13 : 9;
+
+    __device__ void expectations(const CpkSegment &sg, const double *endPrior, double (&tAcc)[kNT], double *eLds,
+                                 double &likelihood) {
+        CpkDiag gb{}, ga{};
+        CpkDiag g = dc.get(sg.dTop, true);
+        for (int d2 = sg.dTop; d2 > sg.tbPrev; d2--) {
+            const bool seeded = d2 == sg.dTop;
+            const int W = g.width;
+            const bool emit = d2 <= sg.tbFrom;
+            const CpkDiag g1 = dc.get(d2 - 1, true);               // F[d2-1]: always alive (d2-1 >= tbPrev)
+            const bool haveM2 = emit && d2 - 2 >= sg.tbPrev;       // F[d2-2] is gone at d2 == tbPrev+1
+            const CpkDiag g2 = haveM2 ? dc.get(d2 - 2, true) : CpkDiag{};
+            double *cur = rbuf(d2);
+            const int xlo = (d2 + g.xmyL) >> 1;
+            BwdCtx c;
+            c.d2 = d2;
+            c.xlo = xlo;
+            c.db = (g.xmyL - 1 - gb.xmyL) >> 1;
+            c.wB = seeded ? 0 : gb.width;
+            c.da = (g.xmyL - ga.xmyL) >> 1;
+            c.wA = (!seeded && d2 + 2 <= sg.dTop) ? ga.width : 0;
+            c.pb = rbuf(d2 + 1);
+            c.pa = rbuf(d2 + 2);
+            c.seeded = seeded;
+            c.endPrior = endPrior;
+            double total = 0.0;
+            if (emit) {
+                total = ld_self(totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
+                likelihood += total;  // once per diagonal (:743)
+            }
+            const int dl = (g.xmyL - 1 - g1.xmyL) >> 1;  // lower neighbour (d2-1, xmy-1) is cell k+dl of F[d2-1]
+            const int dm = (g.xmyL - g2.xmyL) >> 1;      // middle neighbour (d2-2, xmy) is cell k+dm of F[d2-2]
+            const double *f1 = ringAt(g1), *f2 = ringAt(g2);
+            const int w1 = g1.width, w2 = haveM2 ? g2.width : 0;
+            for (int k = lane; k < W; k += CPK_WAVE) {
+                const int kk[1] = {k};
+                double v[1][S];
+                bwdCells<1>(c, kk, v);
+#pragma unroll
+                for (int s = 0; s < S; s++) cur[s * stride + k + 1] = v[0][s];
+                if (!emit) continue;
+                const int x = xlo + k, y = d2 - x;
+                const int cX = sxp[x], cY = syp[y];
+                const double eX = em[25 + cX], eM = em[cX * 5 + cY], eY = em[30 + cY];
+                const bool acgt = cX < CPK_SYM_N && cY < CPK_SYM_N;
+                const int eIdx = cX * 4 + cY;
+                const int kL = k + dl, kU = k + dl + 1, kM = k + dm;
+                const bool okL = (unsigned)kL < (unsigned)w1, okU = (unsigned)kU < (unsigned)w1,
+                           okM = (unsigned)kM < (unsigned)w2;
+                const int qL = okL ? kL : 0, qU = okU ? kU : 0, qM = okM ? kM : 0;
+                auto F1 = [&](int s, int q, bool ok) {
+                    const double val = ld_self(f1 + (size_t)s * w1 + q);
+                    return ok ? val : NEG_INF;
+                };
+                auto F2 = [&](int s) {
+                    const double val = okM ? ld_self(f2 + (size_t)s * w2 + qM) : NEG_INF;
+                    return val;
+                };
+                // one (transition, emission) event: impl/pairwiseAligner.c:426-431
+                auto event = [&](int ti, double from, int to, double eP, double tP) {
+                    const double p = exp(from + v[0][to] + (eP + tP) - total);
+                    tAcc[ti] += p;
+                    if (acgt) atomicAdd(&eLds[to * 16 + eIdx], p);
+                };
+                if (S == 5) {
+                    const double lM = F1(0, qL, okL), lSX = F1(1, qL, okL), lLX = F1(3, qL, okL);
+                    const double uM = F1(0, qU, okU), uSY = F1(2, qU, okU), uLY = F1(4, qU, okU);
+                    event(0, lM, 1, eX, m.shortOpenX);
+                    event(1, lSX, 1, eX, m.shortExtendX);
+                    event(2, lM, 3, eX, m.longOpenX);
+                    event(3, lLX, 3, eX, m.longExtendX);
+                    event(4, F2(0), 0, eM, m.matchContinue);
+                    event(5, F2(1), 0, eM, m.matchFromShortX);
+                    event(6, F2(2), 0, eM, m.matchFromShortY);
+                    event(7, F2(3), 0, eM, m.matchFromLongX);
+                    event(8, F2(4), 0, eM, m.matchFromLongY);
+                    event(9, uM, 2, eY, m.shortOpenY);
+                    event(10, uSY, 2, eY, m.shortExtendY);
+                    event(11, uM, 4, eY, m.longOpenY);
+                    event(12, uLY, 4, eY, m.longExtendY);
+                } else {
+                    const double lM = F1(0, qL, okL), lGX = F1(1, qL, okL), lGY = F1(2, qL, okL);
+                    const double uM = F1(0, qU, okU), uGX = F1(1, qU, okU), uGY = F1(2, qU, okU);
+                    event(0, lM, 1, eX, m.shortOpenX);
+                    event(1, lGX, 1, eX, m.shortExtendX);
+                    event(2, lGY, 1, eX, m.shortSwitchToX);
+                    event(3, F2(0), 0, eM, m.matchContinue);
+                    event(4, F2(1), 0, eM, m.matchFromShortX);
+                    event(5, F2(2), 0, eM, m.matchFromShortY);
+                    event(6, uM, 2, eY, m.shortOpenY);
+                    event(7, uGY, 2, eY, m.shortExtendY);
+                    event(8, uGX, 2, eY, m.shortSwitchToY);
+                }
+            }
+            roll_fence<!FAST>();
+            ga = gb;
+            gb = g;
+            g = g1;
         }
     }
 
@@ -774,6 +884,13 @@ cpecan_pairhmm_sweep(const KArgs a) {
         em[25 + lane] = m.gapXEm[lane];
         em[30 + lane] = m.gapYEm[lane];
     }
+    double *eLds = lds + 56;  // emission-expectation sums of this wave (expectation emitter)
+    for (int i = lane; i < 80; i += CPK_WAVE) eLds[i] = 0.0;
+    constexpr int kNT = S == 5 ? 13 : 9;
+    double tAcc[kNT];
+#pragma unroll
+    for (int i = 0; i < kNT; i++) tAcc[i] = 0.0;
+    double likelihood = 0.0;
     double *roll = FAST ? (lds + kLdsHeader) : (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles);
     uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + kLdsHeader + (size_t)3 * S * stride);
     // every rolling cell starts as -inf; position 0 of each row is never written again (the guard)
@@ -873,15 +990,16 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 if (a.geo.debug & 2) continue;  // diagnostic: time the forward sweep alone (no traceback, no output)
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
                 int nCand[NL];
-                sw.template traceback<NL>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
+                sw.template traceback<NL, EMIT != CPECAN_EMIT_EXPECT>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
                 roll_fence<true>();  // candidate / cbuf / mbuf stores of all lanes are complete before they are re-read
                 sw.foldTotals(sg, table);
                 if (a.geo.debug & 1) {
                     for (int d2 = sg.tbPrev + 1 + lane; d2 <= sg.tbFrom; d2 += CPK_WAVE)
                         a.dbgTotals[rg.dbgDiagOff + d2] = ld_self(sw.totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
                 }
+                if (EMIT == CPECAN_EMIT_EXPECT) sw.expectations(sg, endPrior, tAcc, eLds, likelihood);
 #pragma unroll
-                for (int l = 0; l < NL; l++) {
+                for (int l = 0; l < (EMIT == CPECAN_EMIT_EXPECT ? 0 : NL); l++) {
                     if (lane == 0) a.segStarts[(size_t)l * a.nSegsTotal + rg.segOff + si] = count[l];
                     count[l] = sw.emitMatches(sg, sw.cand + (size_t)l * a.geo.fbCells, nCand[l],
                                               a.triples + 3 * ((size_t)l * a.outTriplesPerList + rg.outOff), rg.outCap,
@@ -901,6 +1019,25 @@ cpecan_pairhmm_sweep(const KArgs a) {
 #pragma unroll
         for (int l = 0; l < NL; l++)
             if (lane == 0) a.outCounts[(size_t)l * a.geo.nRegions + r] = count[l];
+    }
+    if (EMIT == CPECAN_EMIT_EXPECT) {
+        // one partial result per resident wave: [0,25) transitions [from*S+to], [25,105) emissions, [105] likelihood
+        __syncthreads();
+        double *dst = a.expectOut + (size_t)blockIdx.x * 128;
+        constexpr int kFrom5[13] = {0, 1, 0, 3, 0, 1, 2, 3, 4, 0, 2, 0, 4}, kTo5[13] = {1, 1, 3, 3, 0, 0, 0, 0, 0, 2, 2, 4, 4};
+        constexpr int kFrom3[9] = {0, 1, 2, 0, 1, 2, 0, 2, 1}, kTo3[9] = {1, 1, 1, 0, 0, 0, 2, 2, 2};
+        for (int i = lane; i < 25; i += CPK_WAVE) dst[i] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kNT; i++) {
+            double v = tAcc[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            const int idx = S == 5 ? kFrom5[i] * 5 + kTo5[i] : kFrom3[i] * 3 + kTo3[i];
+            if (lane == 0) dst[idx] = v;
+        }
+        for (int i = lane; i < 80; i += CPK_WAVE) dst[25 + i] = eLds[i];
+        if (lane == 0) dst[105] = likelihood;
     }
 }
 
@@ -924,7 +1061,7 @@ struct CpkDevice {
     CpkSegment *dSegs = nullptr;
     uint8_t *dSymbols = nullptr;
     CpkModel *dModel = nullptr;
-    double *dRing = nullptr; Candidate *dCand = nullptr; double *dForward = nullptr; double *dC = nullptr, *dM = nullptr, *dTotals = nullptr, *dGroll = nullptr;
+    double *dRing = nullptr; Candidate *dCand = nullptr; double *dForward = nullptr, *dExpect = nullptr; double *dC = nullptr, *dM = nullptr, *dTotals = nullptr, *dGroll = nullptr;
     int32_t *dCounts = nullptr, *dSegStarts = nullptr, *dTriples = nullptr;
     unsigned int *dQueue = nullptr;
     double *dDbgFb = nullptr, *dDbgTotals = nullptr;
@@ -960,13 +1097,14 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
 
 static void free_all(CpkDevice *d) {
     void *ptrs[] = {d->dRegions, d->dDiags, d->dSegs, d->dSymbols, d->dModel, d->dRing, d->dCand, d->dC, d->dM,
-                    d->dTotals, d->dGroll, d->dCounts, d->dSegStarts, d->dTriples, d->dQueue, d->dDbgFb, d->dDbgTotals, d->dForward};
+                    d->dTotals, d->dGroll, d->dCounts, d->dSegStarts, d->dTriples, d->dQueue, d->dDbgFb, d->dDbgTotals, d->dForward, d->dExpect};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     d->dRegions = nullptr; d->dDiags = nullptr; d->dSegs = nullptr; d->dSymbols = nullptr; d->dModel = nullptr;
     d->dRing = d->dC = d->dM = d->dTotals = d->dGroll = nullptr;
     d->dCand = nullptr;
     d->dForward = nullptr;
+    d->dExpect = nullptr;
     d->dCounts = d->dSegStarts = d->dTriples = nullptr;
     d->dQueue = nullptr;
     d->dDbgFb = d->dDbgTotals = nullptr;
@@ -1002,6 +1140,7 @@ static KernelFn pick_kernel(const CpkGeometry &g) {
     }
     CPK_PICK(CPECAN_EMIT_MATCH)
     CPK_PICK(CPECAN_EMIT_INDEL)
+    CPK_PICK(CPECAN_EMIT_EXPECT)
     CPK_PICK(kEmitForward)
 #undef CPK_PICK
     return nullptr;
@@ -1075,6 +1214,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (int rc = dev_alloc(d, &d->dRing, (size_t)slots * geo->ringCells * S)) return rc;
     if (int rc = dev_alloc(d, &d->dCand, (size_t)slots * geo->fbCells * (geo->emit == CPECAN_EMIT_INDEL ? 3 : 1))) return rc;
     if (int rc = dev_alloc(d, &d->dForward, (size_t)geo->nRegions)) return rc;
+    if (int rc = dev_alloc(d, &d->dExpect, (size_t)slots * 128)) return rc;
     if (int rc = dev_alloc(d, &d->dC, (size_t)slots * geo->refreshCells)) return rc;
     if (int rc = dev_alloc(d, &d->dM, (size_t)slots * geo->refreshCells)) return rc;
     if (int rc = dev_alloc(d, &d->dTotals, (size_t)slots * geo->maxRefresh)) return rc;
@@ -1084,6 +1224,8 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (int rc = dev_alloc(d, &d->dSegStarts, (size_t)nLists * nSegs)) return rc;
     if (int rc = dev_alloc(d, &d->dTriples, (size_t)nLists * outTriplesPerList * 3)) return rc;
     if (int rc = dev_alloc(d, &d->dQueue, 1)) return rc;
+    HIP_TRY(hipMemset(d->dCounts, 0, sizeof(int32_t) * (size_t)nLists * geo->nRegions));
+    HIP_TRY(hipMemset(d->dSegStarts, 0, sizeof(int32_t) * (size_t)nLists * (nSegs ? nSegs : 1)));
     if (geo->debug) {
         if (int rc = dev_alloc(d, &d->dDbgFb, (size_t)dbgCells)) return rc;
         if (int rc = dev_alloc(d, &d->dDbgTotals, (size_t)dbgDiags)) return rc;
@@ -1150,6 +1292,7 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.nSegsTotal = d->nSegs;
     a.queue = d->dQueue;
     a.forwardOut = d->dForward;
+    a.expectOut = d->dExpect;
     a.dbgFb = d->dDbgFb;
     a.dbgTotals = d->dDbgTotals;
     HIP_TRY(hipMemsetAsync(d->dQueue, 0, sizeof(unsigned int), st));
@@ -1190,6 +1333,14 @@ extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segSt
     (void)hipEventDestroy(e1);
     if (expect && d->geo.emit == kEmitForward)
         HIP_TRY(hipMemcpy(expect, d->dForward, sizeof(double) * (size_t)d->geo.nRegions, hipMemcpyDeviceToHost));
+    if (expect && d->geo.emit == CPECAN_EMIT_EXPECT) {
+        // sum the per-wave partials (every launched wave wrote its 106 values, zeros included)
+        std::vector<double> part((size_t)d->slots * 128);
+        HIP_TRY(hipMemcpy(part.data(), d->dExpect, sizeof(double) * part.size(), hipMemcpyDeviceToHost));
+        for (int i = 0; i < 106; i++) expect[i] = 0.0;
+        for (int w = 0; w < d->slots; w++)
+            for (int i = 0; i < 106; i++) expect[i] += part[(size_t)w * 128 + i];
+    }
     return CPECAN_OK;
 }
 

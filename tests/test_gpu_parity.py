@@ -269,3 +269,77 @@ def test_forward_probability_matches_oracle_and_reference_properties():
     p5 = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=40, dynamicAnchorExpansion=1)
     got = api.computeForwardProbability(sx, sy, a, p5, api.stateMachine5_construct())
     assert got == ob.forward_prob(ob.model(0), sx, sy, a, ob.params(diagonalExpansion=40, dynamicAnchorExpansion=1))
+
+
+# ---- expectation emitter (diagonalCalculationExpectations, pairwiseAligner.c:735-746) ----
+
+def _assert_hmm_close(got, want, S, rel=1e-5):
+    for i in range(S * S):
+        assert abs(got.transitions[i] - want.T[i]) <= rel * abs(want.T[i]) + 1e-12, ("T", i, got.transitions[i], want.T[i])
+    for i in range(S * 16):
+        assert abs(got.emissions[i] - want.E[i]) <= rel * abs(want.E[i]) + 1e-12, ("E", i, got.emissions[i], want.E[i])
+    assert abs(got.likelihood - want.likelihood) <= rel * abs(want.likelihood) + 1e-9
+
+
+def test_expectations_known_answers():
+    # 5-state, pseudo count 0, AGCG vs AGTTCG
+    h = api.hmm_constructEmpty(0.0, api.fiveState)
+    api.getExpectationsUsingAnchors(api.stateMachine5_construct(), h, "AGCG", "AGTTCG", (),
+                                    api.pairwiseAlignmentBandingParameters_construct())
+    assert abs(h.likelihood + 175.193211612) < 1e-8
+    assert abs(h.transitions[0] - 3.010391804) < 1e-8
+    assert abs(h.transitions[1] - 0.000751913) < 1e-8
+    assert abs(h.emissions[0] - 0.994467322) < 1e-8
+
+
+@pytest.mark.parametrize("mtype", [0, 1, 2, 3])
+def test_expectations_match_oracle(mtype):
+    rng = random.Random(81 + mtype)
+    ph, oh = api.hmm_constructEmpty(0.0, mtype), ob.hmm(mtype, 0.0)
+    S = ph.stateNumber
+    for i in range(S * S):
+        ph.transitions[i] = oh.T[i] = 0.05 + rng.random()
+    for i in range(S * 16):
+        ph.emissions[i] = oh.E[i] = 0.05 + rng.random()
+    api.hmm_normalise(ph)
+    ob.lib().orc_hmm_normalise(oh)
+    sm, om = api.hmm_getStateMachine(ph), ob.model_from_hmm(oh)
+    problems = [(_rand_seq(rng, rng.randrange(10, 100)),) for _ in range(6)]
+    problems = [(sx, _evolve(rng, sx), ()) for (sx,) in problems]
+    sx, sy, a = make_pair(11, mtype, 1300, 20)  # several traceback segments: exercises the freed-F[d-2] quirk
+    problems.append((sx, sy, a))
+    kw = dict(diagonalExpansion=20)
+    acc_g, acc_o = api.hmm_constructEmpty(1e-12, mtype), ob.hmm(mtype, 1e-12)
+    with api.Batch(sm, api.pairwiseAlignmentBandingParameters_construct(**kw), emit=api.EMIT_EXPECT) as b:
+        for sx, sy, a in problems:
+            b.add(sx, sy, a, True, False)
+        b.upload()
+        b.run()
+        b.download()
+        b.expectations(acc_g)
+    for sx, sy, a in problems:
+        ob.expectations(om, acc_o, sx, sy, a, ob.params(**kw), True, False)
+    _assert_hmm_close(acc_g, acc_o, S)
+
+
+def test_em_iterations_likelihood_monotone_on_gpu():
+    # tests/pairwiseAlignerTest.c:1091-1143 (test_em), 3-state, on the HIP path
+    rng = random.Random(91)
+    sx = _rand_seq(rng, 80)
+    sy = _evolve(rng, sx)
+    h = api.hmm_constructEmpty(0.0, api.threeState)
+    for i in range(9):
+        h.transitions[i] = rng.random()
+    for i in range(48):
+        h.emissions[i] = rng.random()
+    api.hmm_normalise(h)
+    sm = api.hmm_getStateMachine(h)
+    p = api.pairwiseAlignmentBandingParameters_construct()
+    prev = float("-inf")
+    for _ in range(6):
+        acc = api.hmm_constructEmpty(1e-12, api.threeState)
+        api.getExpectationsUsingAnchors(sm, acc, sx, sy, (), p)
+        api.hmm_normalise(acc)
+        assert prev <= acc.likelihood * 0.95
+        prev = acc.likelihood
+        sm = api.hmm_getStateMachine(acc)
