@@ -1,0 +1,71 @@
+"""Multi-GPU plumbing for the hot path: one process per GPU, pairs sharded statically,
+no data-path collective for posteriors; the EM expectation step adds ONE all-reduce(SUM) of the count vector
+(transitions S*S, emissions S*16, likelihood) -- the GPU counterpart of cPecanEm.py:184-188 summing per-shard
+expectation files.  torch.distributed backend "nccl" is RCCL on ROCm; "gloo" is used by the CPU tests."""
+import ctypes as C
+
+import numpy as np
+
+from . import api
+
+
+def shard_bounds(n_items, rank, world_size):
+    """Contiguous static shard [lo, hi) of n_items for this rank; shards differ in size by at most one."""
+    base, extra = divmod(int(n_items), int(world_size))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def hmm_to_vector(hmm):
+    """(transitions[S*S], emissions[S*16], likelihood) as one float64 vector."""
+    S = hmm.stateNumber
+    return np.concatenate([np.array(hmm.transitions[:S * S], dtype=np.float64),
+                           np.array(hmm.emissions[:S * 16], dtype=np.float64),
+                           np.array([hmm.likelihood], dtype=np.float64)])
+
+
+def vector_to_hmm(vec, hmm):
+    S = hmm.stateNumber
+    for i in range(S * S):
+        hmm.transitions[i] = float(vec[i])
+    for i in range(S * 16):
+        hmm.emissions[i] = float(vec[S * S + i])
+    hmm.likelihood = float(vec[S * S + S * 16])
+    return hmm
+
+
+def allreduce_hmm(hmm, device=None):
+    """In-place sum of expectation counts over all ranks (one collective of S*S + S*16 + 1 doubles)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return hmm
+    t = torch.from_numpy(hmm_to_vector(hmm))
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return vector_to_hmm(t.cpu().numpy(), hmm)
+
+
+def expectation_step(sM, problems, p, pseudo=1e-12, device_index=0, reduce_device=None):
+    """One E-step over this rank's problems on its GPU, then the all-reduce; returns the summed (un-normalised) Hmm.
+    problems: iterable of (sX, sY, anchors, raggedLeft, raggedRight)."""
+    acc = api.hmm_constructEmpty(0.0, sM.type)
+    with api.Batch(sM, p, emit=api.EMIT_EXPECT, device=device_index) as b:
+        n = 0
+        for sx, sy, anchors, rl, rr in problems:
+            b.add(sx, sy, anchors, rl, rr)
+            n += 1
+        if n:
+            b.upload()
+            b.run()
+            b.download()
+            b.expectations(acc)
+    allreduce_hmm(acc, reduce_device)
+    # the reference seeds every shard's Hmm with the pseudo count (cPecanRealign.c:493); add it once globally
+    S = acc.stateNumber
+    for i in range(S * S):
+        acc.transitions[i] += pseudo
+    for i in range(S * 16):
+        acc.emissions[i] += pseudo
+    return acc

@@ -1,0 +1,83 @@
+"""world_size-2 gloo tests (CPU) of the N>1 path: static sharding of pairs and the EM count all-reduce.
+Per-shard expectation counts come from the oracle here (no GPU in this container); the code under test is the
+product's sharding and collective plumbing (cpecan_amd/dist.py)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import oracle_binding as ob
+from cpecan_amd import api, dist as cdist
+from cpecan_amd.workload import make_batch
+
+
+def test_shard_bounds_cover_without_overlap():
+    for n in (0, 1, 7, 8, 9, 10000):
+        for w in (1, 2, 3, 8):
+            spans = [cdist.shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c and b - a >= d - c >= b - a - 1
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    problems = make_batch(5, 12, 150, 10)
+    lo, hi = cdist.shard_bounds(len(problems), rank, world)
+    om, op = ob.model(ob.FIVE_STATE), ob.params(diagonalExpansion=10)
+    oacc = ob.hmm(ob.FIVE_STATE, 0.0)
+    for sx, sy, a in problems[lo:hi]:
+        ob.expectations(om, oacc, sx, sy, a, op, True, True)
+    # hand the shard's counts to the product's Hmm type and all-reduce them
+    h = api.hmm_constructEmpty(0.0, api.fiveState)
+    for i in range(25):
+        h.transitions[i] = oacc.T[i]
+    for i in range(80):
+        h.emissions[i] = oacc.E[i]
+    h.likelihood = oacc.likelihood
+    cdist.allreduce_hmm(h)
+    if rank == 0:
+        np.save(out_path, cdist.hmm_to_vector(h))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_allreduce_of_expectation_counts(tmp_path):
+    out = str(tmp_path / "sum.npy")
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    problems = make_batch(5, 12, 150, 10)
+    om, op = ob.model(ob.FIVE_STATE), ob.params(diagonalExpansion=10)
+    oacc = ob.hmm(ob.FIVE_STATE, 0.0)
+    for sx, sy, a in problems:
+        ob.expectations(om, oacc, sx, sy, a, op, True, True)
+    want = np.concatenate([np.array(oacc.T[:25]), np.array(oacc.E[:80]), [oacc.likelihood]])
+    assert np.allclose(got, want, rtol=1e-12, atol=0)
+
+
+def test_hmm_vector_round_trip():
+    h = api.hmm_constructEmpty(0.0, api.threeState)
+    for i in range(9):
+        h.transitions[i] = i + 0.5
+    for i in range(48):
+        h.emissions[i] = 100 + i
+    h.likelihood = -12.25
+    v = cdist.hmm_to_vector(h)
+    assert v.shape == (58,)
+    g = cdist.vector_to_hmm(v, api.hmm_constructEmpty(0.0, api.threeState))
+    assert list(g.transitions)[:9] == list(h.transitions)[:9] and g.likelihood == h.likelihood

@@ -343,3 +343,16 @@ def test_em_iterations_likelihood_monotone_on_gpu():
         assert prev <= acc.likelihood * 0.95
         prev = acc.likelihood
         sm = api.hmm_getStateMachine(acc)
+
+
+def test_expectation_step_helper_single_rank():
+    """cpecan_amd.dist.expectation_step on one GPU (world size 1: the all-reduce is the identity)."""
+    from cpecan_amd import dist as cdist
+    problems = make_batch(5, 6, 150, 10)
+    sm = api.stateMachine5_construct()
+    p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=10)
+    acc = cdist.expectation_step(sm, [(sx, sy, a, True, True) for sx, sy, a in problems], p, pseudo=1e-12)
+    oacc = ob.hmm(ob.FIVE_STATE, 1e-12)
+    for sx, sy, a in problems:
+        ob.expectations(ob.model(0), oacc, sx, sy, a, ob.params(diagonalExpansion=10), True, True)
+    _assert_hmm_close(acc, oacc, 5)
