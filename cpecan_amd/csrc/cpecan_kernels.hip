@@ -111,26 +111,44 @@ struct __attribute__((aligned(16))) Cubic {
     double c3, c2, c1, c0;
 };
 
+// The segment of d = hi - lo is found without fp64 compares.  For d >= 0 the IEEE bit pattern is monotone, and
+// d <= T  <=>  bits(d) - 1 < bits(T); all three thresholds (1.0, 2.5, 4.5) have a zero low dword and their high
+// dwords are multiples of 2^17, so the segment is a function of  (hi32(bits(d) - 1)) >> 17.  The table has one
+// 32-byte row of coefficients per such bucket from (0.875,1] (row 0, also every smaller d) to d > 7 (row 25):
+// rows 0 -> d<=1, 1..10 -> (1,2.5], 11..17 -> (2.5,4.5], 18.. -> above.  NaN / +inf land on the last row; the
+// result is then `hi` anyway.  Exact for every double, including the thresholds themselves.
+constexpr int kCubicRows = 26;
+constexpr int kCubicBase = 0x3FF00000 >> 17;  // bucket of (1.0, 1.125]
+
 __device__ __forceinline__ void fill_cubics(double *t) {
     const float c[16] = {-0.009350833524763f, 0.130659527668286f, 0.498799810682272f, 0.693203116424741f,
                          -0.014532321752540f, 0.139942324101744f, 0.495635523139337f, 0.692140569840976f,
                          -0.004605031767994f, 0.063427417320019f, 0.695956496475118f, 0.514272634594009f,
                          -0.000458661602210f, 0.009695946122598f, 0.930734667215156f, 0.168037164329057f};
-    const int l = threadIdx.x;
-    if (l < 16) {
+    for (int i = threadIdx.x; i < kCubicRows * 4; i += CPK_WAVE) {
+        const int row = i >> 2, col = i & 3;
+        const int seg = row == 0 ? 0 : (row <= 10 ? 1 : (row <= 17 ? 2 : 3));
+        const int idx = seg * 4 + col;
         float v = c[0];
 #pragma unroll
-        for (int i = 1; i < 16; i++) v = l == i ? c[i] : v;
-        t[l] = (double)v;
+        for (int j = 1; j < 16; j++) v = idx == j ? c[j] : v;
+        t[i] = (double)v;
     }
+}
+
+__device__ __forceinline__ int cubic_row(double d) {
+    const int lo = __double2loint(d), hi = __double2hiint(d);
+    const int h = hi - (lo == 0 ? 1 : 0);           // high dword of bits(d) - 1
+    int row = (h >> 17) - (kCubicBase - 1);         // arithmetic shift: d == 0 gives h = -1 -> negative -> row 0
+    row = row < 0 ? 0 : (row > kCubicRows - 1 ? kCubicRows - 1 : row);
+    return row;
 }
 
 __device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
     const double hi = __builtin_fmax(x, y);
     const double lo = __builtin_fmin(x, y);
     const double d = hi - lo;
-    const int seg = (d > 1.0) + (d > 2.5) + (d > 4.5);  // NaN -> 0, +inf -> 3: any row will do, the result is hi
-    const Cubic q = tab[seg];
+    const Cubic q = tab[cubic_row(d)];
     double r = q.c3 * d;
     r = r + q.c2;
     r = r * d;
@@ -154,7 +172,7 @@ __device__ __forceinline__ void logadd_n(const Cubic *tab, double (&acc)[N], con
         d[i] = hi[i] - lo[i];
     }
 #pragma unroll
-    for (int i = 0; i < N; i++) q[i] = tab[(d[i] > 1.0) + (d[i] > 2.5) + (d[i] > 4.5)];
+    for (int i = 0; i < N; i++) q[i] = tab[cubic_row(d[i])];
     double r[N];
 #pragma unroll
     for (int i = 0; i < N; i++) r[i] = q[i].c3 * d[i];
@@ -243,7 +261,8 @@ struct DiagCache {
     }
 };
 
-constexpr int kLdsHeader = 136;  // doubles of LDS in front of the rolling buffers: 16 cubics + 40 emissions + 80 expectation sums
+constexpr int kLdsCubics = 104;  // 26 rows x 4 coefficients
+constexpr int kLdsHeader = kLdsCubics + 40 + 80;  // doubles of LDS in front of the rolling buffers: cubics + emissions + expectation sums
 constexpr int kPrefetch = 3;  // passes (of 64 cells) of F.match prefetched one diagonal ahead in the traceback
 constexpr float kCandMargin = 3.0f;  // log-space slack of the candidate filter (see DESIGN.md "candidate filter")
 
@@ -256,7 +275,7 @@ struct Sweep {
     DiagCache dc;
     const uint8_t *sxp;  // padded symbols: sxp[x] = symbol of base x-1, sxp[0] = sxp[lX+1] = N
     const uint8_t *syp;
-    double *roll;        // 3 rolling buffers [3][S][stride]; position 0 of each row = -inf guard
+    double *roll;        // 2S+1 rows of `stride` doubles; position 0 of each row = -inf guard
     const double *em;    // LDS emissions: [0..24] match, [25..29] gapX, [30..34] gapY
     const Cubic *lg;     // LDS logAdd cubics
     double *ring;
@@ -269,7 +288,13 @@ struct Sweep {
     CpkDiag f1, f2;
     bool storeRing = true;  // false for the forward-probability mode: nothing reads the forward values back
 
-    __device__ __forceinline__ double *rbuf(int d) const { return roll + (size_t)((d + 3) % 3) * S * stride; }
+    // LDS rows (2S+1 rows of `stride` doubles, position 0 of every row is the -inf guard):
+    //  forward layout : two diagonals, fbuf(d) = rows [(d&1)*S, (d&1)*S + S); F[d] overwrites F[d-2] in place
+    //  backward layout: match row in a ring of three, bM(d) = row (d mod 3); the other states in two alternating
+    //                   groups, bG(d) + s*stride = row 3 + (d&1)*(S-1) + (s-1) for s >= 1
+    __device__ __forceinline__ double *fbuf(int d) const { return roll + (size_t)(d & 1) * S * stride; }
+    __device__ __forceinline__ double *bM(int d) const { return roll + (size_t)((d + 3) % 3) * stride; }
+    __device__ __forceinline__ double *bG(int d) const { return roll + (size_t)(2 + (d & 1) * (S - 1)) * stride; }
     __device__ __forceinline__ double *ringAt(const CpkDiag &g) const { return ring + (size_t)g.ringOff * S; }
 
     // ---- forward: impl/pairwiseAligner.c:609-629 with stateMachine{5,3}_cellCalculate as the per-cell body ----
@@ -373,19 +398,26 @@ struct Sweep {
         c.w1 = f1.width;
         c.dm = (g.xmyL - f2.xmyL) >> 1;      // middle neighbour (d-2, xmy) is cell k+dm
         c.w2 = d >= 2 ? f2.width : 0;
-        c.p1 = rbuf(d - 1);
-        c.p2 = rbuf(d - 2);
-        double *cur = rbuf(d);
+        c.p1 = fbuf(d - 1);
+        c.p2 = fbuf(d - 2);
+        double *cur = fbuf(d);  // same rows as F[d-2]: updated in place
         double *out = ringAt(g);
-        for (int k0 = lane; k0 < W; k0 += CPK_WAVE) {
-            const int kk[1] = {k0};
-            double v[1][S];
-            fwdCells<1>(c, kk, v);
+        // A group of 64 cells reads F[d-2] at k+dm and writes F[d] at k.  With dm >= 0 ascending groups never read a
+        // position an earlier group has overwritten; with dm < 0 descending groups never do (DESIGN.md "LDS layout").
+        const int nPass = (W + CPK_WAVE - 1) / CPK_WAVE;
+        const bool ascending = c.dm >= 0;
+        for (int i = 0; i < nPass; i++) {
+            const int k0 = (ascending ? i : nPass - 1 - i) * CPK_WAVE + lane;
+            if (k0 < W) {
+                const int kk[1] = {k0};
+                double v[1][S];
+                fwdCells<1>(c, kk, v);
 #pragma unroll
-            for (int s = 0; s < S; s++) cur[s * stride + k0 + 1] = v[0][s];
-            if (storeRing) {
+                for (int s = 0; s < S; s++) cur[s * stride + k0 + 1] = v[0][s];
+                if (storeRing) {
 #pragma unroll
-                for (int s = 0; s < S; s++) out[(size_t)s * W + k0] = v[0][s];
+                    for (int s = 0; s < S; s++) out[(size_t)s * W + k0] = v[0][s];
+                }
             }
         }
         roll_fence<!FAST>();
@@ -396,7 +428,7 @@ struct Sweep {
     // Puts diagonal d of the forward ring back into its rolling buffer (after a traceback used the buffers).
     __device__ void reloadForward(const CpkDiag &g, int d) {
         const int W = g.width;
-        double *cur = rbuf(d);
+        double *cur = fbuf(d);
         const double *src = ringAt(g);
         for (int k = lane; k < W; k += CPK_WAVE) {
 #pragma unroll
@@ -438,7 +470,7 @@ struct Sweep {
                 const int iU = guard_pos(k[q] + c.db, c.wB);      // cell (x, y+1): its "upper" neighbour is the target
                 const int iL = guard_pos(k[q] + c.db + 1, c.wB);  // cell (x+1, y): its "lower" neighbour is the target
                 const int iA = guard_pos(k[q] + c.da, c.wA);      // cell (x+1, y+1): its "middle" neighbour is the target
-                const double aM = pa[0 * stride + iA];
+                const double aM = pa[iA];
                 const double uSY = pb[2 * stride + iU], uLY = pb[4 * stride + iU];
                 const double lSX = pb[1 * stride + iL], lLX = pb[3 * stride + iL];
                 // per target state: (1) middle term from d2+2, (2) upper-block terms, (3) lower-block terms
@@ -477,7 +509,7 @@ struct Sweep {
                 const int iU = guard_pos(k[q] + c.db, c.wB);
                 const int iL = guard_pos(k[q] + c.db + 1, c.wB);
                 const int iA = guard_pos(k[q] + c.da, c.wA);
-                const double aM = pa[0 * stride + iA];
+                const double aM = pa[iA];
                 const double uGY = pb[2 * stride + iU];
                 const double lGX = pb[1 * stride + iL];
                 acc[q * 3 + 0] = aM + (eM + m.matchContinue);
@@ -556,7 +588,7 @@ struct Sweep {
                         fmNext[l][q] = k < gnext.width ? ld_self(src + (size_t)l * gnext.width + k) : 0.0;
                     }
             }
-            double *cur = rbuf(d2);
+            double *curM = bM(d2), *curG = bG(d2);
             const double *fsrc = ringAt(g);
             const int xlo = (d2 + g.xmyL) >> 1;
             BwdCtx c;
@@ -566,8 +598,8 @@ struct Sweep {
             c.wB = seeded ? 0 : gb.width;
             c.da = (g.xmyL - ga.xmyL) >> 1;      // source (d2+2, xmy) is cell k+da
             c.wA = (!seeded && d2 + 2 <= sg.dTop) ? ga.width : 0;
-            c.pb = rbuf(d2 + 1);
-            c.pa = rbuf(d2 + 2);
+            c.pb = bG(d2 + 1);
+            c.pa = bM(d2 + 2);
             c.seeded = seeded;
             c.endPrior = endPrior;
             const float keepFrom = lastMax + logThr - kCandMargin;  // wave-uniform
@@ -581,8 +613,9 @@ struct Sweep {
                 double v[1][S];
                 bwdCells<1>(c, kk, v);
                 if (on) {
+                    curM[k0 + 1] = v[0][0];
 #pragma unroll
-                    for (int s = 0; s < S; s++) cur[s * stride + k0 + 1] = v[0][s];
+                    for (int s = 1; s < S; s++) curG[s * stride + k0 + 1] = v[0][s];
                 }
                 if (emit) {
                     const int x = xlo + k0, y = d2 - x;
@@ -644,7 +677,7 @@ struct Sweep {
                         else if (pass == 1) f0 = fmCur[0][1];
                         else if (pass == 2) f0 = fmCur[0][2];
                         else f0 = ld_self(fsrc + k);
-                        fbf = (float)(f0 + cur[0 * stride + k + 1]);
+                        fbf = (float)(f0 + curM[k + 1]);
                     }
                     diagMax = fmaxf(diagMax, wave_max_f32(fbf));
                 }
@@ -657,7 +690,7 @@ struct Sweep {
                 const int Wn = gb.width, Wp = gnext.width;
                 const int dmm = (gb.xmyL - gnext.xmyL) >> 1;
                 const double *fprev = ringAt(gnext);
-                const double *bn = rbuf(d2 + 1);
+                const double *bn = bM(d2 + 1);
                 const int xlon = (d2 + 1 + gb.xmyL) >> 1;
                 for (int k = lane; k < Wn; k += CPK_WAVE) {
                     const int x = xlon + k, y = d2 + 1 - x;
@@ -712,7 +745,7 @@ struct Sweep {
             const CpkDiag g1 = dc.get(d2 - 1, true);               // F[d2-1]: always alive (d2-1 >= tbPrev)
             const bool haveM2 = emit && d2 - 2 >= sg.tbPrev;       // F[d2-2] is gone at d2 == tbPrev+1
             const CpkDiag g2 = haveM2 ? dc.get(d2 - 2, true) : CpkDiag{};
-            double *cur = rbuf(d2);
+            double *curM = bM(d2), *curG = bG(d2);
             const int xlo = (d2 + g.xmyL) >> 1;
             BwdCtx c;
             c.d2 = d2;
@@ -721,8 +754,8 @@ struct Sweep {
             c.wB = seeded ? 0 : gb.width;
             c.da = (g.xmyL - ga.xmyL) >> 1;
             c.wA = (!seeded && d2 + 2 <= sg.dTop) ? ga.width : 0;
-            c.pb = rbuf(d2 + 1);
-            c.pa = rbuf(d2 + 2);
+            c.pb = bG(d2 + 1);
+            c.pa = bM(d2 + 2);
             c.seeded = seeded;
             c.endPrior = endPrior;
             double total = 0.0;
@@ -738,8 +771,9 @@ struct Sweep {
                 const int kk[1] = {k};
                 double v[1][S];
                 bwdCells<1>(c, kk, v);
+                curM[k + 1] = v[0][0];
 #pragma unroll
-                for (int s = 0; s < S; s++) cur[s * stride + k + 1] = v[0][s];
+                for (int s = 1; s < S; s++) curG[s * stride + k + 1] = v[0][s];
                 if (!emit) continue;
                 const int x = xlo + k, y = d2 - x;
                 const int cX = sxp[x], cY = syp[y];
@@ -875,16 +909,16 @@ cpecan_pairhmm_sweep(const KArgs a) {
     const CpkModel &m = *a.model;
     const int stride = a.geo.rollStride;
 
-    // LDS (doubles): [0,16) logAdd cubics | [16,56) emission tables | rolling buffers (FAST) | symbol strings (FAST)
+    // LDS (doubles): logAdd cubics | emission tables | expectation sums | rolling buffers (FAST) | symbol strings (FAST)
     fill_cubics(lds);
     const Cubic *lg = reinterpret_cast<const Cubic *>(lds);
-    double *em = lds + 16;
+    double *em = lds + kLdsCubics;
     if (lane < 25) em[lane] = m.matchEm[lane];
     if (lane < 5) {
         em[25 + lane] = m.gapXEm[lane];
         em[30 + lane] = m.gapYEm[lane];
     }
-    double *eLds = lds + 56;  // emission-expectation sums of this wave (expectation emitter)
+    double *eLds = lds + kLdsCubics + 40;  // emission-expectation sums of this wave (expectation emitter)
     for (int i = lane; i < 80; i += CPK_WAVE) eLds[i] = 0.0;
     constexpr int kNT = S == 5 ? 13 : 9;
     double tAcc[kNT];
@@ -892,9 +926,9 @@ cpecan_pairhmm_sweep(const KArgs a) {
     for (int i = 0; i < kNT; i++) tAcc[i] = 0.0;
     double likelihood = 0.0;
     double *roll = FAST ? (lds + kLdsHeader) : (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles);
-    uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + kLdsHeader + (size_t)3 * S * stride);
+    uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + kLdsHeader + (size_t)(2 * S + 1) * stride);
     // every rolling cell starts as -inf; position 0 of each row is never written again (the guard)
-    for (int i = lane; i < 3 * S * stride; i += CPK_WAVE) roll[i] = NEG_INF;
+    for (int i = lane; i < (2 * S + 1) * stride; i += CPK_WAVE) roll[i] = NEG_INF;
     __syncthreads();
 
     const size_t slot = blockIdx.x;
@@ -947,14 +981,14 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 sw.dc.load(0);
                 const double *startPrior = rg.raggedLeft ? m.raggedStart : m.start;
                 const CpkDiag g0 = sw.dc.get(0, false);
-                double *cur0 = sw.rbuf(0);
+                double *cur0 = sw.fbuf(0);
                 if (lane < S) cur0[lane * stride + 1] = startPrior[lane];
                 roll_fence<!FAST>();
                 sw.f1 = g0;
                 sw.f2 = g0;
                 for (int d = 1; d <= N; d++) sw.forward(d);
                 const double *endPrior = rg.raggedRight ? m.raggedEnd : m.end;
-                const double *last = sw.rbuf(N);
+                const double *last = sw.fbuf(N);
                 const int W = sw.f1.width;
                 total = NEG_INF;  // dpDiagonal_dotProduct (:513-523) over the cells of diagonal N, every lane alike
                 for (int k = 0; k < W; k++) {
@@ -973,7 +1007,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
             const double *startPrior = rg.raggedLeft ? m.raggedStart : m.start;
             {
                 const CpkDiag g0 = sw.dc.get(0, false);
-                double *cur = sw.rbuf(0);
+                double *cur = sw.fbuf(0);
                 double *o0 = sw.ringAt(g0);
                 if (lane < S) {
                     cur[lane * stride + 1] = startPrior[lane];
@@ -1169,7 +1203,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     // LDS: 40 doubles of emission tables + (fast path) three rolling buffers + both padded symbol strings
     d->ldsBytes = sizeof(double) * kLdsHeader;
     if (!geo->useGlobalRoll)
-        d->ldsBytes += sizeof(double) * (size_t)3 * S * geo->rollStride + (size_t)((geo->seqLdsBytes + 15) / 16 * 16);
+        d->ldsBytes += sizeof(double) * (size_t)(2 * S + 1) * geo->rollStride + (size_t)((geo->seqLdsBytes + 15) / 16 * 16);
     KernelFn fn = pick_kernel(*geo);
     if (!fn) {
         cpk_set_error("no kernel for emitter %d", geo->emit);
@@ -1204,6 +1238,14 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     int64_t slots = (int64_t)perCU * d->numCUs;
     if (slots > geo->nRegions) slots = geo->nRegions;
     if (slots < 1) slots = 1;
+    {
+        // Even out the rounds: with R = ceil(regions / slots) rounds, ceil(regions / R) waves do the same work in the
+        // same number of rounds with fewer waves competing per SIMD (10 000 equal pairs: 1667 waves x 6 pairs instead
+        // of 1792 waves of which 1044 do 6 and 748 do 5).
+        const int64_t rounds = (geo->nRegions + slots - 1) / slots;
+        const int64_t even = (geo->nRegions + rounds - 1) / rounds;
+        if (even >= 1 && even < slots) slots = even;
+    }
     d->slots = (int)slots;
 
     if (int rc = dev_alloc(d, &d->dRegions, (size_t)geo->nRegions)) return rc;
