@@ -786,14 +786,15 @@ int cpecan_batch_upload(cpecan_batch *b) {
     geo.rollStride = geo.maxWidth + 1;
     {
         int64_t seqMax = 0;
-        for (int64_t i = 0; i < b->nRegions; i++) seqMax = imax(seqMax, b->regions[i].lX + b->regions[i].lY + 4);
+        for (int64_t i = 0; i < b->nRegions; i++) /* two symbols per byte in LDS */
+            seqMax = imax(seqMax, (b->regions[i].lX + 3) / 2 + (b->regions[i].lY + 3) / 2);
         geo.seqLdsBytes = (int32_t)imin(seqMax, (int64_t)1 << 30);
     }
     geo.refreshCells = (int64_t)geo.maxWidth * geo.maxRefresh;
     if (geo.refreshCells < 1) geo.refreshCells = 1;
     geo.rollDoubles = (int64_t)(2 * S + 1) * geo.rollStride;
     /* LDS budget: beyond 64 KiB per wave (rolling buffers + symbol strings) the batch takes the global-memory path */
-    geo.useGlobalRoll = (sizeof(double) * (size_t)(224 + geo.rollDoubles) + (size_t)geo.seqLdsBytes + 16 > 64 * 1024);
+    geo.useGlobalRoll = (sizeof(double) * (size_t)(136 + geo.rollDoubles) + (size_t)geo.seqLdsBytes + 16 > 64 * 1024);
     b->geo = geo;
     b->segs = segs;
     b->nSegs = nSegs;

@@ -113,35 +113,32 @@ struct __attribute__((aligned(16))) Cubic {
 
 // The segment of d = hi - lo is found without fp64 compares.  For d >= 0 the IEEE bit pattern is monotone, and
 // d <= T  <=>  bits(d) - 1 < bits(T); all three thresholds (1.0, 2.5, 4.5) have a zero low dword and their high
-// dwords are multiples of 2^17, so the segment is a function of  (hi32(bits(d) - 1)) >> 17.  The table has one
-// 32-byte row of coefficients per such bucket from (0.875,1] (row 0, also every smaller d) to d > 7 (row 25):
-// rows 0 -> d<=1, 1..10 -> (1,2.5], 11..17 -> (2.5,4.5], 18.. -> above.  NaN / +inf land on the last row; the
-// result is then `hi` anyway.  Exact for every double, including the thresholds themselves.
-constexpr int kCubicRows = 26;
-constexpr int kCubicBase = 0x3FF00000 >> 17;  // bucket of (1.0, 1.125]
-
+// dwords are multiples of 2^17, so the segment is a function of the bucket  b = (hi32(bits(d) - 1) >> 17) - 0x1FF7:
+// b <= 0 -> d <= 1;  1..10 -> (1, 2.5];  11..17 -> (2.5, 4.5];  18.. -> above, i.e. segment = number of set bits of
+// {0, 10, 17} below position b.  Exact for every double, thresholds included.  NaN / +inf / d >= 8 may pick any
+// segment: the result is `hi` then.  The table keeps 4 rows of 32 bytes (conflict-free for ds_read_b128); a 26-row
+// table indexed by bucket measured 100x the LDS bank conflicts.
 __device__ __forceinline__ void fill_cubics(double *t) {
     const float c[16] = {-0.009350833524763f, 0.130659527668286f, 0.498799810682272f, 0.693203116424741f,
                          -0.014532321752540f, 0.139942324101744f, 0.495635523139337f, 0.692140569840976f,
                          -0.004605031767994f, 0.063427417320019f, 0.695956496475118f, 0.514272634594009f,
                          -0.000458661602210f, 0.009695946122598f, 0.930734667215156f, 0.168037164329057f};
-    for (int i = threadIdx.x; i < kCubicRows * 4; i += CPK_WAVE) {
-        const int row = i >> 2, col = i & 3;
-        const int seg = row == 0 ? 0 : (row <= 10 ? 1 : (row <= 17 ? 2 : 3));
-        const int idx = seg * 4 + col;
+    const int l = threadIdx.x;
+    if (l < 16) {
         float v = c[0];
 #pragma unroll
-        for (int j = 1; j < 16; j++) v = idx == j ? c[j] : v;
-        t[i] = (double)v;
+        for (int i = 1; i < 16; i++) v = l == i ? c[i] : v;
+        t[l] = (double)v;
     }
 }
 
 __device__ __forceinline__ int cubic_row(double d) {
     const int lo = __double2loint(d), hi = __double2hiint(d);
-    const int h = hi - (lo == 0 ? 1 : 0);           // high dword of bits(d) - 1
-    int row = (h >> 17) - (kCubicBase - 1);         // arithmetic shift: d == 0 gives h = -1 -> negative -> row 0
-    row = row < 0 ? 0 : (row > kCubicRows - 1 ? kCubicRows - 1 : row);
-    return row;
+    const int h = hi - (lo == 0 ? 1 : 0);                    // high dword of bits(d) - 1 (d == 0 gives -1)
+    int b = (h >> 17) - ((0x3FF00000 >> 17) - 1);            // arithmetic shift keeps small d negative
+    b = b < 0 ? 0 : (b > 31 ? 31 : b);
+    const unsigned below = (1u << b) - 1u;                   // bits 0..b-1
+    return __builtin_popcount(below & ((1u << 0) | (1u << 10) | (1u << 17)));
 }
 
 __device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
@@ -261,8 +258,9 @@ struct DiagCache {
     }
 };
 
-constexpr int kLdsCubics = 104;  // 26 rows x 4 coefficients
-constexpr int kLdsHeader = kLdsCubics + 40 + 80;  // doubles of LDS in front of the rolling buffers: cubics + emissions + expectation sums
+constexpr int kLdsCubics = 16;  // 4 rows x 4 coefficients
+// doubles of LDS in front of the rolling rows: cubics + emissions (+ expectation sums for that emitter only)
+__host__ __device__ constexpr int lds_header_doubles(int emit) { return kLdsCubics + 40 + (emit == CPECAN_EMIT_EXPECT ? 80 : 0); }
 constexpr int kPrefetch = 3;  // passes (of 64 cells) of F.match prefetched one diagonal ahead in the traceback
 constexpr float kCandMargin = 3.0f;  // log-space slack of the candidate filter (see DESIGN.md "candidate filter")
 
@@ -273,8 +271,12 @@ struct Sweep {
     const KArgs &a;
     const KConsts &m;  // kernarg-resident constants
     DiagCache dc;
-    const uint8_t *sxp;  // padded symbols: sxp[x] = symbol of base x-1, sxp[0] = sxp[lX+1] = N
+    // padded symbol strings: symbol p of X is the base x-1 (p = 0 and p = lX+1 read as N).  FAST: two symbols per
+    // byte in LDS (low nibble = even p); otherwise one byte per symbol in global memory.
+    const uint8_t *sxp;
     const uint8_t *syp;
+    __device__ __forceinline__ int symX(int p) const { return FAST ? (sxp[p >> 1] >> ((p & 1) * 4)) & 15 : sxp[p]; }
+    __device__ __forceinline__ int symY(int p) const { return FAST ? (syp[p >> 1] >> ((p & 1) * 4)) & 15 : syp[p]; }
     double *roll;        // 2S+1 rows of `stride` doubles; position 0 of each row = -inf guard
     const double *em;    // LDS emissions: [0..24] match, [25..29] gapX, [30..34] gapY
     const Cubic *lg;     // LDS logAdd cubics
@@ -311,8 +313,8 @@ struct Sweep {
 #pragma unroll
         for (int q = 0; q < NC; q++) {
             const int x = c.xlo + k[q], y = c.d - x;
-            cX[q] = sxp[x];
-            cY[q] = syp[y];
+            cX[q] = symX(x);
+            cY[q] = symY(y);
         }
         const double *p1 = c.p1, *p2 = c.p2;
         if (S == 5) {
@@ -458,8 +460,8 @@ struct Sweep {
 #pragma unroll
         for (int q = 0; q < NC; q++) {
             const int x = c.xlo + k[q], y = c.d2 - x;
-            cX1[q] = sxp[x + 1];  // symbols of the source cells (x+1,.) and (.,y+1)
-            cY1[q] = syp[y + 1];
+            cX1[q] = symX(x + 1);  // symbols of the source cells (x+1,.) and (.,y+1)
+            cY1[q] = symY(y + 1);
         }
         const double *pb = c.pb, *pa = c.pa;
         if (S == 5) {
@@ -694,7 +696,7 @@ struct Sweep {
                 const int xlon = (d2 + 1 + gb.xmyL) >> 1;
                 for (int k = lane; k < Wn; k += CPK_WAVE) {
                     const int x = xlon + k, y = d2 + 1 - x;
-                    const double eM = em[sxp[x] * 5 + syp[y]];
+                    const double eM = em[symX(x) * 5 + symY(y)];
                     const int kp = k + dmm;
                     const bool ok = kp >= 0 && kp < Wp;
                     const int kq = ok ? kp : 0;
@@ -776,7 +778,7 @@ struct Sweep {
                 for (int s = 1; s < S; s++) curG[s * stride + k + 1] = v[0][s];
                 if (!emit) continue;
                 const int x = xlo + k, y = d2 - x;
-                const int cX = sxp[x], cY = syp[y];
+                const int cX = symX(x), cY = symY(y);
                 const double eX = em[25 + cX], eM = em[cX * 5 + cY], eY = em[30 + cY];
                 const bool acgt = cX < CPK_SYM_N && cY < CPK_SYM_N;
                 const int eIdx = cX * 4 + cY;
@@ -919,14 +921,16 @@ cpecan_pairhmm_sweep(const KArgs a) {
         em[30 + lane] = m.gapYEm[lane];
     }
     double *eLds = lds + kLdsCubics + 40;  // emission-expectation sums of this wave (expectation emitter)
-    for (int i = lane; i < 80; i += CPK_WAVE) eLds[i] = 0.0;
+    if (EMIT == CPECAN_EMIT_EXPECT)
+        for (int i = lane; i < 80; i += CPK_WAVE) eLds[i] = 0.0;
     constexpr int kNT = S == 5 ? 13 : 9;
     double tAcc[kNT];
 #pragma unroll
     for (int i = 0; i < kNT; i++) tAcc[i] = 0.0;
     double likelihood = 0.0;
-    double *roll = FAST ? (lds + kLdsHeader) : (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles);
-    uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + kLdsHeader + (size_t)(2 * S + 1) * stride);
+    constexpr int kHeader = lds_header_doubles(EMIT);
+    double *roll = FAST ? (lds + kHeader) : (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles);
+    uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + kHeader + (size_t)(2 * S + 1) * stride);
     // every rolling cell starts as -inf; position 0 of each row is never written again (the guard)
     for (int i = lane; i < (2 * S + 1) * stride; i += CPK_WAVE) roll[i] = NEG_INF;
     __syncthreads();
@@ -944,9 +948,16 @@ cpecan_pairhmm_sweep(const KArgs a) {
         const int lX = rg.lX, lY = rg.lY, N = lX + lY;
         const uint8_t *gx = a.symbols + rg.seqXOff, *gy = a.symbols + rg.seqYOff;
         if (FAST) {
-            // stage N + bases + N of both strings into LDS (byte reads per cell come from here)
-            for (int i = lane; i < lX + 2; i += CPK_WAVE) seqLds[i] = gx[i];
-            for (int i = lane; i < lY + 2; i += CPK_WAVE) seqLds[lX + 2 + i] = gy[i];
+            // stage N + bases + N of both strings into LDS, two symbols per byte (per-cell reads come from here)
+            const int bx = (lX + 3) >> 1, by = (lY + 3) >> 1;
+            for (int i = lane; i < bx; i += CPK_WAVE) {
+                const int lo4 = gx[2 * i], hi4 = 2 * i + 1 < lX + 2 ? gx[2 * i + 1] : CPK_SYM_N;
+                seqLds[i] = (uint8_t)(lo4 | (hi4 << 4));
+            }
+            for (int i = lane; i < by; i += CPK_WAVE) {
+                const int lo4 = gy[2 * i], hi4 = 2 * i + 1 < lY + 2 ? gy[2 * i + 1] : CPK_SYM_N;
+                seqLds[bx + i] = (uint8_t)(lo4 | (hi4 << 4));
+            }
             roll_fence<false>();
         }
         const CpkDiag *table = a.diags + rg.diagOff;
@@ -954,7 +965,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                           a.kc,
                           DiagCache{table, N, 0, lane, 0, 0, 0, 0},
                           FAST ? seqLds : gx,
-                          FAST ? seqLds + lX + 2 : gy,
+                          FAST ? seqLds + ((lX + 3) >> 1) : gy,
                           roll,
                           em,
                           lg,
@@ -1201,7 +1212,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     const int S = geo->nStates;
 
     // LDS: 40 doubles of emission tables + (fast path) three rolling buffers + both padded symbol strings
-    d->ldsBytes = sizeof(double) * kLdsHeader;
+    d->ldsBytes = sizeof(double) * lds_header_doubles(geo->emit);
     if (!geo->useGlobalRoll)
         d->ldsBytes += sizeof(double) * (size_t)(2 * S + 1) * geo->rollStride + (size_t)((geo->seqLdsBytes + 15) / 16 * 16);
     KernelFn fn = pick_kernel(*geo);
