@@ -23,6 +23,23 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def measured_traffic(config, n_pairs):
+    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json: FETCH_SIZE and
+    WRITE_SIZE collected in separate runs of this very command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950).  Counters cannot be read from inside bench.py, so the figure is only quoted for the exact workload it
+    was measured on (config B, 10 000 pairs); otherwise null."""
+    import glob
+    if config != "B" or n_pairs != 10000:
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    try:
+        return json.load(open(files[-1]))["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def build_batch(api, workload, cfg, n_pairs, first, device):
     mtype = api.fiveState if cfg["model"] == "fiveState" else api.threeState
     sm = api.stateMachine5_construct(mtype) if mtype == api.fiveState else api.stateMachine3_construct(mtype)
@@ -147,12 +164,12 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "cpecan_pairhmm_sweep<%d, true>" % S,
+                "kernel": "cpecan_pairhmm_sweep<%d, true, 0>" % S,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(args.config, n_pairs),
                 "bytes_per_cell": bytes_per_cell,
                 "kernel_ms": kernel_ms,
             },
