@@ -1,0 +1,438 @@
+/*
+ * cpecan_dropin.c -- reference-named entry points (include/cpecan_dropin.h) on top of the C ABI.
+ * Host-side glue only: list <-> array conversion, struct flattening, error mapping (st_errAbort semantics:
+ * print and abort, as impl/pairwiseAligner.c:1044 and impl/stateMachine.c:36 do).
+ */
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "cpecan_dropin.h"
+
+static void die(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vfprintf(stderr, fmt, ap);
+    va_end(ap);
+    fputc('\n', stderr);
+    abort();
+}
+
+/* ---------------- minimal sonLib containers (weak) ---------------- */
+struct _stList {
+    void **items;
+    int64_t length, capacity;
+    void (*destructElement)(void *);
+};
+struct _stIntTuple {
+    int64_t length;
+    int64_t v[4];
+};
+#define WEAK __attribute__((weak))
+
+WEAK stList *stList_construct3(int64_t size, void (*destructElement)(void *)) {
+    stList *l = calloc(1, sizeof *l);
+    if (!l) die("out of memory");
+    l->capacity = size > 8 ? size : 8;
+    l->items = calloc((size_t)l->capacity, sizeof(void *));
+    l->length = size;
+    l->destructElement = destructElement;
+    return l;
+}
+WEAK stList *stList_construct(void) { return stList_construct3(0, NULL); }
+WEAK void stList_destruct(stList *l) {
+    if (!l) return;
+    if (l->destructElement)
+        for (int64_t i = 0; i < l->length; i++)
+            if (l->items[i]) l->destructElement(l->items[i]);
+    free(l->items);
+    free(l);
+}
+WEAK int64_t stList_length(stList *l) { return l ? l->length : 0; }
+WEAK void *stList_get(stList *l, int64_t i) { return l->items[i]; }
+WEAK void stList_append(stList *l, void *item) {
+    if (l->length == l->capacity) {
+        l->capacity *= 2;
+        l->items = realloc(l->items, sizeof(void *) * (size_t)l->capacity);
+        if (!l->items) die("out of memory");
+    }
+    l->items[l->length++] = item;
+}
+WEAK stIntTuple *stIntTuple_construct3(int64_t a, int64_t b, int64_t c) {
+    stIntTuple *t = malloc(sizeof *t);
+    if (!t) die("out of memory");
+    t->length = 3;
+    t->v[0] = a; t->v[1] = b; t->v[2] = c; t->v[3] = 0;
+    return t;
+}
+WEAK stIntTuple *stIntTuple_construct2(int64_t a, int64_t b) {
+    stIntTuple *t = stIntTuple_construct3(a, b, 0);
+    t->length = 2;
+    return t;
+}
+static stIntTuple *tuple4(int64_t a, int64_t b, int64_t c, int64_t d) {
+    stIntTuple *t = stIntTuple_construct3(a, b, c);
+    t->length = 4;
+    t->v[3] = d;
+    return t;
+}
+WEAK void stIntTuple_destruct(stIntTuple *t) { free(t); }
+WEAK int64_t stIntTuple_get(stIntTuple *t, int64_t i) { return t->v[i]; }
+WEAK int64_t stIntTuple_length(stIntTuple *t) { return t->length; }
+
+/* ---------------- state machines ---------------- */
+typedef struct {
+    StateMachine model; /* must be first: callers hold StateMachine* */
+    uint64_t magic;
+    cpecan_model flat;
+} OwnStateMachine;
+#define OWN_MAGIC 0x6350656341644d44ull
+
+const cpecan_model *stateMachine_flat(StateMachine *sM) {
+    OwnStateMachine *o = (OwnStateMachine *)sM;
+    return (sM && o->magic == OWN_MAGIC) ? &o->flat : NULL;
+}
+static const cpecan_model *flat_or_die(StateMachine *sM) {
+    const cpecan_model *m = stateMachine_flat(sM);
+    if (!m) die("cpecan_hip: StateMachine with a foreign vtable cannot run on the GPU path");
+    return m;
+}
+/* priors: impl/stateMachine.c:401-448 (five state), :648-687 (three state) */
+static double prior_start(StateMachine *sM, int64_t s) { (void)sM; return s == 0 ? 0.0 : -INFINITY; }
+static double prior_ragged_start(StateMachine *sM, int64_t s) {
+    if (sM->stateNumber == 5) return (s == 3 || s == 4) ? 0.0 : -INFINITY;
+    return (s == 1 || s == 2) ? 0.0 : -INFINITY;
+}
+static double prior_end(StateMachine *sM, int64_t s) {
+    const cpecan_model *m = flat_or_die(sM);
+    switch (s) {
+    case 0: return m->matchContinue;
+    case 1: return m->matchFromShortGapX;
+    case 2: return m->matchFromShortGapY;
+    case 3: return m->matchFromLongGapX;
+    case 4: return m->matchFromLongGapY;
+    }
+    return 0.0;
+}
+static double prior_ragged_end(StateMachine *sM, int64_t s) {
+    const cpecan_model *m = flat_or_die(sM);
+    if (sM->stateNumber == 5) {
+        switch (s) {
+        case 0: case 1: return m->gapLongOpenX;
+        case 2: return m->gapLongOpenY;
+        case 3: return m->gapLongExtendX;
+        case 4: return m->gapLongExtendY;
+        }
+        return 0.0;
+    }
+    switch (s) {
+    case 0: return (m->gapShortOpenX + m->gapShortOpenY) / 2.0;
+    case 1: return m->gapShortExtendX;
+    case 2: return m->gapShortExtendY;
+    }
+    return 0.0;
+}
+static void cell_calculate_stub(StateMachine *sM, double *current, double *lower, double *middle, double *upper, Symbol cX,
+                                Symbol cY, void (*doTransition)(double *, double *, int64_t, int64_t, double, double, void *),
+                                void *extraArgs) {
+    (void)sM; (void)current; (void)lower; (void)middle; (void)upper; (void)cX; (void)cY; (void)doTransition; (void)extraArgs;
+    die("cpecan_hip: cellCalculate is evaluated on the GPU only (use getAlignedPairsUsingAnchors & co.)");
+}
+static StateMachine *wrap_model(const cpecan_model *m) {
+    OwnStateMachine *o = calloc(1, sizeof *o);
+    if (!o) die("out of memory");
+    o->magic = OWN_MAGIC;
+    o->flat = *m;
+    o->model.type = (StateMachineType)m->type;
+    o->model.stateNumber = (m->type == CPECAN_FIVE_STATE || m->type == CPECAN_FIVE_STATE_ASYM) ? 5 : 3;
+    o->model.matchState = 0;
+    o->model.gapXState = 1;
+    o->model.gapYState = 2;
+    o->model.startStateProb = prior_start;
+    o->model.endStateProb = prior_end;
+    o->model.raggedStartStateProb = prior_ragged_start;
+    o->model.raggedEndStateProb = prior_ragged_end;
+    o->model.cellCalculate = cell_calculate_stub;
+    return &o->model;
+}
+StateMachine *stateMachine5_construct(StateMachineType type) {
+    if (type != fiveState && type != fiveStateAsymmetric) die("Wrong type for five state %i", (int)type);
+    cpecan_model m;
+    cpecan_model_default(&m, (int32_t)type);
+    return wrap_model(&m);
+}
+StateMachine *stateMachine3_construct(StateMachineType type) {
+    if (type != threeState && type != threeStateAsymmetric)
+        die("Tried to create a three state state-machine with the wrong type");
+    cpecan_model m;
+    cpecan_model_default(&m, (int32_t)type);
+    return wrap_model(&m);
+}
+void stateMachine_destruct(StateMachine *sM) { free(sM); }
+
+/* ---------------- Hmm ---------------- */
+Hmm *hmm_constructEmpty(double pseudo, StateMachineType type) {
+    cpecan_hmm f;
+    if (cpecan_hmm_init(&f, (int32_t)type, pseudo) != CPECAN_OK) die("Unrecognised state type: %i", (int)type);
+    Hmm *h = malloc(sizeof *h);
+    if (!h) die("out of memory");
+    h->type = type;
+    h->stateNumber = f.stateNumber;
+    h->transitions = malloc(sizeof(double) * (size_t)(h->stateNumber * h->stateNumber));
+    h->emissions = malloc(sizeof(double) * (size_t)(h->stateNumber * 16));
+    for (int64_t i = 0; i < h->stateNumber * h->stateNumber; i++) h->transitions[i] = pseudo;
+    for (int64_t i = 0; i < h->stateNumber * 16; i++) h->emissions[i] = pseudo;
+    h->likelihood = 0.0;
+    return h;
+}
+void hmm_destruct(Hmm *h) {
+    free(h->transitions);
+    free(h->emissions);
+    free(h);
+}
+static void to_flat(const Hmm *h, cpecan_hmm *f) {
+    cpecan_hmm_init(f, (int32_t)h->type, 0.0);
+    memcpy(f->transitions, h->transitions, sizeof(double) * (size_t)(h->stateNumber * h->stateNumber));
+    memcpy(f->emissions, h->emissions, sizeof(double) * (size_t)(h->stateNumber * 16));
+    f->likelihood = h->likelihood;
+}
+static void from_flat(const cpecan_hmm *f, Hmm *h) {
+    memcpy(h->transitions, f->transitions, sizeof(double) * (size_t)(h->stateNumber * h->stateNumber));
+    memcpy(h->emissions, f->emissions, sizeof(double) * (size_t)(h->stateNumber * 16));
+    h->likelihood = f->likelihood;
+}
+double hmm_getTransition(Hmm *h, int64_t from, int64_t to) { return h->transitions[from * h->stateNumber + to]; }
+void hmm_setTransition(Hmm *h, int64_t from, int64_t to, double p) { h->transitions[from * h->stateNumber + to] = p; }
+void hmm_addToTransitionExpectation(Hmm *h, int64_t from, int64_t to, double p) { h->transitions[from * h->stateNumber + to] += p; }
+double hmm_getEmissionsExpectation(Hmm *h, int64_t s, Symbol x, Symbol y) { return h->emissions[s * 16 + x * 4 + y]; }
+void hmm_setEmissionsExpectation(Hmm *h, int64_t s, Symbol x, Symbol y, double p) { h->emissions[s * 16 + x * 4 + y] = p; }
+void hmm_addToEmissionsExpectation(Hmm *h, int64_t s, Symbol x, Symbol y, double p) { h->emissions[s * 16 + x * 4 + y] += p; }
+void hmm_normalise(Hmm *h) {
+    cpecan_hmm f;
+    to_flat(h, &f);
+    cpecan_hmm_normalise(&f);
+    from_flat(&f, h);
+}
+void hmm_write(Hmm *h, FILE *fh) { /* impl/stateMachine.c:133-143 */
+    fprintf(fh, "%i\t", (int)h->type);
+    for (int64_t i = 0; i < h->stateNumber * h->stateNumber; i++) fprintf(fh, "%f\t", h->transitions[i]);
+    fprintf(fh, "%f\n", h->likelihood);
+    for (int64_t i = 0; i < h->stateNumber * 16; i++) fprintf(fh, "%f\t", h->emissions[i]);
+    fprintf(fh, "\n");
+}
+Hmm *hmm_loadFromFile(const char *fileName) {
+    cpecan_hmm f;
+    if (cpecan_hmm_load(&f, fileName) != CPECAN_OK) die("Failed to parse the input state machine file %s", fileName);
+    Hmm *h = hmm_constructEmpty(0.0, (StateMachineType)f.type);
+    from_flat(&f, h);
+    return h;
+}
+StateMachine *hmm_getStateMachine(Hmm *h) {
+    cpecan_hmm f;
+    to_flat(h, &f);
+    cpecan_model m;
+    if (cpecan_model_from_hmm(&m, &f) != CPECAN_OK) return NULL;
+    return wrap_model(&m);
+}
+
+/* ---------------- parameters ---------------- */
+PairwiseAlignmentParameters *pairwiseAlignmentBandingParameters_construct(void) { /* impl/pairwiseAligner.c:1334-1348 */
+    PairwiseAlignmentParameters *p = malloc(sizeof *p);
+    if (!p) die("out of memory");
+    p->threshold = 0.01;
+    p->minDiagsBetweenTraceBack = 1000;
+    p->traceBackDiagonals = 40;
+    p->diagonalExpansion = 20;
+    p->constraintDiagonalTrim = 14;
+    p->anchorMatrixBiggerThanThis = 500 * 500;
+    p->repeatMaskMatrixBiggerThanThis = 500 * 500;
+    p->splitMatrixBiggerThanThis = (int64_t)3000 * 3000;
+    p->alignAmbiguityCharacters = 0;
+    p->gapGamma = 0.5;
+    p->dynamicAnchorExpansion = 0;
+    return p;
+}
+void pairwiseAlignmentBandingParameters_destruct(PairwiseAlignmentParameters *p) { free(p); }
+
+static void flatten_params(const PairwiseAlignmentParameters *p, cpecan_params *q) {
+    cpecan_params_default(q);
+    q->threshold = p->threshold;
+    q->minDiagsBetweenTraceBack = p->minDiagsBetweenTraceBack;
+    q->traceBackDiagonals = p->traceBackDiagonals;
+    q->diagonalExpansion = p->diagonalExpansion;
+    q->splitMatrixBiggerThanThis = p->splitMatrixBiggerThanThis;
+    q->dynamicAnchorExpansion = p->dynamicAnchorExpansion ? 1 : 0;
+}
+static int64_t *flatten_anchors(stList *anchorPairs, int64_t *n) {
+    *n = anchorPairs ? stList_length(anchorPairs) : 0;
+    int64_t *a = malloc(sizeof(int64_t) * 3 * (size_t)(*n ? *n : 1));
+    if (!a) die("out of memory");
+    for (int64_t i = 0; i < *n; i++) {
+        stIntTuple *tp = stList_get(anchorPairs, i);
+        a[3 * i] = stIntTuple_get(tp, 0);
+        a[3 * i + 1] = stIntTuple_get(tp, 1);
+        a[3 * i + 2] = stIntTuple_length(tp) > 2 ? stIntTuple_get(tp, 2) : 0;
+    }
+    return a;
+}
+static stList *list_of(const int32_t *tr, int64_t n) {
+    stList *l = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    for (int64_t i = 0; i < n; i++) stList_append(l, stIntTuple_construct3(tr[3 * i], tr[3 * i + 1], tr[3 * i + 2]));
+    return l;
+}
+static void check(int rc, const char *what) {
+    if (rc != CPECAN_OK) die("cpecan_hip: %s failed (%d): %s", what, rc, cpecan_last_error());
+}
+
+/* ---------------- the path: impl/pairwiseAligner.c:1431-1513, :936 ---------------- */
+stList *getAlignedPairsUsingAnchors(StateMachine *sM, const char *sX, const char *sY, stList *anchorPairs,
+                                    PairwiseAlignmentParameters *p, bool raggedLeft, bool raggedRight) {
+    cpecan_params q;
+    flatten_params(p, &q);
+    int64_t n, cnt = 0;
+    int64_t *anchors = flatten_anchors(anchorPairs, &n);
+    int32_t *tr = NULL;
+    check(cpecan_get_aligned_pairs_using_anchors(flat_or_die(sM), sX, sY, anchors, n, &q, raggedLeft, raggedRight, &tr, &cnt),
+          "getAlignedPairsUsingAnchors");
+    free(anchors);
+    stList *l = list_of(tr, cnt);
+    cpecan_free(tr);
+    return l;
+}
+void getAlignedPairsWithIndelsUsingAnchors(StateMachine *sM, const char *sX, const char *sY, stList *anchorPairs,
+                                           PairwiseAlignmentParameters *p, stList **alignedPairs, stList **gapXPairs,
+                                           stList **gapYPairs, bool raggedLeft, bool raggedRight) {
+    cpecan_params q;
+    flatten_params(p, &q);
+    int64_t n, c0 = 0, c1 = 0, c2 = 0;
+    int64_t *anchors = flatten_anchors(anchorPairs, &n);
+    int32_t *t0 = NULL, *t1 = NULL, *t2 = NULL;
+    check(cpecan_get_aligned_pairs_with_indels_using_anchors(flat_or_die(sM), sX, sY, anchors, n, &q, raggedLeft, raggedRight,
+                                                             &t0, &c0, &t1, &c1, &t2, &c2),
+          "getAlignedPairsWithIndelsUsingAnchors");
+    free(anchors);
+    *alignedPairs = list_of(t0, c0);
+    *gapXPairs = list_of(t1, c1);
+    *gapYPairs = list_of(t2, c2);
+    cpecan_free(t0);
+    cpecan_free(t1);
+    cpecan_free(t2);
+}
+void getExpectationsUsingAnchors(StateMachine *sM, Hmm *hmmExpectations, const char *sX, const char *sY, stList *anchorPairs,
+                                 PairwiseAlignmentParameters *p, bool raggedLeft, bool raggedRight) {
+    cpecan_params q;
+    flatten_params(p, &q);
+    int64_t n;
+    int64_t *anchors = flatten_anchors(anchorPairs, &n);
+    cpecan_batch *b = NULL;
+    check(cpecan_batch_create(&b, flat_or_die(sM), &q, CPECAN_EMIT_EXPECT, 0), "cpecan_batch_create");
+    if (cpecan_batch_add(b, sX, (int64_t)strlen(sX), sY, (int64_t)strlen(sY), anchors, n, raggedLeft, raggedRight) < 0)
+        die("cpecan_hip: invalid anchors");
+    check(cpecan_batch_upload(b), "cpecan_batch_upload");
+    check(cpecan_batch_run(b, NULL), "cpecan_batch_run");
+    check(cpecan_batch_download(b), "cpecan_batch_download");
+    cpecan_hmm acc;
+    to_flat(hmmExpectations, &acc);
+    check(cpecan_batch_expectations(b, &acc), "cpecan_batch_expectations");
+    from_flat(&acc, hmmExpectations);
+    cpecan_batch_destroy(b);
+    free(anchors);
+}
+double computeForwardProbability(char *seqX, char *seqY, stList *anchorPairs, PairwiseAlignmentParameters *p, StateMachine *sM,
+                                 bool raggedLeft, bool raggedRight) {
+    cpecan_params q;
+    flatten_params(p, &q);
+    int64_t n;
+    int64_t *anchors = flatten_anchors(anchorPairs, &n);
+    double lp = 0.0;
+    check(cpecan_compute_forward_probability(flat_or_die(sM), seqX, seqY, anchors, n, &q, raggedLeft, raggedRight, &lp),
+          "computeForwardProbability");
+    free(anchors);
+    return lp;
+}
+
+/* ---------------- geometry: impl/pairwiseAligner.c:30-78, 183-277, 1230 ---------------- */
+int64_t diagonal_getXay(Diagonal d) { return d.xay; }
+int64_t diagonal_getMinXmy(Diagonal d) { return d.xmyL; }
+int64_t diagonal_getMaxXmy(Diagonal d) { return d.xmyR; }
+int64_t diagonal_getWidth(Diagonal d) { return (d.xmyR - d.xmyL) / 2 + 1; }
+int64_t diagonal_getXCoordinate(int64_t xay, int64_t xmy) { return (xay + xmy) / 2; }
+int64_t diagonal_getYCoordinate(int64_t xay, int64_t xmy) { return (xay - xmy) / 2; }
+int64_t diagonal_equals(Diagonal p, Diagonal q) { return p.xay == q.xay && p.xmyL == q.xmyL && p.xmyR == q.xmyR; }
+
+struct _band {
+    Diagonal *diagonals;
+    int64_t lXalY;
+};
+Band *band_construct(stList *anchorPairs, int64_t lX, int64_t lY, int64_t expansion) {
+    int64_t n;
+    int64_t *anchors = flatten_anchors(anchorPairs, &n);
+    int64_t *flat = malloc(sizeof(int64_t) * 3 * (size_t)(lX + lY + 1));
+    check(cpecan_band(anchors, n, lX, lY, expansion, 0, flat), "band_construct");
+    Band *b = malloc(sizeof *b);
+    b->lXalY = lX + lY;
+    b->diagonals = malloc(sizeof(Diagonal) * (size_t)(lX + lY + 1));
+    for (int64_t d = 0; d <= lX + lY; d++) {
+        b->diagonals[d].xay = flat[3 * d];
+        b->diagonals[d].xmyL = flat[3 * d + 1];
+        b->diagonals[d].xmyR = flat[3 * d + 2];
+    }
+    free(flat);
+    free(anchors);
+    return b;
+}
+void band_destruct(Band *b) {
+    free(b->diagonals);
+    free(b);
+}
+struct _bandIterator {
+    Band *band;
+    int64_t index;
+};
+BandIterator *bandIterator_construct(Band *band) {
+    BandIterator *it = malloc(sizeof *it);
+    it->band = band;
+    it->index = 0;
+    return it;
+}
+BandIterator *bandIterator_clone(BandIterator *it) {
+    BandIterator *c2 = malloc(sizeof *c2);
+    *c2 = *it;
+    return c2;
+}
+void bandIterator_destruct(BandIterator *it) { free(it); }
+Diagonal bandIterator_getNext(BandIterator *it) { /* saturates at the last diagonal, :263-270 */
+    Diagonal d = it->band->diagonals[it->index > it->band->lXalY ? it->band->lXalY : it->index];
+    if (it->index <= it->band->lXalY) it->index++;
+    return d;
+}
+Diagonal bandIterator_getPrevious(BandIterator *it) { /* saturates at the first, :272-277 */
+    if (it->index > 0) it->index--;
+    return it->band->diagonals[it->index];
+}
+Symbol symbol_convertCharToSymbol(char i) {
+    switch (i) {
+    case 'A': case 'a': return a;
+    case 'C': case 'c': return c;
+    case 'G': case 'g': return g;
+    case 'T': case 't': return t;
+    default: return n;
+    }
+}
+char symbol_convertSymbolToChar(Symbol i) {
+    static const char k[] = "ACGTN";
+    return (i >= a && i <= t) ? k[i] : 'N';
+}
+stList *getSplitPoints(stList *anchorPairs, int64_t lX, int64_t lY, int64_t maxMatrixSize, bool raggedLeft, bool raggedRight) {
+    int64_t n;
+    int64_t *anchors = flatten_anchors(anchorPairs, &n);
+    int64_t *out = malloc(sizeof(int64_t) * 4 * (size_t)(n + 2));
+    int64_t cnt = cpecan_split_points(anchors, n, lX, lY, maxMatrixSize, raggedLeft, raggedRight, out);
+    if (cnt < 0) die("cpecan_hip: invalid anchors for getSplitPoints");
+    stList *l = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    for (int64_t i = 0; i < cnt; i++) stList_append(l, tuple4(out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]));
+    free(out);
+    free(anchors);
+    return l;
+}

@@ -1,0 +1,160 @@
+/*
+ * cpecan_dropin.h -- the reference's own symbol names for the hot path, layered on include/cpecan_hip.h.
+ *
+ * A C caller of cPecan (impl/multipleAligner.c:660, cPecanAlign.c:123, cPecanRealign.c:532,537) can include this
+ * header instead of inc/pairwiseAligner.h + inc/stateMachine.h and link libcpecan_hip.so: same names, same argument
+ * meaning, same struct layouts for the types callers touch.
+ *
+ *   struct _stateMachine      inc/stateMachine.h:37-55      (vtable layout kept; see cellCalculate note below)
+ *   Hmm                       inc/stateMachine.h:61-67
+ *   PairwiseAlignmentParameters inc/pairwiseAligner.h:28-41
+ *   Diagonal                  inc/pairwiseAligner.h:116-120
+ *
+ * sonLib: the reference takes stList / stIntTuple from sonLib, which is not vendored.  This library carries a
+ * minimal implementation of exactly the container calls the API needs, exported as WEAK symbols so that a real
+ * sonLib linked into the same program takes precedence.
+ *
+ * Not provided (out of the hot path): getAlignedPairs / getExpectations without anchors (they
+ * shell out to lastz, impl/pairwiseAligner.c:1032-1042), MEA / reweighting helpers, DpMatrix/DpDiagonal primitives.
+ * sM->cellCalculate is a stub that aborts: per-cell recurrences are evaluated on the GPU only.
+ */
+#ifndef CPECAN_DROPIN_H_
+#define CPECAN_DROPIN_H_
+
+#include <stdbool.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "cpecan_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- minimal sonLib subset (weak) ---- */
+typedef struct _stList stList;
+typedef struct _stIntTuple stIntTuple;
+stList *stList_construct(void);
+stList *stList_construct3(int64_t size, void (*destructElement)(void *));
+void stList_destruct(stList *list);
+int64_t stList_length(stList *list);
+void *stList_get(stList *list, int64_t index);
+void stList_append(stList *list, void *item);
+stIntTuple *stIntTuple_construct2(int64_t a, int64_t b);
+stIntTuple *stIntTuple_construct3(int64_t a, int64_t b, int64_t c);
+void stIntTuple_destruct(stIntTuple *t);
+int64_t stIntTuple_get(stIntTuple *t, int64_t index);
+int64_t stIntTuple_length(stIntTuple *t);
+
+/* ---- inc/stateMachine.h ---- */
+#define SYMBOL_NUMBER 5
+#define SYMBOL_NUMBER_NO_N 4
+typedef enum { a = 0, c = 1, g = 2, t = 3, n = 4 } Symbol;
+typedef enum { fiveState = 0, fiveStateAsymmetric = 1, threeState = 2, threeStateAsymmetric = 3 } StateMachineType;
+
+typedef struct _stateMachine StateMachine;
+struct _stateMachine {
+    StateMachineType type;
+    int64_t stateNumber;
+    int64_t matchState;
+    int64_t gapXState;
+    int64_t gapYState;
+    double (*startStateProb)(StateMachine *sM, int64_t state);
+    double (*endStateProb)(StateMachine *sM, int64_t state);
+    double (*raggedEndStateProb)(StateMachine *sM, int64_t state);
+    double (*raggedStartStateProb)(StateMachine *sM, int64_t state);
+    void (*cellCalculate)(StateMachine *sM, double *current, double *lower, double *middle, double *upper, Symbol cX,
+                          Symbol cY, void (*doTransition)(double *, double *, int64_t, int64_t, double, double, void *),
+                          void *extraArgs);
+};
+
+typedef struct _hmm {
+    StateMachineType type;
+    double *transitions;
+    double *emissions;
+    double likelihood;
+    int64_t stateNumber;
+} Hmm;
+
+Hmm *hmm_constructEmpty(double pseudoExpectation, StateMachineType type);
+void hmm_destruct(Hmm *hmm);
+void hmm_write(Hmm *hmm, FILE *fileHandle);
+void hmm_addToTransitionExpectation(Hmm *hmm, int64_t from, int64_t to, double p);
+double hmm_getTransition(Hmm *hmm, int64_t from, int64_t to);
+void hmm_setTransition(Hmm *hmm, int64_t from, int64_t to, double p);
+void hmm_addToEmissionsExpectation(Hmm *hmm, int64_t state, Symbol x, Symbol y, double p);
+double hmm_getEmissionsExpectation(Hmm *hmm, int64_t state, Symbol x, Symbol y);
+void hmm_setEmissionsExpectation(Hmm *hmm, int64_t state, Symbol x, Symbol y, double p);
+Hmm *hmm_loadFromFile(const char *fileName);
+void hmm_normalise(Hmm *hmm);
+StateMachine *hmm_getStateMachine(Hmm *hmm);
+StateMachine *stateMachine5_construct(StateMachineType type);
+StateMachine *stateMachine3_construct(StateMachineType type);
+void stateMachine_destruct(StateMachine *stateMachine);
+/* the flattened parameters behind a StateMachine built by this library (NULL for a foreign vtable) */
+const cpecan_model *stateMachine_flat(StateMachine *sM);
+
+/* ---- inc/pairwiseAligner.h ---- */
+#define PAIR_ALIGNMENT_PROB_1 10000000
+typedef struct _pairwiseAlignmentBandingParameters {
+    double threshold;
+    int64_t minDiagsBetweenTraceBack;
+    int64_t traceBackDiagonals;
+    int64_t diagonalExpansion;
+    int64_t constraintDiagonalTrim;
+    int64_t anchorMatrixBiggerThanThis;
+    int64_t repeatMaskMatrixBiggerThanThis;
+    int64_t splitMatrixBiggerThanThis;
+    bool alignAmbiguityCharacters;
+    float gapGamma;
+    bool dynamicAnchorExpansion;
+} PairwiseAlignmentParameters;
+
+PairwiseAlignmentParameters *pairwiseAlignmentBandingParameters_construct(void);
+void pairwiseAlignmentBandingParameters_destruct(PairwiseAlignmentParameters *p);
+
+stList *getAlignedPairsUsingAnchors(StateMachine *sM, const char *sX, const char *sY, stList *anchorPairs,
+                                    PairwiseAlignmentParameters *p, bool alignmentHasRaggedLeftEnd,
+                                    bool alignmentHasRaggedRightEnd);
+void getAlignedPairsWithIndelsUsingAnchors(StateMachine *sM, const char *sX, const char *sY, stList *anchorPairs,
+                                           PairwiseAlignmentParameters *p, stList **alignedPairs, stList **gapXPairs,
+                                           stList **gapYPairs, bool alignmentHasRaggedLeftEnd,
+                                           bool alignmentHasRaggedRightEnd);
+void getExpectationsUsingAnchors(StateMachine *sM, Hmm *hmmExpectations, const char *sX, const char *sY,
+                                 stList *anchorPairs, PairwiseAlignmentParameters *p, bool alignmentHasRaggedLeftEnd,
+                                 bool alignmentHasRaggedRightEnd);
+double computeForwardProbability(char *seqX, char *seqY, stList *anchorPairs, PairwiseAlignmentParameters *p,
+                                 StateMachine *sM, bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
+
+typedef struct _diagonal {
+    int64_t xay;
+    int64_t xmyL;
+    int64_t xmyR;
+} Diagonal;
+int64_t diagonal_getXay(Diagonal diagonal);
+int64_t diagonal_getMinXmy(Diagonal diagonal);
+int64_t diagonal_getMaxXmy(Diagonal diagonal);
+int64_t diagonal_getWidth(Diagonal diagonal);
+int64_t diagonal_getXCoordinate(int64_t xay, int64_t xmy);
+int64_t diagonal_getYCoordinate(int64_t xay, int64_t xmy);
+int64_t diagonal_equals(Diagonal diagonal1, Diagonal diagonal2);
+
+typedef struct _band Band;
+Band *band_construct(stList *anchorPairs, int64_t lX, int64_t lY, int64_t expansion);
+void band_destruct(Band *band);
+typedef struct _bandIterator BandIterator;
+BandIterator *bandIterator_construct(Band *band);
+void bandIterator_destruct(BandIterator *bandIterator);
+BandIterator *bandIterator_clone(BandIterator *bandIterator);
+Diagonal bandIterator_getNext(BandIterator *bandIterator);
+Diagonal bandIterator_getPrevious(BandIterator *bandIterator);
+
+Symbol symbol_convertCharToSymbol(char i);
+char symbol_convertSymbolToChar(Symbol i);
+stList *getSplitPoints(stList *anchorPairs, int64_t lX, int64_t lY, int64_t maxMatrixSize, bool alignmentHasRaggedLeftEnd,
+                       bool alignmentHasRaggedRightEnd);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

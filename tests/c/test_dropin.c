@@ -1,0 +1,166 @@
+/* C-level test of the reference-named drop-in layer (include/cpecan_dropin.h).  Mirrors the fixed-input parts of the
+ * reference's tests/pairwiseAlignerTest.c: test_bands (:69), test_getSplitPoints (:578), test_hmm (:997),
+ * test_symbol (:146), test_diagonalDPCalculations pair set (:242) and the SURVEY 8c known answers.
+ * usage: test_dropin cpu | gpu */
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "cpecan_dropin.h"
+
+static int failures = 0;
+#define CHECK(cond)                                                        \
+    do {                                                                   \
+        if (!(cond)) {                                                     \
+            fprintf(stderr, "FAIL %s:%d: %s\n", __FILE__, __LINE__, #cond); \
+            failures++;                                                    \
+        }                                                                  \
+    } while (0)
+
+static int diag_is(Diagonal d, int64_t xay, int64_t l, int64_t r) { return d.xay == xay && d.xmyL == l && d.xmyR == r; }
+
+static void test_bands(void) {
+    stList *anchors = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    stList_append(anchors, stIntTuple_construct2(1, 0));
+    stList_append(anchors, stIntTuple_construct2(2, 1));
+    stList_append(anchors, stIntTuple_construct2(3, 3));
+    Band *band = band_construct(anchors, 6, 5, 2);
+    BandIterator *it = bandIterator_construct(band);
+    const int64_t gold[12][3] = {{0, 0, 0}, {1, -1, 1}, {2, -2, 2}, {3, -1, 3}, {4, -2, 4}, {5, -1, 3},
+                                 {6, -2, 4}, {7, -3, 3}, {8, -2, 2}, {9, -1, 3}, {10, 0, 2}, {11, 1, 1}};
+    for (int i = 0; i < 12; i++) CHECK(diag_is(bandIterator_getNext(it), gold[i][0], gold[i][1], gold[i][2]));
+    CHECK(diag_is(bandIterator_getNext(it), 11, 1, 1)); /* saturates */
+    for (int i = 11; i >= 0; i--) CHECK(diag_is(bandIterator_getPrevious(it), gold[i][0], gold[i][1], gold[i][2]));
+    CHECK(diag_is(bandIterator_getPrevious(it), 0, 0, 0));
+    bandIterator_destruct(it);
+    band_destruct(band);
+    stList_destruct(anchors);
+}
+
+static int rect_is(stList *l, int64_t i, int64_t x1, int64_t y1, int64_t x2, int64_t y2) {
+    stIntTuple *t4 = stList_get(l, i);
+    return stIntTuple_get(t4, 0) == x1 && stIntTuple_get(t4, 1) == y1 && stIntTuple_get(t4, 2) == x2 && stIntTuple_get(t4, 3) == y2;
+}
+
+static void test_split_points(void) {
+    const int64_t size = 2000 * 2000;
+    stList *anchors = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    stList *s = getSplitPoints(anchors, 3000, 1000, size, 0, 0);
+    CHECK(stList_length(s) == 1 && rect_is(s, 0, 0, 0, 3000, 1000));
+    stList_destruct(s);
+    s = getSplitPoints(anchors, 20000, 25000, size, 1, 1);
+    CHECK(stList_length(s) == 0);
+    stList_destruct(s);
+    s = getSplitPoints(anchors, 20000, 25000, size, 0, 0);
+    CHECK(stList_length(s) == 2 && rect_is(s, 0, 0, 0, 2000, 2000) && rect_is(s, 1, 18000, 23000, 20000, 25000));
+    stList_destruct(s);
+    const int64_t pts[8][2] = {{2000, 2000}, {4002, 4001}, {5000, 5000}, {8000, 6000}, {9000, 9000}, {10000, 14000}, {15000, 15000}, {16000, 16000}};
+    for (int i = 0; i < 8; i++) stList_append(anchors, stIntTuple_construct2(pts[i][0], pts[i][1]));
+    s = getSplitPoints(anchors, 20000, 25000, size, 0, 0);
+    CHECK(stList_length(s) == 5);
+    CHECK(rect_is(s, 0, 0, 0, 3001, 3001) && rect_is(s, 1, 3002, 3001, 9500, 11001) && rect_is(s, 2, 9501, 12000, 12001, 14500));
+    CHECK(rect_is(s, 3, 13000, 14501, 18000, 18001) && rect_is(s, 4, 18001, 23000, 20000, 25000));
+    stList_destruct(s);
+    stList_destruct(anchors);
+}
+
+static void test_hmm(StateMachineType type) {
+    Hmm *h = hmm_constructEmpty(0.0, type);
+    const int64_t S = h->stateNumber;
+    for (int64_t f = 0; f < S; f++)
+        for (int64_t to = 0; to < S; to++) hmm_addToTransitionExpectation(h, f, to, (double)(f * S + to));
+    for (int64_t s = 0; s < S; s++)
+        for (int x = 0; x < 4; x++)
+            for (int y = 0; y < 4; y++) hmm_addToEmissionsExpectation(h, s, (Symbol)x, (Symbol)y, (double)(s * 16 + x * 4 + y));
+    const char *path = "./cpecan_dropin_test.hmm";
+    FILE *fh = fopen(path, "w");
+    hmm_write(h, fh);
+    fclose(fh);
+    hmm_destruct(h);
+    h = hmm_loadFromFile(path);
+    remove(path);
+    CHECK(h->type == type && h->stateNumber == S);
+    for (int64_t f = 0; f < S; f++)
+        for (int64_t to = 0; to < S; to++) CHECK(hmm_getTransition(h, f, to) == (double)(f * S + to));
+    hmm_normalise(h);
+    for (int64_t f = 0; f < S; f++) {
+        const double z = (double)(f * S * S + (S * (S - 1)) / 2);
+        for (int64_t to = 0; to < S; to++) CHECK(hmm_getTransition(h, f, to) == (double)(f * S + to) / z);
+    }
+    hmm_destruct(h);
+}
+
+static void test_symbols(void) {
+    const char *s = "AcGTntNCG";
+    const Symbol want[9] = {a, c, g, t, n, t, n, c, g};
+    for (int i = 0; i < 9; i++) CHECK(symbol_convertCharToSymbol(s[i]) == want[i]);
+    CHECK(symbol_convertSymbolToChar(g) == 'G' && symbol_convertSymbolToChar(n) == 'N');
+}
+
+static void test_models(void) {
+    StateMachine *sM = stateMachine5_construct(fiveState);
+    CHECK(sM->stateNumber == 5 && sM->matchState == 0 && sM->gapXState == 1 && sM->gapYState == 2);
+    CHECK(sM->startStateProb(sM, 0) == 0.0 && isinf(sM->startStateProb(sM, 1)));
+    CHECK(sM->endStateProb(sM, 0) == -0.030064059121770816 && sM->endStateProb(sM, 3) == -5.673280173170473);
+    CHECK(sM->raggedStartStateProb(sM, 3) == 0.0 && isinf(sM->raggedStartStateProb(sM, 0)));
+    CHECK(sM->raggedEndStateProb(sM, 4) == -0.003442492794189331);
+    stateMachine_destruct(sM);
+    sM = stateMachine3_construct(threeState);
+    CHECK(sM->stateNumber == 3 && sM->raggedEndStateProb(sM, 0) == (-4.21256642 + -4.21256642) / 2.0);
+    stateMachine_destruct(sM);
+    PairwiseAlignmentParameters *p = pairwiseAlignmentBandingParameters_construct();
+    CHECK(p->threshold == 0.01 && p->minDiagsBetweenTraceBack == 1000 && p->traceBackDiagonals == 40 &&
+          p->diagonalExpansion == 20 && p->splitMatrixBiggerThanThis == 9000000 && p->gapGamma == 0.5f);
+    pairwiseAlignmentBandingParameters_destruct(p);
+}
+
+static void test_known_answers_gpu(void) {
+    StateMachine *sM5 = stateMachine5_construct(fiveState), *sM3 = stateMachine3_construct(threeState);
+    PairwiseAlignmentParameters *p = pairwiseAlignmentBandingParameters_construct();
+    stList *anchors = stList_construct();
+    p->threshold = 0.2;
+    stList *pairs = getAlignedPairsUsingAnchors(sM5, "AGCG", "AGTTCG", anchors, p, 0, 0);
+    const int64_t gold[4][3] = {{9944673, 0, 0}, {9259684, 1, 1}, {8665179, 2, 4}, {9893294, 3, 5}};
+    CHECK(stList_length(pairs) == 4);
+    for (int i = 0; i < 4 && i < stList_length(pairs); i++) {
+        stIntTuple *tp = stList_get(pairs, i);
+        CHECK(stIntTuple_get(tp, 0) == gold[i][0] && stIntTuple_get(tp, 1) == gold[i][1] && stIntTuple_get(tp, 2) == gold[i][2]);
+    }
+    stList_destruct(pairs);
+    p->threshold = 0.01;
+    char sx[] = "AGCG", sy[] = "AGTTCG";
+    CHECK(fabs(computeForwardProbability(sx, sy, anchors, p, sM5, 0, 0) + 17.519321161239) < 1e-11);
+    CHECK(fabs(computeForwardProbability(sx, sy, anchors, p, sM3, 0, 0) + 17.381039440328) < 1e-11);
+    CHECK(fabs(computeForwardProbability(sx, sy, anchors, p, sM3, 1, 1) + 20.651524037167) < 1e-11);
+    Hmm *h = hmm_constructEmpty(0.0, fiveState);
+    getExpectationsUsingAnchors(sM5, h, "AGCG", "AGTTCG", anchors, p, 0, 0);
+    CHECK(fabs(h->likelihood + 175.193211612) < 1e-8 && fabs(hmm_getTransition(h, 0, 0) - 3.010391804) < 1e-8);
+    CHECK(fabs(hmm_getTransition(h, 0, 1) - 0.000751913) < 1e-8 && fabs(hmm_getEmissionsExpectation(h, 0, a, a) - 0.994467322) < 1e-8);
+    hmm_destruct(h);
+    stList *m, *gx, *gy;
+    getAlignedPairsWithIndelsUsingAnchors(sM3, "ACGTACGTTTACG", "ACGTCGTTTAACG", anchors, p, &m, &gx, &gy, 0, 0);
+    CHECK(stList_length(m) > 8 && stList_length(gx) > 0 && stList_length(gy) > 0);
+    stList_destruct(m);
+    stList_destruct(gx);
+    stList_destruct(gy);
+    stList_destruct(anchors);
+    pairwiseAlignmentBandingParameters_destruct(p);
+    stateMachine_destruct(sM5);
+    stateMachine_destruct(sM3);
+}
+
+int main(int argc, char **argv) {
+    const int gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
+    test_bands();
+    test_split_points();
+    test_hmm(fiveState);
+    test_hmm(fiveStateAsymmetric);
+    test_hmm(threeState);
+    test_hmm(threeStateAsymmetric);
+    test_symbols();
+    test_models();
+    if (gpu) test_known_answers_gpu();
+    printf("%s: %d failure(s)\n", gpu ? "gpu" : "cpu", failures);
+    return failures != 0;
+}

@@ -24,6 +24,16 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), name
     assert declared == set(api.EXPORTS)
+    # the reference-named layer: every function include/cpecan_dropin.h declares is exported too
+    dropin = open(os.path.join(ROOT, "include", "cpecan_dropin.h")).read()
+    dropin = re.sub(r"/\*.*?\*/", "", dropin, flags=re.S)
+    names = set(re.findall(r"\b([A-Za-z_][A-Za-z_0-9]*)\s*\([^;{]*\)\s*;", dropin))
+    names -= {"void", "double", "sizeof"}
+    names = {n for n in names if not n.startswith("(")}
+    assert {"getAlignedPairsUsingAnchors", "getExpectationsUsingAnchors", "computeForwardProbability",
+            "stateMachine5_construct", "hmm_loadFromFile", "band_construct", "stList_append"} <= names
+    for name in sorted(names):
+        assert hasattr(L, name), name
 
 
 def test_band_golden_and_vs_oracle():
