@@ -605,6 +605,31 @@ struct Sweep {
             c.seeded = seeded;
             c.endPrior = endPrior;
             const float keepFrom = lastMax + logThr - kCandMargin;  // wave-uniform
+            // Refresh diagonals read more of F: the remaining states of F[d2] (cell dot products) and all states of
+            // F[d2-1] at the straddle offset.  Those loads are issued HERE, before the compute loop of the diagonal,
+            // and consumed after it, so their HBM latency hides behind a few thousand cycles of arithmetic
+            // (they used to be loaded and waited for on the spot: ~25 % of the traceback time of a lone wave).
+            double rfC[S][kPrefetch];  // F[d2][s][k], s >= NL   (rows < NL are in fmCur)
+            double rfS[S][kPrefetch];  // F[d2-1][s][k + dmm] for cell k of diagonal d2+1, -inf outside F[d2-1]
+            const bool straddle = refresh && d2 + 1 <= sg.dTop;
+            const int Wn = gb.width, Wp = gnext.width;
+            const int dmm = (gb.xmyL - gnext.xmyL) >> 1;
+            const double *fprev = ringAt(gnext);
+            if (refresh) {
+#pragma unroll
+                for (int q = 0; q < kPrefetch; q++) {
+                    const int k = q * CPK_WAVE + lane;
+#pragma unroll
+                    for (int s2 = NL; s2 < S; s2++) rfC[s2][q] = k < W ? ld_self(fsrc + (size_t)s2 * W + k) : 0.0;
+                    const int kp = k + dmm;
+                    const bool ok = straddle && k < Wn && kp >= 0 && kp < Wp;
+#pragma unroll
+                    for (int s2 = 0; s2 < S; s2++) {
+                        const double val = ok ? ld_self(fprev + (size_t)s2 * Wp + kp) : NEG_INF;
+                        rfS[s2][q] = val;
+                    }
+                }
+            }
             // Wave-uniform loop (the candidate counts must stay identical in every lane): lanes past the end of the
             // diagonal recompute its last cell and have their stores masked.
             int pass = 0;
@@ -632,16 +657,6 @@ struct Sweep {
                         fbv[l] = f0 + v[0][l];
                     }
                     if (on && dbgFb) dbgFb[g.cellOff + k0] = fbv[0];
-                    if (refresh && on) {
-                        // cell_dotProduct over states, pairwiseAligner.c:402-408
-                        double t = fbv[0];
-#pragma unroll
-                        for (int s = 1; s < S; s++) {
-                            const double fs = s < NL ? fbv[s] : ld_self(fsrc + (size_t)s * W + k0) + v[0][s];
-                            t = logadd(lg, t, fs);
-                        }
-                        cbuf[(size_t)k0 * J + jr] = t;
-                    }
                     // candidate filter: a cell survives when it is within log(threshold) - margin of the bound on the
                     // total probability (DESIGN.md "candidate filter").  Match cells need x > 0 and y > 0, gapX cells
                     // x > 0, gapY cells y > 0 (pairwiseAligner.c:680, :719, :725).
@@ -663,57 +678,87 @@ struct Sweep {
                     }
                 }
             }
-            // The bound is renewed on refresh diagonals only (every 10th): max(this diagonal's maximum, old bound - 1).
-            // The reference itself asserts that consecutive totals differ by less than 1.0 (pairwiseAligner.c:834), so
-            // the decayed old bound stays below the current total.  Wave-uniform loop: all lanes join the shuffles.
-            if (refresh && CANDS) {
-                float diagMax = -__builtin_huge_valf();
-                pass = 0;
-                for (int kb = 0; kb < W; kb += CPK_WAVE, pass++) {
-                    const int k = kb + lane;
-                    const int x = xlo + k, y = d2 - x;
-                    float fbf = -__builtin_huge_valf();
-                    if (k < W && x > 0 && y > 0) {
-                        double f0;
-                        if (pass == 0) f0 = fmCur[0][0];
-                        else if (pass == 1) f0 = fmCur[0][1];
-                        else if (pass == 2) f0 = fmCur[0][2];
-                        else f0 = ld_self(fsrc + k);
-                        fbf = (float)(f0 + curM[k + 1]);
-                    }
-                    diagMax = fmaxf(diagMax, wave_max_f32(fbf));
-                }
-                lastMax = fmaxf(diagMax, lastMax - 1.0f);
-            }
             roll_fence<!FAST>();
-            if (refresh && d2 + 1 <= sg.dTop) {
-                // matches straddling d2: middle-block forward step from F[d2-1] into the cells of d2+1, times B[d2+1]
-                // (pairwiseAligner.c:643-651).  Non-match states of the temporary stay -inf and drop out exactly.
-                const int Wn = gb.width, Wp = gnext.width;
-                const int dmm = (gb.xmyL - gnext.xmyL) >> 1;
-                const double *fprev = ringAt(gnext);
-                const double *bn = bM(d2 + 1);
-                const int xlon = (d2 + 1 + gb.xmyL) >> 1;
-                for (int k = lane; k < Wn; k += CPK_WAVE) {
-                    const int x = xlon + k, y = d2 + 1 - x;
-                    const double eM = em[symX(x) * 5 + symY(y)];
-                    const int kp = k + dmm;
-                    const bool ok = kp >= 0 && kp < Wp;
-                    const int kq = ok ? kp : 0;
-                    double f[S];
+            if (refresh) {
+                // (a) cell dot products over states (cell_dotProduct, pairwiseAligner.c:402-408) and, for the candidate
+                //     bound, this diagonal's largest F.m + B.m: renewed every 10th diagonal as
+                //     max(this diagonal's maximum, old bound - 1); the reference itself asserts that consecutive totals
+                //     differ by less than 1.0 (:834), so the decayed bound stays below the current total.
+                float diagMax = -__builtin_huge_valf();
+                auto dotCell = [&](int k, const double (&fRow)[S]) {
+                    double t = fRow[0] + curM[k + 1];
+                    const int x = xlo + k, y = d2 - x;
+                    const float fbf = (x > 0 && y > 0) ? (float)t : -__builtin_huge_valf();
 #pragma unroll
-                    for (int s = 0; s < S; s++) {
-                        const double val = ld_self(fprev + (size_t)s * Wp + kq);
-                        f[s] = ok ? val : NEG_INF;
+                    for (int s2 = 1; s2 < S; s2++) t = logadd(lg, t, fRow[s2] + curG[s2 * stride + k + 1]);
+                    cbuf[(size_t)k * J + jr] = t;
+                    return fbf;
+                };
+#pragma unroll
+                for (int q = 0; q < kPrefetch; q++) {
+                    const int k = q * CPK_WAVE + lane;
+                    float fbf = -__builtin_huge_valf();
+                    if (q * CPK_WAVE < W) {  // wave-uniform
+                        if (k < W) {
+                            double fRow[S];
+#pragma unroll
+                            for (int s2 = 0; s2 < S; s2++) fRow[s2] = s2 < NL ? fmCur[s2][q] : rfC[s2][q];
+                            fbf = dotCell(k, fRow);
+                        }
+                        if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
                     }
-                    double t = f[0] + (eM + m.matchContinue);
-                    t = logadd(lg, t, f[1] + (eM + m.matchFromShortX));
-                    t = logadd(lg, t, f[2] + (eM + m.matchFromShortY));
-                    if (S == 5) {
-                        t = logadd(lg, t, f[3] + (eM + m.matchFromLongX));
-                        t = logadd(lg, t, f[4] + (eM + m.matchFromLongY));
+                }
+                for (int kb = kPrefetch * CPK_WAVE; kb < W; kb += CPK_WAVE) {  // diagonals wider than the prefetch
+                    const int k = kb + lane;
+                    float fbf = -__builtin_huge_valf();
+                    if (k < W) {
+                        double fRow[S];
+#pragma unroll
+                        for (int s2 = 0; s2 < S; s2++) fRow[s2] = ld_self(fsrc + (size_t)s2 * W + k);
+                        fbf = dotCell(k, fRow);
                     }
-                    mbuf[(size_t)k * J + jr] = t + bn[0 * stride + k + 1];
+                    if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
+                }
+                if (CANDS) lastMax = fmaxf(diagMax, lastMax - 1.0f);
+                // (b) matches straddling d2: middle-block forward step from F[d2-1] into the cells of d2+1, times
+                //     B[d2+1] (pairwiseAligner.c:643-651).  Non-match states of the temporary stay -inf and drop out.
+                if (straddle) {
+                    const double *bn = bM(d2 + 1);
+                    const int xlon = (d2 + 1 + gb.xmyL) >> 1;
+                    auto straddleCell = [&](int k, const double (&f)[S]) {
+                        const int x = xlon + k, y = d2 + 1 - x;
+                        const double eM = em[symX(x) * 5 + symY(y)];
+                        double t = f[0] + (eM + m.matchContinue);
+                        t = logadd(lg, t, f[1] + (eM + m.matchFromShortX));
+                        t = logadd(lg, t, f[2] + (eM + m.matchFromShortY));
+                        if (S == 5) {
+                            t = logadd(lg, t, f[3] + (eM + m.matchFromLongX));
+                            t = logadd(lg, t, f[4] + (eM + m.matchFromLongY));
+                        }
+                        mbuf[(size_t)k * J + jr] = t + bn[k + 1];
+                    };
+#pragma unroll
+                    for (int q = 0; q < kPrefetch; q++) {
+                        const int k = q * CPK_WAVE + lane;
+                        if (k < Wn) {
+                            double f[S];
+#pragma unroll
+                            for (int s2 = 0; s2 < S; s2++) f[s2] = rfS[s2][q];
+                            straddleCell(k, f);
+                        }
+                    }
+                    for (int k = kPrefetch * CPK_WAVE + lane; k < Wn; k += CPK_WAVE) {
+                        const int kp = k + dmm;
+                        const bool ok = kp >= 0 && kp < Wp;
+                        const int kq = ok ? kp : 0;
+                        double f[S];
+#pragma unroll
+                        for (int s2 = 0; s2 < S; s2++) {
+                            const double val = ld_self(fprev + (size_t)s2 * Wp + kq);
+                            f[s2] = ok ? val : NEG_INF;
+                        }
+                        straddleCell(k, f);
+                    }
                 }
             }
             // slide the window of table entries and prefetched F rows down one diagonal
