@@ -549,47 +549,33 @@ struct Sweep {
         float lastMax = -__builtin_huge_valf();
         CpkDiag gb{}, ga{};  // table entries of d2+1 and d2+2
         CpkDiag g = dc.get(sg.dTop, true);
-        // F rows of the emitted states for the first emitted diagonal, prefetched (list l emits state l)
-        double fmCur[NL][kPrefetch];
-#pragma unroll
-        for (int l = 0; l < NL; l++)
-#pragma unroll
-            for (int q = 0; q < kPrefetch; q++) fmCur[l][q] = 0.0;
-        if (sg.dTop <= sg.tbFrom) {
-            const double *src = ringAt(g);
+        CpkDiag gnext = sg.dTop >= 1 ? dc.get(sg.dTop - 1, true) : CpkDiag{};  // entry of d2-1
+        // F rows of the emitted states (list l emits state l), prefetched TWO diagonals ahead of their use: one
+        // diagonal of arithmetic (~1.3 us) is shorter than a loaded HBM round trip.
+        double fmCur[NL][kPrefetch], fmNext[NL][kPrefetch];
+        auto emitted = [&](int d) { return d > sg.tbPrev && d <= sg.tbFrom; };
+        auto loadRows = [&](const CpkDiag &gd, bool want, double (&dst)[NL][kPrefetch]) {
+            const double *src = ringAt(gd);
 #pragma unroll
             for (int l = 0; l < NL; l++)
 #pragma unroll
                 for (int q = 0; q < kPrefetch; q++) {
                     const int k = q * CPK_WAVE + lane;
-                    fmCur[l][q] = k < g.width ? ld_self(src + (size_t)l * g.width + k) : 0.0;
+                    dst[l][q] = (want && k < gd.width) ? ld_self(src + (size_t)l * gd.width + k) : 0.0;
                 }
-        }
+        };
+        loadRows(g, emitted(sg.dTop), fmCur);
+        loadRows(gnext, emitted(sg.dTop - 1), fmNext);
         for (int d2 = sg.dTop; d2 > sg.tbPrev; d2--) {
             const bool seeded = d2 == sg.dTop;
             const int W = g.width;
             const bool emit = d2 <= sg.tbFrom;
             const bool refresh = emit && ((sg.tbFrom - d2) % CPK_REFRESH_PERIOD == 0);
             const int jr = (sg.tbFrom - d2) / CPK_REFRESH_PERIOD;
-            // prefetch the F rows of the next diagonal down while this one is computed
-            CpkDiag gnext{};
-            double fmNext[NL][kPrefetch];
-#pragma unroll
-            for (int l = 0; l < NL; l++)
-#pragma unroll
-                for (int q = 0; q < kPrefetch; q++) fmNext[l][q] = 0.0;
-            const bool nextEmit = d2 - 1 > sg.tbPrev && d2 - 1 <= sg.tbFrom;
-            if (d2 - 1 >= 0) gnext = dc.get(d2 - 1, true);
-            if (nextEmit) {
-                const double *src = ringAt(gnext);
-#pragma unroll
-                for (int l = 0; l < NL; l++)
-#pragma unroll
-                    for (int q = 0; q < kPrefetch; q++) {
-                        const int k = q * CPK_WAVE + lane;
-                        fmNext[l][q] = k < gnext.width ? ld_self(src + (size_t)l * gnext.width + k) : 0.0;
-                    }
-            }
+            // issue the loads for diagonal d2-2 now
+            const CpkDiag gnext2 = d2 >= 2 ? dc.get(d2 - 2, true) : CpkDiag{};
+            double fmNext2[NL][kPrefetch];
+            loadRows(gnext2, d2 >= 2 && emitted(d2 - 2), fmNext2);
             double *curM = bM(d2), *curG = bG(d2);
             const double *fsrc = ringAt(g);
             const int xlo = (d2 + g.xmyL) >> 1;
@@ -765,10 +751,14 @@ struct Sweep {
             ga = gb;
             gb = g;
             g = gnext;
+            gnext = gnext2;
 #pragma unroll
             for (int l = 0; l < NL; l++)
 #pragma unroll
-                for (int q = 0; q < kPrefetch; q++) fmCur[l][q] = fmNext[l][q];
+                for (int q = 0; q < kPrefetch; q++) {
+                    fmCur[l][q] = fmNext[l][q];
+                    fmNext[l][q] = fmNext2[l][q];
+                }
         }
     }
 
@@ -894,11 +884,21 @@ struct Sweep {
             const int Wm = (on && r + 1 <= sg.dTop) ? table[r + 1].width : 0;
             double total = NEG_INF, straddle = NEG_INF;
             const int WcMax = wave_max_i32(Wc), WmMax = wave_max_i32(Wm);
-            for (int k = 0; k < WcMax; k++) {
-                if (k < Wc) total = logadd(lg, total, ld_self(cbuf + (size_t)k * J + j));
+            // loads are issued eight at a time, then folded in order; padding with -inf leaves the fold unchanged
+            // because logAdd(x, -inf) returns x exactly
+            for (int k = 0; k < WcMax; k += 8) {
+                double x[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = k + i < Wc ? ld_self(cbuf + (size_t)(k + i) * J + j) : NEG_INF;
+#pragma unroll
+                for (int i = 0; i < 8; i++) total = logadd(lg, total, x[i]);
             }
-            for (int k = 0; k < WmMax; k++) {
-                if (k < Wm) straddle = logadd(lg, straddle, ld_self(mbuf + (size_t)k * J + j));
+            for (int k = 0; k < WmMax; k += 8) {
+                double x[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) x[i] = k + i < Wm ? ld_self(mbuf + (size_t)(k + i) * J + j) : NEG_INF;
+#pragma unroll
+                for (int i = 0; i < 8; i++) straddle = logadd(lg, straddle, x[i]);
             }
             if (on) {
                 if (r + 1 <= sg.dTop) total = logadd(lg, total, straddle);
