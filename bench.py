@@ -176,8 +176,8 @@ def main():
             "e2e": {"upload_s": upload_s, "download_and_assemble_s": d2h_s, "pairs_emitted": int(st.pairs),
                     "device_bytes": int(st.deviceBytes), "waves": int(st.wavesPerLaunch)},
         }
-        if not args.no_cpu_baseline:
-            # the GPU box gives one GPU a 16-core share of its host CPUs; do not oversubscribe it
+        if not args.no_cpu_baseline and world == 1:
+            # (rank 0, N=1 only) the GPU box gives one GPU a 16-core share of its host CPUs; do not oversubscribe it
             threads = int(os.environ.get("CPECAN_BENCH_CPU_THREADS", min(os.cpu_count() or 1, 16)))
             sample = problems[:min(len(problems), 64 * threads)]
             v, ccells, dt = cpu_baseline(cfg, sample, threads)

@@ -69,9 +69,23 @@ def make_batch(seed, n_pairs, length, expansion, first=0, **kw):
     return [make_pair(seed, first + i, length, expansion, **kw) for i in range(n_pairs)]
 
 
+def make_realign_batch(seed, n_pairs, min_len=100, max_len=5000, expansion=4, first=0):
+    """BASELINE config 4 (cPecanRealign mode): lengths log-uniform in [min_len, max_len]; anchors = every
+    aligned column of the true alignment whose bases are equal (cPecanRealign.c:525-529 keeps exact matches only)."""
+    out = []
+    for i in range(n_pairs):
+        u = _unit(splitmix64(seed ^ 0xC0FFEE, [first + i]))[0]
+        length = int(round(np.exp(np.log(min_len) + u * (np.log(max_len) - np.log(min_len)))))
+        out.append(make_pair(seed, first + i, length, expansion, anchor_every=1))
+    return out
+
+
 # The BASELINE.json configs this repo measures (SURVEY.md section 8d).
 CONFIGS = {
     "plumbing": dict(seed=1, n_pairs=1, length=200, expansion=0, model="fiveState", anchors=False),
     "A": dict(seed=2, n_pairs=1000, length=1000, expansion=50, model="threeState", anchors=True),
     "B": dict(seed=3, n_pairs=10000, length=2000, expansion=100, model="fiveState", anchors=True),
+    # configs 4 and 5 of BASELINE.json are parity / multi-GPU cases, not bench lines (see tests/test_gpu_parity.py):
+    #  4: make_realign_batch(seed=4, 50000 pairs, 100-5000 bp, expansion 4), ragged ends, splitMatrixBiggerThanThis=10
+    #  5: make_batch(seed=5, 100000 pairs, 1000 bp, expansion 10), expectation emitter + all-reduce of the counts
 }

@@ -356,3 +356,34 @@ def test_expectation_step_helper_single_rank():
     for sx, sy, a in problems:
         ob.expectations(ob.model(0), oacc, sx, sy, a, ob.params(diagonalExpansion=10), True, True)
     _assert_hmm_close(acc, oacc, 5)
+
+
+# ---- BASELINE configs 4 and 5 on samples ----
+
+def test_config4_realign_sample_mixed_lengths_split_regions():
+    """configs[3]: cPecanRealign mode -- mixed lengths, anchors on every exact-match column, diagonalExpansion 4,
+    splitMatrixBiggerThanThis 10, ragged ends (cPecanRealign.c:355-357, 537).  40-pair sample vs the oracle."""
+    from cpecan_amd.workload import make_realign_batch
+    problems = make_realign_batch(4, 40, 100, 3000, 4)
+    kw = dict(diagonalExpansion=4, splitMatrixBiggerThanThis=10)
+    worst, st = _check_batch(0, problems, [(True, True)] * len(problems), **kw)
+    assert st.regions >= len(problems)  # anchor gaps whose matrix exceeds 10 cells open extra regions
+
+
+def test_config5_expectation_sample_band10():
+    """configs[4]: EM expectation step, 1 kb pairs, diagonalExpansion 10; 48-pair sample vs the oracle."""
+    problems = make_batch(5, 48, 1000, 10)
+    kw = dict(diagonalExpansion=10)
+    acc = api.hmm_constructEmpty(1e-12, api.fiveState)
+    with api.Batch(api.stateMachine5_construct(), api.pairwiseAlignmentBandingParameters_construct(**kw),
+                   emit=api.EMIT_EXPECT) as b:
+        for sx, sy, a in problems:
+            b.add(sx, sy, a, True, True)
+        b.upload()
+        b.run()
+        b.download()
+        b.expectations(acc)
+    oacc = ob.hmm(ob.FIVE_STATE, 1e-12)
+    for sx, sy, a in problems:
+        ob.expectations(ob.model(0), oacc, sx, sy, a, ob.params(**kw), True, True)
+    _assert_hmm_close(acc, oacc, 5)
