@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcpecan_hip.so")
+LIB_PATH = os.environ.get("CPECAN_LIB") or os.path.join(_HERE, "libcpecan_hip.so")  # CPECAN_LIB: A/B builds of the same ABI (tools/)
 
 fiveState, fiveStateAsymmetric, threeState, threeStateAsymmetric = 0, 1, 2, 3  # inc/stateMachine.h:28-33
 EMIT_MATCH, EMIT_INDEL, EMIT_EXPECT, EMIT_FORWARD = 0, 1, 2, 3

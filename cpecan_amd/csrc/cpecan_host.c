@@ -641,58 +641,84 @@ int cpecan_batch_upload(cpecan_batch *b) {
     const int S = is_five(b->model.type) ? 5 : 3;
     int rc = CPECAN_OK;
 
-    /* pass 1: bands -> per-region cell counts, total diagonals */
-    int64_t totalDiags = 0;
-    for (int64_t i = 0; i < b->nRegions; i++) totalDiags += b->regions[i].lX + b->regions[i].lY + 1;
-    CpkDiag *diags = malloc(sizeof(CpkDiag) * (size_t)totalDiags);
+    /* pass 1: bands -> per-region cell counts.  Regions are independent: one OpenMP task each. */
+    int64_t totalDiags = 0, maxN = 0;
+    CpkDiag *diags = NULL;
     int64_t *diagStart = malloc(sizeof(int64_t) * (size_t)b->nRegions);
     CostKey *keys = malloc(sizeof(CostKey) * (size_t)b->nRegions);
-    int64_t maxN = 0;
-    for (int64_t i = 0; i < b->nRegions; i++) maxN = imax(maxN, b->regions[i].lX + b->regions[i].lY);
-    int64_t *lo = malloc(sizeof(int64_t) * (size_t)(maxN + 1) * 2), *hi = lo ? lo + maxN + 1 : NULL;
-    if (!diags || !diagStart || !keys || !lo) {
+    int32_t *segCount = malloc(sizeof(int32_t) * (size_t)b->nRegions);
+    CpkSegment *segs = NULL;
+    int64_t nSegs = 0;
+    if (!diagStart || !keys || !segCount) {
         rc = CPECAN_ENOMEM;
         goto fail1;
     }
+    for (int64_t i = 0; i < b->nRegions; i++) {
+        const int64_t N = b->regions[i].lX + b->regions[i].lY;
+        diagStart[i] = totalDiags;
+        totalDiags += N + 1;
+        maxN = imax(maxN, N);
+    }
+    diags = malloc(sizeof(CpkDiag) * (size_t)totalDiags);
+    if (!diags) {
+        rc = CPECAN_ENOMEM;
+        goto fail1;
+    }
+    int64_t badRegion = -1;
+#pragma omp parallel
     {
-        int64_t at = 0;
+        int64_t *lo = malloc(sizeof(int64_t) * (size_t)(maxN + 1) * 2), *hi = lo ? lo + maxN + 1 : NULL;
+        if (!lo) {
+#pragma omp critical(cpk_plan)
+            rc = CPECAN_ENOMEM;
+        }
+#pragma omp for schedule(dynamic, 16)
         for (int64_t i = 0; i < b->nRegions; i++) {
             HostRegion *r = &b->regions[i];
             const int64_t N = r->lX + r->lY;
+            keys[i].cells = 0;
+            keys[i].index = i;
+            if (!lo) continue;
             /* the forward-probability path always uses the static band (pairwiseAligner.c:894) */
-            rc = build_band(b->anchors + 3 * r->anchorOff, r->nAnchors, r->lX, r->lY, p->diagonalExpansion,
-                            b->emit == CPECAN_EMIT_FORWARD ? 0 : p->dynamicAnchorExpansion, lo, hi);
-            if (rc != CPECAN_OK) {
-                cpk_set_error("region %lld of problem %lld: anchors do not define a valid band", (long long)i,
-                              (long long)r->problem);
-                goto fail1;
-            }
-            diagStart[i] = at;
+            int rcBand = build_band(b->anchors + 3 * r->anchorOff, r->nAnchors, r->lX, r->lY, p->diagonalExpansion,
+                                    b->emit == CPECAN_EMIT_FORWARD ? 0 : p->dynamicAnchorExpansion, lo, hi);
+            CpkDiag *dg = diags + diagStart[i];
             int64_t cells = 0;
-            for (int64_t d = 0; d <= N; d++) {
+            for (int64_t d = 0; d <= N && rcBand == CPECAN_OK; d++) {
                 const int64_t w = (hi[d] - lo[d]) / 2 + 1;
                 if (cells + w >= (int64_t)1 << 31) {
-                    rc = CPECAN_EINVAL;
-                    cpk_set_error("region too large for 32-bit cell offsets");
-                    goto fail1;
+                    rcBand = CPECAN_EINVAL;
+                    break;
                 }
-                diags[at + d].xmyL = (int32_t)lo[d];
-                diags[at + d].width = (int32_t)w;
-                diags[at + d].cellOff = (int32_t)cells;
-                diags[at + d].ringOff = 0;
+                dg[d].xmyL = (int32_t)lo[d];
+                dg[d].width = (int32_t)w;
+                dg[d].cellOff = (int32_t)cells;
+                dg[d].ringOff = 0;
                 cells += w;
+            }
+            if (rcBand != CPECAN_OK) {
+#pragma omp critical(cpk_plan)
+                {
+                    rc = rcBand;
+                    if (badRegion < 0 || i < badRegion) badRegion = i;
+                }
+                continue;
             }
             r->cells = cells;
             keys[i].cells = N > 0 ? cells : 0;
-            keys[i].index = i;
-            at += N + 1;
         }
+        free(lo);
+    }
+    if (rc != CPECAN_OK) {
+        if (badRegion >= 0)
+            cpk_set_error("region %lld of problem %lld: anchors do not define a valid band (or the band exceeds 2^31 cells)",
+                          (long long)badRegion, (long long)b->regions[badRegion].problem);
+        goto fail1;
     }
     qsort(keys, (size_t)b->nRegions, sizeof(CostKey), by_cost_desc); /* longest first: the work queue is LPT */
 
-    /* pass 2: traceback schedule per region (pairwiseAligner.c:791-810), forward ring layout, scratch sizes */
-    int64_t nSegs = 0, capSegs = 0;
-    CpkSegment *segs = NULL;
+    /* pass 2: traceback schedule per region (pairwiseAligner.c:791-810), forward ring layout, scratch sizes.
+     * 2a counts the segments (serial prefix sums fix every offset), 2b fills them in parallel. */
     b->devRegions = calloc((size_t)b->nRegions, sizeof(CpkRegion));
     b->devToHost = malloc(sizeof(int64_t) * (size_t)b->nRegions);
     if (!b->devRegions || !b->devToHost) {
@@ -705,76 +731,111 @@ int cpecan_batch_upload(cpecan_batch *b) {
     geo.nStates = S;
     geo.emit = b->emit;
     geo.debug = b->debug;
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int64_t di = 0; di < b->nRegions; di++) {
+        const HostRegion *r = &b->regions[keys[di].index];
+        const CpkDiag *dg = diags + diagStart[keys[di].index];
+        const int64_t N = r->lX + r->lY;
+        int64_t tracedBackTo = 0;
+        int32_t n = 0;
+        for (int64_t d = 1; d <= N; d++) {
+            const int atEnd = d == N;
+            if (!atEnd && !(d >= tracedBackTo + p->minDiagsBetweenTraceBack && dg[d].width <= p->diagonalExpansion * 2 + 1))
+                continue;
+            n++;
+            tracedBackTo = d - (atEnd ? 0 : p->traceBackDiagonals + 1);
+        }
+        segCount[di] = n;
+    }
     int64_t outAt = 0, dbgCells = 0, dbgDiags = 0, totalCells = 0;
     for (int64_t di = 0; di < b->nRegions; di++) {
         const int64_t hiRegion = keys[di].index;
         HostRegion *r = &b->regions[hiRegion];
+        CpkRegion *g = &b->devRegions[di];
         r->devIndex = di;
         b->devToHost[di] = hiRegion;
-        CpkRegion *g = &b->devRegions[di];
-        CpkDiag *dg = diags + diagStart[hiRegion];
-        const int64_t N = r->lX + r->lY;
-        g->seqXOff = r->seqXOff;
-        g->seqYOff = r->seqYOff;
-        g->diagOff = diagStart[hiRegion];
         g->segOff = nSegs;
-        g->lX = (int32_t)r->lX;
-        g->lY = (int32_t)r->lY;
-        g->raggedLeft = r->raggedLeft;
-        g->raggedRight = r->raggedRight;
+        g->nSeg = segCount[di];
+        nSegs += segCount[di];
         g->dbgCellOff = dbgCells;
         g->dbgDiagOff = dbgDiags;
         if (b->debug) {
             dbgCells += r->cells;
-            dbgDiags += N + 1;
+            dbgDiags += r->lX + r->lY + 1;
         }
         totalCells += r->cells;
-        int32_t maxW = 0;
-        for (int64_t d = 0; d <= N; d++) maxW = dg[d].width > maxW ? dg[d].width : maxW;
-        g->maxWidth = maxW;
-        geo.maxWidth = maxW > geo.maxWidth ? maxW : geo.maxWidth;
-        /* segments */
-        int64_t tracedBackTo = 0, liveMax = 0, fbMax = 0;
-        int32_t refreshMax = 0;
-        for (int64_t d = 1; d <= N; d++) {
-            const int atEnd = d == N;
-            const int tracebackPoint =
-                d >= tracedBackTo + p->minDiagsBetweenTraceBack && dg[d].width <= p->diagonalExpansion * 2 + 1;
-            if (!atEnd && !tracebackPoint) continue;
-            if (grow((void **)&segs, &capSegs, nSegs + 1, sizeof(CpkSegment))) {
-                rc = CPECAN_ENOMEM;
-                goto fail2;
-            }
-            CpkSegment *sg = &segs[nSegs++];
-            memset(sg, 0, sizeof *sg);
-            sg->tbPrev = (int32_t)tracedBackTo;
-            sg->dTop = (int32_t)d;
-            sg->tbFrom = (int32_t)(d - (atEnd ? 0 : p->traceBackDiagonals + 1));
-            sg->atEnd = atEnd;
-            sg->nRefresh = (int32_t)((sg->tbFrom - (sg->tbPrev + 1)) / CPK_REFRESH_PERIOD + 1);
-            refreshMax = sg->nRefresh > refreshMax ? sg->nRefresh : refreshMax;
-            /* forward diagonals tbPrev..dTop are live during this traceback */
-            const int64_t live = (int64_t)dg[d].cellOff + dg[d].width - dg[tracedBackTo].cellOff;
-            liveMax = imax(liveMax, live);
-            const int64_t fbCells = (int64_t)dg[sg->tbFrom].cellOff + dg[sg->tbFrom].width - dg[sg->tbPrev + 1].cellOff;
-            fbMax = imax(fbMax, fbCells);
-            g->nSeg++;
-            tracedBackTo = sg->tbFrom;
-        }
-        /* ring: diagonals are laid down one after another and never straddle the end of the ring */
-        const int64_t ringCells = liveMax + maxW;
-        int64_t pos = 0;
-        for (int64_t d = 0; d <= N; d++) {
-            if (pos + dg[d].width > ringCells) pos = 0;
-            dg[d].ringOff = (int32_t)pos;
-            pos += dg[d].width;
-        }
-        geo.ringCells = imax(geo.ringCells, ringCells);
-        geo.fbCells = imax(geo.fbCells, fbMax);
-        geo.maxRefresh = refreshMax > geo.maxRefresh ? refreshMax : geo.maxRefresh;
         g->outCap = (int32_t)default_out_cap(b, r);
         g->outOff = outAt;
         outAt += g->outCap;
+    }
+    segs = calloc((size_t)(nSegs ? nSegs : 1), sizeof(CpkSegment));
+    if (!segs) {
+        rc = CPECAN_ENOMEM;
+        goto fail2;
+    }
+#pragma omp parallel
+    {
+        int32_t tMaxW = 0, tRefresh = 0;
+        int64_t tRing = 0, tFb = 0;
+#pragma omp for schedule(dynamic, 16) nowait
+        for (int64_t di = 0; di < b->nRegions; di++) {
+            const int64_t hiRegion = keys[di].index;
+            const HostRegion *r = &b->regions[hiRegion];
+            CpkRegion *g = &b->devRegions[di];
+            CpkDiag *dg = diags + diagStart[hiRegion];
+            const int64_t N = r->lX + r->lY;
+            g->seqXOff = r->seqXOff;
+            g->seqYOff = r->seqYOff;
+            g->diagOff = diagStart[hiRegion];
+            g->lX = (int32_t)r->lX;
+            g->lY = (int32_t)r->lY;
+            g->raggedLeft = r->raggedLeft;
+            g->raggedRight = r->raggedRight;
+            int32_t maxW = 0;
+            for (int64_t d = 0; d <= N; d++) maxW = dg[d].width > maxW ? dg[d].width : maxW;
+            g->maxWidth = maxW;
+            tMaxW = maxW > tMaxW ? maxW : tMaxW;
+            /* segments */
+            int64_t tracedBackTo = 0, liveMax = 0, fbMax = 0;
+            CpkSegment *sg = segs + g->segOff;
+            for (int64_t d = 1; d <= N; d++) {
+                const int atEnd = d == N;
+                const int tracebackPoint =
+                    d >= tracedBackTo + p->minDiagsBetweenTraceBack && dg[d].width <= p->diagonalExpansion * 2 + 1;
+                if (!atEnd && !tracebackPoint) continue;
+                sg->tbPrev = (int32_t)tracedBackTo;
+                sg->dTop = (int32_t)d;
+                sg->tbFrom = (int32_t)(d - (atEnd ? 0 : p->traceBackDiagonals + 1));
+                sg->atEnd = atEnd;
+                sg->nRefresh = (int32_t)((sg->tbFrom - (sg->tbPrev + 1)) / CPK_REFRESH_PERIOD + 1);
+                tRefresh = sg->nRefresh > tRefresh ? sg->nRefresh : tRefresh;
+                /* forward diagonals tbPrev..dTop are live during this traceback */
+                const int64_t live = (int64_t)dg[d].cellOff + dg[d].width - dg[tracedBackTo].cellOff;
+                liveMax = imax(liveMax, live);
+                const int64_t fbCells =
+                    (int64_t)dg[sg->tbFrom].cellOff + dg[sg->tbFrom].width - dg[sg->tbPrev + 1].cellOff;
+                fbMax = imax(fbMax, fbCells);
+                tracedBackTo = sg->tbFrom;
+                sg++;
+            }
+            /* ring: diagonals are laid down one after another and never straddle the end of the ring */
+            const int64_t ringCells = liveMax + maxW;
+            int64_t pos = 0;
+            for (int64_t d = 0; d <= N; d++) {
+                if (pos + dg[d].width > ringCells) pos = 0;
+                dg[d].ringOff = (int32_t)pos;
+                pos += dg[d].width;
+            }
+            tRing = imax(tRing, ringCells);
+            tFb = imax(tFb, fbMax);
+        }
+#pragma omp critical(cpk_plan)
+        {
+            geo.maxWidth = tMaxW > geo.maxWidth ? tMaxW : geo.maxWidth;
+            geo.maxRefresh = tRefresh > geo.maxRefresh ? tRefresh : geo.maxRefresh;
+            geo.ringCells = imax(geo.ringCells, tRing);
+            geo.fbCells = imax(geo.fbCells, tFb);
+        }
     }
     if (b->emit == CPECAN_EMIT_FORWARD) { /* no traceback: nothing is kept of the forward matrix */
         geo.ringCells = 1;
@@ -794,7 +855,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
     if (geo.refreshCells < 1) geo.refreshCells = 1;
     geo.rollDoubles = (int64_t)(2 * S + 1) * geo.rollStride;
     /* LDS budget: beyond 64 KiB per wave (rolling buffers + symbol strings) the batch takes the global-memory path */
-    geo.useGlobalRoll = (sizeof(double) * (size_t)(136 + geo.rollDoubles) + (size_t)geo.seqLdsBytes + 16 > 64 * 1024);
+    geo.useGlobalRoll = (sizeof(double) * (size_t)(136 + 768 + geo.rollDoubles) + (size_t)geo.seqLdsBytes + 16 > 64 * 1024);
     b->geo = geo;
     b->segs = segs;
     b->nSegs = nSegs;
@@ -822,7 +883,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
     free(diags);
     free(diagStart);
     free(keys);
-    free(lo);
+    free(segCount);
     return CPECAN_OK;
 
 fail2:
@@ -837,7 +898,7 @@ fail1:
     free(diags);
     free(diagStart);
     free(keys);
-    free(lo);
+    free(segCount);
     return rc;
 }
 
@@ -889,7 +950,6 @@ static int assemble_problem(cpecan_batch *b, int64_t pi, const int32_t *counts, 
         }
         pr->triples[l] = dst;
         pr->nTriples[l] = total;
-        b->stats.pairs += total;
     }
     return CPECAN_OK;
 }
@@ -955,7 +1015,18 @@ int cpecan_batch_download(cpecan_batch *b) {
         }
     }
     if (rc == CPECAN_OK && b->emit != CPECAN_EMIT_FORWARD && b->emit != CPECAN_EMIT_EXPECT) {
-        for (int64_t i = 0; i < b->nProblems && rc == CPECAN_OK; i++) rc = assemble_problem(b, i, counts, segStarts, triples);
+        int64_t pairs = 0; /* problems are independent: assemble their lists in parallel */
+#pragma omp parallel for schedule(dynamic, 16) reduction(+ : pairs)
+        for (int64_t i = 0; i < b->nProblems; i++) {
+            const int rcI = assemble_problem(b, i, counts, segStarts, triples);
+            if (rcI != CPECAN_OK) {
+#pragma omp critical(cpk_plan)
+                rc = rcI;
+            } else {
+                for (int l = 0; l < b->nLists; l++) pairs += b->problems[i].nTriples[l];
+            }
+        }
+        b->stats.pairs = pairs;
     }
     if (rc == CPECAN_OK) b->downloaded = 1;
     free(counts);

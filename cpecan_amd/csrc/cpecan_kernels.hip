@@ -111,10 +111,10 @@ struct __attribute__((aligned(16))) Cubic {
     double c3, c2, c1, c0;
 };
 
-// The segment of d = hi - lo is found without fp64 compares.  For d >= 0 the IEEE bit pattern is monotone, and
-// d <= T  <=>  bits(d) - 1 < bits(T); all three thresholds (1.0, 2.5, 4.5) have a zero low dword and their high
-// dwords are multiples of 2^17, so the segment is a function of the bucket  b = (hi32(bits(d) - 1) >> 17) - 0x1FF7:
-// b <= 0 -> d <= 1;  1..10 -> (1, 2.5];  11..17 -> (2.5, 4.5];  18.. -> above, i.e. segment = number of set bits of
+// The segment of d = hi - lo is found without fp64 compares.  For d >= 0 the IEEE bit pattern is monotone; the three
+// thresholds (1.0, 2.5, 4.5) have a zero low dword and high dwords that are multiples of 2^17, so the segment is a
+// function of the bucket  b = ((bits(d) + 2^49 - 1) >> 49) - (bits(1.0) >> 49), saturated at 0:
+// b == 0 -> d <= 1;  1..10 -> (1, 2.5];  11..17 -> (2.5, 4.5];  18.. -> above, i.e. segment = number of set bits of
 // {0, 10, 17} below position b.  Exact for every double, thresholds included.  NaN / +inf / d >= 8 may pick any
 // segment: the result is `hi` then.  The table keeps 4 rows of 32 bytes (conflict-free for ds_read_b128); a 26-row
 // table indexed by bucket measured 100x the LDS bank conflicts.
@@ -133,12 +133,13 @@ __device__ __forceinline__ void fill_cubics(double *t) {
 }
 
 __device__ __forceinline__ int cubic_row(double d) {
-    const int lo = __double2loint(d), hi = __double2hiint(d);
-    const int h = hi - (lo == 0 ? 1 : 0);                    // high dword of bits(d) - 1 (d == 0 gives -1)
-    int b = (h >> 17) - ((0x3FF00000 >> 17) - 1);            // arithmetic shift keeps small d negative
-    b = b < 0 ? 0 : (b > 31 ? 31 : b);
-    const unsigned below = (1u << b) - 1u;                   // bits 0..b-1
-    return __builtin_popcount(below & ((1u << 0) | (1u << 10) | (1u << 17)));
+    // bits(d) > bits(T)  <=>  bits(d) + 2^49 - 1 >= bits(T) + 2^49 for the three thresholds (multiples of 2^49), so the
+    // bucket is the high part of one 64-bit add; the saturating subtract sends every d <= 1 (d == 0 included) to
+    // bucket 0, and v_bfe_u32 reads only 5 bits of its width, which is harmless: buckets above 24 mean d >= 8.
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(d) + ((1ull << 49) - 1ull);
+    const unsigned h = (unsigned)(bits >> 32) >> 17;
+    const unsigned b = __builtin_elementwise_sub_sat(h, 0x3FF00000u >> 17);
+    return __builtin_popcount(__builtin_amdgcn_ubfe((1u << 0) | (1u << 10) | (1u << 17), 0u, b));
 }
 
 __device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
@@ -261,6 +262,12 @@ struct DiagCache {
 constexpr int kLdsCubics = 16;  // 4 rows x 4 coefficients
 // doubles of LDS in front of the rolling rows: cubics + emissions (+ expectation sums for that emitter only)
 __host__ __device__ constexpr int lds_header_doubles(int emit) { return kLdsCubics + 40 + (emit == CPECAN_EMIT_EXPECT ? 80 : 0); }
+// doubles of LDS behind the rolling rows for the candidate staging rings (16-byte Candidates, 128 per list; none for
+// the forward-only and expectation emitters)
+__host__ __device__ constexpr int lds_stage_doubles(int emit) {
+    return emit == CPECAN_EMIT_MATCH ? 2 * 128 : (emit == CPECAN_EMIT_INDEL ? 3 * 2 * 128 : 0);
+}
+constexpr int kStage = 128;  // LDS staging slots per candidate list (two waves' worth: flushed 64 at a time)
 constexpr int kPrefetch = 3;  // passes (of 64 cells) of F.match prefetched one diagonal ahead in the traceback
 constexpr float kCandMargin = 3.0f;  // log-space slack of the candidate filter (see DESIGN.md "candidate filter")
 
@@ -277,38 +284,57 @@ struct Sweep {
     const uint8_t *syp;
     __device__ __forceinline__ int symX(int p) const { return FAST ? (sxp[p >> 1] >> ((p & 1) * 4)) & 15 : sxp[p]; }
     __device__ __forceinline__ int symY(int p) const { return FAST ? (syp[p >> 1] >> ((p & 1) * 4)) & 15 : syp[p]; }
-    double *roll;        // 2S+1 rows of `stride` doubles; position 0 of each row = -inf guard
+    double *roll;        // rolling buffers: `stride` positions of R = 2S+1 doubles; position 0 = -inf guard
     const double *em;    // LDS emissions: [0..24] match, [25..29] gapX, [30..34] gapY
     const Cubic *lg;     // LDS logAdd cubics
     double *ring;
     Candidate *cand;
+    Candidate *stage;  // LDS: kStage candidates per output list, see traceback()
     double *cbuf, *mbuf, *totals;
     int stride;
     int lane;
+    int laneR;  // lane * R
     int N;
     // forward sweep state: the two previous diagonals' table entries
     CpkDiag f1, f2;
     bool storeRing = true;  // false for the forward-probability mode: nothing reads the forward values back
 
-    // LDS rows (2S+1 rows of `stride` doubles, position 0 of every row is the -inf guard):
-    //  forward layout : two diagonals, fbuf(d) = rows [(d&1)*S, (d&1)*S + S); F[d] overwrites F[d-2] in place
-    //  backward layout: match row in a ring of three, bM(d) = row (d mod 3); the other states in two alternating
-    //                   groups, bG(d) + s*stride = row 3 + (d&1)*(S-1) + (s-1) for s >= 1
-    __device__ __forceinline__ double *fbuf(int d) const { return roll + (size_t)(d & 1) * S * stride; }
-    __device__ __forceinline__ double *bM(int d) const { return roll + (size_t)((d + 3) % 3) * stride; }
-    __device__ __forceinline__ double *bG(int d) const { return roll + (size_t)(2 + (d & 1) * (S - 1)) * stride; }
+    // Rolling buffers, position-major: element (row r, position i) is roll[i * R + r], R = 2S+1 rows, positions
+    // 0..stride-1, position 0 of every row is the -inf guard.  With the row a compile-time offset the rows of one
+    // position cost one address VGPR and immediate offsets (adjacent rows pair up into ds_read2/ds_write2_b64), and
+    // a lane stride of R*8 bytes (R odd) is bank-conflict-free for 8-byte accesses.
+    //  forward layout : two diagonals, F[d] = rows [(d&1)*S, (d&1)*S + S); F[d] overwrites F[d-2] in place
+    //  backward layout: match row in a ring of three, B[d].match = row (d mod 3); the other states in two alternating
+    //                   groups, B[d][s] = row 3 + (d&1)*(S-1) + (s-1) for s >= 1
+    //  fbuf1/bM1/bG1 return the row pointer at position 1 (cell 0); bG1(d)[s + kR] is state s >= 1 of cell k
+    static constexpr int R = 2 * S + 1;
+    // Cell k of a diagonal lives at position k+1, i.e. at element offset k*R from a row pointer that already points at
+    // position 1 (fbuf1/bM1/bG1 below).  Cell indices are kept premultiplied by R ("kR"): lane*R is computed once per
+    // kernel and everything added to it per diagonal / per group is wave-uniform, so no per-access multiply is left.
+    // sel(iR, wR): element offset of neighbour cell i of a diagonal with w cells (wR = w*R; w = 0: no such diagonal),
+    // or the offset of the -inf guard (position 0) when the neighbour is outside the band.
+    __device__ __forceinline__ static int sel(int iR, int wR) { return ((unsigned)iR < (unsigned)wR) ? iR : -R; }
+    __device__ __forceinline__ double *fbuf1(int d) const { return roll + R + (d & 1) * S; }
+    __device__ __forceinline__ double *bM1(int d) const { return roll + R + (d + 3) % 3; }
+    __device__ __forceinline__ double *bG1(int d) const { return roll + R + 2 + (d & 1) * (S - 1); }
+    // Forward ring in HBM, per diagonal of W cells: the match row [W], then the other states cell-major [W][S-1]
+    // (the traceback reads the match row on its own; a cell's remaining states go out as one 32-byte run).
+    __device__ __forceinline__ static size_t ringIdx(int W, int s, int k) {
+        return s == 0 ? (size_t)k : (size_t)W + (size_t)k * (S - 1) + (size_t)(s - 1);
+    }
     __device__ __forceinline__ double *ringAt(const CpkDiag &g) const { return ring + (size_t)g.ringOff * S; }
 
     // ---- forward: impl/pairwiseAligner.c:609-629 with stateMachine{5,3}_cellCalculate as the per-cell body ----
     struct FwdCtx {
-        int d, xlo, dl, w1, dm, w2;
-        const double *p1, *p2;
+        int d, xlo, dlR, w1R, dmR, w2R;  // neighbour shifts and widths premultiplied by R
+        const double *p1, *p2;           // F[d-1], F[d-2] rows at position 1
     };
 
     // NC cells (NC = 1 or 2, 64 lanes apart on the same diagonal) computed together.  Fold order per state is the
     // reference's transition-list order; independent folds advance in lock-step (logadd_n).
     template <int NC>
-    __device__ __forceinline__ void fwdCells(const FwdCtx &c, const int (&k)[NC], double (&v)[NC][S]) const {
+    __device__ __forceinline__ void fwdCells(const FwdCtx &c, const int (&k)[NC], const int (&kR)[NC],
+                                             double (&v)[NC][S]) const {
         int cX[NC], cY[NC];
 #pragma unroll
         for (int q = 0; q < NC; q++) {
@@ -323,13 +349,13 @@ struct Sweep {
 #pragma unroll
             for (int q = 0; q < NC; q++) {
                 const double eX = em[25 + cX[q]], eM = em[cX[q] * 5 + cY[q]], eY = em[30 + cY[q]];
-                const int iL = guard_pos(k[q] + c.dl, c.w1);
-                const int iU = guard_pos(k[q] + c.dl + 1, c.w1);
-                const int iM = guard_pos(k[q] + c.dm, c.w2);
-                const double lM = p1[0 * stride + iL], lSX = p1[1 * stride + iL], lLX = p1[3 * stride + iL];
-                const double uM = p1[0 * stride + iU], uSY = p1[2 * stride + iU], uLY = p1[4 * stride + iU];
-                const double mM = p2[0 * stride + iM], mSX = p2[1 * stride + iM], mSY = p2[2 * stride + iM],
-                             mLX = p2[3 * stride + iM], mLY = p2[4 * stride + iM];
+                const int iL = sel(kR[q] + c.dlR, c.w1R);
+                const int iU = sel(kR[q] + c.dlR + R, c.w1R);
+                const int iM = sel(kR[q] + c.dmR, c.w2R);
+                const double lM = p1[0 + iL], lSX = p1[1 + iL], lLX = p1[3 + iL];
+                const double uM = p1[0 + iU], uSY = p1[2 + iU], uLY = p1[4 + iU];
+                const double mM = p2[0 + iM], mSX = p2[1 + iM], mSY = p2[2 + iM],
+                             mLX = p2[3 + iM], mLY = p2[4 + iM];
                 // first two terms of every state's fold: lower block :454-462, middle :463-470, upper :471-479
                 acc[q * 5 + 0] = mM + (eM + m.matchContinue);
                 t[q * 5 + 0] = mSX + (eM + m.matchFromShortX);
@@ -365,12 +391,12 @@ struct Sweep {
 #pragma unroll
             for (int q = 0; q < NC; q++) {
                 const double eX = em[25 + cX[q]], eM = em[cX[q] * 5 + cY[q]], eY = em[30 + cY[q]];
-                const int iL = guard_pos(k[q] + c.dl, c.w1);
-                const int iU = guard_pos(k[q] + c.dl + 1, c.w1);
-                const int iM = guard_pos(k[q] + c.dm, c.w2);
-                const double lM = p1[0 * stride + iL], lGX = p1[1 * stride + iL], lGY = p1[2 * stride + iL];
-                const double uM = p1[0 * stride + iU], uGX = p1[1 * stride + iU], uGY = p1[2 * stride + iU];
-                const double mM = p2[0 * stride + iM], mGX = p2[1 * stride + iM], mGY = p2[2 * stride + iM];
+                const int iL = sel(kR[q] + c.dlR, c.w1R);
+                const int iU = sel(kR[q] + c.dlR + R, c.w1R);
+                const int iM = sel(kR[q] + c.dmR, c.w2R);
+                const double lM = p1[0 + iL], lGX = p1[1 + iL], lGY = p1[2 + iL];
+                const double uM = p1[0 + iU], uGX = p1[1 + iU], uGY = p1[2 + iU];
+                const double mM = p2[0 + iM], mGX = p2[1 + iM], mGY = p2[2 + iM];
                 acc[q * 3 + 0] = mM + (eM + m.matchContinue);
                 t[q * 3 + 0] = mGX + (eM + m.matchFromShortX);
                 u[q * 3 + 0] = mGY + (eM + m.matchFromShortY);
@@ -396,29 +422,33 @@ struct Sweep {
         FwdCtx c;
         c.d = d;
         c.xlo = (d + g.xmyL) >> 1;
-        c.dl = (g.xmyL - 1 - f1.xmyL) >> 1;  // lower neighbour (d-1, xmy-1) is cell k+dl, upper is k+dl+1
-        c.w1 = f1.width;
-        c.dm = (g.xmyL - f2.xmyL) >> 1;      // middle neighbour (d-2, xmy) is cell k+dm
-        c.w2 = d >= 2 ? f2.width : 0;
-        c.p1 = fbuf(d - 1);
-        c.p2 = fbuf(d - 2);
-        double *cur = fbuf(d);  // same rows as F[d-2]: updated in place
+        const int dl = (g.xmyL - 1 - f1.xmyL) >> 1;  // lower neighbour (d-1, xmy-1) is cell k+dl, upper is k+dl+1
+        const int dm = (g.xmyL - f2.xmyL) >> 1;      // middle neighbour (d-2, xmy) is cell k+dm
+        c.dlR = dl * R;
+        c.w1R = f1.width * R;
+        c.dmR = dm * R;
+        c.w2R = d >= 2 ? f2.width * R : 0;
+        c.p1 = fbuf1(d - 1);
+        c.p2 = fbuf1(d - 2);
+        double *cur = fbuf1(d);  // same rows as F[d-2]: updated in place
         double *out = ringAt(g);
         // A group of 64 cells reads F[d-2] at k+dm and writes F[d] at k.  With dm >= 0 ascending groups never read a
         // position an earlier group has overwritten; with dm < 0 descending groups never do (DESIGN.md "LDS layout").
         const int nPass = (W + CPK_WAVE - 1) / CPK_WAVE;
-        const bool ascending = c.dm >= 0;
+        const bool ascending = dm >= 0;
         for (int i = 0; i < nPass; i++) {
-            const int k0 = (ascending ? i : nPass - 1 - i) * CPK_WAVE + lane;
+            const int kb = (ascending ? i : nPass - 1 - i) * CPK_WAVE;
+            const int k0 = kb + lane;
             if (k0 < W) {
                 const int kk[1] = {k0};
+                const int kkR[1] = {kb * R + laneR};
                 double v[1][S];
-                fwdCells<1>(c, kk, v);
+                fwdCells<1>(c, kk, kkR, v);
 #pragma unroll
-                for (int s = 0; s < S; s++) cur[s * stride + k0 + 1] = v[0][s];
+                for (int s = 0; s < S; s++) cur[s + kkR[0]] = v[0][s];
                 if (storeRing) {
 #pragma unroll
-                    for (int s = 0; s < S; s++) out[(size_t)s * W + k0] = v[0][s];
+                    for (int s = 0; s < S; s++) out[ringIdx(W, s, k0)] = v[0][s];
                 }
             }
         }
@@ -430,32 +460,26 @@ struct Sweep {
     // Puts diagonal d of the forward ring back into its rolling buffer (after a traceback used the buffers).
     __device__ void reloadForward(const CpkDiag &g, int d) {
         const int W = g.width;
-        double *cur = fbuf(d);
+        double *cur = fbuf1(d);
         const double *src = ringAt(g);
-        for (int k = lane; k < W; k += CPK_WAVE) {
+        for (int kb = 0; kb < W; kb += CPK_WAVE) {
+            const int k = kb + lane;
+            if (k < W) {
 #pragma unroll
-            for (int s = 0; s < S; s++) cur[s * stride + k + 1] = ld_self(src + (size_t)s * W + k);
+                for (int s = 0; s < S; s++) cur[s + kb * R + laneR] = ld_self(src + ringIdx(W, s, k));
+            }
         }
         roll_fence<!FAST>();
     }
 
     struct BwdCtx {
-        int d2, xlo, db, wB, da, wA;
-        const double *pb, *pa;
-        bool seeded;
-        const double *endPrior;
+        int d2, xlo, dbR, wBR, daR, wAR;  // source shifts and widths premultiplied by R
+        const double *pb, *pa;            // B[d2+1] gap rows, B[d2+2] match row, at position 1
     };
     // B[d2][k] gathered from B[d2+1], B[d2+2] in the reference's scatter order, NC cells at a time
     template <int NC>
-    __device__ __forceinline__ void bwdCells(const BwdCtx &c, const int (&k)[NC], double (&v)[NC][S]) const {
-        if (c.seeded) {
-            // every cell of the top diagonal gets the end-state prior (pairwiseAligner.c:798-799)
-#pragma unroll
-            for (int q = 0; q < NC; q++)
-#pragma unroll
-                for (int s = 0; s < S; s++) v[q][s] = c.endPrior[s];
-            return;
-        }
+    __device__ __forceinline__ void bwdCells(const BwdCtx &c, const int (&k)[NC], const int (&kR)[NC],
+                                             double (&v)[NC][S]) const {
         int cX1[NC], cY1[NC];
 #pragma unroll
         for (int q = 0; q < NC; q++) {
@@ -469,12 +493,12 @@ struct Sweep {
 #pragma unroll
             for (int q = 0; q < NC; q++) {
                 const double eX = em[25 + cX1[q]], eM = em[cX1[q] * 5 + cY1[q]], eY = em[30 + cY1[q]];
-                const int iU = guard_pos(k[q] + c.db, c.wB);      // cell (x, y+1): its "upper" neighbour is the target
-                const int iL = guard_pos(k[q] + c.db + 1, c.wB);  // cell (x+1, y): its "lower" neighbour is the target
-                const int iA = guard_pos(k[q] + c.da, c.wA);      // cell (x+1, y+1): its "middle" neighbour is the target
+                const int iU = sel(kR[q] + c.dbR, c.wBR);      // cell (x, y+1): its "upper" neighbour is the target
+                const int iL = sel(kR[q] + c.dbR + R, c.wBR);  // cell (x+1, y): its "lower" neighbour is the target
+                const int iA = sel(kR[q] + c.daR, c.wAR);      // cell (x+1, y+1): its "middle" neighbour is the target
                 const double aM = pa[iA];
-                const double uSY = pb[2 * stride + iU], uLY = pb[4 * stride + iU];
-                const double lSX = pb[1 * stride + iL], lLX = pb[3 * stride + iL];
+                const double uSY = pb[2 + iU], uLY = pb[4 + iU];
+                const double lSX = pb[1 + iL], lLX = pb[3 + iL];
                 // per target state: (1) middle term from d2+2, (2) upper-block terms, (3) lower-block terms
                 acc[q * 5 + 0] = aM + (eM + m.matchContinue);
                 t[q * 5 + 0] = uSY + (eY + m.shortOpenY);
@@ -508,12 +532,12 @@ struct Sweep {
 #pragma unroll
             for (int q = 0; q < NC; q++) {
                 const double eX = em[25 + cX1[q]], eM = em[cX1[q] * 5 + cY1[q]], eY = em[30 + cY1[q]];
-                const int iU = guard_pos(k[q] + c.db, c.wB);
-                const int iL = guard_pos(k[q] + c.db + 1, c.wB);
-                const int iA = guard_pos(k[q] + c.da, c.wA);
+                const int iU = sel(kR[q] + c.dbR, c.wBR);
+                const int iL = sel(kR[q] + c.dbR + R, c.wBR);
+                const int iA = sel(kR[q] + c.daR, c.wAR);
                 const double aM = pa[iA];
-                const double uGY = pb[2 * stride + iU];
-                const double lGX = pb[1 * stride + iL];
+                const double uGY = pb[2 + iU];
+                const double lGX = pb[1 + iL];
                 acc[q * 3 + 0] = aM + (eM + m.matchContinue);
                 t[q * 3 + 0] = uGY + (eY + m.shortOpenY);
                 u[q * 3 + 0] = lGX + (eX + m.shortOpenX);
@@ -544,15 +568,33 @@ struct Sweep {
     __device__ void traceback(const CpkSegment &sg, const double *endPrior, double *dbgFb, int (&nCand)[NL]) {
         const int J = sg.nRefresh;
         const float logThr = (float)log(m.threshold);  // -inf for threshold 0: every cell is a candidate
+        // Candidates are staged in LDS (a ring of kStage slots per list) and go to HBM 64 at a time as one coalesced
+        // store.  A store per group would sit between the F prefetch below and its use: loads and stores share vmcnt
+        // on gfx9, the compiler then waits with vmcnt(0) at every diagonal, i.e. for the write acknowledgement too.
+        int pend[NL], head[NL];  // staged entries and ring position of the oldest, per list (wave-uniform)
 #pragma unroll
-        for (int l = 0; l < NL; l++) nCand[l] = 0;
+        for (int l = 0; l < NL; l++) nCand[l] = pend[l] = head[l] = 0;
+        auto flush = [&](int l, int n) {  // the n <= 64 oldest staged candidates of list l -> cand[l][nCand[l]..]
+            if (lane < n) {
+                cand[(size_t)l * a.geo.fbCells + nCand[l] + lane] = stage[l * kStage + ((head[l] + lane) & (kStage - 1))];
+            }
+            head[l] = (head[l] + n) & (kStage - 1);
+            pend[l] -= n;
+            nCand[l] += n;
+        };
         float lastMax = -__builtin_huge_valf();
+        double ep[S];  // end prior: loaded AND waited for here (the empty asm consumes the registers); a value whose
+                       // load may still be pending at the loop head costs a vmcnt(0) in front of every group
+#pragma unroll
+        for (int s = 0; s < S; s++) ep[s] = endPrior[s];
+#pragma unroll
+        for (int s = 0; s < S; s++) asm volatile("" : "+v"(ep[s]));
         CpkDiag gb{}, ga{};  // table entries of d2+1 and d2+2
         CpkDiag g = dc.get(sg.dTop, true);
         CpkDiag gnext = sg.dTop >= 1 ? dc.get(sg.dTop - 1, true) : CpkDiag{};  // entry of d2-1
         // F rows of the emitted states (list l emits state l), prefetched TWO diagonals ahead of their use: one
         // diagonal of arithmetic (~1.3 us) is shorter than a loaded HBM round trip.
-        double fmCur[NL][kPrefetch], fmNext[NL][kPrefetch];
+        double fmCur[NL][kPrefetch];
         auto emitted = [&](int d) { return d > sg.tbPrev && d <= sg.tbFrom; };
         auto loadRows = [&](const CpkDiag &gd, bool want, double (&dst)[NL][kPrefetch]) {
             const double *src = ringAt(gd);
@@ -561,11 +603,14 @@ struct Sweep {
 #pragma unroll
                 for (int q = 0; q < kPrefetch; q++) {
                     const int k = q * CPK_WAVE + lane;
-                    dst[l][q] = (want && k < gd.width) ? ld_self(src + (size_t)l * gd.width + k) : 0.0;
+                    dst[l][q] = (want && k < gd.width) ? ld_self(src + ringIdx(gd.width, l, k)) : 0.0;
                 }
         };
         loadRows(g, emitted(sg.dTop), fmCur);
-        loadRows(gnext, emitted(sg.dTop - 1), fmNext);
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+#pragma unroll
+            for (int q = 0; q < kPrefetch; q++) asm volatile("" : "+v"(fmCur[l][q]));  // complete before the loop
         for (int d2 = sg.dTop; d2 > sg.tbPrev; d2--) {
             const bool seeded = d2 == sg.dTop;
             const int W = g.width;
@@ -573,23 +618,22 @@ struct Sweep {
             const bool refresh = emit && ((sg.tbFrom - d2) % CPK_REFRESH_PERIOD == 0);
             const int jr = (sg.tbFrom - d2) / CPK_REFRESH_PERIOD;
             // issue the loads for diagonal d2-2 now
+            // issue the loads for diagonal d2-1 now: one diagonal of arithmetic covers the HBM round trip
+            double fmNext[NL][kPrefetch];
+            loadRows(gnext, d2 >= 1 && emitted(d2 - 1), fmNext);
             const CpkDiag gnext2 = d2 >= 2 ? dc.get(d2 - 2, true) : CpkDiag{};
-            double fmNext2[NL][kPrefetch];
-            loadRows(gnext2, d2 >= 2 && emitted(d2 - 2), fmNext2);
-            double *curM = bM(d2), *curG = bG(d2);
+            double *curM = bM1(d2), *curG = bG1(d2);
             const double *fsrc = ringAt(g);
             const int xlo = (d2 + g.xmyL) >> 1;
             BwdCtx c;
             c.d2 = d2;
             c.xlo = xlo;
-            c.db = (g.xmyL - 1 - gb.xmyL) >> 1;  // source (d2+1, xmy-1) is cell k+db, source (d2+1, xmy+1) is k+db+1
-            c.wB = seeded ? 0 : gb.width;
-            c.da = (g.xmyL - ga.xmyL) >> 1;      // source (d2+2, xmy) is cell k+da
-            c.wA = (!seeded && d2 + 2 <= sg.dTop) ? ga.width : 0;
-            c.pb = bG(d2 + 1);
-            c.pa = bM(d2 + 2);
-            c.seeded = seeded;
-            c.endPrior = endPrior;
+            c.dbR = ((g.xmyL - 1 - gb.xmyL) >> 1) * R;  // source (d2+1, xmy-1) is cell k+db, (d2+1, xmy+1) is k+db+1
+            c.wBR = seeded ? 0 : gb.width * R;
+            c.daR = ((g.xmyL - ga.xmyL) >> 1) * R;      // source (d2+2, xmy) is cell k+da
+            c.wAR = (!seeded && d2 + 2 <= sg.dTop) ? ga.width * R : 0;
+            c.pb = bG1(d2 + 1);
+            c.pa = bM1(d2 + 2);
             const float keepFrom = lastMax + logThr - kCandMargin;  // wave-uniform
             // Refresh diagonals read more of F: the remaining states of F[d2] (cell dot products) and all states of
             // F[d2-1] at the straddle offset.  Those loads are issued HERE, before the compute loop of the diagonal,
@@ -606,42 +650,42 @@ struct Sweep {
                 for (int q = 0; q < kPrefetch; q++) {
                     const int k = q * CPK_WAVE + lane;
 #pragma unroll
-                    for (int s2 = NL; s2 < S; s2++) rfC[s2][q] = k < W ? ld_self(fsrc + (size_t)s2 * W + k) : 0.0;
+                    for (int s2 = NL; s2 < S; s2++) rfC[s2][q] = k < W ? ld_self(fsrc + ringIdx(W, s2, k)) : 0.0;
                     const int kp = k + dmm;
                     const bool ok = straddle && k < Wn && kp >= 0 && kp < Wp;
 #pragma unroll
                     for (int s2 = 0; s2 < S; s2++) {
-                        const double val = ok ? ld_self(fprev + (size_t)s2 * Wp + kp) : NEG_INF;
+                        const double val = ok ? ld_self(fprev + ringIdx(Wp, s2, kp)) : NEG_INF;
                         rfS[s2][q] = val;
                     }
                 }
             }
-            // Wave-uniform loop (the candidate counts must stay identical in every lane): lanes past the end of the
-            // diagonal recompute its last cell and have their stores masked.
-            int pass = 0;
-            for (int kb = 0; kb < W; kb += CPK_WAVE, pass++) {
-                const int k0 = kb + lane;
+            // One group of 64 cells.  Wave-uniform (the candidate counts must stay identical in every lane): lanes past
+            // the end of the diagonal recompute its last cell and have their stores masked.  f0 = F[d2][l][k0].
+            const int lastR = (W - 1) * R;
+            auto group = [&](int kb, const double (&f0)[NL]) {
+                const int k0 = kb + lane, kR0 = kb * R + laneR;
                 const bool on = k0 < W;
-                const int kk[1] = {on ? k0 : W - 1};
                 double v[1][S];
-                bwdCells<1>(c, kk, v);
-                if (on) {
-                    curM[k0 + 1] = v[0][0];
+                if (seeded) {
+                    // every cell of the top diagonal gets the end-state prior (pairwiseAligner.c:798-799)
 #pragma unroll
-                    for (int s = 1; s < S; s++) curG[s * stride + k0 + 1] = v[0][s];
+                    for (int s = 0; s < S; s++) v[0][s] = ep[s];
+                } else {
+                    const int kk[1] = {on ? k0 : W - 1};
+                    const int kkR[1] = {on ? kR0 : lastR};
+                    bwdCells<1>(c, kk, kkR, v);
+                }
+                if (on) {
+                    curM[kR0] = v[0][0];
+#pragma unroll
+                    for (int s = 1; s < S; s++) curG[s + kR0] = v[0][s];
                 }
                 if (emit) {
                     const int x = xlo + k0, y = d2 - x;
                     double fbv[NL];
 #pragma unroll
-                    for (int l = 0; l < NL; l++) {
-                        double f0;
-                        if (pass == 0) f0 = fmCur[l][0];
-                        else if (pass == 1) f0 = fmCur[l][1];
-                        else if (pass == 2) f0 = fmCur[l][2];
-                        else f0 = on ? ld_self(fsrc + (size_t)l * W + k0) : 0.0;
-                        fbv[l] = f0 + v[0][l];
-                    }
+                    for (int l = 0; l < NL; l++) fbv[l] = f0[l] + v[0][l];
                     if (on && dbgFb) dbgFb[g.cellOff + k0] = fbv[0];
                     // candidate filter: a cell survives when it is within log(threshold) - margin of the bound on the
                     // total probability (DESIGN.md "candidate filter").  Match cells need x > 0 and y > 0, gapX cells
@@ -658,11 +702,29 @@ struct Sweep {
                             cd.fb = fbv[l];
                             cd.x = x;
                             cd.y = y;
-                            cand[(size_t)l * a.geo.fbCells + nCand[l] + rank] = cd;
+                            stage[l * kStage + ((head[l] + pend[l] + rank) & (kStage - 1))] = cd;
                         }
-                        nCand[l] += __popcll(mask);
+                        pend[l] += __popcll(mask);
+                        if (pend[l] >= CPK_WAVE) flush(l, CPK_WAVE);
                     }
                 }
+            };
+            // the first kPrefetch groups take F from the prefetched registers (compile-time group index) ...
+#pragma unroll
+            for (int q = 0; q < kPrefetch; q++) {
+                if (q * CPK_WAVE < W) {
+                    double f0[NL];
+#pragma unroll
+                    for (int l = 0; l < NL; l++) f0[l] = fmCur[l][q];
+                    group(q * CPK_WAVE, f0);
+                }
+            }
+            // ... wider diagonals load it on the spot
+            for (int kb = kPrefetch * CPK_WAVE; kb < W; kb += CPK_WAVE) {
+                double f0[NL];
+#pragma unroll
+                for (int l = 0; l < NL; l++) f0[l] = (emit && kb + lane < W) ? ld_self(fsrc + ringIdx(W, l, kb + lane)) : 0.0;
+                group(kb, f0);
             }
             roll_fence<!FAST>();
             if (refresh) {
@@ -671,12 +733,12 @@ struct Sweep {
                 //     max(this diagonal's maximum, old bound - 1); the reference itself asserts that consecutive totals
                 //     differ by less than 1.0 (:834), so the decayed bound stays below the current total.
                 float diagMax = -__builtin_huge_valf();
-                auto dotCell = [&](int k, const double (&fRow)[S]) {
-                    double t = fRow[0] + curM[k + 1];
+                auto dotCell = [&](int k, int kR, const double (&fRow)[S]) {
+                    double t = fRow[0] + curM[kR];
                     const int x = xlo + k, y = d2 - x;
                     const float fbf = (x > 0 && y > 0) ? (float)t : -__builtin_huge_valf();
 #pragma unroll
-                    for (int s2 = 1; s2 < S; s2++) t = logadd(lg, t, fRow[s2] + curG[s2 * stride + k + 1]);
+                    for (int s2 = 1; s2 < S; s2++) t = logadd(lg, t, fRow[s2] + curG[s2 + kR]);
                     cbuf[(size_t)k * J + jr] = t;
                     return fbf;
                 };
@@ -689,7 +751,7 @@ struct Sweep {
                             double fRow[S];
 #pragma unroll
                             for (int s2 = 0; s2 < S; s2++) fRow[s2] = s2 < NL ? fmCur[s2][q] : rfC[s2][q];
-                            fbf = dotCell(k, fRow);
+                            fbf = dotCell(k, q * CPK_WAVE * R + laneR, fRow);
                         }
                         if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
                     }
@@ -700,8 +762,8 @@ struct Sweep {
                     if (k < W) {
                         double fRow[S];
 #pragma unroll
-                        for (int s2 = 0; s2 < S; s2++) fRow[s2] = ld_self(fsrc + (size_t)s2 * W + k);
-                        fbf = dotCell(k, fRow);
+                        for (int s2 = 0; s2 < S; s2++) fRow[s2] = ld_self(fsrc + ringIdx(W, s2, k));
+                        fbf = dotCell(k, kb * R + laneR, fRow);
                     }
                     if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
                 }
@@ -709,9 +771,9 @@ struct Sweep {
                 // (b) matches straddling d2: middle-block forward step from F[d2-1] into the cells of d2+1, times
                 //     B[d2+1] (pairwiseAligner.c:643-651).  Non-match states of the temporary stay -inf and drop out.
                 if (straddle) {
-                    const double *bn = bM(d2 + 1);
+                    const double *bn = bM1(d2 + 1);
                     const int xlon = (d2 + 1 + gb.xmyL) >> 1;
-                    auto straddleCell = [&](int k, const double (&f)[S]) {
+                    auto straddleCell = [&](int k, int kR, const double (&f)[S]) {
                         const int x = xlon + k, y = d2 + 1 - x;
                         const double eM = em[symX(x) * 5 + symY(y)];
                         double t = f[0] + (eM + m.matchContinue);
@@ -721,7 +783,7 @@ struct Sweep {
                             t = logadd(lg, t, f[3] + (eM + m.matchFromLongX));
                             t = logadd(lg, t, f[4] + (eM + m.matchFromLongY));
                         }
-                        mbuf[(size_t)k * J + jr] = t + bn[k + 1];
+                        mbuf[(size_t)k * J + jr] = t + bn[kR];
                     };
 #pragma unroll
                     for (int q = 0; q < kPrefetch; q++) {
@@ -730,7 +792,7 @@ struct Sweep {
                             double f[S];
 #pragma unroll
                             for (int s2 = 0; s2 < S; s2++) f[s2] = rfS[s2][q];
-                            straddleCell(k, f);
+                            straddleCell(k, q * CPK_WAVE * R + laneR, f);
                         }
                     }
                     for (int k = kPrefetch * CPK_WAVE + lane; k < Wn; k += CPK_WAVE) {
@@ -740,10 +802,10 @@ struct Sweep {
                         double f[S];
 #pragma unroll
                         for (int s2 = 0; s2 < S; s2++) {
-                            const double val = ld_self(fprev + (size_t)s2 * Wp + kq);
+                            const double val = ld_self(fprev + ringIdx(Wp, s2, kq));
                             f[s2] = ok ? val : NEG_INF;
                         }
-                        straddleCell(k, f);
+                        straddleCell(k, (k - lane) * R + laneR, f);
                     }
                 }
             }
@@ -752,14 +814,19 @@ struct Sweep {
             gb = g;
             g = gnext;
             gnext = gnext2;
+            // The empty asm consumes the prefetched registers HERE, one whole diagonal after their loads were issued and
+            // before the next prefetch goes out: left to itself hipcc waits at the first use inside the next diagonal,
+            // behind the next prefetch, with vmcnt(0) -- the full HBM round trip exposed on every diagonal.
 #pragma unroll
             for (int l = 0; l < NL; l++)
 #pragma unroll
                 for (int q = 0; q < kPrefetch; q++) {
+                    asm volatile("" : "+v"(fmNext[l][q]));
                     fmCur[l][q] = fmNext[l][q];
-                    fmNext[l][q] = fmNext2[l][q];
                 }
         }
+#pragma unroll
+        for (int l = 0; l < (CANDS ? NL : 0); l++) flush(l, pend[l]);
     }
 
     // ---- expectation step (diagonalCalculationExpectations, pairwiseAligner.c:735-746; updateExpectations :418-432).
@@ -773,6 +840,9 @@ struct Sweep {
 
     __device__ void expectations(const CpkSegment &sg, const double *endPrior, double (&tAcc)[kNT], double *eLds,
                                  double &likelihood) {
+        double ep[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) ep[s] = endPrior[s];
         CpkDiag gb{}, ga{};
         CpkDiag g = dc.get(sg.dTop, true);
         for (int d2 = sg.dTop; d2 > sg.tbPrev; d2--) {
@@ -782,19 +852,17 @@ struct Sweep {
             const CpkDiag g1 = dc.get(d2 - 1, true);               // F[d2-1]: always alive (d2-1 >= tbPrev)
             const bool haveM2 = emit && d2 - 2 >= sg.tbPrev;       // F[d2-2] is gone at d2 == tbPrev+1
             const CpkDiag g2 = haveM2 ? dc.get(d2 - 2, true) : CpkDiag{};
-            double *curM = bM(d2), *curG = bG(d2);
+            double *curM = bM1(d2), *curG = bG1(d2);
             const int xlo = (d2 + g.xmyL) >> 1;
             BwdCtx c;
             c.d2 = d2;
             c.xlo = xlo;
-            c.db = (g.xmyL - 1 - gb.xmyL) >> 1;
-            c.wB = seeded ? 0 : gb.width;
-            c.da = (g.xmyL - ga.xmyL) >> 1;
-            c.wA = (!seeded && d2 + 2 <= sg.dTop) ? ga.width : 0;
-            c.pb = bG(d2 + 1);
-            c.pa = bM(d2 + 2);
-            c.seeded = seeded;
-            c.endPrior = endPrior;
+            c.dbR = ((g.xmyL - 1 - gb.xmyL) >> 1) * R;
+            c.wBR = seeded ? 0 : gb.width * R;
+            c.daR = ((g.xmyL - ga.xmyL) >> 1) * R;
+            c.wAR = (!seeded && d2 + 2 <= sg.dTop) ? ga.width * R : 0;
+            c.pb = bG1(d2 + 1);
+            c.pa = bM1(d2 + 2);
             double total = 0.0;
             if (emit) {
                 total = ld_self(totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
@@ -804,13 +872,21 @@ struct Sweep {
             const int dm = (g.xmyL - g2.xmyL) >> 1;      // middle neighbour (d2-2, xmy) is cell k+dm of F[d2-2]
             const double *f1 = ringAt(g1), *f2 = ringAt(g2);
             const int w1 = g1.width, w2 = haveM2 ? g2.width : 0;
-            for (int k = lane; k < W; k += CPK_WAVE) {
+            for (int kb = 0; kb < W; kb += CPK_WAVE) {
+                const int k = kb + lane;
+                if (k >= W) continue;
                 const int kk[1] = {k};
+                const int kkR[1] = {kb * R + laneR};
                 double v[1][S];
-                bwdCells<1>(c, kk, v);
-                curM[k + 1] = v[0][0];
+                if (seeded) {
 #pragma unroll
-                for (int s = 1; s < S; s++) curG[s * stride + k + 1] = v[0][s];
+                    for (int s = 0; s < S; s++) v[0][s] = ep[s];
+                } else {
+                    bwdCells<1>(c, kk, kkR, v);
+                }
+                curM[kkR[0]] = v[0][0];
+#pragma unroll
+                for (int s = 1; s < S; s++) curG[s + kkR[0]] = v[0][s];
                 if (!emit) continue;
                 const int x = xlo + k, y = d2 - x;
                 const int cX = symX(x), cY = symY(y);
@@ -822,11 +898,11 @@ struct Sweep {
                            okM = (unsigned)kM < (unsigned)w2;
                 const int qL = okL ? kL : 0, qU = okU ? kU : 0, qM = okM ? kM : 0;
                 auto F1 = [&](int s, int q, bool ok) {
-                    const double val = ld_self(f1 + (size_t)s * w1 + q);
+                    const double val = ld_self(f1 + ringIdx(w1, s, q));
                     return ok ? val : NEG_INF;
                 };
                 auto F2 = [&](int s) {
-                    const double val = okM ? ld_self(f2 + (size_t)s * w2 + qM) : NEG_INF;
+                    const double val = okM ? ld_self(f2 + ringIdx(w2, s, qM)) : NEG_INF;
                     return val;
                 };
                 // one (transition, emission) event: impl/pairwiseAligner.c:426-431
@@ -949,12 +1025,13 @@ struct Sweep {
 constexpr int kEmitForward = 3;
 
 template <int S, bool FAST, int EMIT>
-__global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(1, 2)))
+__global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 cpecan_pairhmm_sweep(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const CpkModel &m = *a.model;
     const int stride = a.geo.rollStride;
+    constexpr int R = 2 * S + 1;  // rows of the rolling buffers (Sweep::R)
 
     // LDS (doubles): logAdd cubics | emission tables | expectation sums | rolling buffers (FAST) | symbol strings (FAST)
     fill_cubics(lds);
@@ -975,7 +1052,9 @@ cpecan_pairhmm_sweep(const KArgs a) {
     double likelihood = 0.0;
     constexpr int kHeader = lds_header_doubles(EMIT);
     double *roll = FAST ? (lds + kHeader) : (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles);
-    uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + kHeader + (size_t)(2 * S + 1) * stride);
+    Candidate *stageLds = reinterpret_cast<Candidate *>(lds + kHeader + (FAST ? (size_t)(2 * S + 1) * stride : 0));
+    constexpr int kStageDoubles = lds_stage_doubles(EMIT);
+    uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + kHeader + (size_t)(2 * S + 1) * stride + kStageDoubles);
     // every rolling cell starts as -inf; position 0 of each row is never written again (the guard)
     for (int i = lane; i < (2 * S + 1) * stride; i += CPK_WAVE) roll[i] = NEG_INF;
     __syncthreads();
@@ -1016,11 +1095,13 @@ cpecan_pairhmm_sweep(const KArgs a) {
                           lg,
                           a.ring + slot * (size_t)a.geo.ringCells * S,
                           a.cand + slot * (size_t)a.geo.fbCells * (EMIT == CPECAN_EMIT_INDEL ? 3 : 1),
+                          stageLds,
                           a.cbuf + slot * (size_t)a.geo.refreshCells,
                           a.mbuf + slot * (size_t)a.geo.refreshCells,
                           a.totals + slot * (size_t)a.geo.maxRefresh,
                           stride,
                           lane,
+                          lane * R,
                           N,
                           CpkDiag{},
                           CpkDiag{}};
@@ -1037,20 +1118,20 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 sw.dc.load(0);
                 const double *startPrior = rg.raggedLeft ? m.raggedStart : m.start;
                 const CpkDiag g0 = sw.dc.get(0, false);
-                double *cur0 = sw.fbuf(0);
-                if (lane < S) cur0[lane * stride + 1] = startPrior[lane];
+                double *cur0 = sw.fbuf1(0);
+                if (lane < S) cur0[lane] = startPrior[lane];
                 roll_fence<!FAST>();
                 sw.f1 = g0;
                 sw.f2 = g0;
                 for (int d = 1; d <= N; d++) sw.forward(d);
                 const double *endPrior = rg.raggedRight ? m.raggedEnd : m.end;
-                const double *last = sw.fbuf(N);
+                const double *last = sw.fbuf1(N);
                 const int W = sw.f1.width;
                 total = NEG_INF;  // dpDiagonal_dotProduct (:513-523) over the cells of diagonal N, every lane alike
                 for (int k = 0; k < W; k++) {
-                    double t = last[0 * stride + k + 1] + endPrior[0];
+                    double t = last[0 + k * R] + endPrior[0];
 #pragma unroll
-                    for (int s = 1; s < S; s++) t = logadd(lg, t, last[s * stride + k + 1] + endPrior[s]);
+                    for (int s = 1; s < S; s++) t = logadd(lg, t, last[s + k * R] + endPrior[s]);
                     total = logadd(lg, total, t);
                 }
             }
@@ -1063,10 +1144,10 @@ cpecan_pairhmm_sweep(const KArgs a) {
             const double *startPrior = rg.raggedLeft ? m.raggedStart : m.start;
             {
                 const CpkDiag g0 = sw.dc.get(0, false);
-                double *cur = sw.fbuf(0);
+                double *cur = sw.fbuf1(0);
                 double *o0 = sw.ringAt(g0);
                 if (lane < S) {
-                    cur[lane * stride + 1] = startPrior[lane];
+                    cur[lane] = startPrior[lane];
                     o0[lane] = startPrior[lane];
                 }
                 roll_fence<!FAST>();
@@ -1257,7 +1338,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     const int S = geo->nStates;
 
     // LDS: 40 doubles of emission tables + (fast path) three rolling buffers + both padded symbol strings
-    d->ldsBytes = sizeof(double) * lds_header_doubles(geo->emit);
+    d->ldsBytes = sizeof(double) * (lds_header_doubles(geo->emit) + lds_stage_doubles(geo->emit));
     if (!geo->useGlobalRoll)
         d->ldsBytes += sizeof(double) * (size_t)(2 * S + 1) * geo->rollStride + (size_t)((geo->seqLdsBytes + 15) / 16 * 16);
     KernelFn fn = pick_kernel(*geo);
