@@ -592,10 +592,10 @@ struct Sweep {
         CpkDiag gb{}, ga{};  // table entries of d2+1 and d2+2
         CpkDiag g = dc.get(sg.dTop, true);
         CpkDiag gnext = sg.dTop >= 1 ? dc.get(sg.dTop - 1, true) : CpkDiag{};  // entry of d2-1
-        // F rows of the emitted states (list l emits state l), prefetched TWO diagonals ahead of their use: one
-        // diagonal of arithmetic (~1.3 us) is shorter than a loaded HBM round trip.
+        // F rows of the emitted states (list l emits state l), prefetched one diagonal ahead of their use.  wantF: the
+        // emitted diagonals plus the one above the first refresh point (its F.m + B.m feeds the straddle term).
         double fmCur[NL][kPrefetch];
-        auto emitted = [&](int d) { return d > sg.tbPrev && d <= sg.tbFrom; };
+        auto emitted = [&](int d) { return d > sg.tbPrev && d <= sg.tbFrom + 1 && d <= sg.dTop; };
         auto loadRows = [&](const CpkDiag &gd, bool want, double (&dst)[NL][kPrefetch]) {
             const double *src = ringAt(gd);
 #pragma unroll
@@ -617,7 +617,12 @@ struct Sweep {
             const bool emit = d2 <= sg.tbFrom;
             const bool refresh = emit && ((sg.tbFrom - d2) % CPK_REFRESH_PERIOD == 0);
             const int jr = (sg.tbFrom - d2) / CPK_REFRESH_PERIOD;
-            // issue the loads for diagonal d2-2 now
+            // "Matches straddling diagonal r" (pairwiseAligner.c:643-651) is a middle-block forward step from F[r-1] into the
+            // cells of r+1, times B[r+1].  The match state is reached through the middle block only, so that step IS
+            // F[r+1].match (same terms, same order: stateMachine.c:463-470 / :703-707), and the series to fold is
+            // F[r+1].m + B[r+1].m -- the fb values this loop forms anyway, one diagonal before the refresh point.
+            const bool feeds = d2 - 1 > sg.tbPrev && d2 - 1 <= sg.tbFrom && ((sg.tbFrom - (d2 - 1)) % CPK_REFRESH_PERIOD == 0);
+            const int jrNext = (sg.tbFrom - (d2 - 1)) / CPK_REFRESH_PERIOD;
             // issue the loads for diagonal d2-1 now: one diagonal of arithmetic covers the HBM round trip
             double fmNext[NL][kPrefetch];
             loadRows(gnext, d2 >= 1 && emitted(d2 - 1), fmNext);
@@ -635,29 +640,16 @@ struct Sweep {
             c.pb = bG1(d2 + 1);
             c.pa = bM1(d2 + 2);
             const float keepFrom = lastMax + logThr - kCandMargin;  // wave-uniform
-            // Refresh diagonals read more of F: the remaining states of F[d2] (cell dot products) and all states of
-            // F[d2-1] at the straddle offset.  Those loads are issued HERE, before the compute loop of the diagonal,
-            // and consumed after it, so their HBM latency hides behind a few thousand cycles of arithmetic
-            // (they used to be loaded and waited for on the spot: ~25 % of the traceback time of a lone wave).
+            // Refresh diagonals read the remaining states of F[d2] (cell dot products).  Those loads are issued HERE,
+            // before the compute loop of the diagonal, and consumed after it, so their HBM latency hides behind a few
+            // thousand cycles of arithmetic.
             double rfC[S][kPrefetch];  // F[d2][s][k], s >= NL   (rows < NL are in fmCur)
-            double rfS[S][kPrefetch];  // F[d2-1][s][k + dmm] for cell k of diagonal d2+1, -inf outside F[d2-1]
-            const bool straddle = refresh && d2 + 1 <= sg.dTop;
-            const int Wn = gb.width, Wp = gnext.width;
-            const int dmm = (gb.xmyL - gnext.xmyL) >> 1;
-            const double *fprev = ringAt(gnext);
             if (refresh) {
 #pragma unroll
                 for (int q = 0; q < kPrefetch; q++) {
                     const int k = q * CPK_WAVE + lane;
 #pragma unroll
                     for (int s2 = NL; s2 < S; s2++) rfC[s2][q] = k < W ? ld_self(fsrc + ringIdx(W, s2, k)) : 0.0;
-                    const int kp = k + dmm;
-                    const bool ok = straddle && k < Wn && kp >= 0 && kp < Wp;
-#pragma unroll
-                    for (int s2 = 0; s2 < S; s2++) {
-                        const double val = ok ? ld_self(fprev + ringIdx(Wp, s2, kp)) : NEG_INF;
-                        rfS[s2][q] = val;
-                    }
                 }
             }
             // One group of 64 cells.  Wave-uniform (the candidate counts must stay identical in every lane): lanes past
@@ -681,6 +673,7 @@ struct Sweep {
 #pragma unroll
                     for (int s = 1; s < S; s++) curG[s + kR0] = v[0][s];
                 }
+                if (feeds && on) mbuf[(size_t)k0 * J + jrNext] = f0[0] + v[0][0];  // every cell of the diagonal (:647)
                 if (emit) {
                     const int x = xlo + k0, y = d2 - x;
                     double fbv[NL];
@@ -723,7 +716,8 @@ struct Sweep {
             for (int kb = kPrefetch * CPK_WAVE; kb < W; kb += CPK_WAVE) {
                 double f0[NL];
 #pragma unroll
-                for (int l = 0; l < NL; l++) f0[l] = (emit && kb + lane < W) ? ld_self(fsrc + ringIdx(W, l, kb + lane)) : 0.0;
+                for (int l = 0; l < NL; l++)
+                    f0[l] = ((emit || feeds) && kb + lane < W) ? ld_self(fsrc + ringIdx(W, l, kb + lane)) : 0.0;
                 group(kb, f0);
             }
             roll_fence<!FAST>();
@@ -768,46 +762,6 @@ struct Sweep {
                     if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
                 }
                 if (CANDS) lastMax = fmaxf(diagMax, lastMax - 1.0f);
-                // (b) matches straddling d2: middle-block forward step from F[d2-1] into the cells of d2+1, times
-                //     B[d2+1] (pairwiseAligner.c:643-651).  Non-match states of the temporary stay -inf and drop out.
-                if (straddle) {
-                    const double *bn = bM1(d2 + 1);
-                    const int xlon = (d2 + 1 + gb.xmyL) >> 1;
-                    auto straddleCell = [&](int k, int kR, const double (&f)[S]) {
-                        const int x = xlon + k, y = d2 + 1 - x;
-                        const double eM = em[symX(x) * 5 + symY(y)];
-                        double t = f[0] + (eM + m.matchContinue);
-                        t = logadd(lg, t, f[1] + (eM + m.matchFromShortX));
-                        t = logadd(lg, t, f[2] + (eM + m.matchFromShortY));
-                        if (S == 5) {
-                            t = logadd(lg, t, f[3] + (eM + m.matchFromLongX));
-                            t = logadd(lg, t, f[4] + (eM + m.matchFromLongY));
-                        }
-                        mbuf[(size_t)k * J + jr] = t + bn[kR];
-                    };
-#pragma unroll
-                    for (int q = 0; q < kPrefetch; q++) {
-                        const int k = q * CPK_WAVE + lane;
-                        if (k < Wn) {
-                            double f[S];
-#pragma unroll
-                            for (int s2 = 0; s2 < S; s2++) f[s2] = rfS[s2][q];
-                            straddleCell(k, q * CPK_WAVE * R + laneR, f);
-                        }
-                    }
-                    for (int k = kPrefetch * CPK_WAVE + lane; k < Wn; k += CPK_WAVE) {
-                        const int kp = k + dmm;
-                        const bool ok = kp >= 0 && kp < Wp;
-                        const int kq = ok ? kp : 0;
-                        double f[S];
-#pragma unroll
-                        for (int s2 = 0; s2 < S; s2++) {
-                            const double val = ld_self(fprev + ringIdx(Wp, s2, kq));
-                            f[s2] = ok ? val : NEG_INF;
-                        }
-                        straddleCell(k, (k - lane) * R + laneR, f);
-                    }
-                }
             }
             // slide the window of table entries and prefetched F rows down one diagonal
             ga = gb;
