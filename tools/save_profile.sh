@@ -1,0 +1,22 @@
+#!/bin/bash
+# copies the judged artifacts of gpurun_out/<tag> (written by tools/profile_round.sh) into profiles/<tag>_*
+set -e
+tag=$1
+src=gpurun_out/$tag
+cp $src/bench.json profiles/${tag}_bench.json
+cp $src/traffic.json profiles/${tag}_traffic.json
+cp $src/stats/*/*_kernel_stats.csv profiles/${tag}_kernel_stats.csv
+python3 - $src profiles/$tag <<'PY'
+import csv, glob, sys
+src, dst = sys.argv[1], sys.argv[2]
+kt = glob.glob(src + '/stats/*/*_kernel_trace.csv')[0]
+rows = list(csv.DictReader(open(kt)))
+keep = [r for r in rows if 'pairhmm' in r['Kernel_Name']]
+w = csv.DictWriter(open(dst + '_kernel_trace.csv', 'w', newline=''), fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
+for name in ('fetch', 'write'):
+    f = glob.glob(src + '/' + name + '/*/*_counter_collection.csv')[0]
+    rows = list(csv.DictReader(open(f)))
+    keep = [r for r in rows if 'pairhmm' in r['Kernel_Name']]
+    w = csv.DictWriter(open(dst + '_pmc_' + name + '.csv', 'w', newline=''), fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
+PY
+ls -la profiles/${tag}_*
