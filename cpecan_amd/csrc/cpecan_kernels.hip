@@ -246,6 +246,17 @@ struct DiagCache {
         // otherwise hipcc puts a vmcnt(0) at the branch merge and every diagonal waits for its ring stores
         asm volatile("" ::"v"(eXmyL), "v"(eWidth), "v"(eRing), "v"(eCell));
     }
+    // entry held by lane l of the current chunk (l wave-uniform).  The hot loops walk a chunk with load() outside the
+    // loop over its 64 diagonals: a lazy refill inside the loop costs a range check, a branch and a round of VGPR
+    // copies at its merge point on every diagonal.
+    __device__ __forceinline__ CpkDiag at(int l) const {
+        CpkDiag g;
+        g.xmyL = __builtin_amdgcn_readlane(eXmyL, l);
+        g.width = __builtin_amdgcn_readlane(eWidth, l);
+        g.ringOff = __builtin_amdgcn_readlane(eRing, l);
+        g.cellOff = __builtin_amdgcn_readlane(eCell, l);
+        return g;
+    }
     // descending = the caller walks towards lower diagonals (refill so that d is the LAST lane of the chunk)
     __device__ __forceinline__ CpkDiag get(int d, bool descending) {
         if (d < base || d >= base + CPK_WAVE) load(descending ? d - (CPK_WAVE - 1) : d);
@@ -416,8 +427,7 @@ struct Sweep {
         }
     }
 
-    __device__ void forward(int d) {
-        const CpkDiag g = dc.get(d, false);
+    __device__ void forward(int d, const CpkDiag &g) {
         const int W = g.width;
         FwdCtx c;
         c.d = d;
@@ -594,39 +604,45 @@ struct Sweep {
         CpkDiag gnext = sg.dTop >= 1 ? dc.get(sg.dTop - 1, true) : CpkDiag{};  // entry of d2-1
         // F rows of the emitted states (list l emits state l), prefetched one diagonal ahead of their use.  wantF: the
         // emitted diagonals plus the one above the first refresh point (its F.m + B.m feeds the straddle term).
+        // The loads are unconditional (lanes past the end of the diagonal re-read its last cell, diagonals that are not
+        // emitted are read all the same): a predicate per load costs more instructions than the load.
         double fmCur[NL][kPrefetch];
-        auto emitted = [&](int d) { return d > sg.tbPrev && d <= sg.tbFrom + 1 && d <= sg.dTop; };
-        auto loadRows = [&](const CpkDiag &gd, bool want, double (&dst)[NL][kPrefetch]) {
+        auto loadRows = [&](const CpkDiag &gd, double (&dst)[NL][kPrefetch]) {
             const double *src = ringAt(gd);
 #pragma unroll
             for (int l = 0; l < NL; l++)
 #pragma unroll
                 for (int q = 0; q < kPrefetch; q++) {
                     const int k = q * CPK_WAVE + lane;
-                    dst[l][q] = (want && k < gd.width) ? ld_self(src + ringIdx(gd.width, l, k)) : 0.0;
+                    dst[l][q] = ld_self(src + ringIdx(gd.width, l, k < gd.width ? k : gd.width - 1));
                 }
         };
-        loadRows(g, emitted(sg.dTop), fmCur);
+        loadRows(g, fmCur);
 #pragma unroll
         for (int l = 0; l < NL; l++)
 #pragma unroll
             for (int q = 0; q < kPrefetch; q++) asm volatile("" : "+v"(fmCur[l][q]));  // complete before the loop
-        for (int d2 = sg.dTop; d2 > sg.tbPrev; d2--) {
+        // Refresh points (every 10th emitted diagonal, counted from tbFrom) as a countdown: no division per diagonal.
+        int untilRefresh = sg.dTop - sg.tbFrom;  // diagonals until the next refresh point
+        int jr = 0;                              // ... and its index
+        for (int d2 = sg.dTop; d2 > sg.tbPrev;) {
+          // Table entries of the 64 diagonals ending at d2-2: each diagonal of the sweep needs one new entry, that of d2-2.
+          dc.load(d2 - 2 - (CPK_WAVE - 1));
+          for (int ci = CPK_WAVE - 1; ci >= 0 && d2 > sg.tbPrev; ci--, d2--) {
             const bool seeded = d2 == sg.dTop;
             const int W = g.width;
             const bool emit = d2 <= sg.tbFrom;
-            const bool refresh = emit && ((sg.tbFrom - d2) % CPK_REFRESH_PERIOD == 0);
-            const int jr = (sg.tbFrom - d2) / CPK_REFRESH_PERIOD;
+            const bool refresh = untilRefresh == 0;
             // "Matches straddling diagonal r" (pairwiseAligner.c:643-651) is a middle-block forward step from F[r-1] into the
             // cells of r+1, times B[r+1].  The match state is reached through the middle block only, so that step IS
             // F[r+1].match (same terms, same order: stateMachine.c:463-470 / :703-707), and the series to fold is
             // F[r+1].m + B[r+1].m -- the fb values this loop forms anyway, one diagonal before the refresh point.
-            const bool feeds = d2 - 1 > sg.tbPrev && d2 - 1 <= sg.tbFrom && ((sg.tbFrom - (d2 - 1)) % CPK_REFRESH_PERIOD == 0);
-            const int jrNext = (sg.tbFrom - (d2 - 1)) / CPK_REFRESH_PERIOD;
+            const bool feeds = untilRefresh == 1 && d2 - 1 > sg.tbPrev;
+            const int jrNext = jr;
             // issue the loads for diagonal d2-1 now: one diagonal of arithmetic covers the HBM round trip
             double fmNext[NL][kPrefetch];
-            loadRows(gnext, d2 >= 1 && emitted(d2 - 1), fmNext);
-            const CpkDiag gnext2 = d2 >= 2 ? dc.get(d2 - 2, true) : CpkDiag{};
+            loadRows(gnext, fmNext);
+            const CpkDiag gnext2 = dc.at(ci);  // entry of d2-2 (of diagonal 0 when d2 < 2: not used then)
             double *curM = bM1(d2), *curG = bG1(d2);
             const double *fsrc = ringAt(g);
             const int xlo = (d2 + g.xmyL) >> 1;
@@ -778,6 +794,13 @@ struct Sweep {
                     asm volatile("" : "+v"(fmNext[l][q]));
                     fmCur[l][q] = fmNext[l][q];
                 }
+            if (refresh) {
+                untilRefresh = CPK_REFRESH_PERIOD - 1;
+                jr++;
+            } else {
+                untilRefresh--;
+            }
+          }
         }
 #pragma unroll
         for (int l = 0; l < (CANDS ? NL : 0); l++) flush(l, pend[l]);
@@ -1077,7 +1100,11 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 roll_fence<!FAST>();
                 sw.f1 = g0;
                 sw.f2 = g0;
-                for (int d = 1; d <= N; d++) sw.forward(d);
+                for (int d = 1; d <= N;) {
+                    sw.dc.load(d);  // table entries of diagonals d .. d+63
+                    const int dEnd = d + CPK_WAVE - 1 < N ? d + CPK_WAVE - 1 : N;
+                    for (; d <= dEnd; d++) sw.forward(d, sw.dc.at(d - sw.dc.base));
+                }
                 const double *endPrior = rg.raggedRight ? m.raggedEnd : m.end;
                 const double *last = sw.fbuf1(N);
                 const int W = sw.f1.width;
@@ -1111,7 +1138,11 @@ cpecan_pairhmm_sweep(const KArgs a) {
             int d = 1;
             for (int si = 0; si < rg.nSeg; si++) {
                 const CpkSegment sg = a.segs[rg.segOff + si];
-                for (; d <= sg.dTop; d++) sw.forward(d);
+                while (d <= sg.dTop) {
+                    sw.dc.load(d);  // table entries of diagonals d .. d+63
+                    const int dEnd = d + CPK_WAVE - 1 < sg.dTop ? d + CPK_WAVE - 1 : sg.dTop;
+                    for (; d <= dEnd; d++) sw.forward(d, sw.dc.at(d - sw.dc.base));
+                }
                 if (a.geo.debug & 2) continue;  // diagnostic: time the forward sweep alone (no traceback, no output)
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
                 int nCand[NL];
