@@ -272,7 +272,10 @@ struct DiagCache {
 
 constexpr int kLdsCubics = 16;  // 4 rows x 4 coefficients
 // doubles of LDS in front of the rolling rows: cubics + emissions (+ expectation sums for that emitter only)
-__host__ __device__ constexpr int lds_header_doubles(int emit) { return kLdsCubics + 40 + (emit == CPECAN_EMIT_EXPECT ? 80 : 0); }
+constexpr int kLdsWeights = 168;  // (emission + transition) sums, see Sweep::wt: 25*5 + 5*4 + 5*4 = 165, padded
+__host__ __device__ constexpr int lds_header_doubles(int emit) {
+    return kLdsCubics + 40 + kLdsWeights + (emit == CPECAN_EMIT_EXPECT ? 80 : 0);
+}
 // doubles of LDS behind the rolling rows for the candidate staging rings (16-byte Candidates, 128 per list; none for
 // the forward-only and expectation emitters)
 __host__ __device__ constexpr int lds_stage_doubles(int emit) {
@@ -297,6 +300,13 @@ struct Sweep {
     __device__ __forceinline__ int symY(int p) const { return FAST ? (syp[p >> 1] >> ((p & 1) * 4)) & 15 : syp[p]; }
     double *roll;        // rolling buffers: `stride` positions of R = 2S+1 doubles; position 0 = -inf guard
     const double *em;    // LDS emissions: [0..24] match, [25..29] gapX, [30..34] gapY
+    // LDS (emission + transition) sums, the second operand of every DP term `from + (eP + tP)` (pairwiseAligner.c:384):
+    //   wt[(cX*5 + cY)*kWM + i]             match emission + {matchContinue, matchFromShortX, matchFromShortY, [matchFromLongX, matchFromLongY]}
+    //   wt[25*kWM + cX*kWG + i]             gapX emission  + {open, extend, [longOpen, longExtend] | switchToX}
+    //   wt[25*kWM + 5*kWG + cY*kWG + i]     gapY emission  + the same for Y
+    // One table fetch replaces an emission fetch plus one fp64 add per term (13 adds per cell and direction).
+    const double *wt;
+    static constexpr int kWM = S == 5 ? 5 : 3, kWG = S == 5 ? 4 : 3;
     const Cubic *lg;     // LDS logAdd cubics
     double *ring;
     Candidate *cand;
@@ -359,7 +369,8 @@ struct Sweep {
             double acc[NC * 5], t[NC * 5], m2[NC], m3[NC], m4[NC];
 #pragma unroll
             for (int q = 0; q < NC; q++) {
-                const double eX = em[25 + cX[q]], eM = em[cX[q] * 5 + cY[q]], eY = em[30 + cY[q]];
+                const double *wM = wt + (cX[q] * 5 + cY[q]) * kWM, *wX = wt + 25 * kWM + cX[q] * kWG,
+                             *wY = wt + 25 * kWM + 5 * kWG + cY[q] * kWG;
                 const int iL = sel(kR[q] + c.dlR, c.w1R);
                 const int iU = sel(kR[q] + c.dlR + R, c.w1R);
                 const int iM = sel(kR[q] + c.dmR, c.w2R);
@@ -368,19 +379,19 @@ struct Sweep {
                 const double mM = p2[0 + iM], mSX = p2[1 + iM], mSY = p2[2 + iM],
                              mLX = p2[3 + iM], mLY = p2[4 + iM];
                 // first two terms of every state's fold: lower block :454-462, middle :463-470, upper :471-479
-                acc[q * 5 + 0] = mM + (eM + m.matchContinue);
-                t[q * 5 + 0] = mSX + (eM + m.matchFromShortX);
-                acc[q * 5 + 1] = lM + (eX + m.shortOpenX);
-                t[q * 5 + 1] = lSX + (eX + m.shortExtendX);
-                acc[q * 5 + 2] = uM + (eY + m.shortOpenY);
-                t[q * 5 + 2] = uSY + (eY + m.shortExtendY);
-                acc[q * 5 + 3] = lM + (eX + m.longOpenX);
-                t[q * 5 + 3] = lLX + (eX + m.longExtendX);
-                acc[q * 5 + 4] = uM + (eY + m.longOpenY);
-                t[q * 5 + 4] = uLY + (eY + m.longExtendY);
-                m2[q] = mSY + (eM + m.matchFromShortY);
-                m3[q] = mLX + (eM + m.matchFromLongX);
-                m4[q] = mLY + (eM + m.matchFromLongY);
+                acc[q * 5 + 0] = mM + wM[0];
+                t[q * 5 + 0] = mSX + wM[1];
+                acc[q * 5 + 1] = lM + wX[0];
+                t[q * 5 + 1] = lSX + wX[1];
+                acc[q * 5 + 2] = uM + wY[0];
+                t[q * 5 + 2] = uSY + wY[1];
+                acc[q * 5 + 3] = lM + wX[2];
+                t[q * 5 + 3] = lLX + wX[3];
+                acc[q * 5 + 4] = uM + wY[2];
+                t[q * 5 + 4] = uLY + wY[3];
+                m2[q] = mSY + wM[2];
+                m3[q] = mLX + wM[3];
+                m4[q] = mLY + wM[4];
             }
             logadd_n<NC * 5>(lg, acc, t);
             // the match state folds three more terms, in order
@@ -401,22 +412,23 @@ struct Sweep {
             double acc[NC * 3], t[NC * 3], u[NC * 3];
 #pragma unroll
             for (int q = 0; q < NC; q++) {
-                const double eX = em[25 + cX[q]], eM = em[cX[q] * 5 + cY[q]], eY = em[30 + cY[q]];
+                const double *wM = wt + (cX[q] * 5 + cY[q]) * kWM, *wX = wt + 25 * kWM + cX[q] * kWG,
+                             *wY = wt + 25 * kWM + 5 * kWG + cY[q] * kWG;
                 const int iL = sel(kR[q] + c.dlR, c.w1R);
                 const int iU = sel(kR[q] + c.dlR + R, c.w1R);
                 const int iM = sel(kR[q] + c.dmR, c.w2R);
                 const double lM = p1[0 + iL], lGX = p1[1 + iL], lGY = p1[2 + iL];
                 const double uM = p1[0 + iU], uGX = p1[1 + iU], uGY = p1[2 + iU];
                 const double mM = p2[0 + iM], mGX = p2[1 + iM], mGY = p2[2 + iM];
-                acc[q * 3 + 0] = mM + (eM + m.matchContinue);
-                t[q * 3 + 0] = mGX + (eM + m.matchFromShortX);
-                u[q * 3 + 0] = mGY + (eM + m.matchFromShortY);
-                acc[q * 3 + 1] = lM + (eX + m.shortOpenX);
-                t[q * 3 + 1] = lGX + (eX + m.shortExtendX);
-                u[q * 3 + 1] = lGY + (eX + m.shortSwitchToX);
-                acc[q * 3 + 2] = uM + (eY + m.shortOpenY);
-                t[q * 3 + 2] = uGY + (eY + m.shortExtendY);
-                u[q * 3 + 2] = uGX + (eY + m.shortSwitchToY);
+                acc[q * 3 + 0] = mM + wM[0];
+                t[q * 3 + 0] = mGX + wM[1];
+                u[q * 3 + 0] = mGY + wM[2];
+                acc[q * 3 + 1] = lM + wX[0];
+                t[q * 3 + 1] = lGX + wX[1];
+                u[q * 3 + 1] = lGY + wX[2];
+                acc[q * 3 + 2] = uM + wY[0];
+                t[q * 3 + 2] = uGY + wY[1];
+                u[q * 3 + 2] = uGX + wY[2];
             }
             logadd_n<NC * 3>(lg, acc, t);
             logadd_n<NC * 3>(lg, acc, u);
@@ -502,7 +514,8 @@ struct Sweep {
             double acc[NC * 5], t[NC * 5], m2[NC], m3[NC], m4[NC];
 #pragma unroll
             for (int q = 0; q < NC; q++) {
-                const double eX = em[25 + cX1[q]], eM = em[cX1[q] * 5 + cY1[q]], eY = em[30 + cY1[q]];
+                const double *wM = wt + (cX1[q] * 5 + cY1[q]) * kWM, *wX = wt + 25 * kWM + cX1[q] * kWG,
+                             *wY = wt + 25 * kWM + 5 * kWG + cY1[q] * kWG;
                 const int iU = sel(kR[q] + c.dbR, c.wBR);      // cell (x, y+1): its "upper" neighbour is the target
                 const int iL = sel(kR[q] + c.dbR + R, c.wBR);  // cell (x+1, y): its "lower" neighbour is the target
                 const int iA = sel(kR[q] + c.daR, c.wAR);      // cell (x+1, y+1): its "middle" neighbour is the target
@@ -510,19 +523,19 @@ struct Sweep {
                 const double uSY = pb[2 + iU], uLY = pb[4 + iU];
                 const double lSX = pb[1 + iL], lLX = pb[3 + iL];
                 // per target state: (1) middle term from d2+2, (2) upper-block terms, (3) lower-block terms
-                acc[q * 5 + 0] = aM + (eM + m.matchContinue);
-                t[q * 5 + 0] = uSY + (eY + m.shortOpenY);
-                m2[q] = uLY + (eY + m.longOpenY);
-                m3[q] = lSX + (eX + m.shortOpenX);
-                m4[q] = lLX + (eX + m.longOpenX);
-                acc[q * 5 + 1] = aM + (eM + m.matchFromShortX);
-                t[q * 5 + 1] = lSX + (eX + m.shortExtendX);
-                acc[q * 5 + 2] = aM + (eM + m.matchFromShortY);
-                t[q * 5 + 2] = uSY + (eY + m.shortExtendY);
-                acc[q * 5 + 3] = aM + (eM + m.matchFromLongX);
-                t[q * 5 + 3] = lLX + (eX + m.longExtendX);
-                acc[q * 5 + 4] = aM + (eM + m.matchFromLongY);
-                t[q * 5 + 4] = uLY + (eY + m.longExtendY);
+                acc[q * 5 + 0] = aM + wM[0];
+                t[q * 5 + 0] = uSY + wY[0];
+                m2[q] = uLY + wY[2];
+                m3[q] = lSX + wX[0];
+                m4[q] = lLX + wX[2];
+                acc[q * 5 + 1] = aM + wM[1];
+                t[q * 5 + 1] = lSX + wX[1];
+                acc[q * 5 + 2] = aM + wM[2];
+                t[q * 5 + 2] = uSY + wY[1];
+                acc[q * 5 + 3] = aM + wM[3];
+                t[q * 5 + 3] = lLX + wX[3];
+                acc[q * 5 + 4] = aM + wM[4];
+                t[q * 5 + 4] = uLY + wY[3];
             }
             logadd_n<NC * 5>(lg, acc, t);
             double am[NC];
@@ -541,22 +554,23 @@ struct Sweep {
             double acc[NC * 3], t[NC * 3], u[NC * 3];
 #pragma unroll
             for (int q = 0; q < NC; q++) {
-                const double eX = em[25 + cX1[q]], eM = em[cX1[q] * 5 + cY1[q]], eY = em[30 + cY1[q]];
+                const double *wM = wt + (cX1[q] * 5 + cY1[q]) * kWM, *wX = wt + 25 * kWM + cX1[q] * kWG,
+                             *wY = wt + 25 * kWM + 5 * kWG + cY1[q] * kWG;
                 const int iU = sel(kR[q] + c.dbR, c.wBR);
                 const int iL = sel(kR[q] + c.dbR + R, c.wBR);
                 const int iA = sel(kR[q] + c.daR, c.wAR);
                 const double aM = pa[iA];
                 const double uGY = pb[2 + iU];
                 const double lGX = pb[1 + iL];
-                acc[q * 3 + 0] = aM + (eM + m.matchContinue);
-                t[q * 3 + 0] = uGY + (eY + m.shortOpenY);
-                u[q * 3 + 0] = lGX + (eX + m.shortOpenX);
-                acc[q * 3 + 1] = aM + (eM + m.matchFromShortX);
-                t[q * 3 + 1] = uGY + (eY + m.shortSwitchToY);
-                u[q * 3 + 1] = lGX + (eX + m.shortExtendX);
-                acc[q * 3 + 2] = aM + (eM + m.matchFromShortY);
-                t[q * 3 + 2] = uGY + (eY + m.shortExtendY);
-                u[q * 3 + 2] = lGX + (eX + m.shortSwitchToX);
+                acc[q * 3 + 0] = aM + wM[0];
+                t[q * 3 + 0] = uGY + wY[0];
+                u[q * 3 + 0] = lGX + wX[0];
+                acc[q * 3 + 1] = aM + wM[1];
+                t[q * 3 + 1] = uGY + wY[2];
+                u[q * 3 + 1] = lGX + wX[1];
+                acc[q * 3 + 2] = aM + wM[2];
+                t[q * 3 + 2] = uGY + wY[1];
+                u[q * 3 + 2] = lGX + wX[2];
             }
             logadd_n<NC * 3>(lg, acc, t);
             logadd_n<NC * 3>(lg, acc, u);
@@ -1019,7 +1033,32 @@ cpecan_pairhmm_sweep(const KArgs a) {
         em[25 + lane] = m.gapXEm[lane];
         em[30 + lane] = m.gapYEm[lane];
     }
-    double *eLds = lds + kLdsCubics + 40;  // emission-expectation sums of this wave (expectation emitter)
+    double *wt = lds + kLdsCubics + 40;
+    {
+        constexpr int kWM = S == 5 ? 5 : 3, kWG = S == 5 ? 4 : 3;
+        const KConsts &kc = a.kc;
+        for (int i = lane; i < 25 * kWM + 10 * kWG; i += CPK_WAVE) {
+            double e, t;
+            if (i < 25 * kWM) {
+                const int j = i % kWM;
+                e = m.matchEm[i / kWM];
+                t = j == 0 ? kc.matchContinue : j == 1 ? kc.matchFromShortX : j == 2 ? kc.matchFromShortY
+                  : j == 3 ? kc.matchFromLongX : kc.matchFromLongY;
+            } else {
+                const int r = i - 25 * kWM, y = r >= 5 * kWG, c = (r - y * 5 * kWG) / kWG, j = (r - y * 5 * kWG) % kWG;
+                e = y ? m.gapYEm[c] : m.gapXEm[c];
+                if (S == 5) {
+                    t = j == 0 ? (y ? kc.shortOpenY : kc.shortOpenX) : j == 1 ? (y ? kc.shortExtendY : kc.shortExtendX)
+                      : j == 2 ? (y ? kc.longOpenY : kc.longOpenX) : (y ? kc.longExtendY : kc.longExtendX);
+                } else {
+                    t = j == 0 ? (y ? kc.shortOpenY : kc.shortOpenX) : j == 1 ? (y ? kc.shortExtendY : kc.shortExtendX)
+                      : (y ? kc.shortSwitchToY : kc.shortSwitchToX);
+                }
+            }
+            wt[i] = e + t;
+        }
+    }
+    double *eLds = lds + kLdsCubics + 40 + kLdsWeights;  // emission-expectation sums of this wave (expectation emitter)
     if (EMIT == CPECAN_EMIT_EXPECT)
         for (int i = lane; i < 80; i += CPK_WAVE) eLds[i] = 0.0;
     constexpr int kNT = S == 5 ? 13 : 9;
@@ -1069,6 +1108,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                           FAST ? seqLds + ((lX + 3) >> 1) : gy,
                           roll,
                           em,
+                          wt,
                           lg,
                           a.ring + slot * (size_t)a.geo.ringCells * S,
                           a.cand + slot * (size_t)a.geo.fbCells * (EMIT == CPECAN_EMIT_INDEL ? 3 : 1),
