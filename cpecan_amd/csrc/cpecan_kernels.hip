@@ -318,7 +318,6 @@ struct Sweep {
     int N;
     // forward sweep state: the two previous diagonals' table entries
     CpkDiag f1, f2;
-    bool storeRing = true;  // false for the forward-probability mode: nothing reads the forward values back
 
     // Rolling buffers, position-major: element (row r, position i) is roll[i * R + r], R = 2S+1 rows, positions
     // 0..stride-1, position 0 of every row is the -inf guard.  With the row a compile-time offset the rows of one
@@ -439,7 +438,8 @@ struct Sweep {
         }
     }
 
-    __device__ void forward(int d, const CpkDiag &g) {
+    // ringStates: how many states of F[d] go to the forward ring (0, 1 = match row only, S = all)
+    __device__ void forward(int d, const CpkDiag &g, int ringStates) {
         const int W = g.width;
         FwdCtx c;
         c.d = d;
@@ -468,9 +468,12 @@ struct Sweep {
                 fwdCells<1>(c, kk, kkR, v);
 #pragma unroll
                 for (int s = 0; s < S; s++) cur[s + kkR[0]] = v[0][s];
-                if (storeRing) {
+                if (ringStates > 0) {
+                    out[ringIdx(W, 0, k0)] = v[0][0];
+                    if (ringStates > 1) {
 #pragma unroll
-                    for (int s = 0; s < S; s++) out[ringIdx(W, s, k0)] = v[0][s];
+                        for (int s = 1; s < S; s++) out[ringIdx(W, s, k0)] = v[0][s];
+                    }
                 }
             }
         }
@@ -1126,7 +1129,6 @@ cpecan_pairhmm_sweep(const KArgs a) {
         int count[NL];
 #pragma unroll
         for (int l = 0; l < NL; l++) count[l] = 0;
-        sw.storeRing = EMIT != kEmitForward;
         if (EMIT == kEmitForward) {
             // getForwardProbWithBanding (pairwiseAligner.c:879-931): forward sweep over the whole matrix, then the
             // total probability of the last diagonal against the end prior; no traceback.
@@ -1143,7 +1145,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 for (int d = 1; d <= N;) {
                     sw.dc.load(d);  // table entries of diagonals d .. d+63
                     const int dEnd = d + CPK_WAVE - 1 < N ? d + CPK_WAVE - 1 : N;
-                    for (; d <= dEnd; d++) sw.forward(d, sw.dc.at(d - sw.dc.base));
+                    for (; d <= dEnd; d++) sw.forward(d, sw.dc.at(d - sw.dc.base), 0);  // nothing reads F back
                 }
                 const double *endPrior = rg.raggedRight ? m.raggedEnd : m.end;
                 const double *last = sw.fbuf1(N);
@@ -1176,12 +1178,22 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 sw.f2 = g0;
             }
             int d = 1;
+            int emitSeg = 0, emitFrom = a.segs[rg.segOff].tbFrom;  // the segment whose traceback emits diagonal d: the first with tbFrom >= d
             for (int si = 0; si < rg.nSeg; si++) {
                 const CpkSegment sg = a.segs[rg.segOff + si];
+                // Which states of F[d] the traceback will read back: the match row always (posteriors), every state on the
+                // refresh points of the segment that emits d (cell dot products, pairwiseAligner.c:636-653; the schedule is
+                // known up front) and on the two diagonals the forward sweep is resumed from; the indel and expectation
+                // emitters read every state of every diagonal.  For the match emitter this cuts the ring stores from 8*S to
+                // ~8 + 0.8*(S-1) bytes per cell.
                 while (d <= sg.dTop) {
                     sw.dc.load(d);  // table entries of diagonals d .. d+63
                     const int dEnd = d + CPK_WAVE - 1 < sg.dTop ? d + CPK_WAVE - 1 : sg.dTop;
-                    for (; d <= dEnd; d++) sw.forward(d, sw.dc.at(d - sw.dc.base));
+                    for (; d <= dEnd; d++) {
+                        while (d > emitFrom) emitFrom = a.segs[rg.segOff + ++emitSeg].tbFrom;  // the last segment ends at N
+                        const bool all = EMIT != CPECAN_EMIT_MATCH || (emitFrom - d) % CPK_REFRESH_PERIOD == 0 || d >= sg.dTop - 1;
+                        sw.forward(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
+                    }
                 }
                 if (a.geo.debug & 2) continue;  // diagnostic: time the forward sweep alone (no traceback, no output)
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
