@@ -31,7 +31,9 @@ def measured_traffic(config, n_pairs):
     import glob
     if config != "B" or n_pairs != 10000:
         return None
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")))
+    import re
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")),
+                   key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])  # r01_v9 < r01_v10
     if not files:
         return None
     try:

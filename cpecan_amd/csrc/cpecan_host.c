@@ -412,7 +412,7 @@ typedef struct {
 
 typedef struct {
     int64_t firstRegion, nRegions;
-    int32_t *triples[3];
+    int32_t *triples[3]; /* into cpecan_batch.results (not owned) */
     int64_t nTriples[3];
 } HostProblem;
 
@@ -441,6 +441,7 @@ struct cpecan_batch {
     int64_t dbgCells, dbgDiags;
     CpkDevice *dev;
     double *forward; /* [nRegions] in device order, FORWARD emitter */
+    int32_t *results; /* every emitted triple of the batch, list-ordered: [list][problem][triple] */
     cpecan_stats stats;
 };
 
@@ -489,10 +490,11 @@ int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpe
 static void free_results(cpecan_batch *b) {
     for (int64_t i = 0; i < b->nProblems; i++)
         for (int l = 0; l < 3; l++) {
-            free(b->problems[i].triples[l]);
             b->problems[i].triples[l] = NULL;
             b->problems[i].nTriples[l] = 0;
         }
+    free(b->results);
+    b->results = NULL;
 }
 
 void cpecan_batch_destroy(cpecan_batch *b) {
@@ -917,40 +919,52 @@ int cpecan_batch_run(cpecan_batch *b, void *stream) {
     return rc;
 }
 
-/* Re-assembles one problem's list: regions in order; inside a region the reference pops its sub-list from the
- * back (pairwiseAligner.c:1415-1417), which yields traceback segments in descending order, each already in the
- * order the kernel wrote it (diagonal ascending, x-y descending). */
-static int assemble_problem(cpecan_batch *b, int64_t pi, const int32_t *counts, const int32_t *segStarts,
-                            const int32_t *triples) {
-    HostProblem *pr = &b->problems[pi];
+/* The copy plan of cpk_device_gather for the whole batch: per list, problems in order, regions in order, traceback
+ * segments in DEScending order (each traceback's pairs are prepended, pairwiseAligner.c:1415-1417), every triple shifted
+ * by its region's offset (:1411-1418).  Sets the per-problem result pointers into b->results. */
+static int plan_results(cpecan_batch *b, const int32_t *counts, const int32_t *segStarts, CpkChunk **chunksOut,
+                        int64_t *nChunksOut, int64_t *totalOut) {
+    int64_t total = 0;
+    for (int l = 0; l < b->nLists; l++)
+        for (int64_t di = 0; di < b->nRegions; di++) total += counts[(size_t)l * b->nRegions + di];
+    CpkChunk *chunks = malloc(sizeof(CpkChunk) * (size_t)(b->nLists * (b->nSegs ? b->nSegs : 1)));
+    b->results = malloc(sizeof(int32_t) * 3 * (size_t)(total ? total : 1));
+    if (!chunks || !b->results) {
+        free(chunks);
+        return CPECAN_ENOMEM;
+    }
+    int64_t nChunks = 0, at = 0;
     for (int l = 0; l < b->nLists; l++) {
         const int32_t *cnt = counts + (size_t)l * b->nRegions;
         const int32_t *ss = segStarts + (size_t)l * b->nSegs;
-        const int32_t *tr3 = triples + (size_t)l * b->outTriples * 3;
-        int64_t total = 0;
-        for (int64_t i = 0; i < pr->nRegions; i++) total += cnt[b->regions[pr->firstRegion + i].devIndex];
-        int32_t *dst = malloc(sizeof(int32_t) * 3 * (size_t)(total ? total : 1));
-        if (!dst) return CPECAN_ENOMEM;
-        int64_t at = 0;
-        for (int64_t i = 0; i < pr->nRegions; i++) {
-            const HostRegion *r = &b->regions[pr->firstRegion + i];
-            const CpkRegion *g = &b->devRegions[r->devIndex];
-            const int32_t n = cnt[r->devIndex];
-            for (int s = g->nSeg - 1; s >= 0; s--) {
-                const int32_t from = ss[g->segOff + s];
-                const int32_t to = s + 1 < g->nSeg ? ss[g->segOff + s + 1] : n;
-                const int32_t *src = tr3 + 3 * (g->outOff + from);
-                for (int32_t k = 0; k < to - from; k++) {
-                    dst[3 * at] = src[3 * k];
-                    dst[3 * at + 1] = src[3 * k + 1] + (int32_t)r->x1;
-                    dst[3 * at + 2] = src[3 * k + 2] + (int32_t)r->y1;
-                    at++;
+        for (int64_t pi = 0; pi < b->nProblems; pi++) {
+            HostProblem *pr = &b->problems[pi];
+            pr->triples[l] = b->results + 3 * at;
+            const int64_t first = at;
+            for (int64_t i = 0; i < pr->nRegions; i++) {
+                const HostRegion *r = &b->regions[pr->firstRegion + i];
+                const CpkRegion *g = &b->devRegions[r->devIndex];
+                const int32_t n = cnt[r->devIndex];
+                for (int sgi = g->nSeg - 1; sgi >= 0; sgi--) {
+                    const int32_t from = ss[g->segOff + sgi];
+                    const int32_t to = sgi + 1 < g->nSeg ? ss[g->segOff + sgi + 1] : n;
+                    if (to <= from) continue;
+                    CpkChunk *c = &chunks[nChunks++];
+                    c->src = (int64_t)l * b->outTriples + g->outOff + from;
+                    c->dst = at;
+                    c->len = to - from;
+                    c->dx = (int32_t)r->x1;
+                    c->dy = (int32_t)r->y1;
+                    c->pad = 0;
+                    at += to - from;
                 }
             }
+            pr->nTriples[l] = at - first;
         }
-        pr->triples[l] = dst;
-        pr->nTriples[l] = total;
     }
+    *chunksOut = chunks;
+    *nChunksOut = nChunks;
+    *totalOut = at;
     return CPECAN_OK;
 }
 
@@ -963,15 +977,13 @@ int cpecan_batch_download(cpecan_batch *b) {
         return CPECAN_OK;
     }
     int rc = CPECAN_OK;
-    int32_t *counts = NULL, *segStarts = NULL, *triples = NULL;
+    int32_t *counts = NULL, *segStarts = NULL;
     for (int attempt = 0; attempt < 3; attempt++) {
         free(counts);
         free(segStarts);
-        free(triples);
         counts = malloc(sizeof(int32_t) * (size_t)b->nLists * b->nRegions);
         segStarts = malloc(sizeof(int32_t) * (size_t)b->nLists * (b->nSegs ? b->nSegs : 1));
-        triples = malloc(sizeof(int32_t) * 3 * (size_t)b->nLists * b->outTriples);
-        if (!counts || !segStarts || !triples) {
+        if (!counts || !segStarts) {
             rc = CPECAN_ENOMEM;
             break;
         }
@@ -982,7 +994,7 @@ int cpecan_batch_download(cpecan_batch *b) {
                 break;
             }
         }
-        rc = cpk_device_download(b->dev, counts, segStarts, triples, b->forward, &b->stats.kernelMs, &b->stats.d2hMs);
+        rc = cpk_device_download(b->dev, counts, segStarts, b->forward, &b->stats.kernelMs, &b->stats.d2hMs);
         if (rc != CPECAN_OK) break;
         if (b->emit == CPECAN_EMIT_FORWARD || b->emit == CPECAN_EMIT_EXPECT) break; /* these emitters produce no lists */
         /* did any region overflow its output slice?  If so enlarge exactly and run once more. */
@@ -1015,23 +1027,17 @@ int cpecan_batch_download(cpecan_batch *b) {
         }
     }
     if (rc == CPECAN_OK && b->emit != CPECAN_EMIT_FORWARD && b->emit != CPECAN_EMIT_EXPECT) {
-        int64_t pairs = 0; /* problems are independent: assemble their lists in parallel */
-#pragma omp parallel for schedule(dynamic, 16) reduction(+ : pairs)
-        for (int64_t i = 0; i < b->nProblems; i++) {
-            const int rcI = assemble_problem(b, i, counts, segStarts, triples);
-            if (rcI != CPECAN_OK) {
-#pragma omp critical(cpk_plan)
-                rc = rcI;
-            } else {
-                for (int l = 0; l < b->nLists; l++) pairs += b->problems[i].nTriples[l];
-            }
-        }
-        b->stats.pairs = pairs;
+        /* the lists are put in order on the device; only the emitted triples cross PCIe */
+        CpkChunk *chunks = NULL;
+        int64_t nChunks = 0, total = 0;
+        rc = plan_results(b, counts, segStarts, &chunks, &nChunks, &total);
+        if (rc == CPECAN_OK) rc = cpk_device_gather(b->dev, chunks, nChunks, total, b->results, &b->stats.d2hMs);
+        free(chunks);
+        b->stats.pairs = total;
     }
     if (rc == CPECAN_OK) b->downloaded = 1;
     free(counts);
     free(segStarts);
-    free(triples);
     return rc;
 }
 

@@ -88,6 +88,16 @@ typedef struct {
     int64_t rollDoubles;  /* global rolling buffer per slot, doubles (only when useGlobalRoll) */
 } CpkGeometry;
 
+/* One run of consecutive triples to move into the compact, list-ordered result buffer: the triples of one traceback
+ * segment of one region, shifted by the region's offset inside its problem (pairwiseAligner.c:1411-1418). */
+typedef struct {
+    int64_t src;     /* first triple in the kernel's output (list offset included) */
+    int64_t dst;     /* first triple in the compact buffer */
+    int32_t len;
+    int32_t dx, dy;  /* added to x and y */
+    int32_t pad;
+} CpkChunk;
+
 /* Device-side mirror of a frozen batch; owned by the HIP TU. */
 typedef struct CpkDevice CpkDevice;
 
@@ -103,10 +113,15 @@ int cpk_device_upload(CpkDevice *dev, const CpkGeometry *geo, const CpkModel *mo
                       int64_t dbgCells, int64_t dbgDiags, double *h2dMs);
 int cpk_device_update_regions(CpkDevice *dev, const CpkRegion *regions, int64_t outTriplesPerList);
 int cpk_device_run(CpkDevice *dev, void *stream);
-/* Blocks until the run is complete and copies back counts/triples (and expectation sums). */
+/* Blocks until the run is complete and copies back the per-region counts and per-segment start offsets (and the
+ * expectation sums / forward probabilities). The triples stay on the device: see cpk_device_gather. */
 int cpk_device_download(CpkDevice *dev, int32_t *counts /* [nLists][nRegions] */,
-                        int32_t *segStarts /* [nLists][nSegsTotal] */, int32_t *triples /* [nLists][outTriples*3] */,
-                        double *expect /* [106] */, double *kernelMs, double *d2hMs);
+                        int32_t *segStarts /* [nLists][nSegsTotal] */, double *expect /* [106] */, double *kernelMs,
+                        double *d2hMs);
+/* Moves the chunks into one compact buffer on the device (reference list order, region offsets applied) and copies
+ * that buffer -- `total` triples, nothing else -- to hostOut. */
+int cpk_device_gather(CpkDevice *dev, const CpkChunk *chunks, int64_t nChunks, int64_t total, int32_t *hostOut,
+                      double *d2hMs);
 int cpk_device_debug_fetch(CpkDevice *dev, double *fb, int64_t cells, double *totals, int64_t diags);
 int64_t cpk_device_bytes(const CpkDevice *dev);
 int cpk_device_waves(const CpkDevice *dev);

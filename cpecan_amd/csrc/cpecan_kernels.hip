@@ -1249,6 +1249,23 @@ cpecan_pairhmm_sweep(const KArgs a) {
     }
 }
 
+// Result compaction: the sweep leaves every region's triples in its own slice, segments in processing order.  One
+// workgroup per chunk (a region's segment) copies it to its place in the compact buffer -- problems in order, regions in
+// order, segments DEScending (the reference prepends each traceback's pairs, pairwiseAligner.c:1415-1417) -- and adds
+// the region offset.  The host then fetches exactly the emitted triples instead of the slices' capacity.
+__global__ void __launch_bounds__(256) cpecan_gather_lists(const CpkChunk *chunks, int64_t nChunks,
+                                                           const int32_t *triples, int32_t *out) {
+    for (int64_t c = blockIdx.x; c < nChunks; c += gridDim.x) {
+        const CpkChunk ch = chunks[c];
+        const int32_t *src = triples + 3 * ch.src;
+        int32_t *dst = out + 3 * ch.dst;
+        for (int i = threadIdx.x; i < 3 * ch.len; i += blockDim.x) {
+            const int f = i % 3;
+            dst[i] = src[i] + (f == 1 ? ch.dx : (f == 2 ? ch.dy : 0));
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side of the HIP TU: memory, launch, timing
 // ------------------------------------------------------------------------------------------------
@@ -1271,6 +1288,7 @@ struct CpkDevice {
     CpkModel *dModel = nullptr;
     double *dRing = nullptr; Candidate *dCand = nullptr; double *dForward = nullptr, *dExpect = nullptr; double *dC = nullptr, *dM = nullptr, *dTotals = nullptr, *dGroll = nullptr;
     int32_t *dCounts = nullptr, *dSegStarts = nullptr, *dTriples = nullptr;
+    int32_t *dCompact = nullptr; CpkChunk *dChunks = nullptr; int64_t compactCap = 0, chunkCap = 0;
     unsigned int *dQueue = nullptr;
     double *dDbgFb = nullptr, *dDbgTotals = nullptr;
     int64_t bytes = 0;
@@ -1305,7 +1323,8 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
 
 static void free_all(CpkDevice *d) {
     void *ptrs[] = {d->dRegions, d->dDiags, d->dSegs, d->dSymbols, d->dModel, d->dRing, d->dCand, d->dC, d->dM,
-                    d->dTotals, d->dGroll, d->dCounts, d->dSegStarts, d->dTriples, d->dQueue, d->dDbgFb, d->dDbgTotals, d->dForward, d->dExpect};
+                    d->dTotals, d->dGroll, d->dCounts, d->dSegStarts, d->dTriples, d->dQueue, d->dDbgFb, d->dDbgTotals, d->dForward, d->dExpect,
+                    d->dCompact, d->dChunks};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     d->dRegions = nullptr; d->dDiags = nullptr; d->dSegs = nullptr; d->dSymbols = nullptr; d->dModel = nullptr;
@@ -1314,6 +1333,7 @@ static void free_all(CpkDevice *d) {
     d->dForward = nullptr;
     d->dExpect = nullptr;
     d->dCounts = d->dSegStarts = d->dTriples = nullptr;
+    d->dCompact = nullptr; d->dChunks = nullptr; d->compactCap = d->chunkCap = 0;
     d->dQueue = nullptr;
     d->dDbgFb = d->dDbgTotals = nullptr;
     d->bytes = 0;
@@ -1522,8 +1542,8 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     return CPECAN_OK;
 }
 
-extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segStarts, int32_t *triples, double *expect,
-                                   double *kernelMs, double *d2hMs) {
+extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segStarts, double *expect, double *kernelMs,
+                                   double *d2hMs) {
     HIP_TRY(hipSetDevice(d->device));
     if (!d->ran) {
         cpk_set_error("download before run");
@@ -1539,8 +1559,6 @@ extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segSt
     HIP_TRY(hipEventRecord(e0, nullptr));
     HIP_TRY(hipMemcpy(counts, d->dCounts, sizeof(int32_t) * (size_t)d->nLists * d->geo.nRegions, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(segStarts, d->dSegStarts, sizeof(int32_t) * (size_t)d->nLists * d->nSegs, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(triples, d->dTriples, sizeof(int32_t) * (size_t)d->nLists * d->outTriplesPerList * 3,
-                      hipMemcpyDeviceToHost));
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));
     HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
@@ -1557,6 +1575,42 @@ extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segSt
         for (int w = 0; w < d->slots; w++)
             for (int i = 0; i < 106; i++) expect[i] += part[(size_t)w * 128 + i];
     }
+    return CPECAN_OK;
+}
+
+extern "C" int cpk_device_gather(CpkDevice *d, const CpkChunk *chunks, int64_t nChunks, int64_t total, int32_t *hostOut,
+                                 double *d2hMs) {
+    HIP_TRY(hipSetDevice(d->device));
+    if (nChunks <= 0 || total <= 0) return CPECAN_OK;
+    if (nChunks > d->chunkCap) {
+        if (d->dChunks) (void)hipFree(d->dChunks);
+        d->dChunks = nullptr;
+        HIP_TRY(hipMalloc((void **)&d->dChunks, sizeof(CpkChunk) * (size_t)nChunks));
+        d->chunkCap = nChunks;
+    }
+    if (total > d->compactCap) {
+        if (d->dCompact) (void)hipFree(d->dCompact);
+        d->dCompact = nullptr;
+        HIP_TRY(hipMalloc((void **)&d->dCompact, sizeof(int32_t) * 3 * (size_t)total));
+        d->compactCap = total;
+    }
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, nullptr));
+    HIP_TRY(hipMemcpy(d->dChunks, chunks, sizeof(CpkChunk) * (size_t)nChunks, hipMemcpyHostToDevice));
+    const int64_t blocks = nChunks < 16384 ? nChunks : 16384;
+    hipLaunchKernelGGL(cpecan_gather_lists, dim3((unsigned)blocks), dim3(256), 0, nullptr, d->dChunks, nChunks, d->dTriples,
+                       d->dCompact);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(hostOut, d->dCompact, sizeof(int32_t) * 3 * (size_t)total, hipMemcpyDeviceToHost));
+    HIP_TRY(hipEventRecord(e1, nullptr));
+    HIP_TRY(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (d2hMs) *d2hMs += ms;
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return CPECAN_OK;
 }
 
