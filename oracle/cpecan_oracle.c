@@ -9,6 +9,7 @@
  */
 #include "cpecan_oracle.h"
 
+#include <ctype.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -897,4 +898,163 @@ int64_t orc_batch_aligned_pairs(const OrcModel *m, const char *seqBlob, const in
     (void)nThreads;
     if (cells) *cells = totalCells;
     return totalPairs;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Consumers of the posterior lists
+ * ---------------------------------------------------------------------------------------------- */
+
+/* getIndelProbabilities, impl/pairwiseAligner.c:1519-1534: probability mass of each base that is NOT in a listed pair */
+static int64_t *unaligned_mass(const int64_t *triples, int64_t n, int64_t len, int coord) {
+    int64_t *mass = malloc(sizeof(int64_t) * (size_t)(len > 0 ? len : 1));
+    for (int64_t i = 0; i < len; i++) mass[i] = ORC_PROB_1;
+    for (int64_t i = 0; i < n; i++) mass[triples[3 * i + coord]] -= triples[3 * i];
+    for (int64_t i = 0; i < len; i++)
+        if (mass[i] < 0) mass[i] = 0;
+    return mass;
+}
+
+void orc_reweight_aligned_pairs(int64_t *triples, int64_t n, int64_t lX, int64_t lY, double gapGamma) {
+    if (gapGamma <= 0.0) return; /* :1551 */
+    int64_t *mx = unaligned_mass(triples, n, lX, 1), *my = unaligned_mass(triples, n, lY, 2);
+    for (int64_t i = 0; i < n; i++) {
+        /* :1543: int64 - double * int64, evaluated in double and truncated towards zero on assignment */
+        const int64_t w = triples[3 * i] - gapGamma * (mx[triples[3 * i + 1]] + my[triples[3 * i + 2]]);
+        triples[3 * i] = w;
+    }
+    free(mx);
+    free(my);
+}
+
+static double sum_scores(const int64_t *triples, int64_t n) { /* totalScore, :1578-1585 */
+    double t = 0.0;
+    for (int64_t i = 0; i < n; i++) t += triples[3 * i];
+    return t;
+}
+
+double orc_score_by_posterior(int64_t lX, int64_t lY, const int64_t *triples, int64_t n) { /* :1587-1589 */
+    return 100.0 * ((lX + lY) == 0 ? 0 : (2.0 * sum_scores(triples, n)) / ((lX + lY) * ORC_PROB_1));
+}
+
+double orc_score_by_posterior_ignoring_gaps(const int64_t *triples, int64_t n) { /* :1591-1593 */
+    return 100.0 * sum_scores(triples, n) / ((double)n * ORC_PROB_1);
+}
+
+/* getCumulativeGapProbs, :1603-1619 */
+static int64_t *cumulative_gap_mass(const int64_t *gaps, int64_t n, int64_t len, int coord) {
+    int64_t *cum = calloc((size_t)(len > 0 ? len : 1), sizeof(int64_t));
+    for (int64_t i = 0; i < n; i++) cum[gaps[3 * i + coord]] += gaps[3 * i];
+    for (int64_t i = 1; i < len; i++) cum[i] += cum[i - 1];
+    return cum;
+}
+
+/* getIndelProb, :1621-1625: gap mass of `length` bases starting at `start` */
+static int64_t gap_mass(const int64_t *cum, int64_t start, int64_t length) {
+    return length == 0 ? 0 : cum[start + length - 1] - (start > 0 ? cum[start - 1] : 0);
+}
+
+int64_t orc_mea_alignment(const int64_t *pairs, int64_t n, const int64_t *gapX, int64_t nGapX, const int64_t *gapY,
+                          int64_t nGapY, int64_t lX, int64_t lY, float gapGamma, int64_t *out, double *alignmentScore) {
+    double *best = calloc((size_t)n + 1, sizeof(double));   /* score of the best chain ending at pair i */
+    int64_t *prev = calloc((size_t)n + 1, sizeof(int64_t)); /* its predecessor */
+    char *record = calloc((size_t)n + 1, 1);                /* chain score incl. trailing gaps is a running maximum */
+    int64_t *cy = cumulative_gap_mass(gapY, nGapY, lY, 2), *cx = cumulative_gap_mass(gapX, nGapX, lX, 1);
+    double top = 0;
+    for (int64_t i = 0; i <= n; i++) {
+        int64_t w, x, y;
+        if (i == n) { /* sentinel pair behind both sequences, :1652-1654 */
+            w = 0;
+            x = lX;
+            y = lY;
+        } else {
+            w = pairs[3 * i];
+            x = pairs[3 * i + 1];
+            y = pairs[3 * i + 2];
+        }
+        /* :1660-1661: int64 + (int64 * float): the product and the sum are float arithmetic */
+        double score = w + (gap_mass(cx, 0, x) + gap_mass(cy, 0, y)) * gapGamma;
+        int64_t from = -1;
+        for (int64_t j = i - 1; j >= 0; j--) {
+            const int64_t x2 = pairs[3 * j + 1], y2 = pairs[3 * j + 2];
+            if (x2 < x && y2 < y) {
+                /* :1673-1675: (int64 + double) + float product, truncated to int64 */
+                const int64_t s = w + best[j] + (gap_mass(cx, x2 + 1, x - x2 - 1) + gap_mass(cy, y2 + 1, y - y2 - 1)) * gapGamma;
+                if (s > score) {
+                    score = s;
+                    from = j;
+                }
+                if (record[j]) break; /* :1685: nothing further back can do better */
+            }
+        }
+        prev[i] = from;
+        best[i] = score;
+        /* :1695-1696 */
+        const double s = score + ((x < lX ? gap_mass(cx, x + 1, lX - x - 1) : 0) + (y < lY ? gap_mass(cy, y + 1, lY - y - 1) : 0)) * gapGamma;
+        if (s >= top) {
+            top = s;
+            record[i] = 1;
+        }
+    }
+    int64_t count = 0;
+    for (int64_t i = prev[n]; i >= 0; i = prev[i]) count++;
+    int64_t at = count;
+    for (int64_t i = prev[n]; i >= 0; i = prev[i]) { /* written back to front == built reversed, then flipped (:1714) */
+        at--;
+        out[3 * at] = pairs[3 * i];
+        out[3 * at + 1] = pairs[3 * i + 1];
+        out[3 * at + 2] = pairs[3 * i + 2];
+    }
+    free(best);
+    free(prev);
+    free(record);
+    free(cx);
+    free(cy);
+    if (alignmentScore) *alignmentScore = top;
+    return count;
+}
+
+static int up(char c) { return toupper((unsigned char)c); }
+
+int64_t orc_left_shift_alignment(const int64_t *pairs, int64_t n, const char *sX, const char *sY, int64_t *out) {
+    const int64_t lX = (int64_t)strlen(sX), lY = (int64_t)strlen(sY);
+    int64_t count = 0; /* pairs are produced from the right end, reversed at the end (:1759) */
+    int64_t x = lX, y = lY;
+    for (int64_t i = n - 1; i >= 0; i--) {
+        const int64_t w = pairs[3 * i], x2 = pairs[3 * i + 1], y2 = pairs[3 * i + 2];
+        /* a gap lies between this pair and the last placed one, and the bases left of the gap's right edge match:
+         * slide the edge left, borrowing this pair's score (:1737-1744) */
+        while ((x - x2 > 1 || y - y2 > 1) && up(sX[x - 1]) == up(sY[y - 1])) {
+            out[3 * count] = w;
+            out[3 * count + 1] = x - 1;
+            out[3 * count + 2] = y - 1;
+            count++;
+            x--;
+            y--;
+            if (x2 == x || y2 == y) break; /* slid over an existing pair */
+        }
+        if (x2 < x && y2 < y) {
+            out[3 * count] = w;
+            out[3 * count + 1] = x2;
+            out[3 * count + 2] = y2;
+            count++;
+            x = x2;
+            y = y2;
+        }
+    }
+    /* left end (:1753-1757); the score is borrowed from the first input pair, 1 for an empty input */
+    while (((x > 0) & (y > 0)) && up(sX[x - 1]) == up(sY[y - 1])) {
+        out[3 * count] = n > 0 ? pairs[0] : 1;
+        out[3 * count + 1] = x - 1;
+        out[3 * count + 2] = y - 1;
+        count++;
+        x--;
+        y--;
+    }
+    for (int64_t a = 0, b = count - 1; a < b; a++, b--)
+        for (int f = 0; f < 3; f++) {
+            const int64_t t = out[3 * a + f];
+            out[3 * a + f] = out[3 * b + f];
+            out[3 * b + f] = t;
+        }
+    return count;
 }

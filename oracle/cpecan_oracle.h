@@ -154,6 +154,20 @@ int64_t orc_batch_aligned_pairs(const OrcModel *m, const char *seqBlob, const in
                                 const OrcParams *p, int raggedLeft, int raggedRight, int nThreads,
                                 int64_t *cells);
 
+/* ---- consumers of the posterior lists.  Triples are (score, x, y) int64. ---- */
+/* reweightAlignedPairs2, impl/pairwiseAligner.c:1519-1558: in place; gapGamma <= 0 leaves the list unchanged. */
+void orc_reweight_aligned_pairs(int64_t *triples, int64_t n, int64_t lX, int64_t lY, double gapGamma);
+/* scoreByPosteriorProbability / scoreByPosteriorProbabilityIgnoringGaps, :1578-1597 */
+double orc_score_by_posterior(int64_t lX, int64_t lY, const int64_t *triples, int64_t n);
+double orc_score_by_posterior_ignoring_gaps(const int64_t *triples, int64_t n);
+/* getMaximalExpectedAccuracyPairwiseAlignment, :1603-1724.  gapGamma is the float of PairwiseAlignmentParameters
+ * (inc/pairwiseAligner.h:38): parts of the score arithmetic run in float, as in the reference.  out holds n triples;
+ * returns the number written. */
+int64_t orc_mea_alignment(const int64_t *pairs, int64_t n, const int64_t *gapX, int64_t nGapX, const int64_t *gapY,
+                          int64_t nGapY, int64_t lX, int64_t lY, float gapGamma, int64_t *out, double *alignmentScore);
+/* leftShiftAlignment, :1726-1762.  out holds n + min(lX, lY) + 1 triples; returns the number written. */
+int64_t orc_left_shift_alignment(const int64_t *pairs, int64_t n, const char *sX, const char *sY, int64_t *out);
+
 void orc_free(void *p);
 
 #ifdef __cplusplus

@@ -112,6 +112,16 @@ def lib():
         L.orc_batch_aligned_pairs.restype = C.c_int64
         L.orc_batch_aligned_pairs.argtypes = [C.POINTER(Model), C.c_char_p, i64p, i64p, i64p, C.c_int64,
                                               C.POINTER(Params), C.c_int, C.c_int, C.c_int, i64p]
+        L.orc_reweight_aligned_pairs.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int64, C.c_double]
+        L.orc_score_by_posterior.restype = C.c_double
+        L.orc_score_by_posterior.argtypes = [C.c_int64, C.c_int64, i64p, C.c_int64]
+        L.orc_score_by_posterior_ignoring_gaps.restype = C.c_double
+        L.orc_score_by_posterior_ignoring_gaps.argtypes = [i64p, C.c_int64]
+        L.orc_mea_alignment.restype = C.c_int64
+        L.orc_mea_alignment.argtypes = [i64p, C.c_int64, i64p, C.c_int64, i64p, C.c_int64, C.c_int64, C.c_int64, C.c_float,
+                                        i64p, dp]
+        L.orc_left_shift_alignment.restype = C.c_int64
+        L.orc_left_shift_alignment.argtypes = [i64p, C.c_int64, C.c_char_p, C.c_char_p, i64p]
         L.orc_trace_free.argtypes = [C.POINTER(Trace)]
         L.orc_free.argtypes = [C.c_void_p]
         _lib = L
@@ -287,3 +297,45 @@ def batch_aligned_pairs(m, problems, p=None, ragged_left=False, ragged_right=Fal
     n = lib().orc_batch_aligned_pairs(C.byref(m), bytes(blob), sop, aap, aop, len(problems), C.byref(p),
                                       int(ragged_left), int(ragged_right), int(threads), C.byref(cells))
     return n, cells.value
+
+
+# ---- consumers of the posterior lists ----
+def _triples(t):
+    a = np.ascontiguousarray(np.asarray(t, dtype=np.int64).reshape(-1, 3))
+    return a, a.ctypes.data_as(C.POINTER(C.c_int64)), len(a)
+
+
+def reweight_aligned_pairs(pairs, lX, lY, gap_gamma):
+    a, ptr, n = _triples(pairs)
+    a = a.copy()
+    lib().orc_reweight_aligned_pairs(a.ctypes.data_as(C.POINTER(C.c_int64)), n, lX, lY, float(gap_gamma))
+    return a
+
+
+def score_by_posterior(lX, lY, pairs):
+    a, ptr, n = _triples(pairs)
+    return lib().orc_score_by_posterior(lX, lY, ptr, n)
+
+
+def score_by_posterior_ignoring_gaps(pairs):
+    a, ptr, n = _triples(pairs)
+    return lib().orc_score_by_posterior_ignoring_gaps(ptr, n)
+
+
+def mea_alignment(pairs, gap_x, gap_y, lX, lY, gap_gamma):
+    """Returns (alignment int64[n,3], alignmentScore)."""
+    a, pa, n = _triples(pairs)
+    gx, pgx, ngx = _triples(gap_x)
+    gy, pgy, ngy = _triples(gap_y)
+    out = np.zeros((max(n, 1), 3), dtype=np.int64)
+    score = C.c_double()
+    cnt = lib().orc_mea_alignment(pa, n, pgx, ngx, pgy, ngy, lX, lY, C.c_float(gap_gamma),
+                                  out.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(score))
+    return out[:cnt].copy(), score.value
+
+
+def left_shift_alignment(pairs, sx, sy):
+    a, pa, n = _triples(pairs)
+    out = np.zeros((n + min(len(sx), len(sy)) + 1, 3), dtype=np.int64)
+    cnt = lib().orc_left_shift_alignment(pa, n, _b(sx), _b(sy), out.ctypes.data_as(C.POINTER(C.c_int64)))
+    return out[:cnt].copy()

@@ -295,3 +295,51 @@ def test_split_regions_cover_and_order():
     pairs = ob.aligned_pairs(m, sx, sy, anchors, p, True, True)
     _check_pairs(pairs, len(sx), len(sy))
     assert len(pairs) > 0
+
+
+# ---- consumers of the posterior lists ----
+def test_left_shift_alignment_golden():
+    """tests/pairwiseAlignerTest.c:944-995 (test_leftShiftAlignment)."""
+    fx = GOLD["test_leftShiftAlignment"]
+    pairs = [(fx["score"], x, y) for x, y in zip(fx["alignedX"], fx["alignedY"])]
+    got = ob.left_shift_alignment(pairs, fx["seqX"], fx["seqY"])
+    assert len(got) == len(fx["shiftedX"])
+    assert [int(v) for v in got[:, 1]] == fx["shiftedX"]
+    assert [int(v) for v in got[:, 2]] == fx["shiftedY"]
+
+
+def test_reweight_by_hand():
+    """impl/pairwiseAligner.c:1519-1558 worked by hand: every base keeps PROB_1 minus the listed mass (floored at 0),
+    a pair loses gapGamma times the unaligned mass of its two bases; the result is truncated towards zero."""
+    P = 10000000
+    pairs = [(6000000, 0, 0), (3000000, 0, 1)]
+    got = ob.reweight_aligned_pairs(pairs, 1, 2, 0.5)
+    assert [int(v) for v in got[:, 0]] == [6000000 - (1000000 + 4000000) // 2, 3000000 - (1000000 + 7000000) // 2]
+    # over-subscribed base: mass floored at zero (:1529-1533); gapGamma <= 0 is the identity (:1551)
+    got = ob.reweight_aligned_pairs([(9000000, 0, 0), (9000000, 0, 1)], 1, 2, 1.0)
+    assert [int(v) for v in got[:, 0]] == [9000000 - (0 + 1000000), 9000000 - (0 + 1000000)]
+    assert (ob.reweight_aligned_pairs(pairs, 1, 2, 0.0) == np.array(pairs)).all()
+    assert abs(ob.score_by_posterior(1, 2, pairs) - 100.0 * 2 * 9000000 / (3 * P)) < 1e-12
+    assert abs(ob.score_by_posterior_ignoring_gaps(pairs) - 100.0 * 9000000 / (2 * P)) < 1e-12
+
+
+def test_mea_alignment_properties():
+    """getMaximalExpectedAccuracyPairwiseAlignment (:1628-1724): the result is a strictly increasing chain of input pairs;
+    with no gap mass and gapGamma 0 it is the heaviest chain (checked against an O(n^2) DP on small inputs)."""
+    import random
+    rng = random.Random(5)
+    for _ in range(50):
+        lX, lY = rng.randrange(3, 12), rng.randrange(3, 12)
+        cells = sorted({(rng.randrange(lX), rng.randrange(lY)) for _ in range(rng.randrange(1, 14))},
+                       key=lambda c: (c[0] + c[1], c[1] - c[0]))
+        pairs = [(rng.randrange(1, 10000000), x, y) for x, y in cells]
+        got, score = ob.mea_alignment(pairs, [], [], lX, lY, 0.0)
+        xs = [int(v) for v in got[:, 1]]
+        ys = [int(v) for v in got[:, 2]]
+        assert all(a < b for a, b in zip(xs, xs[1:])) and all(a < b for a, b in zip(ys, ys[1:]))
+        assert {tuple(int(v) for v in r) for r in got} <= set(pairs)
+        best = [0] * len(pairs)
+        for i, (w, x, y) in enumerate(pairs):
+            best[i] = w + max([best[j] for j in range(len(pairs)) if pairs[j][1] < x and pairs[j][2] < y and j < i] + [0])
+        assert score == max(best)
+        assert sum(int(v) for v in got[:, 0]) == score
