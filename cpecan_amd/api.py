@@ -81,7 +81,10 @@ EXPORTS = [
     "cpecan_batch_stats", "cpecan_batch_set_debug", "cpecan_batch_debug_fetch", "cpecan_batch_forward_prob",
     "cpecan_get_aligned_pairs_using_anchors", "cpecan_get_aligned_pairs_with_indels_using_anchors",
     "cpecan_compute_forward_probability", "cpecan_free",
+    "cpecan_batch_set_post", "cpecan_batch_scores", "cpecan_reweight_aligned_pairs", "cpecan_posterior_scores",
+    "cpecan_mea_alignment", "cpecan_left_shift_alignment", "cpecan_get_shifted_mea_alignment",
 ]
+POST_REWEIGHT, POST_MEA, POST_LEFT_SHIFT = 1, 2, 4
 
 _lib = None
 
@@ -135,6 +138,16 @@ def lib():
         C.c_int, C.c_int, dp]
     L.cpecan_free.argtypes = [vp]
     L.cpecan_free.restype = None
+    L.cpecan_batch_set_post.argtypes = [vp, C.c_int, C.c_double]
+    L.cpecan_batch_scores.argtypes = [vp, C.c_int64, dp, dp, dp]
+    L.cpecan_reweight_aligned_pairs.argtypes = [i32p, C.c_int64, C.c_int64, C.c_int64, C.c_double]
+    L.cpecan_posterior_scores.argtypes = [i32p, C.c_int64, C.c_int64, C.c_int64, dp, dp]
+    L.cpecan_mea_alignment.argtypes = [i32p, C.c_int64, i32p, C.c_int64, i32p, C.c_int64, C.c_int64, C.c_int64, C.c_float,
+                                       C.POINTER(i32p), i64p, dp]
+    L.cpecan_left_shift_alignment.argtypes = [i32p, C.c_int64, C.c_char_p, C.c_char_p, C.POINTER(i32p), i64p]
+    L.cpecan_get_shifted_mea_alignment.argtypes = [
+        C.POINTER(StateMachine), C.c_char_p, C.c_char_p, i64p, C.c_int64, C.POINTER(PairwiseAlignmentParameters),
+        C.c_float, C.c_int, C.c_int, C.POINTER(i32p), i64p, dp]
     _lib = L
     return L
 
@@ -291,6 +304,17 @@ class Batch:
             return np.zeros((0, 3), dtype=np.int32)
         return np.ctypeslib.as_array(ptr, shape=(n.value * 3,)).copy().reshape(n.value, 3)
 
+    def set_post(self, flags, gapGamma=0.0):
+        """Consumers applied on the device by download(): POST_REWEIGHT (reweightAlignedPairs2), POST_MEA
+        (getMaximalExpectedAccuracyPairwiseAlignment, result list 3), POST_MEA | POST_LEFT_SHIFT (getShiftedMEAAlignment)."""
+        _check(lib().cpecan_batch_set_post(self._h, int(flags), float(gapGamma)), "cpecan_batch_set_post")
+
+    def scores(self, problem):
+        """(scoreByPosteriorProbability, scoreByPosteriorProbabilityIgnoringGaps, MEA alignment score) of a problem."""
+        a, b, c = C.c_double(), C.c_double(), C.c_double()
+        _check(lib().cpecan_batch_scores(self._h, problem, C.byref(a), C.byref(b), C.byref(c)), "cpecan_batch_scores")
+        return a.value, b.value, c.value
+
     def expectations(self, hmm):
         """Adds the batch's expectation counts into hmm (EMIT_EXPECT), like getExpectationsUsingAnchors on each problem."""
         _check(lib().cpecan_batch_expectations(self._h, C.byref(hmm)), "cpecan_batch_expectations")
@@ -369,3 +393,70 @@ def getExpectationsUsingAnchors(sM, hmmExpectations, sX, sY, anchorPairs, p, ali
         b.download()
         b.expectations(hmmExpectations)
     return hmmExpectations
+
+
+# ---- consumers of the posterior lists; (score, x, y) int32 triples in, GPU in between ----
+def _i32_triples(t):
+    a = np.ascontiguousarray(np.asarray(t, dtype=np.int32).reshape(-1, 3))
+    return a, a.ctypes.data_as(C.POINTER(C.c_int32)), len(a)
+
+
+def reweightAlignedPairs2(alignedPairs, seqLengthX, seqLengthY, gapGamma):  # impl/pairwiseAligner.c:1550
+    a, ptr, n = _i32_triples(alignedPairs)
+    a = a.copy()
+    _check(lib().cpecan_reweight_aligned_pairs(a.ctypes.data_as(C.POINTER(C.c_int32)), n, seqLengthX, seqLengthY,
+                                               float(gapGamma)), "cpecan_reweight_aligned_pairs")
+    return a
+
+
+def _posterior_scores(alignedPairs, lX, lY):
+    a, ptr, n = _i32_triples(alignedPairs)
+    s0, s1 = C.c_double(), C.c_double()
+    _check(lib().cpecan_posterior_scores(ptr, n, lX, lY, C.byref(s0), C.byref(s1)), "cpecan_posterior_scores")
+    return s0.value, s1.value
+
+
+def scoreByPosteriorProbability(lX, lY, alignedPairs):  # impl/pairwiseAligner.c:1587
+    return _posterior_scores(alignedPairs, lX, lY)[0]
+
+
+def scoreByPosteriorProbabilityIgnoringGaps(alignedPairs):  # impl/pairwiseAligner.c:1591
+    return _posterior_scores(alignedPairs, 0, 0)[1]
+
+
+def getMaximalExpectedAccuracyPairwiseAlignment(alignedPairs, gapXPairs, gapYPairs, seqXLength, seqYLength, p=None,
+                                                gapGamma=None):  # impl/pairwiseAligner.c:1628
+    """Returns (alignment int32[n,3], alignmentScore).  gapGamma defaults to the reference's 0.5 (:1345)."""
+    a, pa, n = _i32_triples(alignedPairs)
+    gx, pgx, ngx = _i32_triples(gapXPairs)
+    gy, pgy, ngy = _i32_triples(gapYPairs)
+    out = C.POINTER(C.c_int32)()
+    cnt = C.c_int64()
+    score = C.c_double()
+    _check(lib().cpecan_mea_alignment(pa, n, pgx, ngx, pgy, ngy, seqXLength, seqYLength,
+                                      C.c_float(0.5 if gapGamma is None else gapGamma), C.byref(out), C.byref(cnt),
+                                      C.byref(score)), "cpecan_mea_alignment")
+    return _take_list(out, cnt.value), score.value
+
+
+def leftShiftAlignment(alignedPairs, seqX, seqY):  # impl/pairwiseAligner.c:1726
+    a, pa, n = _i32_triples(alignedPairs)
+    out = C.POINTER(C.c_int32)()
+    cnt = C.c_int64()
+    _check(lib().cpecan_left_shift_alignment(pa, n, _bytes(seqX), _bytes(seqY), C.byref(out), C.byref(cnt)),
+           "cpecan_left_shift_alignment")
+    return _take_list(out, cnt.value)
+
+
+def getShiftedMEAAlignment(seqX, seqY, anchorAlignment, p, sM, alignmentHasRaggedLeftEnd=False,
+                           alignmentHasRaggedRightEnd=False, gapGamma=0.5):  # impl/pairwiseAligner.c:1767
+    """Returns (left-shifted MEA alignment int32[n,3], alignmentScore)."""
+    arr, ptr, n = _anchor_array(anchorAlignment)
+    out = C.POINTER(C.c_int32)()
+    cnt = C.c_int64()
+    score = C.c_double()
+    _check(lib().cpecan_get_shifted_mea_alignment(C.byref(sM), _bytes(seqX), _bytes(seqY), ptr, n, C.byref(p),
+                                                  C.c_float(gapGamma), int(alignmentHasRaggedLeftEnd),
+                                                  int(alignmentHasRaggedRightEnd), C.byref(out), C.byref(cnt),
+                                                  C.byref(score)), "cpecan_get_shifted_mea_alignment")
+    return _take_list(out, cnt.value), score.value

@@ -339,6 +339,86 @@ void getExpectationsUsingAnchors(StateMachine *sM, Hmm *hmmExpectations, const c
     cpecan_batch_destroy(b);
     free(anchors);
 }
+/* ---------------- consumers of the posterior lists: impl/pairwiseAligner.c:1519-1790 ---------------- */
+static int32_t *flatten_triples(stList *l, int64_t *n) { /* (score, x, y) tuples -> int32 triples */
+    *n = l ? stList_length(l) : 0;
+    int32_t *t = malloc(sizeof(int32_t) * 3 * (size_t)(*n ? *n : 1));
+    if (!t) die("out of memory");
+    for (int64_t i = 0; i < *n; i++) {
+        stIntTuple *tp = stList_get(l, i);
+        for (int f = 0; f < 3; f++) t[3 * i + f] = (int32_t)stIntTuple_get(tp, f);
+    }
+    return t;
+}
+stList *reweightAlignedPairs2(stList *alignedPairs, int64_t seqLengthX, int64_t seqLengthY, double gapGamma) {
+    if (gapGamma <= 0.0) return alignedPairs; /* :1551 */
+    int64_t n;
+    int32_t *t = flatten_triples(alignedPairs, &n);
+    check(cpecan_reweight_aligned_pairs(t, n, seqLengthX, seqLengthY, gapGamma), "reweightAlignedPairs2");
+    stList *l = list_of(t, n);
+    free(t);
+    stList_destruct(alignedPairs); /* the reference consumes its input (:1546) */
+    return l;
+}
+double scoreByPosteriorProbability(int64_t lX, int64_t lY, stList *alignedPairs) {
+    int64_t n;
+    int32_t *t = flatten_triples(alignedPairs, &n);
+    double s = 0.0;
+    check(cpecan_posterior_scores(t, n, lX, lY, &s, NULL), "scoreByPosteriorProbability");
+    free(t);
+    return s;
+}
+double scoreByPosteriorProbabilityIgnoringGaps(stList *alignedPairs) {
+    int64_t n;
+    int32_t *t = flatten_triples(alignedPairs, &n);
+    double s = 0.0;
+    check(cpecan_posterior_scores(t, n, 0, 0, NULL, &s), "scoreByPosteriorProbabilityIgnoringGaps");
+    free(t);
+    return s;
+}
+stList *getMaximalExpectedAccuracyPairwiseAlignment(stList *alignedPairs, stList *gapXPairs, stList *gapYPairs,
+                                                    int64_t seqXLength, int64_t seqYLength, double *alignmentScore,
+                                                    PairwiseAlignmentParameters *p) {
+    int64_t n, nx, ny, cnt = 0;
+    int32_t *t = flatten_triples(alignedPairs, &n), *gx = flatten_triples(gapXPairs, &nx), *gy = flatten_triples(gapYPairs, &ny);
+    int32_t *out = NULL;
+    double score = 0.0;
+    check(cpecan_mea_alignment(t, n, gx, nx, gy, ny, seqXLength, seqYLength, p->gapGamma, &out, &cnt, &score),
+          "getMaximalExpectedAccuracyPairwiseAlignment");
+    stList *l = list_of(out, cnt);
+    cpecan_free(out);
+    free(t);
+    free(gx);
+    free(gy);
+    if (alignmentScore) *alignmentScore = score;
+    return l;
+}
+stList *leftShiftAlignment(stList *alignedPairs, char *seqX, char *seqY) {
+    int64_t n, cnt = 0;
+    int32_t *t = flatten_triples(alignedPairs, &n), *out = NULL;
+    check(cpecan_left_shift_alignment(t, n, seqX, seqY, &out, &cnt), "leftShiftAlignment");
+    stList *l = list_of(out, cnt);
+    cpecan_free(out);
+    free(t);
+    return l;
+}
+stList *getShiftedMEAAlignment(char *seqX, char *seqY, stList *anchorAlignment, PairwiseAlignmentParameters *p,
+                               StateMachine *sM, bool raggedLeft, bool raggedRight, double *alignmentScore) {
+    cpecan_params q;
+    flatten_params(p, &q);
+    int64_t n, cnt = 0;
+    int64_t *anchors = flatten_anchors(anchorAlignment, &n);
+    int32_t *out = NULL;
+    double score = 0.0;
+    check(cpecan_get_shifted_mea_alignment(flat_or_die(sM), seqX, seqY, anchors, n, &q, p->gapGamma, raggedLeft, raggedRight,
+                                           &out, &cnt, &score),
+          "getShiftedMEAAlignment");
+    free(anchors);
+    stList *l = list_of(out, cnt);
+    cpecan_free(out);
+    if (alignmentScore) *alignmentScore = score;
+    return l;
+}
 double computeForwardProbability(char *seqX, char *seqY, stList *anchorPairs, PairwiseAlignmentParameters *p, StateMachine *sM,
                                  bool raggedLeft, bool raggedRight) {
     cpecan_params q;

@@ -7,6 +7,7 @@
  * the reference's list order (:1411-1418).  All floating-point DP work happens in cpecan_kernels.hip; there is
  * no CPU implementation of it in this library.
  */
+#include <ctype.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -412,8 +413,11 @@ typedef struct {
 
 typedef struct {
     int64_t firstRegion, nRegions;
-    int32_t *triples[3]; /* into cpecan_batch.results (not owned) */
-    int64_t nTriples[3];
+    int32_t *triples[4]; /* lists 0..2 into cpecan_batch.results, list 3 (MEA alignment) into postMea/postShift; not owned */
+    int64_t nTriples[4];
+    int64_t lX, lY;          /* of the whole problem */
+    int64_t charX, charY;    /* raw upper-case sequences in cpecan_batch.chars */
+    double scores[3];        /* byPosterior, byPosteriorIgnoringGaps, MEA alignment score */
 } HostProblem;
 
 struct cpecan_batch {
@@ -442,6 +446,11 @@ struct cpecan_batch {
     CpkDevice *dev;
     double *forward; /* [nRegions] in device order, FORWARD emitter */
     int32_t *results; /* every emitted triple of the batch, list-ordered: [list][problem][triple] */
+    uint8_t *chars;   /* raw upper-case sequences (leftShiftAlignment compares letters, not symbols) */
+    int64_t nChars, capChars;
+    int postFlags;    /* CPECAN_POST_* applied by download */
+    double postGapGamma;
+    int32_t *postMea, *postShift;
     cpecan_stats stats;
 };
 
@@ -489,12 +498,14 @@ int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpe
 
 static void free_results(cpecan_batch *b) {
     for (int64_t i = 0; i < b->nProblems; i++)
-        for (int l = 0; l < 3; l++) {
+        for (int l = 0; l < 4; l++) {
             b->problems[i].triples[l] = NULL;
             b->problems[i].nTriples[l] = 0;
         }
     free(b->results);
-    b->results = NULL;
+    free(b->postMea);
+    free(b->postShift);
+    b->results = b->postMea = b->postShift = NULL;
 }
 
 void cpecan_batch_destroy(cpecan_batch *b) {
@@ -509,6 +520,7 @@ void cpecan_batch_destroy(cpecan_batch *b) {
     free(b->devToHost);
     free(b->segs);
     free(b->forward);
+    free(b->chars);
     free(b);
 }
 
@@ -575,10 +587,20 @@ int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char
         free(rects);
         return CPECAN_ENOMEM;
     }
+    if (grow((void **)&b->chars, &b->capChars, b->nChars + lX + lY + 1, 1)) {
+        free(rects);
+        return CPECAN_ENOMEM;
+    }
     HostProblem *pr = &b->problems[b->nProblems];
     memset(pr, 0, sizeof *pr);
     pr->firstRegion = b->nRegions;
     pr->nRegions = nRects;
+    pr->lX = lX;
+    pr->lY = lY;
+    pr->charX = b->nChars;
+    for (int64_t i = 0; i < lX; i++) b->chars[b->nChars++] = (uint8_t)toupper((unsigned char)sX[i]);
+    pr->charY = b->nChars;
+    for (int64_t i = 0; i < lY; i++) b->chars[b->nChars++] = (uint8_t)toupper((unsigned char)sY[i]);
     int64_t next = 0; /* anchors are handed to regions in order, pairwiseAligner.c:1296-1308 */
     for (int64_t i = 0; i < nRects; i++) {
         const int64_t x1 = rects[4 * i], y1 = rects[4 * i + 1], x2 = rects[4 * i + 2], y2 = rects[4 * i + 3];
@@ -968,6 +990,109 @@ static int plan_results(cpecan_batch *b, const int32_t *counts, const int32_t *s
     return CPECAN_OK;
 }
 
+/* Fills one consumer descriptor per problem and the scratch totals of the job. */
+static void post_layout(CpkPostJob *job, CpkPostProblem *pp, int64_t i, const int64_t off[3], const int64_t n[3],
+                        int64_t lX, int64_t lY, int64_t charX, int64_t charY) {
+    memset(pp, 0, sizeof *pp);
+    for (int l = 0; l < 3; l++) {
+        pp->off[l] = off[l];
+        pp->n[l] = (int32_t)n[l];
+    }
+    pp->lX = (int32_t)lX;
+    pp->lY = (int32_t)lY;
+    pp->seqOff = job->seqSlots;
+    pp->chainOff = job->chainSlots;
+    pp->charX = charX;
+    pp->charY = charY;
+    pp->meaOut = job->meaCap;
+    pp->shiftOut = job->shiftCap;
+    job->seqSlots += lX + lY;
+    job->chainSlots += n[0] + 1;
+    job->meaCap += n[0];
+    job->shiftCap += n[0] + imin(lX, lY) + 1;
+    (void)i;
+}
+
+static int run_post(cpecan_batch *b) {
+    CpkPostJob job;
+    memset(&job, 0, sizeof job);
+    job.flags = b->postFlags;
+    job.gapGamma = b->postGapGamma;
+    job.nProblems = b->nProblems;
+    CpkPostProblem *pp = malloc(sizeof(CpkPostProblem) * (size_t)(b->nProblems ? b->nProblems : 1));
+    double *scores = malloc(sizeof(double) * 3 * (size_t)(b->nProblems ? b->nProblems : 1));
+    int32_t *counts = malloc(sizeof(int32_t) * 2 * (size_t)(b->nProblems ? b->nProblems : 1));
+    int rc = (pp && scores && counts) ? CPECAN_OK : CPECAN_ENOMEM;
+    for (int64_t i = 0; rc == CPECAN_OK && i < b->nProblems; i++) {
+        const HostProblem *pr = &b->problems[i];
+        int64_t off[3] = {0, 0, 0}, n[3] = {0, 0, 0};
+        for (int l = 0; l < b->nLists; l++) {
+            off[l] = (pr->triples[l] - b->results) / 3;
+            n[l] = pr->nTriples[l];
+        }
+        post_layout(&job, &pp[i], i, off, n, pr->lX, pr->lY, pr->charX, pr->charY);
+    }
+    if (rc == CPECAN_OK) {
+        job.problems = pp;
+        job.scores = scores;
+        job.counts = counts;
+        if (job.flags & CPECAN_POST_MEA) {
+            b->postMea = malloc(sizeof(int32_t) * 3 * (size_t)(job.meaCap ? job.meaCap : 1));
+            job.mea = b->postMea;
+            if (!b->postMea) rc = CPECAN_ENOMEM;
+        }
+        if (rc == CPECAN_OK && (job.flags & CPECAN_POST_LEFT_SHIFT)) {
+            b->postShift = malloc(sizeof(int32_t) * 3 * (size_t)(job.shiftCap ? job.shiftCap : 1));
+            job.shift = b->postShift;
+            job.chars = b->chars;
+            job.nChars = b->nChars;
+            if (!b->postShift) rc = CPECAN_ENOMEM;
+        }
+    }
+    if (rc == CPECAN_OK) rc = cpk_device_post(b->dev, &job);
+    for (int64_t i = 0; rc == CPECAN_OK && i < b->nProblems; i++) {
+        HostProblem *pr = &b->problems[i];
+        for (int k = 0; k < 3; k++) pr->scores[k] = scores[3 * i + k];
+        if (job.flags & CPECAN_POST_LEFT_SHIFT) {
+            pr->triples[3] = b->postShift + 3 * pp[i].shiftOut;
+            pr->nTriples[3] = counts[2 * i + 1];
+        } else if (job.flags & CPECAN_POST_MEA) {
+            pr->triples[3] = b->postMea + 3 * pp[i].meaOut;
+            pr->nTriples[3] = counts[2 * i];
+        }
+    }
+    free(pp);
+    free(scores);
+    free(counts);
+    return rc;
+}
+
+int cpecan_batch_set_post(cpecan_batch *b, int flags, double gapGamma) {
+    if (!b) return CPECAN_EINVAL;
+    if (flags & ~(CPECAN_POST_REWEIGHT | CPECAN_POST_MEA | CPECAN_POST_LEFT_SHIFT)) return CPECAN_EINVAL;
+    if ((flags & CPECAN_POST_LEFT_SHIFT) && !(flags & CPECAN_POST_MEA)) return CPECAN_EINVAL;
+    if ((flags & CPECAN_POST_MEA) && (flags & CPECAN_POST_REWEIGHT)) return CPECAN_EINVAL; /* alternatives in the reference */
+    if ((flags & CPECAN_POST_MEA) && b->emit != CPECAN_EMIT_INDEL) {
+        cpk_set_error("the MEA alignment needs the gap lists: create the batch with CPECAN_EMIT_INDEL");
+        return CPECAN_EINVAL;
+    }
+    if (flags && (b->emit == CPECAN_EMIT_FORWARD || b->emit == CPECAN_EMIT_EXPECT)) return CPECAN_EINVAL;
+    b->postFlags = flags;
+    b->postGapGamma = gapGamma;
+    return CPECAN_OK;
+}
+
+int cpecan_batch_scores(const cpecan_batch *b, int64_t problem, double *byPosterior, double *byPosteriorIgnoringGaps,
+                        double *meaScore) {
+    if (!b || !b->downloaded) return CPECAN_ESTATE;
+    if (problem < 0 || problem >= b->nProblems || b->emit == CPECAN_EMIT_FORWARD || b->emit == CPECAN_EMIT_EXPECT)
+        return CPECAN_EINVAL;
+    if (byPosterior) *byPosterior = b->problems[problem].scores[0];
+    if (byPosteriorIgnoringGaps) *byPosteriorIgnoringGaps = b->problems[problem].scores[1];
+    if (meaScore) *meaScore = b->problems[problem].scores[2];
+    return CPECAN_OK;
+}
+
 int cpecan_batch_download(cpecan_batch *b) {
     if (!b || !b->ran) return CPECAN_ESTATE;
     free_results(b);
@@ -1031,8 +1156,10 @@ int cpecan_batch_download(cpecan_batch *b) {
         CpkChunk *chunks = NULL;
         int64_t nChunks = 0, total = 0;
         rc = plan_results(b, counts, segStarts, &chunks, &nChunks, &total);
-        if (rc == CPECAN_OK) rc = cpk_device_gather(b->dev, chunks, nChunks, total, b->results, &b->stats.d2hMs);
+        if (rc == CPECAN_OK) rc = cpk_device_gather(b->dev, chunks, nChunks, total);
         free(chunks);
+        if (rc == CPECAN_OK) rc = run_post(b); /* consumers of the lists, on the device, before they leave it */
+        if (rc == CPECAN_OK) rc = cpk_device_fetch(b->dev, b->results, total, &b->stats.d2hMs);
         b->stats.pairs = total;
     }
     if (rc == CPECAN_OK) b->downloaded = 1;
@@ -1043,7 +1170,8 @@ int cpecan_batch_download(cpecan_batch *b) {
 
 int cpecan_batch_result(const cpecan_batch *b, int64_t problem, int which, const int32_t **triples, int64_t *n) {
     if (!b || !b->downloaded) return CPECAN_ESTATE;
-    if (problem < 0 || problem >= b->nProblems || which < 0 || which >= b->nLists) return CPECAN_EINVAL;
+    if (problem < 0 || problem >= b->nProblems || which < 0) return CPECAN_EINVAL;
+    if (which >= b->nLists && !(which == 3 && (b->postFlags & CPECAN_POST_MEA))) return CPECAN_EINVAL;
     *triples = b->problems[problem].triples[which];
     *n = b->problems[problem].nTriples[which];
     return CPECAN_OK;
@@ -1100,6 +1228,151 @@ int cpecan_batch_debug_fetch(const cpecan_batch *b, int64_t problem, double *fbM
 /* ------------------------------------------------------------------------------------------------
  * single-problem convenience
  * ---------------------------------------------------------------------------------------------- */
+/* ---- the list consumers on host-held lists: one problem through cpk_post_lists ---- */
+typedef struct {
+    int32_t *buf;    /* concatenated lists */
+    int64_t total;
+    CpkPostProblem pp;
+    CpkPostJob job;
+    uint8_t *chars;
+    double scores[3];
+    int32_t counts[2];
+} PostSingle;
+
+static void post_single_free(PostSingle *ps) {
+    free(ps->buf);
+    free(ps->chars);
+    free(ps->job.mea);
+    free(ps->job.shift);
+}
+
+static int post_single_run(PostSingle *ps, int flags, double gapGamma, const int32_t *lists[3], const int64_t n[3],
+                           int64_t lX, int64_t lY, const char *sX, const char *sY) {
+    memset(ps, 0, sizeof *ps);
+    if (lX < 0 || lY < 0 || lX + lY >= (int64_t)1 << 30) return CPECAN_EINVAL;
+    int64_t off[3], at = 0;
+    for (int l = 0; l < 3; l++) {
+        if (n[l] < 0 || n[l] >= (int64_t)1 << 30 || (n[l] > 0 && !lists[l])) return CPECAN_EINVAL;
+        off[l] = at;
+        at += n[l];
+    }
+    ps->total = at;
+    ps->buf = malloc(sizeof(int32_t) * 3 * (size_t)(at ? at : 1));
+    if (!ps->buf) return CPECAN_ENOMEM;
+    for (int l = 0; l < 3; l++) {
+        for (int64_t i = 0; flags && i < n[l]; i++) { /* coordinates index the mass arrays and the sequences: check them */
+            const int32_t x = lists[l][3 * i + 1], y = lists[l][3 * i + 2];
+            const int okX = x >= 0 && x < lX, okY = y >= 0 && y < lY;
+            if ((l == 0 && !(okX && okY)) || (l == 1 && !okX) || (l == 2 && !okY)) return CPECAN_EINVAL;
+        }
+        if (n[l]) memcpy(ps->buf + 3 * off[l], lists[l], sizeof(int32_t) * 3 * (size_t)n[l]);
+    }
+    ps->job.flags = flags;
+    ps->job.gapGamma = gapGamma;
+    ps->job.nProblems = 1;
+    post_layout(&ps->job, &ps->pp, 0, off, n, lX, lY, 0, lX);
+    ps->job.problems = &ps->pp;
+    ps->job.scores = ps->scores;
+    ps->job.counts = ps->counts;
+    if (flags & CPECAN_POST_MEA) {
+        ps->job.mea = malloc(sizeof(int32_t) * 3 * (size_t)(ps->job.meaCap ? ps->job.meaCap : 1));
+        if (!ps->job.mea) return CPECAN_ENOMEM;
+    }
+    if (flags & CPECAN_POST_LEFT_SHIFT) {
+        if (!sX || !sY) return CPECAN_EINVAL;
+        ps->job.shift = malloc(sizeof(int32_t) * 3 * (size_t)(ps->job.shiftCap ? ps->job.shiftCap : 1));
+        ps->chars = malloc((size_t)(lX + lY + 1));
+        if (!ps->job.shift || !ps->chars) return CPECAN_ENOMEM;
+        for (int64_t i = 0; i < lX; i++) ps->chars[i] = (uint8_t)toupper((unsigned char)sX[i]);
+        for (int64_t i = 0; i < lY; i++) ps->chars[lX + i] = (uint8_t)toupper((unsigned char)sY[i]);
+        ps->job.chars = ps->chars;
+        ps->job.nChars = lX + lY;
+    }
+    return cpk_post_lists(0, ps->buf, ps->total, &ps->job);
+}
+
+static int take_list(const int32_t *src, int64_t n, int32_t **out, int64_t *nOut) {
+    int32_t *t = malloc(sizeof(int32_t) * 3 * (size_t)(n ? n : 1));
+    if (!t) return CPECAN_ENOMEM;
+    if (n) memcpy(t, src, sizeof(int32_t) * 3 * (size_t)n);
+    *out = t;
+    *nOut = n;
+    return CPECAN_OK;
+}
+
+int cpecan_reweight_aligned_pairs(int32_t *triples, int64_t n, int64_t lX, int64_t lY, double gapGamma) {
+    const int32_t *lists[3] = {triples, NULL, NULL};
+    const int64_t ns[3] = {n, 0, 0};
+    PostSingle ps;
+    int rc = post_single_run(&ps, CPECAN_POST_REWEIGHT, gapGamma, lists, ns, lX, lY, NULL, NULL);
+    if (rc == CPECAN_OK && n) memcpy(triples, ps.buf, sizeof(int32_t) * 3 * (size_t)n);
+    post_single_free(&ps);
+    return rc;
+}
+
+int cpecan_posterior_scores(const int32_t *triples, int64_t n, int64_t lX, int64_t lY, double *byPosterior,
+                            double *byPosteriorIgnoringGaps) {
+    const int32_t *lists[3] = {triples, NULL, NULL};
+    const int64_t ns[3] = {n, 0, 0};
+    PostSingle ps;
+    int rc = post_single_run(&ps, 0, 0.0, lists, ns, lX, lY, NULL, NULL);
+    if (rc == CPECAN_OK) {
+        if (byPosterior) *byPosterior = ps.scores[0];
+        if (byPosteriorIgnoringGaps) *byPosteriorIgnoringGaps = ps.scores[1];
+    }
+    post_single_free(&ps);
+    return rc;
+}
+
+int cpecan_mea_alignment(const int32_t *pairs, int64_t n, const int32_t *gapX, int64_t nGapX, const int32_t *gapY,
+                         int64_t nGapY, int64_t lX, int64_t lY, float gapGamma, int32_t **out, int64_t *nOut,
+                         double *alignmentScore) {
+    if (!out || !nOut) return CPECAN_EINVAL;
+    const int32_t *lists[3] = {pairs, gapX, gapY};
+    const int64_t ns[3] = {n, nGapX, nGapY};
+    PostSingle ps;
+    int rc = post_single_run(&ps, CPECAN_POST_MEA, (double)gapGamma, lists, ns, lX, lY, NULL, NULL);
+    if (rc == CPECAN_OK) rc = take_list(ps.job.mea, ps.counts[0], out, nOut);
+    if (rc == CPECAN_OK && alignmentScore) *alignmentScore = ps.scores[2];
+    post_single_free(&ps);
+    return rc;
+}
+
+int cpecan_left_shift_alignment(const int32_t *pairs, int64_t n, const char *sX, const char *sY, int32_t **out,
+                                int64_t *nOut) {
+    if (!out || !nOut || !sX || !sY) return CPECAN_EINVAL;
+    /* LEFT_SHIFT without MEA: the consumer stage shifts list 0 itself (it must be a chain, as in the reference) */
+    const int32_t *lists[3] = {pairs, NULL, NULL};
+    const int64_t ns[3] = {n, 0, 0};
+    PostSingle ps;
+    int rc = post_single_run(&ps, CPECAN_POST_LEFT_SHIFT, 0.0, lists, ns, (int64_t)strlen(sX), (int64_t)strlen(sY), sX, sY);
+    if (rc == CPECAN_OK) rc = take_list(ps.job.shift, ps.counts[1], out, nOut);
+    post_single_free(&ps);
+    return rc;
+}
+
+int cpecan_get_shifted_mea_alignment(const cpecan_model *m, const char *sX, const char *sY, const int64_t *anchors,
+                                     int64_t nAnchors, const cpecan_params *p, float gapGamma, int raggedLeft,
+                                     int raggedRight, int32_t **out, int64_t *nOut, double *alignmentScore) {
+    if (!m || !sX || !sY || !p || !out || !nOut) return CPECAN_EINVAL;
+    cpecan_batch *b = NULL;
+    int rc = cpecan_batch_create(&b, m, p, CPECAN_EMIT_INDEL, 0);
+    if (rc != CPECAN_OK) return rc;
+    rc = cpecan_batch_set_post(b, CPECAN_POST_MEA | CPECAN_POST_LEFT_SHIFT, (double)gapGamma);
+    if (rc == CPECAN_OK) {
+        const int64_t idx = cpecan_batch_add(b, sX, (int64_t)strlen(sX), sY, (int64_t)strlen(sY), anchors, nAnchors,
+                                             raggedLeft, raggedRight);
+        rc = idx < 0 ? (int)idx : CPECAN_OK;
+    }
+    if (rc == CPECAN_OK) rc = cpecan_batch_upload(b);
+    if (rc == CPECAN_OK) rc = cpecan_batch_run(b, NULL);
+    if (rc == CPECAN_OK) rc = cpecan_batch_download(b);
+    if (rc == CPECAN_OK) rc = take_list(b->problems[0].triples[3], b->problems[0].nTriples[3], out, nOut);
+    if (rc == CPECAN_OK && alignmentScore) *alignmentScore = b->problems[0].scores[2];
+    cpecan_batch_destroy(b);
+    return rc;
+}
+
 void cpecan_free(void *p) { free(p); }
 
 /* one problem through a batch of one: create, add, upload, run, download */

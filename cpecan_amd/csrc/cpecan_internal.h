@@ -118,10 +118,43 @@ int cpk_device_run(CpkDevice *dev, void *stream);
 int cpk_device_download(CpkDevice *dev, int32_t *counts /* [nLists][nRegions] */,
                         int32_t *segStarts /* [nLists][nSegsTotal] */, double *expect /* [106] */, double *kernelMs,
                         double *d2hMs);
-/* Moves the chunks into one compact buffer on the device (reference list order, region offsets applied) and copies
- * that buffer -- `total` triples, nothing else -- to hostOut. */
-int cpk_device_gather(CpkDevice *dev, const CpkChunk *chunks, int64_t nChunks, int64_t total, int32_t *hostOut,
-                      double *d2hMs);
+/* Moves the chunks into one compact buffer on the device (reference list order, region offsets applied). */
+int cpk_device_gather(CpkDevice *dev, const CpkChunk *chunks, int64_t nChunks, int64_t total);
+/* Copies the compact buffer -- `total` triples, nothing else -- to hostOut. */
+int cpk_device_fetch(CpkDevice *dev, int32_t *hostOut, int64_t total, double *d2hMs);
+
+/* ---- consumers of the posterior lists, one descriptor per alignment problem ---- */
+typedef struct {
+    int64_t off[3];          /* first triple of the aligned / gapX / gapY list in the triple buffer */
+    int32_t n[3];            /* their lengths */
+    int32_t lX, lY;
+    int32_t pad;
+    int64_t seqOff;          /* first of lX + lY scratch slots (unaligned mass, cumulative gap mass) */
+    int64_t chainOff;        /* first of n[0] + 1 chain-DP slots */
+    int64_t charX, charY;    /* raw upper-case sequences (left shift) */
+    int64_t meaOut;          /* first of n[0] output triples */
+    int64_t shiftOut;        /* first of n[0] + min(lX, lY) + 1 output triples */
+} CpkPostProblem;
+
+typedef struct {
+    int flags;               /* CPECAN_POST_* */
+    double gapGamma;
+    int64_t nProblems;
+    const CpkPostProblem *problems;
+    const uint8_t *chars;    /* host: raw sequences, or NULL */
+    int64_t nChars;
+    int64_t seqSlots, chainSlots, meaCap, shiftCap; /* totals over the problems */
+    /* outputs (host) */
+    double *scores;          /* [nProblems][3]: byPosterior, byPosteriorIgnoringGaps, MEA alignment score */
+    int32_t *counts;         /* [nProblems][2]: MEA pairs, left-shifted pairs */
+    int32_t *mea;            /* [meaCap*3] or NULL */
+    int32_t *shift;          /* [shiftCap*3] or NULL */
+} CpkPostJob;
+
+/* Runs the job on the batch's compact result buffer (after cpk_device_gather, before cpk_device_fetch). */
+int cpk_device_post(CpkDevice *dev, const CpkPostJob *job);
+/* Runs the job on lists given by the host: `triples` (total*3 int32) is uploaded, processed and copied back. */
+int cpk_post_lists(int device, int32_t *triples, int64_t total, const CpkPostJob *job);
 int cpk_device_debug_fetch(CpkDevice *dev, double *fb, int64_t cells, double *totals, int64_t diags);
 int64_t cpk_device_bytes(const CpkDevice *dev);
 int cpk_device_waves(const CpkDevice *dev);

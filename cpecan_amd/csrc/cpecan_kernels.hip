@@ -1266,6 +1266,193 @@ __global__ void __launch_bounds__(256) cpecan_gather_lists(const CpkChunk *chunk
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Consumers of the posterior lists.  Integer / order-defined arithmetic: bit-exact.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPostReweight = 1, kPostMea = 2, kPostLeftShift = 4;  // == CPECAN_POST_*
+
+// reweightAlignedPairs2 (impl/pairwiseAligner.c:1519-1558) + scoreByPosteriorProbability[IgnoringGaps] (:1578-1597).
+// One workgroup per problem.  mass[] = PROB_1 minus the listed mass of every base of X then Y, floored at 0 when read
+// (:1529-1533); a pair keeps  score - gapGamma * (massX + massY), evaluated in double and truncated towards zero (:1543).
+__global__ void __launch_bounds__(256) cpecan_post_reweight(const CpkPostProblem *problems, int32_t *triples, int32_t *mass,
+                                                            double gapGamma, int reweight, double *scores) {
+    const CpkPostProblem pb = problems[blockIdx.x];
+    int32_t *t = triples + 3 * pb.off[0];
+    const int n = pb.n[0];
+    __shared__ long long partial[256];
+    long long sum = 0;  // exact: |score| <= 1e7 * (1 + 2 gapGamma), n < 2^31
+    if (reweight && gapGamma > 0.0) {  // :1551
+        int32_t *mx = mass + pb.seqOff, *my = mx + pb.lX;
+        for (int i = threadIdx.x; i < pb.lX + pb.lY; i += blockDim.x) mx[i] = CPECAN_PROB_1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            atomicSub(&mx[t[3 * i + 1]], t[3 * i]);
+            atomicSub(&my[t[3 * i + 2]], t[3 * i]);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const long long ux = mx[t[3 * i + 1]], uy = my[t[3 * i + 2]];
+            const long long unaligned = (ux < 0 ? 0 : ux) + (uy < 0 ? 0 : uy);
+            const long long w = (long long)((double)(long long)t[3 * i] - gapGamma * (double)unaligned);
+            t[3 * i] = (int32_t)w;
+            sum += w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) sum += t[3 * i];
+    }
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) partial[threadIdx.x] += partial[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double total = (double)partial[0];  // the reference adds int64 scores into a double: exact below 2^53
+        const long long L = (long long)pb.lX + pb.lY;
+        scores[3 * blockIdx.x + 0] = 100.0 * (L == 0 ? 0 : (2.0 * total) / (double)(L * CPECAN_PROB_1));
+        scores[3 * blockIdx.x + 1] = 100.0 * total / ((double)n * CPECAN_PROB_1);
+    }
+}
+
+// getIndelProb (:1621-1625): gap mass of `length` bases starting at `start`
+__device__ __forceinline__ long long gap_mass(const long long *cum, long long start, long long length) {
+    return length == 0 ? 0 : cum[start + length - 1] - (start > 0 ? cum[start - 1] : 0);
+}
+
+// getMaximalExpectedAccuracyPairwiseAlignment (:1628-1724), one LANE per problem: the chain DP walks the pairs in
+// list order with a data-dependent walk back.  gapGamma is the float of PairwiseAlignmentParameters, so
+// `int64 * gapGamma` and `int64 + that` are float arithmetic, `int64 + double + float` is double truncated to int64.
+__global__ void __launch_bounds__(64) cpecan_post_mea(const CpkPostProblem *problems, int64_t nProblems,
+                                                      const int32_t *triples, long long *cum, double *best, int32_t *prev,
+                                                      uint8_t *record, float gapGamma, int32_t *meaOut, int32_t *counts,
+                                                      double *scores) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nProblems) return;
+    const CpkPostProblem pb = problems[p];
+    const int32_t *pairs = triples + 3 * pb.off[0], *gx = triples + 3 * pb.off[1], *gy = triples + 3 * pb.off[2];
+    const int n = pb.n[0];
+    const long long lX = pb.lX, lY = pb.lY;
+    long long *cx = cum + pb.seqOff, *cy = cx + pb.lX;  // getCumulativeGapProbs (:1603-1619)
+    for (long long i = 0; i < lX + lY; i++) cx[i] = 0;
+    for (int i = 0; i < pb.n[1]; i++) cx[gx[3 * i + 1]] += gx[3 * i];
+    for (int i = 0; i < pb.n[2]; i++) cy[gy[3 * i + 2]] += gy[3 * i];
+    for (long long i = 1; i < lX; i++) cx[i] += cx[i - 1];
+    for (long long i = 1; i < lY; i++) cy[i] += cy[i - 1];
+    double *bs = best + pb.chainOff;
+    int32_t *pv = prev + pb.chainOff;
+    uint8_t *rec = record + pb.chainOff;
+    double top = 0;
+    for (int i = 0; i <= n; i++) {
+        long long w, x, y;
+        if (i == n) {  // sentinel behind both sequences (:1652-1654)
+            w = 0;
+            x = lX;
+            y = lY;
+        } else {
+            w = pairs[3 * i];
+            x = pairs[3 * i + 1];
+            y = pairs[3 * i + 2];
+        }
+        double score = (double)((float)w + (float)(gap_mass(cx, 0, x) + gap_mass(cy, 0, y)) * gapGamma);  // :1660-1661
+        int from = -1;
+        for (int j = i - 1; j >= 0; j--) {
+            const long long x2 = pairs[3 * j + 1], y2 = pairs[3 * j + 2];
+            if (x2 < x && y2 < y) {
+                const float g = (float)(gap_mass(cx, x2 + 1, x - x2 - 1) + gap_mass(cy, y2 + 1, y - y2 - 1)) * gapGamma;
+                const long long sc = (long long)(((double)w + bs[j]) + (double)g);  // :1673-1675
+                if ((double)sc > score) {
+                    score = (double)sc;
+                    from = j;
+                }
+                if (rec[j]) break;  // :1685
+            }
+        }
+        pv[i] = from;
+        bs[i] = score;
+        const float tail = (float)((x < lX ? gap_mass(cx, x + 1, lX - x - 1) : 0) + (y < lY ? gap_mass(cy, y + 1, lY - y - 1) : 0)) * gapGamma;
+        const double sc = score + (double)tail;  // :1695-1696
+        rec[i] = 0;
+        if (sc >= top) {
+            top = sc;
+            rec[i] = 1;
+        }
+    }
+    int count = 0;
+    for (int i = pv[n]; i >= 0; i = pv[i]) count++;
+    int32_t *out = meaOut + 3 * pb.meaOut;
+    int at = count;
+    for (int i = pv[n]; i >= 0; i = pv[i]) {  // back to front == built reversed, then flipped (:1714)
+        at--;
+        out[3 * at] = pairs[3 * i];
+        out[3 * at + 1] = pairs[3 * i + 1];
+        out[3 * at + 2] = pairs[3 * i + 2];
+    }
+    counts[2 * p] = count;
+    scores[3 * p + 2] = top;
+}
+
+// LEFT_SHIFT without MEA: list 0 is the chain to shift; put it where the MEA stage would have put its alignment.
+__global__ void __launch_bounds__(256) cpecan_post_copy_chain(const CpkPostProblem *problems, const int32_t *triples,
+                                                              int32_t *meaOut, int32_t *counts) {
+    const CpkPostProblem pb = problems[blockIdx.x];
+    const int32_t *src = triples + 3 * pb.off[0];
+    int32_t *dst = meaOut + 3 * pb.meaOut;
+    for (int i = threadIdx.x; i < 3 * pb.n[0]; i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x == 0) counts[2 * blockIdx.x] = pb.n[0];
+}
+
+// leftShiftAlignment (:1726-1762), one lane per problem, on the MEA alignment.  chars: raw upper-case sequences.
+__global__ void __launch_bounds__(64) cpecan_post_left_shift(const CpkPostProblem *problems, int64_t nProblems,
+                                                             const int32_t *mea, const uint8_t *chars, int32_t *shiftOut,
+                                                             int32_t *counts) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nProblems) return;
+    const CpkPostProblem pb = problems[p];
+    const int32_t *pairs = mea + 3 * pb.meaOut;
+    const int n = counts[2 * p];
+    const uint8_t *sX = chars + pb.charX, *sY = chars + pb.charY;
+    int32_t *out = shiftOut + 3 * pb.shiftOut;
+    int count = 0;
+    int x = pb.lX, y = pb.lY;
+    for (int i = n - 1; i >= 0; i--) {
+        const int w = pairs[3 * i], x2 = pairs[3 * i + 1], y2 = pairs[3 * i + 2];
+        while ((x - x2 > 1 || y - y2 > 1) && sX[x - 1] == sY[y - 1]) {  // :1737-1744
+            out[3 * count] = w;
+            out[3 * count + 1] = x - 1;
+            out[3 * count + 2] = y - 1;
+            count++;
+            x--;
+            y--;
+            if (x2 == x || y2 == y) break;
+        }
+        if (x2 < x && y2 < y) {
+            out[3 * count] = w;
+            out[3 * count + 1] = x2;
+            out[3 * count + 2] = y2;
+            count++;
+            x = x2;
+            y = y2;
+        }
+    }
+    const int first = n > 0 ? pairs[0] : 1;  // :1754
+    while (x > 0 && y > 0 && sX[x - 1] == sY[y - 1]) {
+        out[3 * count] = first;
+        out[3 * count + 1] = x - 1;
+        out[3 * count + 2] = y - 1;
+        count++;
+        x--;
+        y--;
+    }
+    for (int a = 0, b = count - 1; a < b; a++, b--)  // :1759
+        for (int f = 0; f < 3; f++) {
+            const int32_t t = out[3 * a + f];
+            out[3 * a + f] = out[3 * b + f];
+            out[3 * b + f] = t;
+        }
+    counts[2 * p + 1] = count;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side of the HIP TU: memory, launch, timing
 // ------------------------------------------------------------------------------------------------
@@ -1578,8 +1765,7 @@ extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segSt
     return CPECAN_OK;
 }
 
-extern "C" int cpk_device_gather(CpkDevice *d, const CpkChunk *chunks, int64_t nChunks, int64_t total, int32_t *hostOut,
-                                 double *d2hMs) {
+extern "C" int cpk_device_gather(CpkDevice *d, const CpkChunk *chunks, int64_t nChunks, int64_t total) {
     HIP_TRY(hipSetDevice(d->device));
     if (nChunks <= 0 || total <= 0) return CPECAN_OK;
     if (nChunks > d->chunkCap) {
@@ -1594,15 +1780,21 @@ extern "C" int cpk_device_gather(CpkDevice *d, const CpkChunk *chunks, int64_t n
         HIP_TRY(hipMalloc((void **)&d->dCompact, sizeof(int32_t) * 3 * (size_t)total));
         d->compactCap = total;
     }
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, nullptr));
     HIP_TRY(hipMemcpy(d->dChunks, chunks, sizeof(CpkChunk) * (size_t)nChunks, hipMemcpyHostToDevice));
     const int64_t blocks = nChunks < 16384 ? nChunks : 16384;
     hipLaunchKernelGGL(cpecan_gather_lists, dim3((unsigned)blocks), dim3(256), 0, nullptr, d->dChunks, nChunks, d->dTriples,
                        d->dCompact);
     HIP_TRY(hipGetLastError());
+    return CPECAN_OK;
+}
+
+extern "C" int cpk_device_fetch(CpkDevice *d, int32_t *hostOut, int64_t total, double *d2hMs) {
+    HIP_TRY(hipSetDevice(d->device));
+    if (total <= 0) return CPECAN_OK;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    HIP_TRY(hipEventRecord(e0, nullptr));
     HIP_TRY(hipMemcpy(hostOut, d->dCompact, sizeof(int32_t) * 3 * (size_t)total, hipMemcpyDeviceToHost));
     HIP_TRY(hipEventRecord(e1, nullptr));
     HIP_TRY(hipEventSynchronize(e1));
@@ -1611,6 +1803,118 @@ extern "C" int cpk_device_gather(CpkDevice *d, const CpkChunk *chunks, int64_t n
     if (d2hMs) *d2hMs += ms;
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
+    return CPECAN_OK;
+}
+
+// The consumers on a device-resident triple buffer.  Scratch lives for the duration of the call.
+namespace {
+struct PostScratch {
+    std::vector<void *> ptrs;
+    ~PostScratch() {
+        for (void *p : ptrs)
+            if (p) (void)hipFree(p);
+    }
+    template <typename T>
+    int alloc(T **out, size_t count) {
+        void *p = nullptr;
+        if (hipMalloc(&p, (count ? count : 1) * sizeof(T)) != hipSuccess) {
+            cpk_set_error("out of device memory in the list consumers");
+            return CPECAN_ENOMEM;
+        }
+        ptrs.push_back(p);
+        *out = static_cast<T *>(p);
+        return CPECAN_OK;
+    }
+};
+}  // namespace
+
+static int post_core(int32_t *dTriples, const CpkPostJob *job) {
+    const int64_t nP = job->nProblems;
+    if (nP <= 0) return CPECAN_OK;
+    PostScratch sc;
+    CpkPostProblem *dProblems = nullptr;
+    double *dScores = nullptr;
+    int32_t *dCounts = nullptr;
+    if (int rc = sc.alloc(&dProblems, (size_t)nP)) return rc;
+    if (int rc = sc.alloc(&dScores, (size_t)nP * 3)) return rc;
+    if (int rc = sc.alloc(&dCounts, (size_t)nP * 2)) return rc;
+    HIP_TRY(hipMemcpy(dProblems, job->problems, sizeof(CpkPostProblem) * (size_t)nP, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dScores, 0, sizeof(double) * (size_t)nP * 3));
+    HIP_TRY(hipMemset(dCounts, 0, sizeof(int32_t) * (size_t)nP * 2));
+    {
+        int32_t *dMass = nullptr;
+        const bool rw = (job->flags & kPostReweight) != 0;
+        if (int rc = sc.alloc(&dMass, rw ? (size_t)job->seqSlots : 1)) return rc;
+        hipLaunchKernelGGL(cpecan_post_reweight, dim3((unsigned)nP), dim3(256), 0, nullptr, dProblems, dTriples, dMass,
+                           job->gapGamma, rw ? 1 : 0, dScores);
+        HIP_TRY(hipGetLastError());
+    }
+    int32_t *dMea = nullptr, *dShift = nullptr;
+    const unsigned laneBlocks = (unsigned)((nP + 63) / 64);
+    if (job->flags & (kPostMea | kPostLeftShift))
+        if (int rc = sc.alloc(&dMea, (size_t)job->meaCap * 3)) return rc;
+    if (job->flags & kPostMea) {
+        long long *dCum = nullptr;
+        double *dBest = nullptr;
+        int32_t *dPrev = nullptr;
+        uint8_t *dRecord = nullptr;
+        if (int rc = sc.alloc(&dCum, (size_t)job->seqSlots)) return rc;
+        if (int rc = sc.alloc(&dBest, (size_t)job->chainSlots)) return rc;
+        if (int rc = sc.alloc(&dPrev, (size_t)job->chainSlots)) return rc;
+        if (int rc = sc.alloc(&dRecord, (size_t)job->chainSlots)) return rc;
+        hipLaunchKernelGGL(cpecan_post_mea, dim3(laneBlocks), dim3(64), 0, nullptr, dProblems, nP, dTriples, dCum, dBest,
+                           dPrev, dRecord, (float)job->gapGamma, dMea, dCounts, dScores);
+        HIP_TRY(hipGetLastError());
+    } else if (job->flags & kPostLeftShift) {
+        hipLaunchKernelGGL(cpecan_post_copy_chain, dim3((unsigned)nP), dim3(256), 0, nullptr, dProblems, dTriples, dMea,
+                           dCounts);
+        HIP_TRY(hipGetLastError());
+    }
+    if (job->flags & kPostLeftShift) {
+        uint8_t *dChars = nullptr;
+        if (!job->chars) {
+            cpk_set_error("left shift needs the raw sequences");
+            return CPECAN_EINVAL;
+        }
+        if (int rc = sc.alloc(&dChars, (size_t)job->nChars)) return rc;
+        if (int rc = sc.alloc(&dShift, (size_t)job->shiftCap * 3)) return rc;
+        HIP_TRY(hipMemcpy(dChars, job->chars, (size_t)job->nChars, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(cpecan_post_left_shift, dim3(laneBlocks), dim3(64), 0, nullptr, dProblems, nP, dMea, dChars,
+                           dShift, dCounts);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipDeviceSynchronize());
+    if (job->scores) HIP_TRY(hipMemcpy(job->scores, dScores, sizeof(double) * (size_t)nP * 3, hipMemcpyDeviceToHost));
+    if (job->counts) HIP_TRY(hipMemcpy(job->counts, dCounts, sizeof(int32_t) * (size_t)nP * 2, hipMemcpyDeviceToHost));
+    if (job->mea && dMea) HIP_TRY(hipMemcpy(job->mea, dMea, sizeof(int32_t) * 3 * (size_t)job->meaCap, hipMemcpyDeviceToHost));
+    if (job->shift && dShift)
+        HIP_TRY(hipMemcpy(job->shift, dShift, sizeof(int32_t) * 3 * (size_t)job->shiftCap, hipMemcpyDeviceToHost));
+    return CPECAN_OK;
+}
+
+extern "C" int cpk_device_post(CpkDevice *d, const CpkPostJob *job) {
+    HIP_TRY(hipSetDevice(d->device));
+    if (!d->dCompact && job->nProblems > 0) {
+        // every list is empty: the consumers still need a valid base pointer
+        HIP_TRY(hipMalloc((void **)&d->dCompact, sizeof(int32_t) * 3));
+        d->compactCap = 1;
+    }
+    return post_core(d->dCompact, job);
+}
+
+extern "C" int cpk_post_lists(int device, int32_t *triples, int64_t total, const CpkPostJob *job) {
+    const int nDev = cpk_device_count();
+    if (nDev <= 0 || device < 0 || device >= nDev) {
+        cpk_set_error("no usable HIP device (count=%d, requested=%d): the HIP path has no CPU fallback", nDev, device);
+        return CPECAN_ENODEVICE;
+    }
+    HIP_TRY(hipSetDevice(device));
+    PostScratch sc;
+    int32_t *dTriples = nullptr;
+    if (int rc = sc.alloc(&dTriples, (size_t)(total > 0 ? total : 1) * 3)) return rc;
+    if (total > 0) HIP_TRY(hipMemcpy(dTriples, triples, sizeof(int32_t) * 3 * (size_t)total, hipMemcpyHostToDevice));
+    if (int rc = post_core(dTriples, job)) return rc;
+    if (total > 0) HIP_TRY(hipMemcpy(triples, dTriples, sizeof(int32_t) * 3 * (size_t)total, hipMemcpyDeviceToHost));
     return CPECAN_OK;
 }
 

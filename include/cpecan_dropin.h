@@ -126,6 +126,19 @@ void getExpectationsUsingAnchors(StateMachine *sM, Hmm *hmmExpectations, const c
 double computeForwardProbability(char *seqX, char *seqY, stList *anchorPairs, PairwiseAlignmentParameters *p,
                                  StateMachine *sM, bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
 
+/* Consumers of the posterior lists, evaluated on the GPU (inc/pairwiseAligner.h:86-98, :272-290;
+ * impl/pairwiseAligner.c:1519-1790).  reweightAlignedPairs2 consumes its input list unless gapGamma <= 0. */
+stList *reweightAlignedPairs2(stList *alignedPairs, int64_t seqLengthX, int64_t seqLengthY, double gapGamma);
+double scoreByPosteriorProbability(int64_t lX, int64_t lY, stList *alignedPairs);
+double scoreByPosteriorProbabilityIgnoringGaps(stList *alignedPairs);
+stList *getMaximalExpectedAccuracyPairwiseAlignment(stList *alignedPairs, stList *gapXPairs, stList *gapYPairs,
+                                                    int64_t seqXLength, int64_t seqYLength, double *alignmentScore,
+                                                    PairwiseAlignmentParameters *p);
+stList *leftShiftAlignment(stList *alignedPairs, char *seqX, char *seqY);
+stList *getShiftedMEAAlignment(char *seqX, char *seqY, stList *anchorAlignment, PairwiseAlignmentParameters *p,
+                               StateMachine *sM, bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd,
+                               double *alignmentScore);
+
 typedef struct _diagonal {
     int64_t xay;
     int64_t xmyL;

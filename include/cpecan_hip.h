@@ -158,6 +158,21 @@ int cpecan_batch_forward_prob(const cpecan_batch *b, int64_t problem, double *lo
 
 int cpecan_batch_stats(const cpecan_batch *b, cpecan_stats *s);
 
+/* ---- consumers of the posterior lists, run on the device between the sweep and the download ----
+ * REWEIGHT   reweightAlignedPairs2 (pairwiseAligner.c:1550) on every problem's aligned pairs (list 0), in place
+ * MEA        getMaximalExpectedAccuracyPairwiseAlignment (:1628) from lists 0..2 (needs CPECAN_EMIT_INDEL); the alignment
+ *            is result list 3; gapGamma is used as the float of PairwiseAlignmentParameters
+ * LEFT_SHIFT leftShiftAlignment (:1726) of the MEA alignment (list 3 then holds the shifted alignment): MEA | LEFT_SHIFT
+ *            == getShiftedMEAAlignment (:1767)
+ * REWEIGHT and MEA are alternatives in the reference's callers and exclude each other here. */
+enum { CPECAN_POST_REWEIGHT = 1, CPECAN_POST_MEA = 2, CPECAN_POST_LEFT_SHIFT = 4 };
+/* Selects what cpecan_batch_download does to the lists before they leave the device. */
+int cpecan_batch_set_post(cpecan_batch *b, int flags, double gapGamma);
+/* After download: scoreByPosteriorProbability (:1587) and scoreByPosteriorProbabilityIgnoringGaps (:1591) of list 0 (as
+ * downloaded, i.e. reweighted if REWEIGHT was set), and the MEA alignment score (0 without MEA). NULL = not wanted. */
+int cpecan_batch_scores(const cpecan_batch *b, int64_t problem, double *byPosterior, double *byPosteriorIgnoringGaps,
+                        double *meaScore);
+
 /* Debug / test hook: for single-region problem i, copies the per-cell forward+backward match sums
  * (fb[cell] = F.match + B.match at emit time) and the total log-probability used for each diagonal.
  * Buffers must hold `cells` and `diagonals` doubles; needs the batch to have been created with
@@ -181,6 +196,23 @@ int cpecan_get_aligned_pairs_with_indels_using_anchors(const cpecan_model *m, co
 int cpecan_compute_forward_probability(const cpecan_model *m, const char *sX, const char *sY, const int64_t *anchors,
                                        int64_t nAnchors, const cpecan_params *p, int raggedLeft, int raggedRight,
                                        double *logProb);
+/* ---- the consumers on lists held by the caller (one problem; uploaded, processed on the GPU, copied back) ---- */
+/* reweightAlignedPairs2 (:1550): triples (score, x, y) rewritten in place. */
+int cpecan_reweight_aligned_pairs(int32_t *triples, int64_t n, int64_t lX, int64_t lY, double gapGamma);
+/* scoreByPosteriorProbability / ...IgnoringGaps (:1587-1597). */
+int cpecan_posterior_scores(const int32_t *triples, int64_t n, int64_t lX, int64_t lY, double *byPosterior,
+                            double *byPosteriorIgnoringGaps);
+/* getMaximalExpectedAccuracyPairwiseAlignment (:1628): *out is malloc'd (cpecan_free). */
+int cpecan_mea_alignment(const int32_t *pairs, int64_t n, const int32_t *gapX, int64_t nGapX, const int32_t *gapY,
+                         int64_t nGapY, int64_t lX, int64_t lY, float gapGamma, int32_t **out, int64_t *nOut,
+                         double *alignmentScore);
+/* leftShiftAlignment (:1726): *out is malloc'd (cpecan_free). */
+int cpecan_left_shift_alignment(const int32_t *pairs, int64_t n, const char *sX, const char *sY, int32_t **out,
+                                int64_t *nOut);
+/* getShiftedMEAAlignment (:1767). */
+int cpecan_get_shifted_mea_alignment(const cpecan_model *m, const char *sX, const char *sY, const int64_t *anchors,
+                                     int64_t nAnchors, const cpecan_params *p, float gapGamma, int raggedLeft,
+                                     int raggedRight, int32_t **out, int64_t *nOut, double *alignmentScore);
 void cpecan_free(void *p);
 
 #ifdef __cplusplus

@@ -154,7 +154,10 @@ int64_t orc_batch_aligned_pairs(const OrcModel *m, const char *seqBlob, const in
                                 const OrcParams *p, int raggedLeft, int raggedRight, int nThreads,
                                 int64_t *cells);
 
-/* ---- consumers of the posterior lists.  Triples are (score, x, y) int64. ---- */
+/* ---- consumers of the posterior lists.  Triples are (score, x, y) int64. ----
+ * Pinning: orc_left_shift_alignment is pinned by the reference's test vector (tests/pairwiseAlignerTest.c:944-995).
+ * The reference has no test of reweightAlignedPairs2 or of the MEA chain: those two restatements are checked by
+ * hand-worked cases and an independent chain DP only -- PARITY UNPINNED for them. */
 /* reweightAlignedPairs2, impl/pairwiseAligner.c:1519-1558: in place; gapGamma <= 0 leaves the list unchanged. */
 void orc_reweight_aligned_pairs(int64_t *triples, int64_t n, int64_t lX, int64_t lY, double gapGamma);
 /* scoreByPosteriorProbability / scoreByPosteriorProbabilityIgnoringGaps, :1578-1597 */

@@ -150,6 +150,58 @@ static void test_known_answers_gpu(void) {
     stateMachine_destruct(sM3);
 }
 
+/* tests/pairwiseAlignerTest.c:944-995 (test_leftShiftAlignment), through the reference-named GPU entry point; then the
+ * other list consumers on a tiny hand-checked case (impl/pairwiseAligner.c:1519-1597, :1628, :1767). */
+static void test_consumers_gpu(void) {
+    char *seqX = "GATTTACATC", *seqY = "GATTACAATCTG";
+    const int64_t ax[] = {0, 1, 2, 3, 5, 6, 7, 8, 9}, ay[] = {0, 1, 2, 3, 4, 5, 6, 8, 11};
+    const int64_t sx[] = {0, 1, 3, 4, 5, 6, 7, 8, 9}, sy[] = {0, 1, 2, 3, 4, 5, 6, 10, 11};
+    stList *pairs = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    for (int i = 0; i < 9; i++) stList_append(pairs, stIntTuple_construct3(1, ax[i], ay[i]));
+    stList *shifted = leftShiftAlignment(pairs, seqX, seqY);
+    CHECK(stList_length(shifted) == 9);
+    for (int i = 0; i < 9 && i < stList_length(shifted); i++) {
+        stIntTuple *t = stList_get(shifted, i);
+        CHECK(stIntTuple_get(t, 1) == sx[i] && stIntTuple_get(t, 2) == sy[i]);
+    }
+    stList_destruct(shifted);
+    stList_destruct(pairs);
+
+    /* reweighting worked by hand: unaligned mass X[0] = 1e6, Y[0] = 4e6, Y[1] = 7e6, gapGamma 0.5 */
+    stList *l = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    stList_append(l, stIntTuple_construct3(6000000, 0, 0));
+    stList_append(l, stIntTuple_construct3(3000000, 0, 1));
+    CHECK(fabs(scoreByPosteriorProbability(1, 2, l) - 100.0 * 2 * 9000000 / (3.0 * PAIR_ALIGNMENT_PROB_1)) < 1e-12);
+    CHECK(fabs(scoreByPosteriorProbabilityIgnoringGaps(l) - 100.0 * 9000000 / (2.0 * PAIR_ALIGNMENT_PROB_1)) < 1e-12);
+    l = reweightAlignedPairs2(l, 1, 2, 0.5);
+    CHECK(stList_length(l) == 2);
+    CHECK(stIntTuple_get(stList_get(l, 0), 0) == 3500000 && stIntTuple_get(stList_get(l, 1), 0) == -1000000);
+    stList_destruct(l);
+
+    /* MEA of two crossing pairs without gap mass keeps the heavier one; getShiftedMEAAlignment returns a chain */
+    stList *a = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    stList_append(a, stIntTuple_construct3(4000000, 1, 0));
+    stList_append(a, stIntTuple_construct3(7000000, 0, 1));
+    stList *none = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    PairwiseAlignmentParameters *p = pairwiseAlignmentBandingParameters_construct();
+    double score = -1;
+    stList *mea = getMaximalExpectedAccuracyPairwiseAlignment(a, none, none, 2, 2, &score, p);
+    CHECK(stList_length(mea) == 1 && stIntTuple_get(stList_get(mea, 0), 0) == 7000000 && score == 7000000.0);
+    stList_destruct(mea);
+    stList_destruct(a);
+    StateMachine *sM = stateMachine5_construct(fiveState);
+    stList *chain = getShiftedMEAAlignment("AGCGTTACGT", "AGCGTACGT", none, p, sM, 0, 0, &score);
+    CHECK(stList_length(chain) >= 8);
+    for (int64_t i = 1; i < stList_length(chain); i++) {
+        stIntTuple *u = stList_get(chain, i - 1), *v = stList_get(chain, i);
+        CHECK(stIntTuple_get(u, 1) < stIntTuple_get(v, 1) && stIntTuple_get(u, 2) < stIntTuple_get(v, 2));
+    }
+    stList_destruct(chain);
+    stList_destruct(none);
+    stateMachine_destruct(sM);
+    pairwiseAlignmentBandingParameters_destruct(p);
+}
+
 int main(int argc, char **argv) {
     const int gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
     test_bands();
@@ -161,6 +213,7 @@ int main(int argc, char **argv) {
     test_symbols();
     test_models();
     if (gpu) test_known_answers_gpu();
+    if (gpu) test_consumers_gpu();
     printf("%s: %d failure(s)\n", gpu ? "gpu" : "cpu", failures);
     return failures != 0;
 }

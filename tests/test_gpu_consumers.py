@@ -1,0 +1,124 @@
+"""GPU parity tests of the list consumers: reweightAlignedPairs2, posterior scores, the MEA chain and
+leftShiftAlignment, device kernels against the oracle's restatements.  Integer / order-defined arithmetic: bit-exact."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+import oracle_binding as ob
+from cpecan_amd import api
+from test_gpu_parity import _evolve, _rand_anchors, _rand_seq, _sm
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "reference_fixtures.json")))
+
+
+def _problems(rng, n, lo=20, hi=160):
+    out = []
+    for _ in range(n):
+        sx = _rand_seq(rng, rng.randrange(lo, hi))
+        sy = _evolve(rng, sx)
+        if not sy:
+            sy = "A"
+        out.append((sx, sy, _rand_anchors(rng, len(sx), len(sy)) if rng.random() > 0.5 else []))
+    return out
+
+
+def test_left_shift_golden_through_the_gpu():
+    """tests/pairwiseAlignerTest.c:944-995 (test_leftShiftAlignment)."""
+    fx = GOLD["test_leftShiftAlignment"]
+    pairs = [(fx["score"], x, y) for x, y in zip(fx["alignedX"], fx["alignedY"])]
+    got = api.leftShiftAlignment(pairs, fx["seqX"], fx["seqY"])
+    assert got[:, 1].tolist() == fx["shiftedX"] and got[:, 2].tolist() == fx["shiftedY"]
+    assert got[:, 0].tolist() == [1] * 9
+    # empty input: the boundary loop alone, score 1 (:1754)
+    got = api.leftShiftAlignment([], "ACGT", "TTGT")
+    assert got.tolist() == [[1, 2, 2], [1, 3, 3]]
+
+
+def test_reweight_and_scores_standalone_vs_oracle():
+    rng = random.Random(11)
+    p = api.pairwiseAlignmentBandingParameters_construct()
+    for sx, sy, a in _problems(rng, 12):
+        pairs = api.getAlignedPairsUsingAnchors(_sm(0), sx, sy, a, p)
+        for gamma in (0.5, float(np.float32(0.85)), 2.0, 0.0, -1.0):
+            got = api.reweightAlignedPairs2(pairs, len(sx), len(sy), gamma)
+            want = ob.reweight_aligned_pairs(pairs, len(sx), len(sy), gamma)
+            assert (got.astype(np.int64) == want).all()
+        assert api.scoreByPosteriorProbability(len(sx), len(sy), pairs) == ob.score_by_posterior(len(sx), len(sy), pairs)
+        if len(pairs):
+            assert api.scoreByPosteriorProbabilityIgnoringGaps(pairs) == ob.score_by_posterior_ignoring_gaps(pairs)
+
+
+def test_batch_reweight_matches_standalone_and_oracle():
+    rng = random.Random(12)
+    probs = _problems(rng, 40)
+    p = api.pairwiseAlignmentBandingParameters_construct(splitMatrixBiggerThanThis=400)  # split regions too
+    gamma = float(np.float32(0.5))
+
+    def run(flags):
+        with api.Batch(_sm(0), p) as b:
+            b.set_post(flags, gamma)
+            for sx, sy, a in probs:
+                b.add(sx, sy, a, True, True)
+            b.upload()
+            b.run()
+            b.download()
+            return [b.result(i) for i in range(len(probs))], [b.scores(i) for i in range(len(probs))]
+
+    plain, plain_scores = run(0)
+    rew, rew_scores = run(api.POST_REWEIGHT)
+    for i, (sx, sy, a) in enumerate(probs):
+        want = ob.reweight_aligned_pairs(plain[i], len(sx), len(sy), gamma)
+        assert (rew[i].astype(np.int64) == want).all()
+        assert plain_scores[i][0] == ob.score_by_posterior(len(sx), len(sy), plain[i])
+        assert rew_scores[i][0] == ob.score_by_posterior(len(sx), len(sy), want)
+        if len(want):
+            assert rew_scores[i][1] == ob.score_by_posterior_ignoring_gaps(want)
+
+
+def test_mea_and_left_shift_vs_oracle():
+    rng = random.Random(13)
+    probs = _problems(rng, 30)
+    p = api.pairwiseAlignmentBandingParameters_construct()
+    gamma = float(np.float32(0.5))
+    with api.Batch(_sm(0), p, emit=api.EMIT_INDEL) as b:
+        b.set_post(api.POST_MEA | api.POST_LEFT_SHIFT, gamma)
+        for sx, sy, a in probs:
+            b.add(sx, sy, a)
+        b.upload()
+        b.run()
+        b.download()
+        for i, (sx, sy, a) in enumerate(probs):
+            m, gx, gy = b.result(i, 0), b.result(i, 1), b.result(i, 2)
+            mea, score = ob.mea_alignment(m, gx, gy, len(sx), len(sy), gamma)
+            want = ob.left_shift_alignment(mea, sx, sy)
+            got = b.result(i, 3)
+            assert (got.astype(np.int64) == want).all(), i
+            assert b.scores(i)[2] == score
+            # the stages on their own
+            mea_gpu, score_gpu = api.getMaximalExpectedAccuracyPairwiseAlignment(m, gx, gy, len(sx), len(sy), gapGamma=gamma)
+            assert (mea_gpu.astype(np.int64) == mea).all() and score_gpu == score
+            assert (api.leftShiftAlignment(mea, sx, sy).astype(np.int64) == want).all()
+    # getShiftedMEAAlignment end to end on one problem
+    sx, sy, a = probs[0]
+    got, score = api.getShiftedMEAAlignment(sx, sy, a, p, _sm(0), gapGamma=gamma)
+    om, op = ob.model(0), ob.params()
+    m, gx, gy = ob.aligned_pairs_with_indels(om, sx, sy, a, op)
+    mea, _ = ob.mea_alignment(m, gx, gy, len(sx), len(sy), gamma)
+    want = ob.left_shift_alignment(mea, sx, sy)
+    assert got[:, 1:].tolist() == want[:, 1:].tolist()  # scores may differ by one unit of 1e-7 (device exp vs libm)
+
+
+def test_consumer_argument_errors():
+    p = api.pairwiseAlignmentBandingParameters_construct()
+    with api.Batch(_sm(0), p) as b:
+        with pytest.raises(api.CpecanError):
+            b.set_post(api.POST_MEA, 0.5)  # needs the gap lists (EMIT_INDEL)
+        with pytest.raises(api.CpecanError):
+            b.set_post(api.POST_LEFT_SHIFT, 0.5)
+    with pytest.raises(api.CpecanError):
+        api.reweightAlignedPairs2([(5, 3, 0)], 2, 2, 0.5)  # x outside the sequence
