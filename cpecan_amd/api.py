@@ -83,7 +83,9 @@ EXPORTS = [
     "cpecan_compute_forward_probability", "cpecan_free",
     "cpecan_batch_set_post", "cpecan_batch_scores", "cpecan_reweight_aligned_pairs", "cpecan_posterior_scores",
     "cpecan_mea_alignment", "cpecan_left_shift_alignment", "cpecan_get_shifted_mea_alignment",
+    "cpecan_anchors_from_alignment",
 ]
+OP_MATCH, OP_INDEL_X, OP_INDEL_Y = 0, 1, 2
 POST_REWEIGHT, POST_MEA, POST_LEFT_SHIFT = 1, 2, 4
 
 _lib = None
@@ -138,6 +140,9 @@ def lib():
         C.c_int, C.c_int, dp]
     L.cpecan_free.argtypes = [vp]
     L.cpecan_free.restype = None
+    L.cpecan_anchors_from_alignment.restype = C.c_int64
+    L.cpecan_anchors_from_alignment.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_char_p,
+                                                C.c_int64, C.c_char_p, C.c_int64, i64p]
     L.cpecan_batch_set_post.argtypes = [vp, C.c_int, C.c_double]
     L.cpecan_batch_scores.argtypes = [vp, C.c_int64, dp, dp, dp]
     L.cpecan_reweight_aligned_pairs.argtypes = [i32p, C.c_int64, C.c_int64, C.c_int64, C.c_double]
@@ -460,3 +465,18 @@ def getShiftedMEAAlignment(seqX, seqY, anchorAlignment, p, sM, alignmentHasRagge
                                                   int(alignmentHasRaggedRightEnd), C.byref(out), C.byref(cnt),
                                                   C.byref(score)), "cpecan_get_shifted_mea_alignment")
     return _take_list(out, cnt.value), score.value
+
+
+def convertPairwiseForwardStrandAlignmentToAnchorPairs(ops, start1, start2, trim, expansion, seqX=None, seqY=None):
+    """impl/pairwiseAligner.c:979-1003; ops = [(OP_MATCH | OP_INDEL_X | OP_INDEL_Y, length), ...].  With seqX and seqY the
+    exact-match filter of cPecanRealign.c:277-281,529 is applied as well.  Returns int64[n,3] (x, y, expansion)."""
+    o = np.ascontiguousarray(np.asarray(ops, dtype=np.int64).reshape(-1, 2))
+    cap = int(o[o[:, 0] == OP_MATCH, 1].sum()) if len(o) else 0
+    out = np.zeros((max(cap, 1), 3), dtype=np.int64)
+    sx = _bytes(seqX) if seqX is not None else None
+    sy = _bytes(seqY) if seqY is not None else None
+    n = lib().cpecan_anchors_from_alignment(o.ctypes.data_as(C.POINTER(C.c_int64)), len(o), start1, start2, trim, expansion,
+                                            sx, len(sx) if sx else 0, sy, len(sy) if sy else 0,
+                                            out.ctypes.data_as(C.POINTER(C.c_int64)))
+    _check(n, "cpecan_anchors_from_alignment")
+    return out[:n].copy()

@@ -465,6 +465,35 @@ static int grow(void **p, int64_t *cap, int64_t need, size_t elem) {
     return 0;
 }
 
+int64_t cpecan_anchors_from_alignment(const int64_t *ops, int64_t nOps, int64_t start1, int64_t start2, int64_t trim,
+                                      int64_t expansion, const char *sX, int64_t lX, const char *sY, int64_t lY,
+                                      int64_t *anchors) {
+    if (nOps < 0 || (nOps > 0 && !ops) || !anchors || trim < 0) return CPECAN_EINVAL;
+    const int filter = sX && sY;
+    int64_t x = start1, y = start2, n = 0;
+    for (int64_t i = 0; i < nOps; i++) {
+        const int64_t type = ops[2 * i], len = ops[2 * i + 1];
+        if (len < 0 || type < CPECAN_OP_MATCH || type > CPECAN_OP_INDEL_Y) return CPECAN_EINVAL;
+        if (type == CPECAN_OP_MATCH) {
+            for (int64_t l = trim; l < len - trim; l++) { /* :987-989 */
+                const int64_t ax = x + l, ay = y + l;
+                if (filter) {
+                    if (ax < 0 || ay < 0 || ax >= lX || ay >= lY) return CPECAN_EINVAL;
+                    const int cx = toupper((unsigned char)sX[ax]), cy = toupper((unsigned char)sY[ay]);
+                    if (cx != cy || cx == 'N') continue; /* cPecanRealign.c:277-281 */
+                }
+                anchors[3 * n] = ax;
+                anchors[3 * n + 1] = ay;
+                anchors[3 * n + 2] = expansion;
+                n++;
+            }
+        }
+        if (type != CPECAN_OP_INDEL_Y) x += len; /* :991-996 */
+        if (type != CPECAN_OP_INDEL_X) y += len;
+    }
+    return n;
+}
+
 int cpecan_device_count(void) { return cpk_device_count(); }
 const char *cpecan_last_error(void) { return cpk_last_error(); }
 

@@ -115,6 +115,18 @@ int cpecan_band(const int64_t *anchors, int64_t nAnchors, int64_t lX, int64_t lY
 int64_t cpecan_split_points(const int64_t *anchors, int64_t nAnchors, int64_t lX, int64_t lY, int64_t maxMatrixSize,
                             int raggedLeft, int raggedRight, int64_t *out);
 
+/* Anchors from an existing pairwise alignment, as cPecanRealign builds them (cPecanRealign.c:525-529):
+ * convertPairwiseForwardStrandAlignmentToAnchorPairs (pairwiseAligner.c:979-1003) -- every column of a match operation
+ * except `trim` columns at either end of the operation becomes an anchor (x, y, expansion) -- followed, when sX and sY
+ * are given, by the exact-match filter (matchFn, cPecanRealign.c:277-281: keep x,y with equal letters, case-insensitive,
+ * not N).  ops: nOps pairs (type, length), type CPECAN_OP_MATCH / _INDEL_X (consumes X only) / _INDEL_Y (Y only);
+ * start1/start2: first X/Y coordinate of the alignment.  anchors receives up to the sum of the match lengths triples.
+ * Returns the number of anchors, or < 0. */
+enum { CPECAN_OP_MATCH = 0, CPECAN_OP_INDEL_X = 1, CPECAN_OP_INDEL_Y = 2 };
+int64_t cpecan_anchors_from_alignment(const int64_t *ops, int64_t nOps, int64_t start1, int64_t start2, int64_t trim,
+                                      int64_t expansion, const char *sX, int64_t lX, const char *sY, int64_t lY,
+                                      int64_t *anchors);
+
 /* ---- device ---- */
 int cpecan_device_count(void);
 const char *cpecan_last_error(void);

@@ -208,3 +208,23 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".c", ".h", ".hip", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_binding" not in text and "liboracle" not in text and "cpecan_oracle" not in text, f
+
+
+def test_anchors_from_alignment():
+    """convertPairwiseForwardStrandAlignmentToAnchorPairs (impl/pairwiseAligner.c:979-1003) and the exact-match filter of
+    cPecanRealign.c:277-281, worked by hand: host-side integer code, no GPU."""
+    #      x: 0123 4567     y: 01 234567 (two bases inserted in Y after 2 columns, one base of X skipped later)
+    ops = [(api.OP_MATCH, 2), (api.OP_INDEL_X, 0), (api.OP_INDEL_Y, 2), (api.OP_MATCH, 3), (api.OP_INDEL_X, 1), (api.OP_MATCH, 2)]
+    got = api.convertPairwiseForwardStrandAlignmentToAnchorPairs(ops, 0, 0, 0, 4)
+    assert got.tolist() == [[0, 0, 4], [1, 1, 4], [2, 4, 4], [3, 5, 4], [4, 6, 4], [6, 7, 4], [7, 8, 4]]
+    # trim removes `trim` columns at both ends of every match operation (:987)
+    got = api.convertPairwiseForwardStrandAlignmentToAnchorPairs(ops, 10, 20, 1, 0)
+    assert got.tolist() == [[13, 25, 0]]
+    # the filter keeps equal letters (case-insensitive), never N
+    sx, sy = "ACgTNAGT", "AcxxGANAG"
+    got = api.convertPairwiseForwardStrandAlignmentToAnchorPairs(ops, 0, 0, 0, 2, sx, sy)
+    want = [(x, y) for x, y in [(0, 0), (1, 1), (2, 4), (3, 5), (4, 6), (6, 7), (7, 8)]
+            if sx[x].upper() == sy[y].upper() and sx[x].upper() != "N"]
+    assert [tuple(r[:2]) for r in got.tolist()] == want and want == [(0, 0), (1, 1), (2, 4)]
+    with pytest.raises(api.CpecanError):
+        api.convertPairwiseForwardStrandAlignmentToAnchorPairs([(7, 1)], 0, 0, 0, 0)
