@@ -482,6 +482,144 @@ struct Sweep {
         f1 = g;
     }
 
+    // ---- forward sweep as a STREAM of cells (LDS variant).  Diagonals of 101-155 cells fill groups of 64 lanes to 77 %:
+    // the last group of a diagonal is mostly empty.  Here a diagonal's leftover cells (fewer than 64) wait and share
+    // a group with the first cells of the next diagonal: lanes [0, r) finish diagonal A, lanes [r, 64) start
+    // diagonal B = A+1.  Legal when (1) both diagonals run in the same direction (in-place rule above), and (2) B's
+    // cells in the shared group only read cells of A that earlier groups have written:
+    //   ascending : B cells [0, b) read F[A] up to index b + dl_B        -> need b + dl_B < first leftover cell of A
+    //   descending: B cells [W_B - b, W_B) read F[A] down to W_B - b + dl_B -> need that >= end of A's leftover range
+    // Within the shared group every load precedes every store (one instruction stream, LDS in order), so A's
+    // reads of F[A-1] and B's in-place writes over F[A-1] do not collide.  Otherwise the leftover is flushed as a
+    // partly filled group, as before.  Per-lane parameters of the shared group are selects between A's and B's
+    // wave-uniform ones.
+    struct FwdTail {
+        bool has;
+        bool asc;
+        int lo, n;  // leftover cells [lo, lo + n)
+        int W, ringStates;
+        FwdCtx c;
+        double *cur, *out;
+    };
+    FwdTail tail{};
+
+    // one group of cells of ONE diagonal: cells [kb, kb + 64) clipped to [lo, hi)
+    __device__ __forceinline__ void fwdGroupUniform(const FwdCtx &c, double *cur, double *out, int W, int ringStates, int kb,
+                                                    int lo, int hi) {
+        const int k0 = kb + lane;
+        if (k0 >= lo && k0 < hi) {
+            const int kk[1] = {k0};
+            const int kkR[1] = {kb * R + laneR};
+            double v[1][S];
+            fwdCells<1>(c, kk, kkR, v);
+#pragma unroll
+            for (int s = 0; s < S; s++) cur[s + kkR[0]] = v[0][s];
+            if (ringStates > 0) {
+                out[ringIdx(W, 0, k0)] = v[0][0];
+                if (ringStates > 1) {
+#pragma unroll
+                    for (int s = 1; s < S; s++) out[ringIdx(W, s, k0)] = v[0][s];
+                }
+            }
+        }
+    }
+
+    __device__ void flushTail() {
+        if (!tail.has) return;
+        fwdGroupUniform(tail.c, tail.cur, tail.out, tail.W, tail.ringStates, tail.lo, tail.lo, tail.lo + tail.n);
+        tail.has = false;
+    }
+
+    __device__ void forwardStream(int d, const CpkDiag &g, int ringStates) {
+        const int W = g.width;
+        FwdCtx c;
+        c.d = d;
+        c.xlo = (d + g.xmyL) >> 1;
+        const int dl = (g.xmyL - 1 - f1.xmyL) >> 1;
+        const int dm = (g.xmyL - f2.xmyL) >> 1;
+        c.dlR = dl * R;
+        c.w1R = f1.width * R;
+        c.dmR = dm * R;
+        c.w2R = d >= 2 ? f2.width * R : 0;
+        c.p1 = fbuf1(d - 1);
+        c.p2 = fbuf1(d - 2);
+        double *cur = fbuf1(d);
+        double *out = ringAt(g);
+        const bool asc = dm >= 0;
+        int lo = 0, hi = W;  // cells of this diagonal still to do
+        if (tail.has) {
+            const int r = tail.n;
+            const int b = CPK_WAVE - r < W ? CPK_WAVE - r : W;
+            const int kB0 = asc ? 0 : W - b;  // first cell of B's share
+            const bool reads_done = asc ? (b + dl < tail.lo) : (kB0 + dl >= tail.lo + tail.n);
+            if (tail.asc == asc && reads_done) {
+                const bool inA = lane < r;
+                const bool inB = !inA && lane - r < b;
+                // idle lanes (a narrow B) recompute B's first cell and store nothing
+                const int k = inA ? tail.lo + lane : (inB ? kB0 + lane - r : kB0);
+                const int kR = inA ? tail.lo * R + laneR : (inB ? (kB0 - r) * R + laneR : kB0 * R);
+                FwdCtx m;
+                m.d = inA ? tail.c.d : c.d;
+                m.xlo = inA ? tail.c.xlo : c.xlo;
+                m.dlR = inA ? tail.c.dlR : c.dlR;
+                m.w1R = inA ? tail.c.w1R : c.w1R;
+                m.dmR = inA ? tail.c.dmR : c.dmR;
+                m.w2R = inA ? tail.c.w2R : c.w2R;
+                // rows by parity of the diagonal: A writes over F[A-2] in `tail.cur` and reads F[A-1] from the other set,
+                // which is the set B = A+1 writes into: two selects cover p1, p2 and cur
+                double *curL = inA ? tail.cur : cur;
+                m.p1 = inA ? cur : tail.cur;
+                m.p2 = curL;
+                double *outL = inA ? tail.out : out;
+                const int WL = inA ? tail.W : W;
+                const int rsL = inA ? tail.ringStates : ringStates;
+                const int kk[1] = {k};
+                const int kkR[1] = {kR};
+                double v[1][S];
+                fwdCells<1>(m, kk, kkR, v);
+                if (inA || inB) {
+#pragma unroll
+                    for (int s = 0; s < S; s++) curL[s + kR] = v[0][s];
+                    if (rsL > 0) {
+                        outL[ringIdx(WL, 0, k)] = v[0][0];
+                        if (rsL > 1) {
+#pragma unroll
+                            for (int s = 1; s < S; s++) outL[ringIdx(WL, s, k)] = v[0][s];
+                        }
+                    }
+                }
+                tail.has = false;
+                if (asc) lo = b;
+                else hi = W - b;
+            } else {
+                flushTail();
+            }
+        }
+        // whole groups of this diagonal, in its direction; what is left over waits for the next diagonal
+        while (hi - lo >= CPK_WAVE) {
+            if (asc) {
+                fwdGroupUniform(c, cur, out, W, ringStates, lo, lo, hi);
+                lo += CPK_WAVE;
+            } else {
+                fwdGroupUniform(c, cur, out, W, ringStates, hi - CPK_WAVE, lo, hi);
+                hi -= CPK_WAVE;
+            }
+        }
+        if (hi > lo) {
+            tail.has = true;
+            tail.asc = asc;
+            tail.lo = lo;
+            tail.n = hi - lo;
+            tail.W = W;
+            tail.ringStates = ringStates;
+            tail.c = c;
+            tail.cur = cur;
+            tail.out = out;
+        }
+        f2 = f1;
+        f1 = g;
+    }
+
     // Puts diagonal d of the forward ring back into its rolling buffer (after a traceback used the buffers).
     __device__ void reloadForward(const CpkDiag &g, int d) {
         const int W = g.width;
@@ -1145,8 +1283,12 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 for (int d = 1; d <= N;) {
                     sw.dc.load(d);  // table entries of diagonals d .. d+63
                     const int dEnd = d + CPK_WAVE - 1 < N ? d + CPK_WAVE - 1 : N;
-                    for (; d <= dEnd; d++) sw.forward(d, sw.dc.at(d - sw.dc.base), 0);  // nothing reads F back
+                    for (; d <= dEnd; d++) {
+                        if (FAST) sw.forwardStream(d, sw.dc.at(d - sw.dc.base), 0);  // nothing reads F back
+                        else sw.forward(d, sw.dc.at(d - sw.dc.base), 0);
+                    }
                 }
+                if (FAST) sw.flushTail();
                 const double *endPrior = rg.raggedRight ? m.raggedEnd : m.end;
                 const double *last = sw.fbuf1(N);
                 const int W = sw.f1.width;
@@ -1192,9 +1334,11 @@ cpecan_pairhmm_sweep(const KArgs a) {
                     for (; d <= dEnd; d++) {
                         while (d > emitFrom) emitFrom = a.segs[rg.segOff + ++emitSeg].tbFrom;  // the last segment ends at N
                         const bool all = EMIT != CPECAN_EMIT_MATCH || (emitFrom - d) % CPK_REFRESH_PERIOD == 0 || d >= sg.dTop - 1;
-                        sw.forward(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
+                        if (FAST) sw.forwardStream(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
+                        else sw.forward(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
                     }
                 }
+                if (FAST) sw.flushTail();  // the traceback needs every cell of dTop
                 if (a.geo.debug & 2) continue;  // diagnostic: time the forward sweep alone (no traceback, no output)
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
                 int nCand[NL];
