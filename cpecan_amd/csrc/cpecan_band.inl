@@ -1,0 +1,81 @@
+/*
+ * cpecan_band.inl -- the banded region of one DP problem as a stream of anti-diagonals, shared by the C host code
+ * (planning: cell counts, traceback schedule, scratch sizes) and the HIP TU (the kernel that materialises the
+ * per-diagonal table on the device).  Semantics: band_construct / band_constructDynamic,
+ * impl/pairwiseAligner.c:128-234: between consecutive anchors (matrix coordinates = sequence coordinates + 1, a
+ * virtual first anchor (0,0) and last (lX,lY)) the band is the rectangle x in [x_prev - E/2, x_next + E/2],
+ * y in [y_prev - E/2, y_next + E/2], clamped to the matrix and cut by each anti-diagonal.
+ */
+#ifndef CPECAN_BAND_INL_
+#define CPECAN_BAND_INL_
+
+#include <stdint.h>
+
+#ifdef __HIPCC__
+#define CPK_HD __host__ __device__ static inline
+#else
+#define CPK_HD static inline
+#endif
+
+typedef struct {
+    const int64_t *anchors; /* triples (x, y, expansion), coordinates relative to the region */
+    int64_t n, lX, lY;
+    int64_t used;
+    int64_t pX, pY;         /* previous anchor (matrix coordinates) */
+    int64_t qX, qY, qSum;   /* next anchor and its anti-diagonal */
+    int64_t xLo, xHi, yLo, yHi;
+    int64_t e;              /* expansion in force */
+    int dynamic;
+} CpkBandIter;
+
+CPK_HD int64_t cpk_clamp(int64_t v, int64_t hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
+
+/* Returns 0, or -1 for parameters the reference asserts on (pairwiseAligner.c:131, :186). */
+CPK_HD int cpk_band_init(CpkBandIter *it, const int64_t *anchors, int64_t n, int64_t lX, int64_t lY, int64_t expansion,
+                         int dynamic) {
+    if (lX < 0 || lY < 0) return -1;
+    if (!dynamic && (expansion < 0 || expansion % 2 != 0)) return -1;
+    it->anchors = anchors;
+    it->n = n;
+    it->lX = lX;
+    it->lY = lY;
+    it->used = 0;
+    it->pX = it->pY = 0;
+    it->qX = it->qY = it->qSum = 0;
+    it->xLo = it->xHi = it->yLo = it->yHi = 0;
+    it->e = dynamic ? 0 : expansion;
+    it->dynamic = dynamic;
+    return 0;
+}
+
+/* Diagonal d = 0, 1, ..., lX+lY in order: *xmyL / *xmyR receive its inclusive x-y range.  Returns 0, or -1 when the
+ * anchors do not describe a valid band (diagonal_construct would throw, pairwiseAligner.c:31; asserts :159-166). */
+CPK_HD int cpk_band_next(CpkBandIter *it, int64_t d, int64_t *xmyL, int64_t *xmyR) {
+    const int64_t a = it->xLo > d - it->yHi ? it->xLo : d - it->yHi;
+    const int64_t b = it->xHi < d - it->yLo ? it->xHi : d - it->yLo;
+    if (a > b) return -1;
+    *xmyL = 2 * a - d;
+    *xmyR = 2 * b - d;
+    if (it->qSum != d) return 0;
+    /* the anchor's own diagonal has been emitted: move on to the next interval */
+    it->pX = it->qX;
+    it->pY = it->qY;
+    it->qX = it->lX;
+    it->qY = it->lY;
+    if (it->used < it->n) {
+        it->qX = it->anchors[3 * it->used] + 1;
+        it->qY = it->anchors[3 * it->used + 1] + 1;
+        if (it->dynamic) it->e = it->anchors[3 * it->used + 2];
+        it->used++;
+        if (it->qX <= it->pX || it->qY <= it->pY || it->qX > it->lX || it->qY > it->lY || it->e < 0 || it->e % 2 != 0)
+            return -1;
+    }
+    it->qSum = it->qX + it->qY;
+    it->xLo = cpk_clamp(it->pX - it->e / 2, it->lX);
+    it->yHi = cpk_clamp(it->qY + it->e / 2, it->lY);
+    it->xHi = cpk_clamp(it->qX + it->e / 2, it->lX);
+    it->yLo = cpk_clamp(it->pY - it->e / 2, it->lY);
+    return 0;
+}
+
+#endif

@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include "cpecan_internal.h"
+#include "cpecan_band.inl"
 
 /* ------------------------------------------------------------------------------------------------
  * models: impl/stateMachine.c
@@ -284,67 +285,24 @@ static void kernel_model(const cpecan_model *m, double threshold, CpkModel *k) {
 /* ------------------------------------------------------------------------------------------------
  * band and split geometry (integers only)
  * ---------------------------------------------------------------------------------------------- */
-static int64_t clamp_to(int64_t v, int64_t hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 static int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
 static int64_t imin(int64_t a, int64_t b) { return a < b ? a : b; }
 
-/* Band of one region.  For consecutive anchors P and Q (matrix coordinates, virtual first (0,0) and last
- * (lX,lY)) the band between their anti-diagonals is the rectangle [Px-e/2, Qx+e/2] x [Py-e/2, Qy+e/2]
- * clipped to the matrix (pairwiseAligner.c:173-176, 226-229); a diagonal's cells are the lattice points of the
- * rectangle on it, i.e. x in [max(xLo, d - yHi), min(xHi, d - yLo)] -- the closed form of :104-122.
- * Writes xmyL/xmyR per diagonal.  Returns CPECAN_EINVAL where the reference would assert or throw. */
-static int build_band(const int64_t *anchors, int64_t n, int64_t lX, int64_t lY, int64_t expansion, int dynamic,
-                      int64_t *xmyL, int64_t *xmyR) {
-    if (lX < 0 || lY < 0) return CPECAN_EINVAL;
-    if (!dynamic && (expansion < 0 || expansion % 2 != 0)) return CPECAN_EINVAL;
-    int64_t used = 0;
-    int64_t pX = 0, pY = 0;           /* previous anchor */
-    int64_t qSum = 0;                 /* anti-diagonal of the next anchor */
-    int64_t qX = 0, qY = 0;
-    int64_t xLo = 0, xHi = 0, yLo = 0, yHi = 0;
-    int64_t e = dynamic ? 0 : expansion;
-    for (int64_t d = 0; d <= lX + lY; d++) {
-        const int64_t lo = imax(xLo, d - yHi), hi = imin(xHi, d - yLo);
-        if (lo > hi) return CPECAN_EINVAL; /* diagonal_construct would throw, pairwiseAligner.c:31 */
-        xmyL[d] = 2 * lo - d;
-        xmyR[d] = 2 * hi - d;
-        if (qSum != d) continue;
-        pX = qX;
-        pY = qY;
-        qX = lX;
-        qY = lY;
-        if (used < n) {
-            qX = anchors[3 * used] + 1;
-            qY = anchors[3 * used + 1] + 1;
-            if (dynamic) e = anchors[3 * used + 2];
-            used++;
-            if (qX <= pX || qY <= pY || qX > lX || qY > lY || e < 0 || e % 2 != 0) return CPECAN_EINVAL; /* :159-166 */
-        }
-        qSum = qX + qY;
-        xLo = clamp_to(pX - e / 2, lX);
-        yHi = clamp_to(qY + e / 2, lY);
-        xHi = clamp_to(qX + e / 2, lX);
-        yLo = clamp_to(pY - e / 2, lY);
-    }
-    return CPECAN_OK;
-}
-
+/* band_construct / band_constructDynamic (pairwiseAligner.c:128-234) through the shared iterator (cpecan_band.inl). */
 int cpecan_band(const int64_t *anchors, int64_t nAnchors, int64_t lX, int64_t lY, int64_t expansion, int dynamic,
                 int64_t *out) {
     const int64_t n = lX + lY + 1;
-    if (n <= 0 || !out) return CPECAN_EINVAL;
-    int64_t *lo = malloc(sizeof(int64_t) * (size_t)n * 2), *hi = lo + n;
-    if (!lo) return CPECAN_ENOMEM;
-    int rc = build_band(anchors, nAnchors, lX, lY, expansion, dynamic, lo, hi);
-    if (rc == CPECAN_OK) {
-        for (int64_t d = 0; d < n; d++) {
-            out[3 * d] = d;
-            out[3 * d + 1] = lo[d];
-            out[3 * d + 2] = hi[d];
-        }
+    if (n <= 0 || !out || nAnchors < 0) return CPECAN_EINVAL;
+    CpkBandIter it;
+    if (cpk_band_init(&it, anchors, nAnchors, lX, lY, expansion, dynamic)) return CPECAN_EINVAL;
+    for (int64_t d = 0; d < n; d++) {
+        int64_t lo, hi;
+        if (cpk_band_next(&it, d, &lo, &hi)) return CPECAN_EINVAL;
+        out[3 * d] = d;
+        out[3 * d + 1] = lo;
+        out[3 * d + 2] = hi;
     }
-    free(lo);
-    return rc;
+    return CPECAN_OK;
 }
 
 /* getSplitPoints, pairwiseAligner.c:1206-1257.  A gap between consecutive anchors whose matrix exceeds
@@ -668,6 +626,11 @@ typedef struct {
     int64_t index;
 } CostKey;
 
+/* what planning keeps of a region's band walk */
+typedef struct {
+    int64_t maxW, liveMax, fbMax, nSeg, refreshMax;
+} RegionPlan;
+
 static int by_cost_desc(const void *a, const void *b) {
     const CostKey *p = a, *q = b;
     if (p->cells != q->cells) return p->cells > q->cells ? -1 : 1;
@@ -694,15 +657,18 @@ int cpecan_batch_upload(cpecan_batch *b) {
     const int S = is_five(b->model.type) ? 5 : 3;
     int rc = CPECAN_OK;
 
-    /* pass 1: bands -> per-region cell counts.  Regions are independent: one OpenMP task each. */
-    int64_t totalDiags = 0, maxN = 0;
-    CpkDiag *diags = NULL;
+    /* Planning walks every region's band ONCE as a stream of diagonals (cpecan_band.inl) and keeps per-region sums only:
+     * cell count, widest diagonal, the traceback schedule (pairwiseAligner.c:791-810) and the scratch sizes it implies.
+     * The per-diagonal table the kernels read (16 bytes per diagonal, 640 MB at 10 000 pairs x 2 kb) is built on the
+     * device from the anchors by the same iterator (cpk_device_upload).  Regions are independent: OpenMP. */
+    int64_t totalDiags = 0;
     int64_t *diagStart = malloc(sizeof(int64_t) * (size_t)b->nRegions);
+    int64_t *segStart = malloc(sizeof(int64_t) * (size_t)b->nRegions);
     CostKey *keys = malloc(sizeof(CostKey) * (size_t)b->nRegions);
-    int32_t *segCount = malloc(sizeof(int32_t) * (size_t)b->nRegions);
+    RegionPlan *plan = calloc((size_t)b->nRegions, sizeof(RegionPlan));
     CpkSegment *segs = NULL;
-    int64_t nSegs = 0;
-    if (!diagStart || !keys || !segCount) {
+    int64_t nSegs = 0; /* slots: every region gets room for an upper bound on its segment count */
+    if (!diagStart || !segStart || !keys || !plan) {
         rc = CPECAN_ENOMEM;
         goto fail1;
     }
@@ -710,49 +676,84 @@ int cpecan_batch_upload(cpecan_batch *b) {
         const int64_t N = b->regions[i].lX + b->regions[i].lY;
         diagStart[i] = totalDiags;
         totalDiags += N + 1;
-        maxN = imax(maxN, N);
+        segStart[i] = nSegs;
+        /* consecutive traceback points are at least minDiagsBetweenTraceBack - (traceBackDiagonals + 1) >= 1 apart */
+        nSegs += N / (p->minDiagsBetweenTraceBack - p->traceBackDiagonals - 1) + 2;
     }
-    diags = malloc(sizeof(CpkDiag) * (size_t)totalDiags);
-    if (!diags) {
+    segs = calloc((size_t)(nSegs ? nSegs : 1), sizeof(CpkSegment));
+    if (!segs) {
         rc = CPECAN_ENOMEM;
         goto fail1;
     }
+    const int dynamic = b->emit == CPECAN_EMIT_FORWARD ? 0 : p->dynamicAnchorExpansion; /* :894: forward uses the static band */
     int64_t badRegion = -1;
 #pragma omp parallel
     {
-        int64_t *lo = malloc(sizeof(int64_t) * (size_t)(maxN + 1) * 2), *hi = lo ? lo + maxN + 1 : NULL;
-        if (!lo) {
+        /* cell offsets of the last traceBackDiagonals + 3 diagonals: the schedule looks that far back */
+        const int64_t K = p->traceBackDiagonals + 3;
+        int64_t *histOff = malloc(sizeof(int64_t) * (size_t)K * 2), *histW = histOff ? histOff + K : NULL;
+        if (!histOff) {
 #pragma omp critical(cpk_plan)
             rc = CPECAN_ENOMEM;
         }
 #pragma omp for schedule(dynamic, 16)
         for (int64_t i = 0; i < b->nRegions; i++) {
             HostRegion *r = &b->regions[i];
+            RegionPlan *pl = &plan[i];
             const int64_t N = r->lX + r->lY;
             keys[i].cells = 0;
             keys[i].index = i;
-            if (!lo) continue;
-            /* the forward-probability path always uses the static band (pairwiseAligner.c:894) */
-            int rcBand = build_band(b->anchors + 3 * r->anchorOff, r->nAnchors, r->lX, r->lY, p->diagonalExpansion,
-                                    b->emit == CPECAN_EMIT_FORWARD ? 0 : p->dynamicAnchorExpansion, lo, hi);
-            CpkDiag *dg = diags + diagStart[i];
-            int64_t cells = 0;
-            for (int64_t d = 0; d <= N && rcBand == CPECAN_OK; d++) {
-                const int64_t w = (hi[d] - lo[d]) / 2 + 1;
-                if (cells + w >= (int64_t)1 << 31) {
-                    rcBand = CPECAN_EINVAL;
+            if (!histOff) continue;
+            CpkBandIter it;
+            int bad = cpk_band_init(&it, b->anchors + 3 * r->anchorOff, r->nAnchors, r->lX, r->lY, p->diagonalExpansion, dynamic);
+            CpkSegment *sg = segs + segStart[i];
+            int64_t cells = 0, tracedBackTo = 0;
+            int64_t offTracedBackTo = 0; /* cells before diagonal tracedBackTo */
+            int64_t offAfter = 0;        /* cells before diagonal tracedBackTo + 1 */
+            for (int64_t d = 0; d <= N && !bad; d++) {
+                int64_t lo, hi;
+                if (cpk_band_next(&it, d, &lo, &hi)) {
+                    bad = 1;
                     break;
                 }
-                dg[d].xmyL = (int32_t)lo[d];
-                dg[d].width = (int32_t)w;
-                dg[d].cellOff = (int32_t)cells;
-                dg[d].ringOff = 0;
+                const int64_t w = (hi - lo) / 2 + 1;
+                if (cells + w >= (int64_t)1 << 31) {
+                    bad = 1;
+                    break;
+                }
+                histOff[d % K] = cells;
+                histW[d % K] = w;
+                if (d == 1) offAfter = cells; /* tracedBackTo == 0 for the first segment */
+                pl->maxW = w > pl->maxW ? w : pl->maxW;
                 cells += w;
+                if (d == 0) continue;
+                const int atEnd = d == N;
+                const int tracebackPoint =
+                    d >= tracedBackTo + p->minDiagsBetweenTraceBack && w <= p->diagonalExpansion * 2 + 1;
+                if (!atEnd && !tracebackPoint) continue;
+                memset(sg, 0, sizeof *sg);
+                sg->tbPrev = (int32_t)tracedBackTo;
+                sg->dTop = (int32_t)d;
+                sg->tbFrom = (int32_t)(d - (atEnd ? 0 : p->traceBackDiagonals + 1));
+                sg->atEnd = atEnd;
+                sg->nRefresh = (int32_t)((sg->tbFrom - (sg->tbPrev + 1)) / CPK_REFRESH_PERIOD + 1);
+                pl->refreshMax = sg->nRefresh > pl->refreshMax ? sg->nRefresh : pl->refreshMax;
+                /* forward diagonals tbPrev..dTop are live during this traceback */
+                pl->liveMax = imax(pl->liveMax, cells - offTracedBackTo);
+                const int64_t tf = sg->tbFrom;
+                const int64_t fbCells = histOff[tf % K] + histW[tf % K] - offAfter;
+                pl->fbMax = imax(pl->fbMax, fbCells);
+                pl->nSeg++;
+                sg++;
+                /* the next segment starts from tbFrom: remember the cell offsets of tbFrom and tbFrom + 1 */
+                tracedBackTo = tf;
+                offTracedBackTo = histOff[tf % K];
+                offAfter = histOff[tf % K] + histW[tf % K];
             }
-            if (rcBand != CPECAN_OK) {
+            if (bad) {
 #pragma omp critical(cpk_plan)
                 {
-                    rc = rcBand;
+                    rc = CPECAN_EINVAL;
                     if (badRegion < 0 || i < badRegion) badRegion = i;
                 }
                 continue;
@@ -760,7 +761,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
             r->cells = cells;
             keys[i].cells = N > 0 ? cells : 0;
         }
-        free(lo);
+        free(histOff);
     }
     if (rc != CPECAN_OK) {
         if (badRegion >= 0)
@@ -770,8 +771,6 @@ int cpecan_batch_upload(cpecan_batch *b) {
     }
     qsort(keys, (size_t)b->nRegions, sizeof(CostKey), by_cost_desc); /* longest first: the work queue is LPT */
 
-    /* pass 2: traceback schedule per region (pairwiseAligner.c:791-810), forward ring layout, scratch sizes.
-     * 2a counts the segments (serial prefix sums fix every offset), 2b fills them in parallel. */
     b->devRegions = calloc((size_t)b->nRegions, sizeof(CpkRegion));
     b->devToHost = malloc(sizeof(int64_t) * (size_t)b->nRegions);
     if (!b->devRegions || !b->devToHost) {
@@ -784,32 +783,28 @@ int cpecan_batch_upload(cpecan_batch *b) {
     geo.nStates = S;
     geo.emit = b->emit;
     geo.debug = b->debug;
-#pragma omp parallel for schedule(dynamic, 16)
-    for (int64_t di = 0; di < b->nRegions; di++) {
-        const HostRegion *r = &b->regions[keys[di].index];
-        const CpkDiag *dg = diags + diagStart[keys[di].index];
-        const int64_t N = r->lX + r->lY;
-        int64_t tracedBackTo = 0;
-        int32_t n = 0;
-        for (int64_t d = 1; d <= N; d++) {
-            const int atEnd = d == N;
-            if (!atEnd && !(d >= tracedBackTo + p->minDiagsBetweenTraceBack && dg[d].width <= p->diagonalExpansion * 2 + 1))
-                continue;
-            n++;
-            tracedBackTo = d - (atEnd ? 0 : p->traceBackDiagonals + 1);
-        }
-        segCount[di] = n;
-    }
     int64_t outAt = 0, dbgCells = 0, dbgDiags = 0, totalCells = 0;
     for (int64_t di = 0; di < b->nRegions; di++) {
         const int64_t hiRegion = keys[di].index;
         HostRegion *r = &b->regions[hiRegion];
+        const RegionPlan *pl = &plan[hiRegion];
         CpkRegion *g = &b->devRegions[di];
         r->devIndex = di;
         b->devToHost[di] = hiRegion;
-        g->segOff = nSegs;
-        g->nSeg = segCount[di];
-        nSegs += segCount[di];
+        g->seqXOff = r->seqXOff;
+        g->seqYOff = r->seqYOff;
+        g->diagOff = diagStart[hiRegion];
+        g->segOff = segStart[hiRegion];
+        g->anchorOff = r->anchorOff;
+        g->nAnchors = (int32_t)r->nAnchors;
+        g->nSeg = (int32_t)pl->nSeg;
+        g->lX = (int32_t)r->lX;
+        g->lY = (int32_t)r->lY;
+        g->raggedLeft = r->raggedLeft;
+        g->raggedRight = r->raggedRight;
+        g->maxWidth = (int32_t)pl->maxW;
+        /* ring: diagonals are laid down one after another and never straddle the end of the ring */
+        g->ringCap = (int32_t)imin(pl->liveMax + pl->maxW, ((int64_t)1 << 31) - 1);
         g->dbgCellOff = dbgCells;
         g->dbgDiagOff = dbgDiags;
         if (b->debug) {
@@ -820,75 +815,10 @@ int cpecan_batch_upload(cpecan_batch *b) {
         g->outCap = (int32_t)default_out_cap(b, r);
         g->outOff = outAt;
         outAt += g->outCap;
-    }
-    segs = calloc((size_t)(nSegs ? nSegs : 1), sizeof(CpkSegment));
-    if (!segs) {
-        rc = CPECAN_ENOMEM;
-        goto fail2;
-    }
-#pragma omp parallel
-    {
-        int32_t tMaxW = 0, tRefresh = 0;
-        int64_t tRing = 0, tFb = 0;
-#pragma omp for schedule(dynamic, 16) nowait
-        for (int64_t di = 0; di < b->nRegions; di++) {
-            const int64_t hiRegion = keys[di].index;
-            const HostRegion *r = &b->regions[hiRegion];
-            CpkRegion *g = &b->devRegions[di];
-            CpkDiag *dg = diags + diagStart[hiRegion];
-            const int64_t N = r->lX + r->lY;
-            g->seqXOff = r->seqXOff;
-            g->seqYOff = r->seqYOff;
-            g->diagOff = diagStart[hiRegion];
-            g->lX = (int32_t)r->lX;
-            g->lY = (int32_t)r->lY;
-            g->raggedLeft = r->raggedLeft;
-            g->raggedRight = r->raggedRight;
-            int32_t maxW = 0;
-            for (int64_t d = 0; d <= N; d++) maxW = dg[d].width > maxW ? dg[d].width : maxW;
-            g->maxWidth = maxW;
-            tMaxW = maxW > tMaxW ? maxW : tMaxW;
-            /* segments */
-            int64_t tracedBackTo = 0, liveMax = 0, fbMax = 0;
-            CpkSegment *sg = segs + g->segOff;
-            for (int64_t d = 1; d <= N; d++) {
-                const int atEnd = d == N;
-                const int tracebackPoint =
-                    d >= tracedBackTo + p->minDiagsBetweenTraceBack && dg[d].width <= p->diagonalExpansion * 2 + 1;
-                if (!atEnd && !tracebackPoint) continue;
-                sg->tbPrev = (int32_t)tracedBackTo;
-                sg->dTop = (int32_t)d;
-                sg->tbFrom = (int32_t)(d - (atEnd ? 0 : p->traceBackDiagonals + 1));
-                sg->atEnd = atEnd;
-                sg->nRefresh = (int32_t)((sg->tbFrom - (sg->tbPrev + 1)) / CPK_REFRESH_PERIOD + 1);
-                tRefresh = sg->nRefresh > tRefresh ? sg->nRefresh : tRefresh;
-                /* forward diagonals tbPrev..dTop are live during this traceback */
-                const int64_t live = (int64_t)dg[d].cellOff + dg[d].width - dg[tracedBackTo].cellOff;
-                liveMax = imax(liveMax, live);
-                const int64_t fbCells =
-                    (int64_t)dg[sg->tbFrom].cellOff + dg[sg->tbFrom].width - dg[sg->tbPrev + 1].cellOff;
-                fbMax = imax(fbMax, fbCells);
-                tracedBackTo = sg->tbFrom;
-                sg++;
-            }
-            /* ring: diagonals are laid down one after another and never straddle the end of the ring */
-            const int64_t ringCells = liveMax + maxW;
-            int64_t pos = 0;
-            for (int64_t d = 0; d <= N; d++) {
-                if (pos + dg[d].width > ringCells) pos = 0;
-                dg[d].ringOff = (int32_t)pos;
-                pos += dg[d].width;
-            }
-            tRing = imax(tRing, ringCells);
-            tFb = imax(tFb, fbMax);
-        }
-#pragma omp critical(cpk_plan)
-        {
-            geo.maxWidth = tMaxW > geo.maxWidth ? tMaxW : geo.maxWidth;
-            geo.maxRefresh = tRefresh > geo.maxRefresh ? tRefresh : geo.maxRefresh;
-            geo.ringCells = imax(geo.ringCells, tRing);
-            geo.fbCells = imax(geo.fbCells, tFb);
-        }
+        geo.maxWidth = g->maxWidth > geo.maxWidth ? g->maxWidth : geo.maxWidth;
+        geo.maxRefresh = pl->refreshMax > geo.maxRefresh ? (int32_t)pl->refreshMax : geo.maxRefresh;
+        geo.ringCells = imax(geo.ringCells, pl->liveMax + pl->maxW);
+        geo.fbCells = imax(geo.fbCells, pl->fbMax);
     }
     if (b->emit == CPECAN_EMIT_FORWARD) { /* no traceback: nothing is kept of the forward matrix */
         geo.ringCells = 1;
@@ -927,20 +857,20 @@ int cpecan_batch_upload(cpecan_batch *b) {
         rc = cpk_device_create(&b->dev, b->device); /* fails with CPECAN_ENODEVICE when there is no GPU */
         if (rc != CPECAN_OK) goto fail2;
     }
-    rc = cpk_device_upload(b->dev, &geo, &km, b->devRegions, diags, totalDiags, segs, nSegs, b->symbols, b->nSymbols,
-                           b->outTriples, b->nLists, b->dbgCells, b->dbgDiags, &b->stats.h2dMs);
+    rc = cpk_device_upload(b->dev, &geo, &km, b->devRegions, b->anchors, b->nAnchorVals / 3, totalDiags,
+                           p->diagonalExpansion, dynamic, segs, nSegs, b->symbols, b->nSymbols, b->outTriples, b->nLists,
+                           b->dbgCells, b->dbgDiags, &b->stats.h2dMs);
     if (rc != CPECAN_OK) goto fail2;
     b->stats.deviceBytes = cpk_device_bytes(b->dev);
     b->stats.wavesPerLaunch = cpk_device_waves(b->dev);
     b->frozen = 1;
-    free(diags);
     free(diagStart);
+    free(segStart);
     free(keys);
-    free(segCount);
+    free(plan);
     return CPECAN_OK;
 
 fail2:
-    free(segs);
     free(b->devRegions);
     free(b->devToHost);
     b->devRegions = NULL;
@@ -948,10 +878,11 @@ fail2:
     b->segs = NULL;
     b->nSegs = 0;
 fail1:
-    free(diags);
+    if (!b->segs) free(segs);
     free(diagStart);
+    free(segStart);
     free(keys);
-    free(segCount);
+    free(plan);
     return rc;
 }
 

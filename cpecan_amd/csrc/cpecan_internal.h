@@ -46,11 +46,14 @@ typedef struct {
     int64_t outOff;           /* first output triple slot of the region (per output list) */
     int64_t dbgCellOff;       /* debug: first cell in the debug fb array */
     int64_t dbgDiagOff;       /* debug: first diagonal in the debug total array */
+    int64_t anchorOff;        /* first anchor triple of the region (coordinates relative to the region) */
     int32_t lX, lY;
     int32_t nSeg;
     int32_t outCap;           /* capacity in triples (per output list) */
     int32_t raggedLeft, raggedRight;
     int32_t maxWidth;
+    int32_t ringCap;          /* cells of forward ring the region needs: its longest live span + its widest diagonal */
+    int32_t nAnchors;
     int32_t pad;
 } CpkRegion;
 
@@ -107,10 +110,11 @@ const char *cpk_last_error(void);
 int cpk_device_create(CpkDevice **out, int device);
 void cpk_device_destroy(CpkDevice *dev);
 /* Copies the packed inputs to the GPU and sizes every scratch buffer. */
+/* The per-diagonal table (nDiags entries) is built on the device from the anchors (cpecan_band.inl). */
 int cpk_device_upload(CpkDevice *dev, const CpkGeometry *geo, const CpkModel *model, const CpkRegion *regions,
-                      const CpkDiag *diags, int64_t nDiags, const CpkSegment *segs, int64_t nSegs,
-                      const uint8_t *symbols, int64_t nSymbolBytes, int64_t outTriplesPerList, int nLists,
-                      int64_t dbgCells, int64_t dbgDiags, double *h2dMs);
+                      const int64_t *anchors, int64_t nAnchors, int64_t nDiags, int64_t expansion, int dynamic,
+                      const CpkSegment *segs, int64_t nSegs, const uint8_t *symbols, int64_t nSymbolBytes,
+                      int64_t outTriplesPerList, int nLists, int64_t dbgCells, int64_t dbgDiags, double *h2dMs);
 int cpk_device_update_regions(CpkDevice *dev, const CpkRegion *regions, int64_t outTriplesPerList);
 int cpk_device_run(CpkDevice *dev, void *stream);
 /* Blocks until the run is complete and copies back the per-region counts and per-segment start offsets (and the

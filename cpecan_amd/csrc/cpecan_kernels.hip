@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "cpecan_internal.h"
+#include "cpecan_band.inl"
 
 #define NEG_INF (-__builtin_huge_val())
 
@@ -1393,6 +1394,36 @@ cpecan_pairhmm_sweep(const KArgs a) {
     }
 }
 
+// The per-diagonal table the sweeps read, built on the device: one thread per region walks its band with the host's
+// own iterator (cpecan_band.inl; the host has already validated the anchors with it) and writes
+// {x-y of the first cell, width, position in the region's forward ring, cells on earlier diagonals}.  The ring
+// position follows the rule the kernels rely on: diagonals are laid end to end and never straddle the ring's end.
+__global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *regions, int nRegions, const int64_t *anchors,
+                                                              CpkDiag *diags, int64_t expansion, int dynamic) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nRegions) return;
+    const CpkRegion rg = regions[i];
+    CpkDiag *table = diags + rg.diagOff;
+    const int64_t N = (int64_t)rg.lX + rg.lY;
+    CpkBandIter it;
+    cpk_band_init(&it, anchors + 3 * rg.anchorOff, rg.nAnchors, rg.lX, rg.lY, expansion, dynamic);
+    int32_t cells = 0, pos = 0;
+    for (int64_t d = 0; d <= N; d++) {
+        int64_t lo = 0, hi = 0;
+        cpk_band_next(&it, d, &lo, &hi);
+        const int32_t w = (int32_t)((hi - lo) / 2 + 1);
+        if (pos + w > rg.ringCap) pos = 0;
+        CpkDiag e;
+        e.xmyL = (int32_t)lo;
+        e.width = w;
+        e.ringOff = pos;
+        e.cellOff = cells;
+        table[d] = e;
+        pos += w;
+        cells += w;
+    }
+}
+
 // Result compaction: the sweep leaves every region's triples in its own slice, segments in processing order.  One
 // workgroup per chunk (a region's segment) copies it to its place in the compact buffer -- problems in order, regions in
 // order, segments DEScending (the reference prepends each traceback's pairs, pairwiseAligner.c:1415-1417) -- and adds
@@ -1706,9 +1737,10 @@ static KernelFn pick_kernel(const CpkGeometry &g) {
 }
 
 extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const CpkModel *model, const CpkRegion *regions,
-                                 const CpkDiag *diags, int64_t nDiags, const CpkSegment *segs, int64_t nSegs,
-                                 const uint8_t *symbols, int64_t nSymbolBytes, int64_t outTriplesPerList, int nLists,
-                                 int64_t dbgCells, int64_t dbgDiags, double *h2dMs) {
+                                 const int64_t *anchors, int64_t nAnchors, int64_t nDiags, int64_t expansion, int dynamic,
+                                 const CpkSegment *segs, int64_t nSegs, const uint8_t *symbols, int64_t nSymbolBytes,
+                                 int64_t outTriplesPerList, int nLists, int64_t dbgCells, int64_t dbgDiags,
+                                 double *h2dMs) {
     HIP_TRY(hipSetDevice(d->device));
     free_all(d);
     d->geo = *geo;
@@ -1805,7 +1837,20 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     HIP_TRY(hipEventCreate(&e1));
     HIP_TRY(hipEventRecord(e0, nullptr));
     HIP_TRY(hipMemcpy(d->dRegions, regions, sizeof(CpkRegion) * (size_t)geo->nRegions, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d->dDiags, diags, sizeof(CpkDiag) * (size_t)nDiags, hipMemcpyHostToDevice));
+    {
+        // anchors -> per-diagonal table, on the device (the anchors are only needed for this)
+        int64_t *dAnchors = nullptr;
+        HIP_TRY(hipMalloc((void **)&dAnchors, sizeof(int64_t) * 3 * (size_t)(nAnchors > 0 ? nAnchors : 1)));
+        if (nAnchors > 0)
+            HIP_TRY(hipMemcpy(dAnchors, anchors, sizeof(int64_t) * 3 * (size_t)nAnchors, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(cpecan_build_diag_table, dim3((unsigned)((geo->nRegions + 63) / 64)), dim3(64), 0, nullptr,
+                           d->dRegions, geo->nRegions, dAnchors, d->dDiags, expansion, dynamic);
+        const hipError_t launched = hipGetLastError();
+        const hipError_t done = hipDeviceSynchronize();
+        (void)hipFree(dAnchors);
+        HIP_TRY(launched);
+        HIP_TRY(done);
+    }
     HIP_TRY(hipMemcpy(d->dSegs, segs, sizeof(CpkSegment) * (size_t)nSegs, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d->dSymbols, symbols, (size_t)nSymbolBytes, hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d->dModel, model, sizeof(CpkModel), hipMemcpyHostToDevice));

@@ -201,6 +201,22 @@ def test_planning_cell_counts_match_oracle_band():
     assert st.cells == want and st.problems == 6 and st.regions >= 6
 
 
+def test_planning_survives_dense_traceback_schedules():
+    """minDiagsBetweenTraceBack just above traceBackDiagonals + 1: a traceback point nearly every diagonal (the segment
+    table is sized by that spacing, not by minDiagsBetweenTraceBack alone)."""
+    from cpecan_amd.workload import make_batch
+    probs = make_batch(5, 3, 700, 10)
+    kw = dict(diagonalExpansion=10, traceBackDiagonals=3, minDiagsBetweenTraceBack=5)
+    b = api.Batch(api.stateMachine5_construct(), api.pairwiseAlignmentBandingParameters_construct(**kw))
+    for sx, sy, a in probs:
+        b.add(sx, sy, a)
+    try:
+        b.upload()
+    except api.CpecanError:
+        pass
+    assert b.stats().cells == sum(ob.band_cells(sx, sy, a, ob.params(**kw)) for sx, sy, a in probs)
+
+
 def test_product_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "cpecan_amd")
     for dirpath, _, files in os.walk(pkg):
