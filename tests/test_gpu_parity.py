@@ -98,6 +98,31 @@ def test_random_banded_property_like_reference():
         _check_batch(0, [(sx, sy, _rand_anchors(rng, len(sx), len(sy)))], **kw)
 
 
+@pytest.mark.parametrize("mtype", [0, 3])
+def test_random_wide_bands_stream_groups(mtype):
+    """Diagonals of 65-250 cells with per-anchor expansions: two to four groups of 64 per diagonal, leftover cells
+    sharing a group with the next diagonal in both sweep directions, direction switches at every anchor, short
+    traceback schedules on top (the forward sweep treats the band as one stream of cells)."""
+    rng = random.Random(77 + mtype)
+    probs, raggeds = [], []
+    for _ in range(16):
+        sx = _rand_seq(rng, rng.randrange(150, 520))
+        sy = _evolve(rng, sx) or "ACGT"
+        anchors, x, y = [], -1, -1
+        while True:
+            x += rng.randrange(5, 90)
+            y += rng.randrange(5, 90)
+            if x >= len(sx) or y >= len(sy):
+                break
+            anchors.append((x, y, 2 * rng.randrange(20, 110)))
+        probs.append((sx, sy, anchors))
+        raggeds.append((rng.random() > 0.5, rng.random() > 0.5))
+    tbd = rng.randrange(3, 30)
+    _check_batch(mtype, probs, raggeds, dynamicAnchorExpansion=1, traceBackDiagonals=tbd,
+                 minDiagsBetweenTraceBack=tbd + rng.randrange(20, 200), splitMatrixBiggerThanThis=10 ** 12)
+    _check_batch(mtype, probs[:6], raggeds[:6], diagonalExpansion=2 * rng.randrange(40, 100))
+
+
 @pytest.mark.parametrize("mtype", [0, 2])
 def test_ragged_ends_all_combinations(mtype):
     rng = random.Random(31 + mtype)
