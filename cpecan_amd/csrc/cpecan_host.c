@@ -624,6 +624,7 @@ int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char
 typedef struct {
     int64_t cells;
     int64_t index;
+    int cls; /* 0: narrow (packed kernel), 1: wide */
 } CostKey;
 
 /* what planning keeps of a region's band walk */
@@ -633,6 +634,7 @@ typedef struct {
 
 static int by_cost_desc(const void *a, const void *b) {
     const CostKey *p = a, *q = b;
+    if (p->cls != q->cls) return p->cls < q->cls ? -1 : 1;
     if (p->cells != q->cells) return p->cells > q->cells ? -1 : 1;
     return p->index < q->index ? -1 : (p->index > q->index);
 }
@@ -769,7 +771,24 @@ int cpecan_batch_upload(cpecan_batch *b) {
                           (long long)badRegion, (long long)b->regions[badRegion].problem);
         goto fail1;
     }
-    qsort(keys, (size_t)b->nRegions, sizeof(CostKey), by_cost_desc); /* longest first: the work queue is LPT */
+    /* Narrow regions (no diagonal wider than 32 cells: realign-style bands) are packed several to a wave by their own
+     * kernel; they come first in the device order.  Within each class: longest first (the work queues are LPT). */
+    int64_t nNarrow = 0, narrowMaxW = 0;
+    {
+        const char *env = getenv("CPECAN_PACKED"); /* diagnostic: 0 = one wave per region for every region */
+        const int enabled = b->emit == CPECAN_EMIT_MATCH && !b->debug && !(env && atoi(env) == 0);
+        for (int64_t i = 0; enabled && i < b->nRegions; i++)
+            if (plan[i].maxW <= 32 && b->regions[i].lX + b->regions[i].lY > 0) {
+                nNarrow++;
+                narrowMaxW = imax(narrowMaxW, plan[i].maxW);
+            }
+        if (nNarrow < 64 && !(env && atoi(env) >= 2)) nNarrow = 0; /* not worth a second launch (2: always, for tests) */
+        for (int64_t i = 0; i < b->nRegions; i++) {
+            const int narrow = nNarrow && plan[i].maxW <= 32 && b->regions[i].lX + b->regions[i].lY > 0;
+            keys[i].cls = narrow ? 0 : 1;
+        }
+    }
+    qsort(keys, (size_t)b->nRegions, sizeof(CostKey), by_cost_desc);
 
     b->devRegions = calloc((size_t)b->nRegions, sizeof(CpkRegion));
     b->devToHost = malloc(sizeof(int64_t) * (size_t)b->nRegions);
@@ -815,10 +834,24 @@ int cpecan_batch_upload(cpecan_batch *b) {
         g->outCap = (int32_t)default_out_cap(b, r);
         g->outOff = outAt;
         outAt += g->outCap;
-        geo.maxWidth = g->maxWidth > geo.maxWidth ? g->maxWidth : geo.maxWidth;
-        geo.maxRefresh = pl->refreshMax > geo.maxRefresh ? (int32_t)pl->refreshMax : geo.maxRefresh;
-        geo.ringCells = imax(geo.ringCells, pl->liveMax + pl->maxW);
-        geo.fbCells = imax(geo.fbCells, pl->fbMax);
+        if (keys[di].cls == 0) { /* narrow: scratch of the packed kernel's sub-slots */
+            geo.nPacked++;
+            geo.pMaxRefresh = pl->refreshMax > geo.pMaxRefresh ? (int32_t)pl->refreshMax : geo.pMaxRefresh;
+            geo.pRingCells = imax(geo.pRingCells, pl->liveMax + pl->maxW);
+            geo.pFbCells = imax(geo.pFbCells, pl->fbMax);
+        } else {
+            geo.maxWidth = g->maxWidth > geo.maxWidth ? g->maxWidth : geo.maxWidth;
+            geo.maxRefresh = pl->refreshMax > geo.maxRefresh ? (int32_t)pl->refreshMax : geo.maxRefresh;
+            geo.ringCells = imax(geo.ringCells, pl->liveMax + pl->maxW);
+            geo.fbCells = imax(geo.fbCells, pl->fbMax);
+        }
+    }
+    if (geo.nPacked) {
+        geo.packedGW = narrowMaxW <= 8 ? 8 : (narrowMaxW <= 16 ? 16 : 32);
+        if (geo.pMaxRefresh < 1) geo.pMaxRefresh = 1;
+        if (geo.pRingCells < 1) geo.pRingCells = 1;
+        if (geo.pFbCells < 1) geo.pFbCells = 1;
+        geo.pRefreshCells = (int64_t)geo.packedGW * geo.pMaxRefresh;
     }
     if (b->emit == CPECAN_EMIT_FORWARD) { /* no traceback: nothing is kept of the forward matrix */
         geo.ringCells = 1;
@@ -830,8 +863,10 @@ int cpecan_batch_upload(cpecan_batch *b) {
     geo.rollStride = geo.maxWidth + 1;
     {
         int64_t seqMax = 0;
-        for (int64_t i = 0; i < b->nRegions; i++) /* two symbols per byte in LDS */
-            seqMax = imax(seqMax, (b->regions[i].lX + 3) / 2 + (b->regions[i].lY + 3) / 2);
+        for (int64_t di = geo.nPacked; di < b->nRegions; di++) { /* wide regions: two symbols per byte in LDS */
+            const HostRegion *r = &b->regions[keys[di].index];
+            seqMax = imax(seqMax, (r->lX + 3) / 2 + (r->lY + 3) / 2);
+        }
         geo.seqLdsBytes = (int32_t)imin(seqMax, (int64_t)1 << 30);
     }
     geo.refreshCells = (int64_t)geo.maxWidth * geo.maxRefresh;

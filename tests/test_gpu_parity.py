@@ -412,3 +412,45 @@ def test_config5_expectation_sample_band10():
     for sx, sy, a in problems:
         ob.expectations(ob.model(0), oacc, sx, sy, a, ob.params(**kw), True, True)
     _assert_hmm_close(acc, oacc, 5)
+
+
+# ---- narrow bands: the packed kernel (several regions per wave) ----
+@pytest.fixture
+def force_packed(monkeypatch):
+    monkeypatch.setenv("CPECAN_PACKED", "2")  # also for batches of fewer than 64 narrow regions
+
+
+@pytest.mark.parametrize("mtype", [0, 2])
+def test_packed_kernel_realign_sample(force_packed, mtype):
+    """BASELINE config 4 in miniature through the packed kernel: expansion 4, anchors on every matching column, ragged
+    ends, split at 10 (cPecanRealign.c:355-357), lengths 100-3000 (several traceback segments for the long ones)."""
+    from cpecan_amd.workload import make_realign_batch
+    problems = make_realign_batch(4, 70, 100, 3000, 4)
+    worst, st = _check_batch(mtype, problems, [(True, True)] * len(problems), diagonalExpansion=4,
+                             splitMatrixBiggerThanThis=10)
+    assert st.regions >= len(problems)
+
+
+def test_packed_kernel_random_narrow_bands(force_packed):
+    """Group widths 8, 16 and 32; random anchors and traceback schedules; mixed with wide regions in one batch."""
+    rng = random.Random(91)
+    for exp, hi in ((2, 300), (8, 400), (20, 500)):
+        probs, raggeds = [], []
+        for _ in range(24):
+            sx = _rand_seq(rng, rng.randrange(1, hi))
+            sy = _evolve(rng, sx) or "A"
+            anchors, x, y = [], -1, -1
+            while True:
+                x += rng.randrange(1, 6)
+                y += rng.randrange(1, 6)
+                if x >= len(sx) or y >= len(sy):
+                    break
+                anchors.append((x, y, exp))
+            probs.append((sx, sy, anchors))
+            raggeds.append((rng.random() > 0.5, rng.random() > 0.5))
+        # two wide regions ride along: they must take the one-wave-per-region kernel
+        probs += [(_rand_seq(rng, 120), _rand_seq(rng, 130), [])] * 2
+        raggeds += [(False, False)] * 2
+        tbd = rng.randrange(2, 12)
+        _check_batch(0, probs, raggeds, diagonalExpansion=exp, traceBackDiagonals=tbd,
+                     minDiagsBetweenTraceBack=tbd + rng.randrange(3, 60), splitMatrixBiggerThanThis=10 ** 12)
