@@ -624,7 +624,7 @@ int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char
 typedef struct {
     int64_t cells;
     int64_t index;
-    int cls; /* 0: narrow (packed kernel), 1: wide */
+    int cls; /* 0, 1, 2: narrow, at most 8 / 16 / 32 cells per diagonal (packed kernel); 3: wide */
 } CostKey;
 
 /* what planning keeps of a region's band walk */
@@ -773,20 +773,24 @@ int cpecan_batch_upload(cpecan_batch *b) {
     }
     /* Narrow regions (no diagonal wider than 32 cells: realign-style bands) are packed several to a wave by their own
      * kernel; they come first in the device order.  Within each class: longest first (the work queues are LPT). */
-    int64_t nNarrow = 0, narrowMaxW = 0;
     {
         const char *env = getenv("CPECAN_PACKED"); /* diagnostic: 0 = one wave per region for every region */
         const int enabled = b->emit == CPECAN_EMIT_MATCH && !b->debug && !(env && atoi(env) == 0);
-        for (int64_t i = 0; enabled && i < b->nRegions; i++)
-            if (plan[i].maxW <= 32 && b->regions[i].lX + b->regions[i].lY > 0) {
-                nNarrow++;
-                narrowMaxW = imax(narrowMaxW, plan[i].maxW);
-            }
-        if (nNarrow < 64 && !(env && atoi(env) >= 2)) nNarrow = 0; /* not worth a second launch (2: always, for tests) */
+        const int64_t minCount = (env && atoi(env) >= 2) ? 1 : 64; /* a launch is not worth fewer regions (2: always, for tests) */
+        int64_t perClass[4] = {0, 0, 0, 0};
         for (int64_t i = 0; i < b->nRegions; i++) {
-            const int narrow = nNarrow && plan[i].maxW <= 32 && b->regions[i].lX + b->regions[i].lY > 0;
-            keys[i].cls = narrow ? 0 : 1;
+            const int64_t w = plan[i].maxW;
+            const int empty = b->regions[i].lX + b->regions[i].lY == 0;
+            keys[i].cls = (!enabled || empty || w > 32) ? 3 : (w <= 8 ? 0 : (w <= 16 ? 1 : 2));
+            perClass[keys[i].cls]++;
         }
+        for (int k = 0; k < 3; k++) /* a class too small for its own launch joins the next wider one */
+            if (perClass[k] > 0 && perClass[k] < minCount) {
+                for (int64_t i = 0; i < b->nRegions; i++)
+                    if (keys[i].cls == k) keys[i].cls = k + 1;
+                perClass[k + 1] += perClass[k];
+                perClass[k] = 0;
+            }
     }
     qsort(keys, (size_t)b->nRegions, sizeof(CostKey), by_cost_desc);
 
@@ -834,11 +838,12 @@ int cpecan_batch_upload(cpecan_batch *b) {
         g->outCap = (int32_t)default_out_cap(b, r);
         g->outOff = outAt;
         outAt += g->outCap;
-        if (keys[di].cls == 0) { /* narrow: scratch of the packed kernel's sub-slots */
-            geo.nPacked++;
-            geo.pMaxRefresh = pl->refreshMax > geo.pMaxRefresh ? (int32_t)pl->refreshMax : geo.pMaxRefresh;
-            geo.pRingCells = imax(geo.pRingCells, pl->liveMax + pl->maxW);
-            geo.pFbCells = imax(geo.pFbCells, pl->fbMax);
+        if (keys[di].cls < 3) { /* narrow: scratch of the packed kernel's sub-slots */
+            const int k = keys[di].cls;
+            geo.nPacked[k]++;
+            geo.pMaxRefresh[k] = pl->refreshMax > geo.pMaxRefresh[k] ? (int32_t)pl->refreshMax : geo.pMaxRefresh[k];
+            geo.pRingCells[k] = imax(geo.pRingCells[k], pl->liveMax + pl->maxW);
+            geo.pFbCells[k] = imax(geo.pFbCells[k], pl->fbMax);
         } else {
             geo.maxWidth = g->maxWidth > geo.maxWidth ? g->maxWidth : geo.maxWidth;
             geo.maxRefresh = pl->refreshMax > geo.maxRefresh ? (int32_t)pl->refreshMax : geo.maxRefresh;
@@ -846,13 +851,12 @@ int cpecan_batch_upload(cpecan_batch *b) {
             geo.fbCells = imax(geo.fbCells, pl->fbMax);
         }
     }
-    if (geo.nPacked) {
-        geo.packedGW = narrowMaxW <= 8 ? 8 : (narrowMaxW <= 16 ? 16 : 32);
-        if (geo.pMaxRefresh < 1) geo.pMaxRefresh = 1;
-        if (geo.pRingCells < 1) geo.pRingCells = 1;
-        if (geo.pFbCells < 1) geo.pFbCells = 1;
-        geo.pRefreshCells = (int64_t)geo.packedGW * geo.pMaxRefresh;
-    }
+    for (int k = 0; k < 3; k++)
+        if (geo.nPacked[k]) {
+            if (geo.pMaxRefresh[k] < 1) geo.pMaxRefresh[k] = 1;
+            if (geo.pRingCells[k] < 1) geo.pRingCells[k] = 1;
+            if (geo.pFbCells[k] < 1) geo.pFbCells[k] = 1;
+        }
     if (b->emit == CPECAN_EMIT_FORWARD) { /* no traceback: nothing is kept of the forward matrix */
         geo.ringCells = 1;
         geo.fbCells = 1;
@@ -863,7 +867,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
     geo.rollStride = geo.maxWidth + 1;
     {
         int64_t seqMax = 0;
-        for (int64_t di = geo.nPacked; di < b->nRegions; di++) { /* wide regions: two symbols per byte in LDS */
+        for (int64_t di = geo.nPacked[0] + geo.nPacked[1] + geo.nPacked[2]; di < b->nRegions; di++) { /* wide regions: two symbols per byte in LDS */
             const HostRegion *r = &b->regions[keys[di].index];
             seqMax = imax(seqMax, (r->lX + 3) / 2 + (r->lY + 3) / 2);
         }

@@ -89,14 +89,12 @@ typedef struct {
     int64_t fbCells;      /* posterior-candidate scratch per slot, in cells (most emitted cells of one segment) */
     int64_t refreshCells; /* c/m scratch per slot = maxWidth * maxRefresh (each) */
     int64_t rollDoubles;  /* global rolling buffer per slot, doubles (only when useGlobalRoll) */
-    /* Narrow regions (every diagonal at most packedGW cells wide) come first in the device order and are run by the
-     * packed kernel, 64 / packedGW regions per wave; the fields above then describe the remaining (wide) regions only
-     * and these the narrow ones.  packedGW == 0: no packed launch. */
-    int32_t packedGW;
-    int32_t nPacked;
-    int32_t pMaxRefresh;
-    int32_t pad2;
-    int64_t pRingCells, pFbCells, pRefreshCells;
+    /* Narrow regions come first in the device order, by class: every diagonal at most 8 / 16 / 32 cells wide.  Class k
+     * is run by the packed kernel with groups of 8 << k lanes (64 / (8 << k) regions per wave); the fields above then
+     * describe the remaining (wide) regions only and these the narrow classes.  nPacked[k] == 0: no launch. */
+    int32_t nPacked[3];
+    int32_t pMaxRefresh[3];
+    int64_t pRingCells[3], pFbCells[3];
 } CpkGeometry;
 
 /* One run of consecutive triples to move into the compact, list-ordered result buffer: the triples of one traceback

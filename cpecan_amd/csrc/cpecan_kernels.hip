@@ -2005,8 +2005,8 @@ struct CpkDevice {
     int64_t dbgCells = 0, dbgDiags = 0;
     int slots = 0;        // waves of the sweep kernel (wide regions)
     size_t ldsBytes = 0;
-    int pSlots = 0;       // waves of the packed kernel (narrow regions), 64 / packedGW regions each
-    size_t pLdsBytes = 0;
+    int pSlots[3] = {0, 0, 0};  // waves of the packed kernel per class (groups of 8 / 16 / 32 lanes)
+    size_t pLdsBytes[3] = {0, 0, 0};
     // device buffers
     CpkRegion *dRegions = nullptr;
     CpkDiag *dDiags = nullptr;
@@ -2021,6 +2021,10 @@ struct CpkDevice {
     int64_t bytes = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     hipStream_t lastStream = nullptr;
+    // the packed classes run beside the sweep kernel on streams of their own (fork / join around cpk_device_run)
+    hipStream_t sideStream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t sideDone[3] = {nullptr, nullptr, nullptr};
+    int64_t subBase[3] = {0, 0, 0};  // first scratch sub-slot of each packed class (behind the sweep kernel's slots)
     bool ran = false;
 };
 
@@ -2044,6 +2048,10 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
     d->numCUs = prop.multiProcessorCount;
     HIP_TRY(hipEventCreate(&d->evStart));
     HIP_TRY(hipEventCreate(&d->evStop));
+    for (int k = 0; k < 3; k++) {
+        HIP_TRY(hipStreamCreateWithFlags(&d->sideStream[k], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&d->sideDone[k], hipEventDisableTiming));
+    }
     *out = d;
     return CPECAN_OK;
 }
@@ -2072,6 +2080,10 @@ extern "C" void cpk_device_destroy(CpkDevice *d) {
     free_all(d);
     if (d->evStart) (void)hipEventDestroy(d->evStart);
     if (d->evStop) (void)hipEventDestroy(d->evStop);
+    for (int k = 0; k < 3; k++) {
+        if (d->sideStream[k]) (void)hipStreamDestroy(d->sideStream[k]);
+        if (d->sideDone[k]) (void)hipEventDestroy(d->sideDone[k]);
+    }
     delete d;
 }
 
@@ -2086,14 +2098,14 @@ static int dev_alloc(CpkDevice *d, T **p, size_t count) {
 
 using KernelFn = void (*)(const KArgs);
 
-static KernelFn pick_packed_kernel(const CpkGeometry &g) {
+static KernelFn pick_packed_kernel(const CpkGeometry &g, int cls) {  // class k: groups of 8 << k lanes
     if (g.emit != CPECAN_EMIT_MATCH) return nullptr;
-#define CPK_PICK_PACKED(W)                                                                   \
-    if (g.packedGW == (W)) return g.nStates == 5 ? cpecan_pairhmm_packed<5, (W)> : cpecan_pairhmm_packed<3, (W)>;
-    CPK_PICK_PACKED(8)
-    CPK_PICK_PACKED(16)
-    CPK_PICK_PACKED(32)
-#undef CPK_PICK_PACKED
+    const bool five = g.nStates == 5;
+    switch (cls) {
+        case 0: return five ? cpecan_pairhmm_packed<5, 8> : cpecan_pairhmm_packed<3, 8>;
+        case 1: return five ? cpecan_pairhmm_packed<5, 16> : cpecan_pairhmm_packed<3, 16>;
+        case 2: return five ? cpecan_pairhmm_packed<5, 32> : cpecan_pairhmm_packed<3, 32>;
+    }
     return nullptr;
 }
 
@@ -2168,7 +2180,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         cpk_set_error("kernel does not fit on a CU (LDS %zu bytes)", d->ldsBytes);
         return CPECAN_EHIP;
     }
-    const int64_t nWide = geo->nRegions - geo->nPacked;
+    const int64_t nWide = geo->nRegions - geo->nPacked[0] - geo->nPacked[1] - geo->nPacked[2];
     int64_t slots = (int64_t)perCU * d->numCUs;
     if (slots > nWide) slots = nWide;
     if (slots < 1) slots = 1;
@@ -2181,17 +2193,18 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         if (even >= 1 && even < slots) slots = even;
     }
     d->slots = (int)slots;
-    // the packed kernel's waves (narrow regions, 64 / packedGW per wave) and their scratch sub-slots
-    d->pSlots = 0;
-    int64_t subSlots = 0;
-    if (geo->nPacked > 0) {
-        KernelFn pfn = pick_packed_kernel(*geo);
+    // the packed kernel's waves per class (narrow regions, 64 / GW per wave) and their scratch sub-slots
+    int64_t subSlots[3] = {0, 0, 0};
+    for (int k = 0; k < 3; k++) {
+        d->pSlots[k] = 0;
+        if (geo->nPacked[k] <= 0) continue;
+        KernelFn pfn = pick_packed_kernel(*geo, k);
         if (!pfn) {
-            cpk_set_error("no packed kernel for group width %d", geo->packedGW);
+            cpk_set_error("no packed kernel for emitter %d", geo->emit);
             return CPECAN_EINVAL;
         }
-        const int G = CPK_WAVE / geo->packedGW;
-        d->pLdsBytes = sizeof(double) * (size_t)(kLdsCubics + 40 + kLdsWeights) + (size_t)G * pack_group_bytes(S, geo->packedGW);
+        const int GW = 8 << k, G = CPK_WAVE / GW;
+        d->pLdsBytes[k] = sizeof(double) * (size_t)(kLdsCubics + 40 + kLdsWeights) + (size_t)G * pack_group_bytes(S, GW);
         hipFuncAttributes pattr;
         HIP_TRY(hipFuncGetAttributes(&pattr, (const void *)pfn));
         const int pv = ((pattr.numRegs > 0 ? pattr.numRegs : 128) + 7) / 8 * 8;
@@ -2199,42 +2212,47 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         if (pPerSimd > 8) pPerSimd = 8;
         if (pPerSimd < 1) pPerSimd = 1;
         int pPerCU = 4 * pPerSimd;
-        const int pByLds = (int)((160 * 1024) / (d->pLdsBytes + (size_t)pattr.sharedSizeBytes));
+        const int pByLds = (int)((160 * 1024) / (d->pLdsBytes[k] + (size_t)pattr.sharedSizeBytes));
         if (pByLds < pPerCU) pPerCU = pByLds;
         if (const char *cap = getenv("CPECAN_MAX_WAVES_PER_CU")) {
             const int c = atoi(cap);
             if (c >= 1 && c < pPerCU) pPerCU = c;
         }
         int64_t pSlots = (int64_t)pPerCU * d->numCUs;
-        const int64_t wavesNeeded = (geo->nPacked + G - 1) / G;
+        const int64_t wavesNeeded = (geo->nPacked[k] + G - 1) / G;
         if (pSlots > wavesNeeded) pSlots = wavesNeeded;
-        d->pSlots = (int)pSlots;
-        subSlots = pSlots * G;
+        d->pSlots[k] = (int)pSlots;
+        subSlots[k] = pSlots * G;
     }
-    // scratch per slot: the two launches run one after the other on the same stream and share the buffers
-    auto scratch = [&](int64_t wide, int64_t packed) {
-        const int64_t w = nWide > 0 ? slots * wide : 0, p = subSlots * packed;
-        return (size_t)(w > p ? w : p);
+    // scratch per slot: the launches run side by side, each class has its own part of every buffer behind the sweep's
+    auto scratch = [&](int64_t wide, const int64_t (&packed)[3]) {
+        int64_t all = nWide > 0 ? slots * wide : 0;
+        for (int k = 0; k < 3; k++) all += subSlots[k] * packed[k];
+        return (size_t)all;
     };
+    for (int k = 0; k < 3; k++) d->subBase[k] = subSlots[k];  // sub-slot counts, turned into element offsets at launch
+    const int64_t pRing[3] = {geo->pRingCells[0] * S, geo->pRingCells[1] * S, geo->pRingCells[2] * S};
+    const int64_t pRefresh[3] = {(int64_t)8 * geo->pMaxRefresh[0], (int64_t)16 * geo->pMaxRefresh[1], (int64_t)32 * geo->pMaxRefresh[2]};
+    const int64_t pTotals[3] = {geo->pMaxRefresh[0], geo->pMaxRefresh[1], geo->pMaxRefresh[2]};
 
     if (int rc = dev_alloc(d, &d->dRegions, (size_t)geo->nRegions)) return rc;
     if (int rc = dev_alloc(d, &d->dDiags, (size_t)nDiags)) return rc;
     if (int rc = dev_alloc(d, &d->dSegs, (size_t)nSegs)) return rc;
     if (int rc = dev_alloc(d, &d->dSymbols, (size_t)nSymbolBytes)) return rc;
     if (int rc = dev_alloc(d, &d->dModel, 1)) return rc;
-    if (int rc = dev_alloc(d, &d->dRing, scratch(geo->ringCells * S, geo->pRingCells * S))) return rc;
+    if (int rc = dev_alloc(d, &d->dRing, scratch(geo->ringCells * S, pRing))) return rc;
     if (int rc = dev_alloc(d, &d->dCand, scratch(geo->fbCells * (geo->emit == CPECAN_EMIT_INDEL ? 3 : 1), geo->pFbCells))) return rc;
     if (int rc = dev_alloc(d, &d->dForward, (size_t)geo->nRegions)) return rc;
     if (int rc = dev_alloc(d, &d->dExpect, (size_t)slots * 128)) return rc;
-    if (int rc = dev_alloc(d, &d->dC, scratch(geo->refreshCells, geo->pRefreshCells))) return rc;
-    if (int rc = dev_alloc(d, &d->dM, scratch(geo->refreshCells, geo->pRefreshCells))) return rc;
-    if (int rc = dev_alloc(d, &d->dTotals, scratch(geo->maxRefresh, geo->pMaxRefresh))) return rc;
+    if (int rc = dev_alloc(d, &d->dC, scratch(geo->refreshCells, pRefresh))) return rc;
+    if (int rc = dev_alloc(d, &d->dM, scratch(geo->refreshCells, pRefresh))) return rc;
+    if (int rc = dev_alloc(d, &d->dTotals, scratch(geo->maxRefresh, pTotals))) return rc;
     if (geo->useGlobalRoll)
         if (int rc = dev_alloc(d, &d->dGroll, (size_t)slots * geo->rollDoubles)) return rc;
     if (int rc = dev_alloc(d, &d->dCounts, (size_t)nLists * geo->nRegions)) return rc;
     if (int rc = dev_alloc(d, &d->dSegStarts, (size_t)nLists * nSegs)) return rc;
     if (int rc = dev_alloc(d, &d->dTriples, (size_t)nLists * outTriplesPerList * 3)) return rc;
-    if (int rc = dev_alloc(d, &d->dQueue, 2)) return rc;
+    if (int rc = dev_alloc(d, &d->dQueue, 4)) return rc;
     HIP_TRY(hipMemset(d->dCounts, 0, sizeof(int32_t) * (size_t)nLists * geo->nRegions));
     HIP_TRY(hipMemset(d->dSegStarts, 0, sizeof(int32_t) * (size_t)nLists * (nSegs ? nSegs : 1)));
     if (geo->debug) {
@@ -2319,27 +2337,52 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.expectOut = d->dExpect;
     a.dbgFb = d->dDbgFb;
     a.dbgTotals = d->dDbgTotals;
-    HIP_TRY(hipMemsetAsync(d->dQueue, 0, 2 * sizeof(unsigned int), st));
+    HIP_TRY(hipMemsetAsync(d->dQueue, 0, 4 * sizeof(unsigned int), st));
     KernelFn fn = pick_kernel(d->geo);
     HIP_TRY(hipEventRecord(d->evStart, st));
-    if (d->geo.nPacked > 0) {  // narrow regions [0, nPacked): several to a wave
+    int base = 0;
+    const int64_t nWideRun = d->geo.nRegions - d->geo.nPacked[0] - d->geo.nPacked[1] - d->geo.nPacked[2];
+    const int SS = d->geo.nStates;
+    // element offsets of each class's scratch inside the shared buffers: [sweep slots][class 0][class 1][class 2]
+    int64_t oRing = nWideRun > 0 ? (int64_t)d->slots * d->geo.ringCells * SS : 0;
+    int64_t oCand = nWideRun > 0 ? (int64_t)d->slots * d->geo.fbCells * (d->geo.emit == CPECAN_EMIT_INDEL ? 3 : 1) : 0;
+    int64_t oRef = nWideRun > 0 ? (int64_t)d->slots * d->geo.refreshCells : 0;
+    int64_t oTot = nWideRun > 0 ? (int64_t)d->slots * d->geo.maxRefresh : 0;
+    for (int k = 0; k < 3; k++) {  // narrow regions, class by class: several to a wave, on a stream of their own
+        if (d->geo.nPacked[k] <= 0) continue;
         KArgs p = a;
-        p.regionBase = 0;
-        p.regionCount = d->geo.nPacked;
-        p.geo.ringCells = d->geo.pRingCells;
-        p.geo.fbCells = d->geo.pFbCells;
-        p.geo.refreshCells = d->geo.pRefreshCells;
-        p.geo.maxRefresh = d->geo.pMaxRefresh;
-        p.queue = d->dQueue + 1;
-        hipLaunchKernelGGL(pick_packed_kernel(d->geo), dim3((unsigned)d->pSlots), dim3(CPK_WAVE), d->pLdsBytes, st, p);
+        p.regionBase = base;
+        p.regionCount = d->geo.nPacked[k];
+        p.geo.ringCells = d->geo.pRingCells[k];
+        p.geo.fbCells = d->geo.pFbCells[k];
+        p.geo.refreshCells = (int64_t)(8 << k) * d->geo.pMaxRefresh[k];
+        p.geo.maxRefresh = d->geo.pMaxRefresh[k];
+        p.ring = d->dRing + oRing;
+        p.cand = d->dCand + oCand;
+        p.cbuf = d->dC + oRef;
+        p.mbuf = d->dM + oRef;
+        p.totals = d->dTotals + oTot;
+        p.queue = d->dQueue + 1 + k;
+        HIP_TRY(hipStreamWaitEvent(d->sideStream[k], d->evStart, 0));
+        hipLaunchKernelGGL(pick_packed_kernel(d->geo, k), dim3((unsigned)d->pSlots[k]), dim3(CPK_WAVE), d->pLdsBytes[k],
+                           d->sideStream[k], p);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventRecord(d->sideDone[k], d->sideStream[k]));
+        const int64_t subs = d->subBase[k];
+        oRing += subs * p.geo.ringCells * SS;
+        oCand += subs * p.geo.fbCells;
+        oRef += subs * p.geo.refreshCells;
+        oTot += subs * p.geo.maxRefresh;
+        base += d->geo.nPacked[k];
     }
-    a.regionBase = d->geo.nPacked;
-    a.regionCount = d->geo.nRegions - d->geo.nPacked;
+    a.regionBase = base;
+    a.regionCount = d->geo.nRegions - base;
     if (a.regionCount > 0) {
         hipLaunchKernelGGL(fn, dim3((unsigned)d->slots), dim3(CPK_WAVE), d->ldsBytes, st, a);
         HIP_TRY(hipGetLastError());
     }
+    for (int k = 0; k < 3; k++)  // join: the caller's stream continues when every class is done
+        if (d->geo.nPacked[k] > 0) HIP_TRY(hipStreamWaitEvent(st, d->sideDone[k], 0));
     HIP_TRY(hipEventRecord(d->evStop, st));
     d->lastStream = st;
     d->ran = true;
@@ -2551,4 +2594,4 @@ extern "C" int cpk_device_debug_fetch(CpkDevice *d, double *fb, int64_t cells, d
 }
 
 extern "C" int64_t cpk_device_bytes(const CpkDevice *d) { return d->bytes; }
-extern "C" int cpk_device_waves(const CpkDevice *d) { return d->slots + d->pSlots; }
+extern "C" int cpk_device_waves(const CpkDevice *d) { return d->slots + d->pSlots[0] + d->pSlots[1] + d->pSlots[2]; }

@@ -19,7 +19,8 @@ def run(name, probs, emit, raggeds, **pkw):
             st.diagonals / best * 1e3, t1 - t0, st.wavesPerLaunch), flush=True)
 
 n4 = int(sys.argv[1]) if len(sys.argv) > 1 else 5000
-run("config4-like (realign, E=4, split at 10)", workload.make_realign_batch(4, n4, 100, 5000, 4), api.EMIT_MATCH, (True, True),
+maxlen = int(os.environ.get("NARROW_MAXLEN", "5000"))
+run("config4-like (realign, E=4, split at 10)", workload.make_realign_batch(4, n4, 100, maxlen, 4), api.EMIT_MATCH, (True, True),
     diagonalExpansion=4, splitMatrixBiggerThanThis=10)
 if len(sys.argv) > 2:
     sys.exit(0)
