@@ -877,7 +877,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
     if (geo.refreshCells < 1) geo.refreshCells = 1;
     geo.rollDoubles = (int64_t)(2 * S + 1) * geo.rollStride;
     /* LDS budget: beyond 64 KiB per wave (rolling buffers + symbol strings) the batch takes the global-memory path */
-    geo.useGlobalRoll = (sizeof(double) * (size_t)(304 + 768 + geo.rollDoubles) + (size_t)geo.seqLdsBytes + 16 > 64 * 1024);
+    geo.useGlobalRoll = (sizeof(double) * (size_t)(544 + 768 + geo.rollDoubles) + (size_t)geo.seqLdsBytes + 16 > 64 * 1024);
     b->geo = geo;
     b->segs = segs;
     b->nSegs = nSegs;

@@ -159,6 +159,18 @@ __device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
     return (d < 7.5) ? r : hi;
 }
 
+// exp(x) to a relative error of ~1e-7 for x <= ~1 (probabilities): 2^(x log2 e) with the integer part split off in
+// double, the fraction through v_exp_f32, and the scaling by v_ldexp_f64 -- 8 instructions instead of the ~35 of the
+// double-precision exp.  Only for the expectation sums, whose gate is 1e-5 relative (linear-space
+// sums, order-insensitive at 1e-5); the posterior emitters keep the exact exp.  -inf and very negative x give 0.
+__device__ __forceinline__ double exp_1e7(double x) {
+    const double y = x * 1.4426950408889634;  // log2(e)
+    if (!(y > -1000.0)) return 0.0;           // also NaN -> 0: an unreachable transition contributes nothing
+    const double yi = __builtin_rint(y);
+    const float yf = (float)(y - yi);         // in [-0.5, 0.5]
+    return __builtin_ldexp((double)__builtin_amdgcn_exp2f(yf), (int)yi);
+}
+
 // N independent logAdds advanced in lock-step stages (compare/select -> table fetch -> Horner) so that the N LDS
 // table fetches are in flight together instead of one fetch + wait per logAdd.  acc[i] = logAdd(acc[i], t[i]).
 template <int N>
@@ -274,9 +286,10 @@ struct DiagCache {
 
 constexpr int kLdsCubics = 16;  // 4 rows x 4 coefficients
 // doubles of LDS in front of the rolling rows: cubics + emissions (+ expectation sums for that emitter only)
+constexpr int kExpectCopies = 4;  // emission-expectation sums are kept in 4 LDS copies (lane & 3): fewer atomic collisions
 constexpr int kLdsWeights = 168;  // (emission + transition) sums, see Sweep::wt: 25*5 + 5*4 + 5*4 = 165, padded
 __host__ __device__ constexpr int lds_header_doubles(int emit) {
-    return kLdsCubics + 40 + kLdsWeights + (emit == CPECAN_EMIT_EXPECT ? 80 : 0);
+    return kLdsCubics + 40 + kLdsWeights + (emit == CPECAN_EMIT_EXPECT ? kExpectCopies * 80 : 0);
 }
 // doubles of LDS behind the rolling rows for the candidate staging rings (16-byte Candidates, 128 per list; none for
 // the forward-only and expectation emitters)
@@ -1022,6 +1035,23 @@ struct Sweep {
                 if (k >= W) continue;
                 const int kk[1] = {k};
                 const int kkR[1] = {kb * R + laneR};
+                // The forward values of the neighbours are requested FIRST: they do not depend on this cell's backward
+                // values, so their HBM round trip runs beside the backward step instead of after it.
+                const int kL = k + dl, kU = k + dl + 1, kM = k + dm;
+                const bool okL = (unsigned)kL < (unsigned)w1, okU = (unsigned)kU < (unsigned)w1,
+                           okM = (unsigned)kM < (unsigned)w2;
+                const int qL = okL ? kL : 0, qU = okU ? kU : 0, qM = okM ? kM : 0;
+                double fL[S], fU[S], fM[S];  // F[d2-1] at the lower / upper neighbour, F[d2-2] at the middle one
+                if (emit) {
+#pragma unroll
+                    for (int s = 0; s < S; s++) {
+                        // 5 states: the lower block reads M, sX, lX, the upper block M, sY, lY; 3 states: all three
+                        const bool needL = S == 3 || s == 0 || s == 1 || s == 3, needU = S == 3 || s == 0 || s == 2 || s == 4;
+                        fL[s] = needL ? ld_self(f1 + ringIdx(w1, s, qL)) : 0.0;
+                        fU[s] = needU ? ld_self(f1 + ringIdx(w1, s, qU)) : 0.0;
+                        fM[s] = okM ? ld_self(f2 + ringIdx(w2, s, qM)) : NEG_INF;
+                    }
+                }
                 double v[1][S];
                 if (seeded) {
 #pragma unroll
@@ -1033,57 +1063,54 @@ struct Sweep {
 #pragma unroll
                 for (int s = 1; s < S; s++) curG[s + kkR[0]] = v[0][s];
                 if (!emit) continue;
+#pragma unroll
+                for (int s = 0; s < S; s++) {
+                    fL[s] = okL ? fL[s] : NEG_INF;
+                    fU[s] = okU ? fU[s] : NEG_INF;
+                }
                 const int x = xlo + k, y = d2 - x;
                 const int cX = symX(x), cY = symY(y);
                 const double eX = em[25 + cX], eM = em[cX * 5 + cY], eY = em[30 + cY];
                 const bool acgt = cX < CPK_SYM_N && cY < CPK_SYM_N;
                 const int eIdx = cX * 4 + cY;
-                const int kL = k + dl, kU = k + dl + 1, kM = k + dm;
-                const bool okL = (unsigned)kL < (unsigned)w1, okU = (unsigned)kU < (unsigned)w1,
-                           okM = (unsigned)kM < (unsigned)w2;
-                const int qL = okL ? kL : 0, qU = okU ? kU : 0, qM = okM ? kM : 0;
-                auto F1 = [&](int s, int q, bool ok) {
-                    const double val = ld_self(f1 + ringIdx(w1, s, q));
-                    return ok ? val : NEG_INF;
-                };
-                auto F2 = [&](int s) {
-                    const double val = okM ? ld_self(f2 + ringIdx(w2, s, qM)) : NEG_INF;
-                    return val;
-                };
+                double eAcc[S];  // this cell's events summed per target state: one LDS atomic per state, not per event
+#pragma unroll
+                for (int s = 0; s < S; s++) eAcc[s] = 0.0;
                 // one (transition, emission) event: impl/pairwiseAligner.c:426-431
                 auto event = [&](int ti, double from, int to, double eP, double tP) {
-                    const double p = exp(from + v[0][to] + (eP + tP) - total);
+                    const double p = exp_1e7(from + v[0][to] + (eP + tP) - total);
                     tAcc[ti] += p;
-                    if (acgt) atomicAdd(&eLds[to * 16 + eIdx], p);
+                    eAcc[to] += p;
                 };
                 if (S == 5) {
-                    const double lM = F1(0, qL, okL), lSX = F1(1, qL, okL), lLX = F1(3, qL, okL);
-                    const double uM = F1(0, qU, okU), uSY = F1(2, qU, okU), uLY = F1(4, qU, okU);
-                    event(0, lM, 1, eX, m.shortOpenX);
-                    event(1, lSX, 1, eX, m.shortExtendX);
-                    event(2, lM, 3, eX, m.longOpenX);
-                    event(3, lLX, 3, eX, m.longExtendX);
-                    event(4, F2(0), 0, eM, m.matchContinue);
-                    event(5, F2(1), 0, eM, m.matchFromShortX);
-                    event(6, F2(2), 0, eM, m.matchFromShortY);
-                    event(7, F2(3), 0, eM, m.matchFromLongX);
-                    event(8, F2(4), 0, eM, m.matchFromLongY);
-                    event(9, uM, 2, eY, m.shortOpenY);
-                    event(10, uSY, 2, eY, m.shortExtendY);
-                    event(11, uM, 4, eY, m.longOpenY);
-                    event(12, uLY, 4, eY, m.longExtendY);
+                    event(0, fL[0], 1, eX, m.shortOpenX);
+                    event(1, fL[1], 1, eX, m.shortExtendX);
+                    event(2, fL[0], 3, eX, m.longOpenX);
+                    event(3, fL[3], 3, eX, m.longExtendX);
+                    event(4, fM[0], 0, eM, m.matchContinue);
+                    event(5, fM[1], 0, eM, m.matchFromShortX);
+                    event(6, fM[2], 0, eM, m.matchFromShortY);
+                    event(7, fM[3], 0, eM, m.matchFromLongX);
+                    event(8, fM[4], 0, eM, m.matchFromLongY);
+                    event(9, fU[0], 2, eY, m.shortOpenY);
+                    event(10, fU[2], 2, eY, m.shortExtendY);
+                    event(11, fU[0], 4, eY, m.longOpenY);
+                    event(12, fU[4], 4, eY, m.longExtendY);
                 } else {
-                    const double lM = F1(0, qL, okL), lGX = F1(1, qL, okL), lGY = F1(2, qL, okL);
-                    const double uM = F1(0, qU, okU), uGX = F1(1, qU, okU), uGY = F1(2, qU, okU);
-                    event(0, lM, 1, eX, m.shortOpenX);
-                    event(1, lGX, 1, eX, m.shortExtendX);
-                    event(2, lGY, 1, eX, m.shortSwitchToX);
-                    event(3, F2(0), 0, eM, m.matchContinue);
-                    event(4, F2(1), 0, eM, m.matchFromShortX);
-                    event(5, F2(2), 0, eM, m.matchFromShortY);
-                    event(6, uM, 2, eY, m.shortOpenY);
-                    event(7, uGY, 2, eY, m.shortExtendY);
-                    event(8, uGX, 2, eY, m.shortSwitchToY);
+                    event(0, fL[0], 1, eX, m.shortOpenX);
+                    event(1, fL[1], 1, eX, m.shortExtendX);
+                    event(2, fL[2], 1, eX, m.shortSwitchToX);
+                    event(3, fM[0], 0, eM, m.matchContinue);
+                    event(4, fM[1], 0, eM, m.matchFromShortX);
+                    event(5, fM[2], 0, eM, m.matchFromShortY);
+                    event(6, fU[0], 2, eY, m.shortOpenY);
+                    event(7, fU[2], 2, eY, m.shortExtendY);
+                    event(8, fU[1], 2, eY, m.shortSwitchToY);
+                }
+                if (acgt) {  // emissions are counted for ACGT x ACGT cells only (:429)
+                    double *copy = eLds + (lane & (kExpectCopies - 1)) * 80;
+#pragma unroll
+                    for (int s = 0; s < S; s++) atomicAdd(&copy[s * 16 + eIdx], eAcc[s]);
                 }
             }
             roll_fence<!FAST>();
@@ -1217,7 +1244,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
     fill_weights<S>(wt, m, a.kc, lane);
     double *eLds = lds + kLdsCubics + 40 + kLdsWeights;  // emission-expectation sums of this wave (expectation emitter)
     if (EMIT == CPECAN_EMIT_EXPECT)
-        for (int i = lane; i < 80; i += CPK_WAVE) eLds[i] = 0.0;
+        for (int i = lane; i < kExpectCopies * 80; i += CPK_WAVE) eLds[i] = 0.0;
     constexpr int kNT = S == 5 ? 13 : 9;
     double tAcc[kNT];
 #pragma unroll
@@ -1405,7 +1432,11 @@ cpecan_pairhmm_sweep(const KArgs a) {
             const int idx = S == 5 ? kFrom5[i] * 5 + kTo5[i] : kFrom3[i] * 3 + kTo3[i];
             if (lane == 0) dst[idx] = v;
         }
-        for (int i = lane; i < 80; i += CPK_WAVE) dst[25 + i] = eLds[i];
+        for (int i = lane; i < 80; i += CPK_WAVE) {
+            double e = 0.0;
+            for (int k = 0; k < kExpectCopies; k++) e += eLds[k * 80 + i];
+            dst[25 + i] = e;
+        }
         if (lane == 0) dst[105] = likelihood;
     }
 }
