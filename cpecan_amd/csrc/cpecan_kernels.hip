@@ -626,7 +626,11 @@ struct Sweep {
                 hi -= CPK_WAVE;
             }
         }
-        if (hi > lo) {
+        if (hi > lo && W < CPK_WAVE) {
+            // a diagonal of fewer than 64 cells can never share (its first cell would have to be behind the reads of
+            // the next diagonal): do it now
+            fwdGroupUniform(c, cur, out, W, ringStates, lo, lo, hi);
+        } else if (hi > lo) {
             tail.has = true;
             tail.asc = asc;
             tail.lo = lo;
