@@ -454,3 +454,32 @@ def test_packed_kernel_random_narrow_bands(force_packed):
         tbd = rng.randrange(2, 12)
         _check_batch(0, probs, raggeds, diagonalExpansion=exp, traceBackDiagonals=tbd,
                      minDiagsBetweenTraceBack=tbd + rng.randrange(3, 60), splitMatrixBiggerThanThis=10 ** 12)
+
+
+def test_packed_and_sweep_kernels_agree_bit_for_bit(monkeypatch):
+    """The packed kernel runs the sweep kernel's own cell functions: the same batch through either must give identical
+    triples (not just within tolerance), for all three group widths and both model families."""
+    rng = random.Random(123)
+    for mtype, exp in ((0, 2), (2, 6), (1, 14), (3, 26)):
+        probs, raggeds = [], []
+        for _ in range(40):
+            sx = _rand_seq(rng, rng.randrange(30, 700))
+            sy = _evolve(rng, sx) or "C"
+            anchors, x, y = [], -1, -1
+            while True:
+                x += rng.randrange(1, 5)
+                y += rng.randrange(1, 5)
+                if x >= len(sx) or y >= len(sy):
+                    break
+                anchors.append((x, y, exp))
+            probs.append((sx, sy, anchors))
+            raggeds.append((rng.random() > 0.5, rng.random() > 0.5))
+        kw = dict(diagonalExpansion=exp, minDiagsBetweenTraceBack=rng.randrange(60, 300), traceBackDiagonals=rng.randrange(5, 40),
+                  splitMatrixBiggerThanThis=rng.choice([10, 50, 10 ** 12]))
+        monkeypatch.setenv("CPECAN_PACKED", "2")
+        packed, st_p = _run_batch(mtype, probs, raggeds, **kw)
+        monkeypatch.setenv("CPECAN_PACKED", "0")
+        sweep, st_s = _run_batch(mtype, probs, raggeds, **kw)
+        assert st_p.cells == st_s.cells
+        for a, b in zip(packed, sweep):
+            assert a.shape == b.shape and (a == b).all()
