@@ -90,6 +90,7 @@ struct KArgs {
     double *mbuf;      // [slots][refreshCells]  per-cell "match straddling the diagonal" terms, [k][j]
     double *totals;    // [slots][maxRefresh]
     double *groll;     // [slots][rollDoubles]   rolling buffers when they do not fit in LDS
+    double *bring;     // [slots][fbCells*S]     expectation emitter: backward values of the emitted cells of the segment
     int32_t *outCounts;  // [nLists][nRegions]
     int32_t *segStarts;  // [nLists][nSegsTotal]
     int32_t *triples;    // [nLists][outTriplesPerList*3]
@@ -162,10 +163,10 @@ __device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
 // exp(x) to a relative error of ~1e-7 for x <= ~1 (probabilities): 2^(x log2 e) with the integer part split off in
 // double, the fraction through v_exp_f32, and the scaling by v_ldexp_f64 -- 8 instructions instead of the ~35 of the
 // double-precision exp.  Only for the expectation sums, whose gate is 1e-5 relative (linear-space
-// sums, order-insensitive at 1e-5); the posterior emitters keep the exact exp.  -inf and very negative x give 0.
+// sums, order-insensitive at 1e-5); the posterior emitters keep the exact exp.
 __device__ __forceinline__ double exp_1e7(double x) {
-    const double y = x * 1.4426950408889634;  // log2(e)
-    if (!(y > -1000.0)) return 0.0;           // also NaN -> 0: an unreachable transition contributes nothing
+    // branch-free: -inf, NaN (an unreachable transition) and anything below 2^-1100 end as ldexp(.., -1100) == 0
+    const double y = __builtin_fmax(x * 1.4426950408889634 /* log2(e) */, -1100.0);
     const double yi = __builtin_rint(y);
     const float yf = (float)(y - yi);         // in [-0.5, 0.5]
     return __builtin_ldexp((double)__builtin_amdgcn_exp2f(yf), (int)yi);
@@ -523,6 +524,9 @@ struct Sweep {
         double *cur, *out;
     };
     FwdTail tail{};
+    // expectation emitter: backward values of the emitted cells of the segment being traced back, [cell][S], written by
+    // traceback() and read by expectations() (set by the kernel; null for the other emitters)
+    double *bring = nullptr;
 
     // one group of cells of ONE diagonal: cells [kb, kb + 64) clipped to [lo, hi)
     __device__ __forceinline__ void fwdGroupUniform(const FwdCtx &c, double *cur, double *out, int W, int ringStates, int kb,
@@ -777,6 +781,8 @@ struct Sweep {
             pend[l] -= n;
             nCand[l] += n;
         };
+        // expectation emitter: cells of the segment are numbered from the first cell of its lowest emitted diagonal
+        const int bBase = (!CANDS && bring) ? dc.table[sg.tbPrev + 1].cellOff : 0;
         float lastMax = -__builtin_huge_valf();
         double ep[S];  // end prior: loaded AND waited for here (the empty asm consumes the registers); a value whose
                        // load may still be pending at the loop head costs a vmcnt(0) in front of every group
@@ -873,6 +879,11 @@ struct Sweep {
                     curM[kR0] = v[0][0];
 #pragma unroll
                     for (int s = 1; s < S; s++) curG[s + kR0] = v[0][s];
+                }
+                if (!CANDS && bring && emit && on) {  // kept for the expectation step: it needs B again, not its neighbours
+                    double *bo = bring + (size_t)(g.cellOff - bBase + k0) * S;
+#pragma unroll
+                    for (int s = 0; s < S; s++) bo[s] = v[0][s];
                 }
                 if (feeds && on) mbuf[(size_t)k0 * J + jrNext] = f0[0] + v[0][0];  // every cell of the diagonal (:647)
                 if (emit) {
@@ -1000,116 +1011,135 @@ struct Sweep {
     // tAcc: per-lane sums, one per transition in list order; eLds: [state*16 + cX*4 + cY] in LDS (fp64 LDS atomics).
     static constexpr int kNT = S == 5 ? 13 : 9;
 
-    __device__ void expectations(const CpkSegment &sg, const double *endPrior, double (&tAcc)[kNT], double *eLds,
-                                 double &likelihood) {
-        double ep[S];
-#pragma unroll
-        for (int s = 0; s < S; s++) ep[s] = endPrior[s];
-        CpkDiag gb{}, ga{};
-        CpkDiag g = dc.get(sg.dTop, true);
-        for (int d2 = sg.dTop; d2 > sg.tbPrev; d2--) {
-            const bool seeded = d2 == sg.dTop;
-            const int W = g.width;
-            const bool emit = d2 <= sg.tbFrom;
-            const CpkDiag g1 = dc.get(d2 - 1, true);               // F[d2-1]: always alive (d2-1 >= tbPrev)
-            const bool haveM2 = emit && d2 - 2 >= sg.tbPrev;       // F[d2-2] is gone at d2 == tbPrev+1
+    // One group of 64 cells of one emitted diagonal, as the expectation step sees it.
+    struct ExpItem {
+        int d2, kb, W, xlo, dl, dm, w1, w2, cellOff;
+        const double *f1, *f2;
+        double total;
+        bool valid;
+    };
+    // What the step reads for its cell: B of the cell, F[d2-1] at the lower / upper neighbour, F[d2-2] at the middle one.
+    struct ExpLoads {
+        double v[S], fL[S], fU[S], fM[S];
+    };
+
+    __device__ void expectations(const CpkSegment &sg, double (&tAcc)[kNT], double *eLds, double &likelihood) {
+        const int bBase = dc.table[sg.tbPrev + 1].cellOff;
+        // The step has no dependency between cells: it is a stream of (diagonal, group) items.  The loads of the NEXT
+        // item are issued before the events of the current one are computed, so the HBM round trip of 16 values per
+        // cell runs beside ~250 vector instructions instead of in front of them.
+        auto first_of = [&](int d2) {
+            ExpItem it{};
+            it.valid = d2 > sg.tbPrev;
+            if (!it.valid) return it;
+            const CpkDiag g = dc.get(d2, true);
+            const CpkDiag g1 = dc.get(d2 - 1, true);      // F[d2-1]: always alive (d2-1 >= tbPrev)
+            const bool haveM2 = d2 - 2 >= sg.tbPrev;      // F[d2-2] is gone at d2 == tbPrev+1 (:843-845)
             const CpkDiag g2 = haveM2 ? dc.get(d2 - 2, true) : CpkDiag{};
-            double *curM = bM1(d2), *curG = bG1(d2);
-            const int xlo = (d2 + g.xmyL) >> 1;
-            BwdCtx c;
-            c.d2 = d2;
-            c.xlo = xlo;
-            c.dbR = ((g.xmyL - 1 - gb.xmyL) >> 1) * R;
-            c.wBR = seeded ? 0 : gb.width * R;
-            c.daR = ((g.xmyL - ga.xmyL) >> 1) * R;
-            c.wAR = (!seeded && d2 + 2 <= sg.dTop) ? ga.width * R : 0;
-            c.pb = bG1(d2 + 1);
-            c.pa = bM1(d2 + 2);
-            double total = 0.0;
-            if (emit) {
-                total = ld_self(totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
-                likelihood += total;  // once per diagonal (:743)
+            it.d2 = d2;
+            it.kb = 0;
+            it.W = g.width;
+            it.xlo = (d2 + g.xmyL) >> 1;
+            it.dl = (g.xmyL - 1 - g1.xmyL) >> 1;  // lower neighbour (d2-1, xmy-1) is cell k+dl of F[d2-1]
+            it.dm = (g.xmyL - g2.xmyL) >> 1;      // middle neighbour (d2-2, xmy) is cell k+dm of F[d2-2]
+            it.w1 = g1.width;
+            it.w2 = haveM2 ? g2.width : 0;
+            it.cellOff = g.cellOff;
+            it.f1 = ringAt(g1);
+            it.f2 = ringAt(g2);
+            it.total = ld_self(totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
+            return it;
+        };
+        auto next_of = [&](const ExpItem &it) {
+            if (it.kb + CPK_WAVE < it.W) {
+                ExpItem n = it;
+                n.kb += CPK_WAVE;
+                return n;
             }
-            const int dl = (g.xmyL - 1 - g1.xmyL) >> 1;  // lower neighbour (d2-1, xmy-1) is cell k+dl of F[d2-1]
-            const int dm = (g.xmyL - g2.xmyL) >> 1;      // middle neighbour (d2-2, xmy) is cell k+dm of F[d2-2]
-            const double *f1 = ringAt(g1), *f2 = ringAt(g2);
-            const int w1 = g1.width, w2 = haveM2 ? g2.width : 0;
-            for (int kb = 0; kb < W; kb += CPK_WAVE) {
-                const int k = kb + lane;
-                if (k >= W) continue;
-                const int kk[1] = {k};
-                const int kkR[1] = {kb * R + laneR};
-                // The forward values of the neighbours are requested FIRST: they do not depend on this cell's backward
-                // values, so their HBM round trip runs beside the backward step instead of after it.
-                const int kL = k + dl, kU = k + dl + 1, kM = k + dm;
-                const bool okL = (unsigned)kL < (unsigned)w1, okU = (unsigned)kU < (unsigned)w1,
-                           okM = (unsigned)kM < (unsigned)w2;
-                const int qL = okL ? kL : 0, qU = okU ? kU : 0, qM = okM ? kM : 0;
-                double fL[S], fU[S], fM[S];  // F[d2-1] at the lower / upper neighbour, F[d2-2] at the middle one
-                if (emit) {
+            return first_of(it.d2 - 1);
+        };
+        auto issue = [&](const ExpItem &it, ExpLoads &L) {
+            int k = it.kb + lane;
+            k = k < it.W ? k : it.W - 1;  // lanes past the end re-read the last cell
+            const int kL = k + it.dl, kU = k + it.dl + 1, kM = k + it.dm;
+            const int qL = (unsigned)kL < (unsigned)it.w1 ? kL : 0, qU = (unsigned)kU < (unsigned)it.w1 ? kU : 0;
+            const bool okM = (unsigned)kM < (unsigned)it.w2;
+            const int qM = okM ? kM : 0;
+            const double *bo = bring + (size_t)(it.cellOff - bBase + k) * S;
 #pragma unroll
-                    for (int s = 0; s < S; s++) {
-                        // 5 states: the lower block reads M, sX, lX, the upper block M, sY, lY; 3 states: all three
-                        const bool needL = S == 3 || s == 0 || s == 1 || s == 3, needU = S == 3 || s == 0 || s == 2 || s == 4;
-                        fL[s] = needL ? ld_self(f1 + ringIdx(w1, s, qL)) : 0.0;
-                        fU[s] = needU ? ld_self(f1 + ringIdx(w1, s, qU)) : 0.0;
-                        fM[s] = okM ? ld_self(f2 + ringIdx(w2, s, qM)) : NEG_INF;
-                    }
-                }
-                double v[1][S];
-                if (seeded) {
+            for (int s = 0; s < S; s++) {
+                // 5 states: the lower block reads M, sX, lX, the upper block M, sY, lY; 3 states: all three
+                const bool needL = S == 3 || s == 0 || s == 1 || s == 3, needU = S == 3 || s == 0 || s == 2 || s == 4;
+                L.v[s] = it.valid ? ld_self(bo + s) : 0.0;
+                L.fL[s] = (it.valid && needL) ? ld_self(it.f1 + ringIdx(it.w1, s, qL)) : 0.0;
+                L.fU[s] = (it.valid && needU) ? ld_self(it.f1 + ringIdx(it.w1, s, qU)) : 0.0;
+                L.fM[s] = (it.valid && it.w2 > 0) ? ld_self(it.f2 + ringIdx(it.w2, s, qM)) : 0.0;
+            }
+        };
+        ExpItem cur = first_of(sg.tbFrom);
+        ExpLoads Lc;
+        issue(cur, Lc);
+        while (cur.valid) {
+            const ExpItem nxt = next_of(cur);
+            ExpLoads Ln;
+            issue(nxt, Ln);
 #pragma unroll
-                    for (int s = 0; s < S; s++) v[0][s] = ep[s];
-                } else {
-                    bwdCells<1>(c, kk, kkR, v);
-                }
-                curM[kkR[0]] = v[0][0];
-#pragma unroll
-                for (int s = 1; s < S; s++) curG[s + kkR[0]] = v[0][s];
-                if (!emit) continue;
+            for (int s = 0; s < S; s++) {  // the wait for the current item's loads sits here, one item after their issue
+                asm volatile("" : "+v"(Lc.v[s]), "+v"(Lc.fL[s]), "+v"(Lc.fU[s]), "+v"(Lc.fM[s]));
+            }
+            if (cur.kb == 0) likelihood += cur.total;  // once per diagonal (:743)
+            const int k = cur.kb + lane;
+            if (k < cur.W) {
+                const int kL = k + cur.dl, kU = k + cur.dl + 1, kM = k + cur.dm;
+                const bool okL = (unsigned)kL < (unsigned)cur.w1, okU = (unsigned)kU < (unsigned)cur.w1,
+                           okM = (unsigned)kM < (unsigned)cur.w2;
+                double fL[S], fU[S], fM[S];
 #pragma unroll
                 for (int s = 0; s < S; s++) {
-                    fL[s] = okL ? fL[s] : NEG_INF;
-                    fU[s] = okU ? fU[s] : NEG_INF;
+                    fL[s] = okL ? Lc.fL[s] : NEG_INF;
+                    fU[s] = okU ? Lc.fU[s] : NEG_INF;
+                    fM[s] = okM ? Lc.fM[s] : NEG_INF;
                 }
-                const int x = xlo + k, y = d2 - x;
+                const int x = cur.xlo + k, y = cur.d2 - x;
                 const int cX = symX(x), cY = symY(y);
-                const double eX = em[25 + cX], eM = em[cX * 5 + cY], eY = em[30 + cY];
+                // (emission + transition) sums of the events, from the same LDS table as the sweeps (Sweep::wt)
+                const double *wM = wt + (cX * 5 + cY) * kWM, *wX = wt + 25 * kWM + cX * kWG, *wY = wt + 25 * kWM + 5 * kWG + cY * kWG;
                 const bool acgt = cX < CPK_SYM_N && cY < CPK_SYM_N;
                 const int eIdx = cX * 4 + cY;
+                const double total = cur.total;
                 double eAcc[S];  // this cell's events summed per target state: one LDS atomic per state, not per event
 #pragma unroll
                 for (int s = 0; s < S; s++) eAcc[s] = 0.0;
                 // one (transition, emission) event: impl/pairwiseAligner.c:426-431
-                auto event = [&](int ti, double from, int to, double eP, double tP) {
-                    const double p = exp_1e7(from + v[0][to] + (eP + tP) - total);
+                auto event = [&](int ti, double from, int to, double w) {
+                    const double p = exp_1e7(from + Lc.v[to] + w - total);
                     tAcc[ti] += p;
                     eAcc[to] += p;
                 };
                 if (S == 5) {
-                    event(0, fL[0], 1, eX, m.shortOpenX);
-                    event(1, fL[1], 1, eX, m.shortExtendX);
-                    event(2, fL[0], 3, eX, m.longOpenX);
-                    event(3, fL[3], 3, eX, m.longExtendX);
-                    event(4, fM[0], 0, eM, m.matchContinue);
-                    event(5, fM[1], 0, eM, m.matchFromShortX);
-                    event(6, fM[2], 0, eM, m.matchFromShortY);
-                    event(7, fM[3], 0, eM, m.matchFromLongX);
-                    event(8, fM[4], 0, eM, m.matchFromLongY);
-                    event(9, fU[0], 2, eY, m.shortOpenY);
-                    event(10, fU[2], 2, eY, m.shortExtendY);
-                    event(11, fU[0], 4, eY, m.longOpenY);
-                    event(12, fU[4], 4, eY, m.longExtendY);
+                    event(0, fL[0], 1, wX[0]);   // M -> shortX (open)
+                    event(1, fL[1], 1, wX[1]);   // shortX -> shortX
+                    event(2, fL[0], 3, wX[2]);   // M -> longX (open)
+                    event(3, fL[3], 3, wX[3]);   // longX -> longX
+                    event(4, fM[0], 0, wM[0]);   // M -> M
+                    event(5, fM[1], 0, wM[1]);   // shortX -> M
+                    event(6, fM[2], 0, wM[2]);   // shortY -> M
+                    event(7, fM[3], 0, wM[3]);   // longX -> M
+                    event(8, fM[4], 0, wM[4]);   // longY -> M
+                    event(9, fU[0], 2, wY[0]);   // M -> shortY
+                    event(10, fU[2], 2, wY[1]);  // shortY -> shortY
+                    event(11, fU[0], 4, wY[2]);  // M -> longY
+                    event(12, fU[4], 4, wY[3]);  // longY -> longY
                 } else {
-                    event(0, fL[0], 1, eX, m.shortOpenX);
-                    event(1, fL[1], 1, eX, m.shortExtendX);
-                    event(2, fL[2], 1, eX, m.shortSwitchToX);
-                    event(3, fM[0], 0, eM, m.matchContinue);
-                    event(4, fM[1], 0, eM, m.matchFromShortX);
-                    event(5, fM[2], 0, eM, m.matchFromShortY);
-                    event(6, fU[0], 2, eY, m.shortOpenY);
-                    event(7, fU[2], 2, eY, m.shortExtendY);
-                    event(8, fU[1], 2, eY, m.shortSwitchToY);
+                    event(0, fL[0], 1, wX[0]);  // M -> gapX
+                    event(1, fL[1], 1, wX[1]);  // gapX -> gapX
+                    event(2, fL[2], 1, wX[2]);  // gapY -> gapX (switch)
+                    event(3, fM[0], 0, wM[0]);
+                    event(4, fM[1], 0, wM[1]);
+                    event(5, fM[2], 0, wM[2]);
+                    event(6, fU[0], 2, wY[0]);  // M -> gapY
+                    event(7, fU[2], 2, wY[1]);  // gapY -> gapY
+                    event(8, fU[1], 2, wY[2]);  // gapX -> gapY (switch)
                 }
                 if (acgt) {  // emissions are counted for ACGT x ACGT cells only (:429)
                     double *copy = eLds + (lane & (kExpectCopies - 1)) * 80;
@@ -1117,10 +1147,8 @@ struct Sweep {
                     for (int s = 0; s < S; s++) atomicAdd(&copy[s * 16 + eIdx], eAcc[s]);
                 }
             }
-            roll_fence<!FAST>();
-            ga = gb;
-            gb = g;
-            g = g1;
+            cur = nxt;
+            Lc = Ln;
         }
     }
 
@@ -1311,6 +1339,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                           N,
                           CpkDiag{},
                           CpkDiag{}};
+        if (EMIT == CPECAN_EMIT_EXPECT) sw.bring = a.bring + slot * (size_t)a.geo.fbCells * S;
         constexpr int NL = EMIT == CPECAN_EMIT_INDEL ? 3 : 1;
         int count[NL];
 #pragma unroll
@@ -1397,7 +1426,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                     for (int d2 = sg.tbPrev + 1 + lane; d2 <= sg.tbFrom; d2 += CPK_WAVE)
                         a.dbgTotals[rg.dbgDiagOff + d2] = ld_self(sw.totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
                 }
-                if (EMIT == CPECAN_EMIT_EXPECT) sw.expectations(sg, endPrior, tAcc, eLds, likelihood);
+                if (EMIT == CPECAN_EMIT_EXPECT) sw.expectations(sg, tAcc, eLds, likelihood);
 #pragma unroll
                 for (int l = 0; l < (EMIT == CPECAN_EMIT_EXPECT ? 0 : NL); l++) {
                     if (lane == 0) a.segStarts[(size_t)l * a.nSegsTotal + rg.segOff + si] = count[l];
@@ -2048,7 +2077,7 @@ struct CpkDevice {
     CpkSegment *dSegs = nullptr;
     uint8_t *dSymbols = nullptr;
     CpkModel *dModel = nullptr;
-    double *dRing = nullptr; Candidate *dCand = nullptr; double *dForward = nullptr, *dExpect = nullptr; double *dC = nullptr, *dM = nullptr, *dTotals = nullptr, *dGroll = nullptr;
+    double *dRing = nullptr; Candidate *dCand = nullptr; double *dForward = nullptr, *dExpect = nullptr; double *dC = nullptr, *dM = nullptr, *dTotals = nullptr, *dGroll = nullptr, *dBring = nullptr;
     int32_t *dCounts = nullptr, *dSegStarts = nullptr, *dTriples = nullptr;
     int32_t *dCompact = nullptr; CpkChunk *dChunks = nullptr; int64_t compactCap = 0, chunkCap = 0;
     unsigned int *dQueue = nullptr;
@@ -2093,12 +2122,12 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
 
 static void free_all(CpkDevice *d) {
     void *ptrs[] = {d->dRegions, d->dDiags, d->dSegs, d->dSymbols, d->dModel, d->dRing, d->dCand, d->dC, d->dM,
-                    d->dTotals, d->dGroll, d->dCounts, d->dSegStarts, d->dTriples, d->dQueue, d->dDbgFb, d->dDbgTotals, d->dForward, d->dExpect,
+                    d->dTotals, d->dGroll, d->dBring, d->dCounts, d->dSegStarts, d->dTriples, d->dQueue, d->dDbgFb, d->dDbgTotals, d->dForward, d->dExpect,
                     d->dCompact, d->dChunks};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     d->dRegions = nullptr; d->dDiags = nullptr; d->dSegs = nullptr; d->dSymbols = nullptr; d->dModel = nullptr;
-    d->dRing = d->dC = d->dM = d->dTotals = d->dGroll = nullptr;
+    d->dRing = d->dC = d->dM = d->dTotals = d->dGroll = d->dBring = nullptr;
     d->dCand = nullptr;
     d->dForward = nullptr;
     d->dExpect = nullptr;
@@ -2287,6 +2316,8 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (int rc = dev_alloc(d, &d->dCounts, (size_t)nLists * geo->nRegions)) return rc;
     if (int rc = dev_alloc(d, &d->dSegStarts, (size_t)nLists * nSegs)) return rc;
     if (int rc = dev_alloc(d, &d->dTriples, (size_t)nLists * outTriplesPerList * 3)) return rc;
+    if (geo->emit == CPECAN_EMIT_EXPECT)
+        if (int rc = dev_alloc(d, &d->dBring, (size_t)slots * geo->fbCells * S)) return rc;
     if (int rc = dev_alloc(d, &d->dQueue, 4)) return rc;
     HIP_TRY(hipMemset(d->dCounts, 0, sizeof(int32_t) * (size_t)nLists * geo->nRegions));
     HIP_TRY(hipMemset(d->dSegStarts, 0, sizeof(int32_t) * (size_t)nLists * (nSegs ? nSegs : 1)));
@@ -2362,6 +2393,7 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.mbuf = d->dM;
     a.totals = d->dTotals;
     a.groll = d->dGroll;
+    a.bring = d->dBring;
     a.outCounts = d->dCounts;
     a.segStarts = d->dSegStarts;
     a.triples = d->dTriples;
