@@ -1,0 +1,348 @@
+// cpk_packed.inl -- the packed kernel: 64/GW narrow-band regions per wave.
+// Part of the single HIP translation unit cpecan_kernels.hip (included there, in this order); not compiled on its own.
+
+// ------------------------------------------------------------------------------------------------
+// Packed kernel for narrow bands (realign-style work: diagonalExpansion 4-10, diagonals of 5-30 cells).
+// One wave per region leaves most lanes idle there and pays the per-diagonal bookkeeping for a handful of cells.
+// Here a wave runs G = 64 / GW regions at once: lane = (group g, cell c), every diagonal of a narrow region is one
+// group of at most GW cells, so there is no loop over groups and no in-place ordering problem.  Everything that is
+// wave-uniform in the sweep kernel (diagonal counter, table entries, neighbour shifts, row pointers, traceback
+// schedule) is per lane here, identical within a group.  The groups of a wave move in lock-step through the same
+// phases -- forward sweep of segment i, traceback of segment i, totals, emission -- each over its own diagonals; a
+// group that has nothing to do in a phase idles (regions are handed out sorted by size, so neighbours are alike).
+// Arithmetic: the sweep kernel's own cell functions (fwdCellsSym / bwdCellsSym), same order, bit-identical results.
+// Match emitter only; symbols are read from global memory (one byte per symbol).
+// ------------------------------------------------------------------------------------------------
+template <int GW>
+__device__ __forceinline__ float group_max_f32(float v) {
+#pragma unroll
+    for (int off = GW / 2; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// LDS of the packed kernel behind the shared tables, per group: rolling buffers | 64 table entries | two symbol
+// windows | candidate staging ring
+constexpr int kPackChunk = 64;                  // diagonals per staged chunk
+__host__ __device__ constexpr int pack_win_bytes(int gw) { return (kPackChunk + gw + 15) / 8 * 8; }  // a symbol window
+__host__ __device__ constexpr int pack_rows_bytes(int S, int gw) { return (8 * (2 * S + 1) * (gw + 1) + 15) / 16 * 16; }
+__host__ __device__ constexpr int pack_group_bytes(int S, int gw) {  // a multiple of 16: entries and candidates are 16-byte items
+    return pack_rows_bytes(S, gw) + 16 * kPackChunk + 2 * pack_win_bytes(gw) + 16 * 2 * gw;
+}
+
+template <int S, int GW>
+__global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+cpecan_pairhmm_packed(const KArgs a) {
+    constexpr int G = CPK_WAVE / GW;
+    constexpr int R = 2 * S + 1;
+    constexpr int kRowDoubles = R * (GW + 1);
+    constexpr int kWin = pack_win_bytes(GW);
+    constexpr int kStageP = 2 * GW;  // candidate staging slots per group (flushed GW at a time)
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    const int lane = threadIdx.x;
+    const int g = lane / GW, c = lane % GW;
+    const CpkModel &m = *a.model;
+
+    fill_cubics(lds);
+    const Cubic *lg = reinterpret_cast<const Cubic *>(lds);
+    double *wt = lds + kLdsCubics + 40;
+    fill_weights<S>(wt, m, a.kc, lane);
+    uint8_t *mine = reinterpret_cast<uint8_t *>(lds + kLdsCubics + 40 + kLdsWeights) + (size_t)g * pack_group_bytes(S, GW);
+    double *rows = reinterpret_cast<double *>(mine);                                   // rolling buffers
+    int4 *ebuf = reinterpret_cast<int4 *>(mine + pack_rows_bytes(S, GW));              // table entries of the chunk
+    uint8_t *xwin = mine + pack_rows_bytes(S, GW) + 16 * kPackChunk, *ywin = xwin + kWin;  // symbols of the chunk
+    Candidate *stage = reinterpret_cast<Candidate *>(ywin + kWin);                     // candidate ring
+    __syncthreads();
+
+    // the cell functions only need the tables; every position-dependent input is passed per call
+    Sweep<S, false> sw{a, a.kc, DiagCache{nullptr, 0, 0, lane, 0, 0, 0, 0}, nullptr, nullptr, rows, lds + kLdsCubics, wt, lg,
+                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, GW + 1, lane, lane * R, 0, CpkDiag{}, CpkDiag{}};
+    using SW = Sweep<S, false>;
+    const unsigned long long groupBits = (GW == 64 ? ~0ull : ((1ull << GW) - 1ull)) << (g * GW);
+    const unsigned long long belowMe = groupBits & ((1ull << lane) - 1ull);
+    const float logThr = (float)log(a.kc.threshold);
+    const double thr = a.kc.threshold;
+
+    for (;;) {
+        const unsigned int ticket = atomicAdd(a.queue, lane == 0 ? (unsigned)G : 0u);
+        const int tk = __builtin_amdgcn_readfirstlane((int)ticket);
+        if (tk >= a.regionCount) break;
+        const bool have = tk + g < a.regionCount;
+        const int r = a.regionBase + (have ? tk + g : tk);
+        const CpkRegion rg = a.regions[r];
+        const int N = have ? rg.lX + rg.lY : 0;
+        const int nSeg = (have && N > 0) ? rg.nSeg : 0;
+        const CpkDiag *table = a.diags + rg.diagOff;
+        const CpkSegment *segs = a.segs + rg.segOff;
+        const uint8_t *gx = a.symbols + rg.seqXOff, *gy = a.symbols + rg.seqYOff;  // padded: index p = base p-1, N at both ends
+        const size_t sub = (size_t)blockIdx.x * G + g;  // scratch sub-slot of this group
+        double *ring = a.ring + sub * (size_t)a.geo.ringCells * S;
+        Candidate *cand = a.cand + sub * (size_t)a.geo.fbCells;
+        double *cbuf = a.cbuf + sub * (size_t)a.geo.refreshCells, *mbuf = a.mbuf + sub * (size_t)a.geo.refreshCells;
+        double *totals = a.totals + sub * (size_t)a.geo.maxRefresh;
+        int32_t *out = a.triples + 3 * rg.outOff;
+        int count = 0;
+
+        for (int i = c; i < kRowDoubles; i += GW) rows[i] = NEG_INF;  // position 0 stays the -inf guard
+        auto fbuf1 = [&](int d) { return rows + R + (d & 1) * S; };
+        auto bM1 = [&](int d) { return rows + R + (d + 3) % 3; };
+        auto bG1 = [&](int d) { return rows + R + 2 + (d & 1) * (S - 1); };
+        auto ringAt = [&](const CpkDiag &e) { return ring + (size_t)e.ringOff * S; };
+        auto unpack = [](const int4 &t) { return CpkDiag{t.x, t.y, t.z, t.w}; };
+        // Stages the table entries of `cnt` (<= 64) diagonals first, first + step, ... into ebuf and the X / Y symbols
+        // their cells use (shifted by `shift`: the backward step reads the symbols of (x+1, y+1)) into the two windows.
+        // One global round trip per 64 diagonals instead of three per diagonal.
+        auto stage_chunk = [&](bool on, int first, int step, int cnt, int shift, int &x0, int &y0) {
+            for (int i = c; i < kPackChunk; i += GW) {
+                int dd = first + step * (i < cnt ? i : (cnt > 0 ? cnt - 1 : 0));
+                dd = dd < 0 ? 0 : (dd > N ? N : dd);
+                ebuf[i] = on ? *reinterpret_cast<const int4 *>(table + dd) : int4{0, 1, 0, 0};
+            }
+            // both ends of the chunk bound the coordinates in between (x and y never decrease with the diagonal)
+            const int dA = step > 0 ? first : first - (cnt - 1), dB = step > 0 ? first + (cnt - 1) : first;
+            const CpkDiag eA = unpack(ebuf[step > 0 ? 0 : (cnt > 0 ? cnt - 1 : 0)]);
+            const CpkDiag eB = unpack(ebuf[step > 0 ? (cnt > 0 ? cnt - 1 : 0) : 0]);
+            const int xloA = (dA + eA.xmyL) >> 1, xloB = (dB + eB.xmyL) >> 1;
+            x0 = xloA + shift;
+            y0 = dA - (xloA + eA.width - 1) + shift;
+            const int x1 = xloB + eB.width - 1 + shift, y1 = dB - xloB + shift;
+            for (int i = c; i < kWin; i += GW) {
+                const int px = x0 + i, py = y0 + i;
+                xwin[i] = (on && cnt > 0 && px <= x1 && px <= rg.lX + 1) ? gx[px] : (uint8_t)CPK_SYM_N;
+                ywin[i] = (on && cnt > 0 && py <= y1 && py <= rg.lY + 1) ? gy[py] : (uint8_t)CPK_SYM_N;
+            }
+        };
+
+        CpkDiag e1{}, e2{};  // entries of d-1 and d-2 of the forward sweep
+        if (nSeg > 0) {
+            const int4 t0 = *reinterpret_cast<const int4 *>(table);
+            e1 = e2 = unpack(t0);
+            const double *startPrior = rg.raggedLeft ? m.raggedStart : m.start;
+            if (c < S) {  // diagonal 0: the single cell (0,0) holds the start prior (pairwiseAligner.c:776-777)
+                fbuf1(0)[c] = startPrior[c];
+                ringAt(e1)[c] = startPrior[c];
+            }
+        }
+        int d = 1;
+        const int maxSeg = wave_max_i32(nSeg);
+        for (int si = 0; si < maxSeg; si++) {
+            const bool segOn = si < nSeg;
+            CpkSegment sg{};
+            if (segOn) sg = segs[si];
+            // ---------------- forward sweep up to dTop (pairwiseAligner.c:609-629) ----------------
+            while (__ballot(segOn && d <= sg.dTop)) {
+                const bool more = segOn && d <= sg.dTop;
+                const int cnt = more ? (sg.dTop - d + 1 < kPackChunk ? sg.dTop - d + 1 : kPackChunk) : 0;
+                int x0, y0;
+                stage_chunk(more, d, 1, cnt, 0, x0, y0);
+                for (int i = 0; i < kPackChunk; i++) {
+                    if (!__ballot(i < cnt)) break;
+                    const bool act = i < cnt;
+                    const CpkDiag e = act ? unpack(ebuf[i]) : e1;
+                    const int W = e.width;
+                    const bool on = act && c < W;
+                    typename SW::FwdCtx fc;
+                    fc.d = d;
+                    fc.xlo = (d + e.xmyL) >> 1;
+                    fc.dlR = ((e.xmyL - 1 - e1.xmyL) >> 1) * R;
+                    fc.w1R = e1.width * R;
+                    fc.dmR = ((e.xmyL - e2.xmyL) >> 1) * R;
+                    fc.w2R = d >= 2 ? e2.width * R : 0;
+                    fc.p1 = fbuf1(d - 1);
+                    fc.p2 = fbuf1(d - 2);
+                    const int x = fc.xlo + c, y = d - x;
+                    const int cX[1] = {on ? xwin[x - x0] : CPK_SYM_N}, cY[1] = {on ? ywin[y - y0] : CPK_SYM_N};
+                    const int kR[1] = {c * R};
+                    double v[1][S];
+                    sw.template fwdCellsSym<1>(fc, cX, cY, kR, v);
+                    if (on) {
+                        double *cur = fbuf1(d);
+                        double *o = ringAt(e);
+#pragma unroll
+                        for (int s = 0; s < S; s++) cur[s + c * R] = v[0][s];
+#pragma unroll
+                        for (int s = 0; s < S; s++) o[SW::ringIdx(W, s, c)] = v[0][s];
+                    }
+                    if (act) {
+                        e2 = e1;
+                        e1 = e;
+                        d++;
+                    }
+                }
+            }
+            // ---------------- traceback of the segment (pairwiseAligner.c:796-862) ----------------
+            const double *endPrior = (segOn && sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
+            double ep[S];
+#pragma unroll
+            for (int s = 0; s < S; s++) ep[s] = endPrior[s];
+            const int J = sg.nRefresh;
+            int nCand = 0, pend = 0, head = 0;  // candidates in HBM; staged in LDS; ring position of the oldest staged
+            auto flush = [&](int n) {           // the n <= GW oldest staged candidates of this group -> cand[nCand ..]
+                if (c < n) cand[nCand + c] = stage[(head + c) & (kStageP - 1)];
+                head = (head + n) & (kStageP - 1);
+                pend -= n;
+                nCand += n;
+            };
+            float lastMax = -__builtin_huge_valf();
+            int d2 = segOn ? sg.dTop : 0;
+            CpkDiag eb{}, ea{};  // entries of d2+1, d2+2
+            while (__ballot(segOn && d2 > sg.tbPrev)) {
+                const bool more = segOn && d2 > sg.tbPrev;
+                const int cnt = more ? (d2 - sg.tbPrev < kPackChunk ? d2 - sg.tbPrev : kPackChunk) : 0;
+                int x0, y0;
+                stage_chunk(more, d2, -1, cnt, 1, x0, y0);
+                // F.match of the chunk's first diagonal; inside the loop the next diagonal's is requested one step ahead
+                double fNext = 0.0;
+                {
+                    const CpkDiag e = unpack(ebuf[0]);
+                    if (cnt > 0 && c < e.width) fNext = ld_self(ringAt(e) + SW::ringIdx(e.width, 0, c));
+                }
+                for (int i = 0; i < kPackChunk; i++) {
+                    if (!__ballot(i < cnt)) break;
+                    const bool act = i < cnt;
+                    const CpkDiag e = act ? unpack(ebuf[i]) : CpkDiag{0, 1, 0, 0};
+                    const int W = e.width;
+                    const bool on = act && c < W;
+                    asm volatile("" : "+v"(fNext));  // the wait for the prefetched value sits here, a whole step after its load
+                    const double f0 = fNext;
+                    if (i + 1 < kPackChunk) {
+                        const CpkDiag en = unpack(ebuf[i + 1]);
+                        fNext = (i + 1 < cnt && c < en.width) ? ld_self(ringAt(en) + SW::ringIdx(en.width, 0, c)) : 0.0;
+                    }
+                    const bool seeded = d2 == sg.dTop;
+                    const bool emit = act && d2 <= sg.tbFrom;
+                    const int sinceFrom = sg.tbFrom - d2;
+                    const bool refresh = emit && sinceFrom % CPK_REFRESH_PERIOD == 0;
+                    const int jr = sinceFrom / CPK_REFRESH_PERIOD;
+                    // the fb values of the diagonal above a refresh point are its straddle series (see Sweep::traceback)
+                    const bool feeds = act && d2 - 1 > sg.tbPrev && d2 - 1 <= sg.tbFrom &&
+                                       (sg.tbFrom - (d2 - 1)) % CPK_REFRESH_PERIOD == 0;
+                    const int jrNext = (sg.tbFrom - (d2 - 1)) / CPK_REFRESH_PERIOD;
+                    const double *fsrc = ringAt(e);
+                    typename SW::BwdCtx bc;
+                    bc.d2 = d2;
+                    bc.xlo = (d2 + e.xmyL) >> 1;
+                    bc.dbR = ((e.xmyL - 1 - eb.xmyL) >> 1) * R;
+                    bc.wBR = seeded ? 0 : eb.width * R;
+                    bc.daR = ((e.xmyL - ea.xmyL) >> 1) * R;
+                    bc.wAR = (!seeded && d2 + 2 <= sg.dTop) ? ea.width * R : 0;
+                    bc.pb = bG1(d2 + 1);
+                    bc.pa = bM1(d2 + 2);
+                    const int x = bc.xlo + c, y = d2 - x;
+                    // symbols of the source cells (x+1, .) and (., y+1): the windows are staged one to the right
+                    const int cX1[1] = {on ? xwin[x + 1 - x0] : CPK_SYM_N}, cY1[1] = {on ? ywin[y + 1 - y0] : CPK_SYM_N};
+                    const int kR[1] = {c * R};
+                    double v[1][S];
+                    sw.template bwdCellsSym<1>(bc, cX1, cY1, kR, v);
+                    if (seeded) {  // every cell of the top diagonal gets the end-state prior (:798-799)
+#pragma unroll
+                        for (int s = 0; s < S; s++) v[0][s] = ep[s];
+                    }
+                    if (on) {
+                        bM1(d2)[c * R] = v[0][0];
+                        double *curG = bG1(d2);
+#pragma unroll
+                        for (int s = 1; s < S; s++) curG[s + c * R] = v[0][s];
+                    }
+                    const double fbv = f0 + v[0][0];
+                    if (feeds && on) mbuf[(size_t)c * J + jrNext] = fbv;
+                    {
+                        const float keepFrom = lastMax + logThr - kCandMargin;
+                        const bool keep = on && emit && x > 0 && y > 0 && (float)fbv >= keepFrom;
+                        const unsigned long long mask = __ballot(keep);
+                        if (keep) {
+                            Candidate cd;
+                            cd.fb = fbv;
+                            cd.x = x;
+                            cd.y = y;
+                            stage[(head + pend + __popcll(mask & belowMe)) & (kStageP - 1)] = cd;
+                        }
+                        pend += __popcll(mask & groupBits);
+                        if (__ballot(pend >= GW)) {
+                            if (pend >= GW) flush(GW);
+                        }
+                    }
+                    if (__ballot(refresh)) {
+                        // cell dot product over the states (cell_dotProduct :402-408): this lane holds its cell's B values
+                        double t = fbv;
+                        float fbf = -__builtin_huge_valf();
+                        if (refresh && on) {
+#pragma unroll
+                            for (int s2 = 1; s2 < S; s2++)
+                                t = logadd(lg, t, ld_self(fsrc + SW::ringIdx(W, s2, c)) + v[0][s2]);
+                            cbuf[(size_t)c * J + jr] = t;
+                            if (x > 0 && y > 0) fbf = (float)fbv;
+                        }
+                        const float diagMax = group_max_f32<GW>(fbf);
+                        if (refresh) lastMax = fmaxf(diagMax, lastMax - 1.0f);
+                    }
+                    if (act) {
+                        ea = eb;
+                        eb = e;
+                        d2--;
+                    }
+                }
+            }
+            if (__ballot(pend > 0)) flush(pend);
+            roll_fence<true>();  // candidate / cbuf / mbuf stores of the group's lanes are visible to each other
+            // ---------------- totals at the refresh points (:636-653): lane c takes points c, c + GW, ... ----------------
+            for (int j0 = 0; __ballot(segOn && j0 + c < J); j0 += GW) {
+                const int j = j0 + c;
+                if (segOn && j < J) {
+                    const int rr = sg.tbFrom - CPK_REFRESH_PERIOD * j;
+                    const int Wc = table[rr].width;
+                    const int Wm = rr + 1 <= sg.dTop ? table[rr + 1].width : 0;
+                    double total = NEG_INF, straddle = NEG_INF;
+                    for (int k = 0; k < Wc; k++) total = logadd(lg, total, ld_self(cbuf + (size_t)k * J + j));
+                    for (int k = 0; k < Wm; k++) straddle = logadd(lg, straddle, ld_self(mbuf + (size_t)k * J + j));
+                    if (rr + 1 <= sg.dTop) total = logadd(lg, total, straddle);
+                    totals[j] = total;
+                }
+            }
+            roll_fence<true>();
+            // ---------------- thresholded posteriors from the candidates, walked backwards (:655-689) ----------------
+            if (segOn && c == 0) a.segStarts[rg.segOff + si] = count;
+            for (int top = nCand; __ballot(segOn && top > 0); top -= GW) {
+                const int i = top - 1 - c;
+                const bool valid = segOn && top > 0 && i >= 0;
+                double p = 0.0;
+                int x = 0, y = 0;
+                if (valid) {
+                    const double fbv = ld_self(&cand[i].fb);
+                    const long long xy = __hip_atomic_load(reinterpret_cast<const long long *>(&cand[i].x), __ATOMIC_RELAXED,
+                                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
+                    x = (int)(xy & 0xffffffffll);
+                    y = (int)(xy >> 32);
+                    const double total = ld_self(totals + (sg.tbFrom - (x + y)) / CPK_REFRESH_PERIOD);
+                    p = exp(fbv - total);
+                }
+                const bool keep = valid && p >= thr;
+                const unsigned long long mask = __ballot(keep);
+                if (keep) {
+                    if (p > 1.0) p = 1.0;
+                    const int pos = count + __popcll(mask & belowMe);
+                    if (pos < rg.outCap) {
+                        out[3 * (size_t)pos + 0] = (int32_t)floor(p * (double)CPECAN_PROB_1);
+                        out[3 * (size_t)pos + 1] = x - 1;
+                        out[3 * (size_t)pos + 2] = y - 1;
+                    }
+                }
+                count += __popcll(mask & groupBits);
+            }
+            // ---------------- the traceback used the rolling buffers: restore F[dTop-1], F[dTop] ----------------
+            if (segOn && !sg.atEnd) {
+#pragma unroll
+                for (int back = 1; back >= 0; back--) {
+                    const int dd = sg.dTop - back;
+                    const CpkDiag e = back ? e2 : e1;
+                    if (c < e.width) {
+                        const double *src = ringAt(e);
+                        double *cur = fbuf1(dd);
+#pragma unroll
+                        for (int s = 0; s < S; s++) cur[s + c * R] = ld_self(src + SW::ringIdx(e.width, s, c));
+                    }
+                }
+            }
+        }
+        if (have && c == 0) a.outCounts[r] = count;
+    }
+}

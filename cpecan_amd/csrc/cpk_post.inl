@@ -1,0 +1,188 @@
+// cpk_post.inl -- consumers of the posterior lists: reweighting, posterior scores, MEA chain, left shift.
+// Part of the single HIP translation unit cpecan_kernels.hip (included there, in this order); not compiled on its own.
+
+// ------------------------------------------------------------------------------------------------
+// Consumers of the posterior lists.  Integer / order-defined arithmetic: bit-exact.
+// ------------------------------------------------------------------------------------------------
+constexpr int kPostReweight = 1, kPostMea = 2, kPostLeftShift = 4;  // == CPECAN_POST_*
+
+// reweightAlignedPairs2 (impl/pairwiseAligner.c:1519-1558) + scoreByPosteriorProbability[IgnoringGaps] (:1578-1597).
+// One workgroup per problem.  mass[] = PROB_1 minus the listed mass of every base of X then Y, floored at 0 when read
+// (:1529-1533); a pair keeps  score - gapGamma * (massX + massY), evaluated in double and truncated towards zero (:1543).
+__global__ void __launch_bounds__(256) cpecan_post_reweight(const CpkPostProblem *problems, int32_t *triples, int32_t *mass,
+                                                            double gapGamma, int reweight, double *scores) {
+    const CpkPostProblem pb = problems[blockIdx.x];
+    int32_t *t = triples + 3 * pb.off[0];
+    const int n = pb.n[0];
+    __shared__ long long partial[256];
+    long long sum = 0;  // exact: |score| <= 1e7 * (1 + 2 gapGamma), n < 2^31
+    if (reweight && gapGamma > 0.0) {  // :1551
+        int32_t *mx = mass + pb.seqOff, *my = mx + pb.lX;
+        for (int i = threadIdx.x; i < pb.lX + pb.lY; i += blockDim.x) mx[i] = CPECAN_PROB_1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            atomicSub(&mx[t[3 * i + 1]], t[3 * i]);
+            atomicSub(&my[t[3 * i + 2]], t[3 * i]);
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const long long ux = mx[t[3 * i + 1]], uy = my[t[3 * i + 2]];
+            const long long unaligned = (ux < 0 ? 0 : ux) + (uy < 0 ? 0 : uy);
+            const long long w = (long long)((double)(long long)t[3 * i] - gapGamma * (double)unaligned);
+            t[3 * i] = (int32_t)w;
+            sum += w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) sum += t[3 * i];
+    }
+    partial[threadIdx.x] = sum;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) partial[threadIdx.x] += partial[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double total = (double)partial[0];  // the reference adds int64 scores into a double: exact below 2^53
+        const long long L = (long long)pb.lX + pb.lY;
+        scores[3 * blockIdx.x + 0] = 100.0 * (L == 0 ? 0 : (2.0 * total) / (double)(L * CPECAN_PROB_1));
+        scores[3 * blockIdx.x + 1] = 100.0 * total / ((double)n * CPECAN_PROB_1);
+    }
+}
+
+// getIndelProb (:1621-1625): gap mass of `length` bases starting at `start`
+__device__ __forceinline__ long long gap_mass(const long long *cum, long long start, long long length) {
+    return length == 0 ? 0 : cum[start + length - 1] - (start > 0 ? cum[start - 1] : 0);
+}
+
+// getMaximalExpectedAccuracyPairwiseAlignment (:1628-1724), one LANE per problem: the chain DP walks the pairs in
+// list order with a data-dependent walk back.  gapGamma is the float of PairwiseAlignmentParameters, so
+// `int64 * gapGamma` and `int64 + that` are float arithmetic, `int64 + double + float` is double truncated to int64.
+__global__ void __launch_bounds__(64) cpecan_post_mea(const CpkPostProblem *problems, int64_t nProblems,
+                                                      const int32_t *triples, long long *cum, double *best, int32_t *prev,
+                                                      uint8_t *record, float gapGamma, int32_t *meaOut, int32_t *counts,
+                                                      double *scores) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nProblems) return;
+    const CpkPostProblem pb = problems[p];
+    const int32_t *pairs = triples + 3 * pb.off[0], *gx = triples + 3 * pb.off[1], *gy = triples + 3 * pb.off[2];
+    const int n = pb.n[0];
+    const long long lX = pb.lX, lY = pb.lY;
+    long long *cx = cum + pb.seqOff, *cy = cx + pb.lX;  // getCumulativeGapProbs (:1603-1619)
+    for (long long i = 0; i < lX + lY; i++) cx[i] = 0;
+    for (int i = 0; i < pb.n[1]; i++) cx[gx[3 * i + 1]] += gx[3 * i];
+    for (int i = 0; i < pb.n[2]; i++) cy[gy[3 * i + 2]] += gy[3 * i];
+    for (long long i = 1; i < lX; i++) cx[i] += cx[i - 1];
+    for (long long i = 1; i < lY; i++) cy[i] += cy[i - 1];
+    double *bs = best + pb.chainOff;
+    int32_t *pv = prev + pb.chainOff;
+    uint8_t *rec = record + pb.chainOff;
+    double top = 0;
+    for (int i = 0; i <= n; i++) {
+        long long w, x, y;
+        if (i == n) {  // sentinel behind both sequences (:1652-1654)
+            w = 0;
+            x = lX;
+            y = lY;
+        } else {
+            w = pairs[3 * i];
+            x = pairs[3 * i + 1];
+            y = pairs[3 * i + 2];
+        }
+        double score = (double)((float)w + (float)(gap_mass(cx, 0, x) + gap_mass(cy, 0, y)) * gapGamma);  // :1660-1661
+        int from = -1;
+        for (int j = i - 1; j >= 0; j--) {
+            const long long x2 = pairs[3 * j + 1], y2 = pairs[3 * j + 2];
+            if (x2 < x && y2 < y) {
+                const float g = (float)(gap_mass(cx, x2 + 1, x - x2 - 1) + gap_mass(cy, y2 + 1, y - y2 - 1)) * gapGamma;
+                const long long sc = (long long)(((double)w + bs[j]) + (double)g);  // :1673-1675
+                if ((double)sc > score) {
+                    score = (double)sc;
+                    from = j;
+                }
+                if (rec[j]) break;  // :1685
+            }
+        }
+        pv[i] = from;
+        bs[i] = score;
+        const float tail = (float)((x < lX ? gap_mass(cx, x + 1, lX - x - 1) : 0) + (y < lY ? gap_mass(cy, y + 1, lY - y - 1) : 0)) * gapGamma;
+        const double sc = score + (double)tail;  // :1695-1696
+        rec[i] = 0;
+        if (sc >= top) {
+            top = sc;
+            rec[i] = 1;
+        }
+    }
+    int count = 0;
+    for (int i = pv[n]; i >= 0; i = pv[i]) count++;
+    int32_t *out = meaOut + 3 * pb.meaOut;
+    int at = count;
+    for (int i = pv[n]; i >= 0; i = pv[i]) {  // back to front == built reversed, then flipped (:1714)
+        at--;
+        out[3 * at] = pairs[3 * i];
+        out[3 * at + 1] = pairs[3 * i + 1];
+        out[3 * at + 2] = pairs[3 * i + 2];
+    }
+    counts[2 * p] = count;
+    scores[3 * p + 2] = top;
+}
+
+// LEFT_SHIFT without MEA: list 0 is the chain to shift; put it where the MEA stage would have put its alignment.
+__global__ void __launch_bounds__(256) cpecan_post_copy_chain(const CpkPostProblem *problems, const int32_t *triples,
+                                                              int32_t *meaOut, int32_t *counts) {
+    const CpkPostProblem pb = problems[blockIdx.x];
+    const int32_t *src = triples + 3 * pb.off[0];
+    int32_t *dst = meaOut + 3 * pb.meaOut;
+    for (int i = threadIdx.x; i < 3 * pb.n[0]; i += blockDim.x) dst[i] = src[i];
+    if (threadIdx.x == 0) counts[2 * blockIdx.x] = pb.n[0];
+}
+
+// leftShiftAlignment (:1726-1762), one lane per problem, on the MEA alignment.  chars: raw upper-case sequences.
+__global__ void __launch_bounds__(64) cpecan_post_left_shift(const CpkPostProblem *problems, int64_t nProblems,
+                                                             const int32_t *mea, const uint8_t *chars, int32_t *shiftOut,
+                                                             int32_t *counts) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nProblems) return;
+    const CpkPostProblem pb = problems[p];
+    const int32_t *pairs = mea + 3 * pb.meaOut;
+    const int n = counts[2 * p];
+    const uint8_t *sX = chars + pb.charX, *sY = chars + pb.charY;
+    int32_t *out = shiftOut + 3 * pb.shiftOut;
+    int count = 0;
+    int x = pb.lX, y = pb.lY;
+    for (int i = n - 1; i >= 0; i--) {
+        const int w = pairs[3 * i], x2 = pairs[3 * i + 1], y2 = pairs[3 * i + 2];
+        while ((x - x2 > 1 || y - y2 > 1) && sX[x - 1] == sY[y - 1]) {  // :1737-1744
+            out[3 * count] = w;
+            out[3 * count + 1] = x - 1;
+            out[3 * count + 2] = y - 1;
+            count++;
+            x--;
+            y--;
+            if (x2 == x || y2 == y) break;
+        }
+        if (x2 < x && y2 < y) {
+            out[3 * count] = w;
+            out[3 * count + 1] = x2;
+            out[3 * count + 2] = y2;
+            count++;
+            x = x2;
+            y = y2;
+        }
+    }
+    const int first = n > 0 ? pairs[0] : 1;  // :1754
+    while (x > 0 && y > 0 && sX[x - 1] == sY[y - 1]) {
+        out[3 * count] = first;
+        out[3 * count + 1] = x - 1;
+        out[3 * count + 2] = y - 1;
+        count++;
+        x--;
+        y--;
+    }
+    for (int a = 0, b = count - 1; a < b; a++, b--)  // :1759
+        for (int f = 0; f < 3; f++) {
+            const int32_t t = out[3 * a + f];
+            out[3 * a + f] = out[3 * b + f];
+            out[3 * b + f] = t;
+        }
+    counts[2 * p + 1] = count;
+}

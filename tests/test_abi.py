@@ -221,7 +221,7 @@ def test_product_never_touches_the_oracle():
     pkg = os.path.join(ROOT, "cpecan_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
-            if f.endswith((".py", ".c", ".h", ".hip", "Makefile")):
+            if f.endswith((".py", ".c", ".h", ".hip", ".inl", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_binding" not in text and "liboracle" not in text and "cpecan_oracle" not in text, f
 
