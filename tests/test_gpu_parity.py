@@ -483,3 +483,13 @@ def test_packed_and_sweep_kernels_agree_bit_for_bit(monkeypatch):
         assert st_p.cells == st_s.cells
         for a, b in zip(packed, sweep):
             assert a.shape == b.shape and (a == b).all()
+
+
+def test_packed_kernel_degenerate_regions(force_packed):
+    """One-base and one-sided problems, anchors on the very first / last base, through the packed kernel."""
+    probs = [("A", "A", []), ("A", "ACGT", []), ("ACGTAC", "", []), ("", "GGT", []), ("ACGT", "ACGT", [(0, 0, 2), (3, 3, 2)]),
+             ("ACGTACGTAC", "ACGTTACGTAC", [(0, 0, 4)]), ("N", "N", []), ("acgtn", "ACGTN", [(2, 2, 0)])]
+    raggeds = [(False, False), (True, False), (False, True), (True, True)] * 2
+    for mtype in (0, 2):
+        _check_batch(mtype, probs, raggeds, diagonalExpansion=4)
+        _check_batch(mtype, probs, raggeds, diagonalExpansion=0, threshold=0.0)
