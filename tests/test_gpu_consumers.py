@@ -122,3 +122,47 @@ def test_consumer_argument_errors():
             b.set_post(api.POST_LEFT_SHIFT, 0.5)
     with pytest.raises(api.CpecanError):
         api.reweightAlignedPairs2([(5, 3, 0)], 2, 2, 0.5)  # x outside the sequence
+
+
+def test_realign_flow_end_to_end():
+    """The cPecanRealign loop (cPecanRealign.c:509-553) as one batch: anchors from an existing alignment's operations
+    with the exact-match filter, posteriors with expansion 4 / split at 10 / ragged ends, reweighting on the device --
+    against the same steps through the oracle."""
+    rng = random.Random(17)
+    p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=4, splitMatrixBiggerThanThis=10)
+    op = ob.params(diagonalExpansion=4, splitMatrixBiggerThanThis=10)
+    gamma = float(np.float32(0.2))
+    cases = []
+    for _ in range(30):
+        # a "true" alignment as a list of operations, and two sequences that follow it with some substitutions
+        ops, sx, sy = [], [], []
+        for _ in range(rng.randrange(3, 25)):
+            kind = rng.choice([api.OP_MATCH] * 4 + [api.OP_INDEL_X, api.OP_INDEL_Y])
+            n = rng.randrange(1, 30) if kind == api.OP_MATCH else rng.randrange(1, 4)
+            ops.append((kind, n))
+            for _ in range(n):
+                b = rng.choice("ACGT")
+                if kind != api.OP_INDEL_Y:
+                    sx.append(b)
+                if kind != api.OP_INDEL_X:
+                    sy.append(b if kind != api.OP_MATCH or rng.random() > 0.1 else rng.choice("ACGTN"))
+        sx, sy = "".join(sx), "".join(sy)
+        if not sx or not sy:
+            continue
+        anchors = api.convertPairwiseForwardStrandAlignmentToAnchorPairs(ops, 0, 0, 0, 4, sx, sy)
+        assert all(sx[x].upper() == sy[y].upper() != "N" for x, y, _ in anchors.tolist())
+        cases.append((sx, sy, [tuple(a) for a in anchors.tolist()]))
+    with api.Batch(_sm(0), p) as b:
+        b.set_post(api.POST_REWEIGHT, gamma)
+        for sx, sy, a in cases:
+            b.add(sx, sy, a, True, True)
+        b.upload()
+        b.run()
+        b.download()
+        for i, (sx, sy, a) in enumerate(cases):
+            want = ob.aligned_pairs(ob.model(0), sx, sy, a, op, True, True)
+            got = b.result(i)
+            assert got[:, 1:].tolist() == want[:, 1:].tolist()
+            # scores may differ by one unit before reweighting (device exp vs libm): reweight what the GPU produced
+            plain = api.getAlignedPairsUsingAnchors(_sm(0), sx, sy, a, p, True, True)
+            assert (got.astype(np.int64) == ob.reweight_aligned_pairs(plain, len(sx), len(sy), gamma)).all()
