@@ -493,3 +493,13 @@ def test_packed_kernel_degenerate_regions(force_packed):
     for mtype in (0, 2):
         _check_batch(mtype, probs, raggeds, diagonalExpansion=4)
         _check_batch(mtype, probs, raggeds, diagonalExpansion=0, threshold=0.0)
+
+
+def test_packed_kernel_output_overflow_rerun(force_packed):
+    """threshold ~0 on 13-cell-wide bands emits more pairs than the default slices hold: exact re-run, packed kernel."""
+    problems = [make_pair(8, i, 200 + 30 * i, 12, anchor_every=3) for i in range(6)]
+    kw = dict(diagonalExpansion=12, threshold=1e-9)
+    got, st = _run_batch(0, problems, **kw)
+    assert st.launches >= 2
+    for (sx, sy, a), g in zip(problems, got):
+        assert_pairs_match(g, ob.aligned_pairs(ob.model(0), sx, sy, a, ob.params(**kw)), threshold=1e-9)
