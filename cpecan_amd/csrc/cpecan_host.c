@@ -775,7 +775,10 @@ int cpecan_batch_upload(cpecan_batch *b) {
      * kernel; they come first in the device order.  Within each class: longest first (the work queues are LPT). */
     {
         const char *env = getenv("CPECAN_PACKED"); /* diagnostic: 0 = one wave per region for every region */
-        const int enabled = b->emit == CPECAN_EMIT_MATCH && !b->debug && !(env && atoi(env) == 0);
+        /* the packed kernel stages symbol windows assuming a band whose bounds never move backwards: true for a fixed
+         * expansion, not for per-anchor expansions */
+        const int enabled = (b->emit == CPECAN_EMIT_MATCH || b->emit == CPECAN_EMIT_EXPECT) && !b->debug && !dynamic &&
+                            !(env && atoi(env) == 0);
         const int64_t minCount = (env && atoi(env) >= 2) ? 1 : 64; /* a launch is not worth fewer regions (2: always, for tests) */
         int64_t perClass[4] = {0, 0, 0, 0};
         for (int64_t i = 0; i < b->nRegions; i++) {

@@ -172,13 +172,16 @@ static int dev_alloc(CpkDevice *d, T **p, size_t count) {
 using KernelFn = void (*)(const KArgs);
 
 static KernelFn pick_packed_kernel(const CpkGeometry &g, int cls) {  // class k: groups of 8 << k lanes
-    if (g.emit != CPECAN_EMIT_MATCH) return nullptr;
     const bool five = g.nStates == 5;
-    switch (cls) {
-        case 0: return five ? cpecan_pairhmm_packed<5, 8> : cpecan_pairhmm_packed<3, 8>;
-        case 1: return five ? cpecan_pairhmm_packed<5, 16> : cpecan_pairhmm_packed<3, 16>;
-        case 2: return five ? cpecan_pairhmm_packed<5, 32> : cpecan_pairhmm_packed<3, 32>;
-    }
+#define CPK_PICK_PACKED(E)                                                                                         \
+    if (g.emit == (E)) switch (cls) {                                                                              \
+            case 0: return five ? cpecan_pairhmm_packed<5, 8, (E)> : cpecan_pairhmm_packed<3, 8, (E)>;             \
+            case 1: return five ? cpecan_pairhmm_packed<5, 16, (E)> : cpecan_pairhmm_packed<3, 16, (E)>;           \
+            case 2: return five ? cpecan_pairhmm_packed<5, 32, (E)> : cpecan_pairhmm_packed<3, 32, (E)>;           \
+        }
+    CPK_PICK_PACKED(CPECAN_EMIT_MATCH)
+    CPK_PICK_PACKED(CPECAN_EMIT_EXPECT)
+#undef CPK_PICK_PACKED
     return nullptr;
 }
 
@@ -277,7 +280,8 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             return CPECAN_EINVAL;
         }
         const int GW = 8 << k, G = CPK_WAVE / GW;
-        d->pLdsBytes[k] = sizeof(double) * (size_t)(kLdsCubics + 40 + kLdsWeights) + (size_t)G * pack_group_bytes(S, GW);
+        d->pLdsBytes[k] = sizeof(double) * (size_t)(kLdsCubics + 40 + kLdsWeights + (geo->emit == CPECAN_EMIT_EXPECT ? kExpectCopies * 80 : 0)) +
+                          (size_t)G * pack_group_bytes(S, GW);
         hipFuncAttributes pattr;
         HIP_TRY(hipFuncGetAttributes(&pattr, (const void *)pfn));
         const int pv = ((pattr.numRegs > 0 ? pattr.numRegs : 128) + 7) / 8 * 8;
@@ -316,7 +320,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (int rc = dev_alloc(d, &d->dRing, scratch(geo->ringCells * S, pRing))) return rc;
     if (int rc = dev_alloc(d, &d->dCand, scratch(geo->fbCells * (geo->emit == CPECAN_EMIT_INDEL ? 3 : 1), geo->pFbCells))) return rc;
     if (int rc = dev_alloc(d, &d->dForward, (size_t)geo->nRegions)) return rc;
-    if (int rc = dev_alloc(d, &d->dExpect, (size_t)slots * 128)) return rc;
+    if (int rc = dev_alloc(d, &d->dExpect, (size_t)(slots + d->pSlots[0] + d->pSlots[1] + d->pSlots[2]) * 128)) return rc;
     if (int rc = dev_alloc(d, &d->dC, scratch(geo->refreshCells, pRefresh))) return rc;
     if (int rc = dev_alloc(d, &d->dM, scratch(geo->refreshCells, pRefresh))) return rc;
     if (int rc = dev_alloc(d, &d->dTotals, scratch(geo->maxRefresh, pTotals))) return rc;
@@ -325,8 +329,10 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (int rc = dev_alloc(d, &d->dCounts, (size_t)nLists * geo->nRegions)) return rc;
     if (int rc = dev_alloc(d, &d->dSegStarts, (size_t)nLists * nSegs)) return rc;
     if (int rc = dev_alloc(d, &d->dTriples, (size_t)nLists * outTriplesPerList * 3)) return rc;
-    if (geo->emit == CPECAN_EMIT_EXPECT)
-        if (int rc = dev_alloc(d, &d->dBring, (size_t)slots * geo->fbCells * S)) return rc;
+    if (geo->emit == CPECAN_EMIT_EXPECT) {
+        const int64_t pB[3] = {geo->pFbCells[0] * S, geo->pFbCells[1] * S, geo->pFbCells[2] * S};
+        if (int rc = dev_alloc(d, &d->dBring, scratch(geo->fbCells * S, pB))) return rc;
+    }
     if (int rc = dev_alloc(d, &d->dQueue, 4)) return rc;
     HIP_TRY(hipMemset(d->dCounts, 0, sizeof(int32_t) * (size_t)nLists * geo->nRegions));
     HIP_TRY(hipMemset(d->dSegStarts, 0, sizeof(int32_t) * (size_t)nLists * (nSegs ? nSegs : 1)));
@@ -424,6 +430,10 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     int64_t oCand = nWideRun > 0 ? (int64_t)d->slots * d->geo.fbCells * (d->geo.emit == CPECAN_EMIT_INDEL ? 3 : 1) : 0;
     int64_t oRef = nWideRun > 0 ? (int64_t)d->slots * d->geo.refreshCells : 0;
     int64_t oTot = nWideRun > 0 ? (int64_t)d->slots * d->geo.maxRefresh : 0;
+    int64_t oBring = nWideRun > 0 ? (int64_t)d->slots * d->geo.fbCells * SS : 0;
+    int64_t oExpect = (int64_t)d->slots * 128;  // the sweep kernel's waves come first in the partial-sum array
+    if (d->geo.emit == CPECAN_EMIT_EXPECT)
+        HIP_TRY(hipMemsetAsync(d->dExpect, 0, sizeof(double) * 128 * (size_t)(d->slots + d->pSlots[0] + d->pSlots[1] + d->pSlots[2]), st));
     for (int k = 0; k < 3; k++) {  // narrow regions, class by class: several to a wave, on a stream of their own
         if (d->geo.nPacked[k] <= 0) continue;
         KArgs p = a;
@@ -438,6 +448,8 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
         p.cbuf = d->dC + oRef;
         p.mbuf = d->dM + oRef;
         p.totals = d->dTotals + oTot;
+        p.bring = d->dBring ? d->dBring + oBring : nullptr;
+        p.expectOut = d->dExpect + oExpect;
         p.queue = d->dQueue + 1 + k;
         HIP_TRY(hipStreamWaitEvent(d->sideStream[k], d->evStart, 0));
         hipLaunchKernelGGL(pick_packed_kernel(d->geo, k), dim3((unsigned)d->pSlots[k]), dim3(CPK_WAVE), d->pLdsBytes[k],
@@ -449,6 +461,8 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
         oCand += subs * p.geo.fbCells;
         oRef += subs * p.geo.refreshCells;
         oTot += subs * p.geo.maxRefresh;
+        oBring += subs * p.geo.fbCells * SS;
+        oExpect += (int64_t)d->pSlots[k] * 128;
         base += d->geo.nPacked[k];
     }
     a.regionBase = base;
@@ -492,10 +506,11 @@ extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segSt
         HIP_TRY(hipMemcpy(expect, d->dForward, sizeof(double) * (size_t)d->geo.nRegions, hipMemcpyDeviceToHost));
     if (expect && d->geo.emit == CPECAN_EMIT_EXPECT) {
         // sum the per-wave partials (every launched wave wrote its 106 values, zeros included)
-        std::vector<double> part((size_t)d->slots * 128);
+        const int nWaves = d->slots + d->pSlots[0] + d->pSlots[1] + d->pSlots[2];
+        std::vector<double> part((size_t)nWaves * 128);
         HIP_TRY(hipMemcpy(part.data(), d->dExpect, sizeof(double) * part.size(), hipMemcpyDeviceToHost));
         for (int i = 0; i < 106; i++) expect[i] = 0.0;
-        for (int w = 0; w < d->slots; w++)
+        for (int w = 0; w < nWaves; w++)
             for (int i = 0; i < 106; i++) expect[i] += part[(size_t)w * 128 + i];
     }
     return CPECAN_OK;

@@ -29,7 +29,7 @@ __host__ __device__ constexpr int pack_group_bytes(int S, int gw) {  // a multip
     return pack_rows_bytes(S, gw) + 16 * kPackChunk + 2 * pack_win_bytes(gw) + 16 * 2 * gw;
 }
 
-template <int S, int GW>
+template <int S, int GW, int EMIT>  // EMIT: CPECAN_EMIT_MATCH or CPECAN_EMIT_EXPECT
 __global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
 cpecan_pairhmm_packed(const KArgs a) {
     constexpr int G = CPK_WAVE / GW;
@@ -46,7 +46,21 @@ cpecan_pairhmm_packed(const KArgs a) {
     const Cubic *lg = reinterpret_cast<const Cubic *>(lds);
     double *wt = lds + kLdsCubics + 40;
     fill_weights<S>(wt, m, a.kc, lane);
-    uint8_t *mine = reinterpret_cast<uint8_t *>(lds + kLdsCubics + 40 + kLdsWeights) + (size_t)g * pack_group_bytes(S, GW);
+    constexpr bool kExpect = EMIT == CPECAN_EMIT_EXPECT;
+    double *em = lds + kLdsCubics;
+    if (kExpect) {  // raw emissions are only needed to tell N from ACGT: the events use the weight table
+        if (lane < 25) em[lane] = m.matchEm[lane];
+    }
+    double *eLds = lds + kLdsCubics + 40 + kLdsWeights;  // expectation emitter: emission sums of this wave, four copies
+    if (kExpect)
+        for (int i = lane; i < kExpectCopies * 80; i += CPK_WAVE) eLds[i] = 0.0;
+    constexpr int kNT = S == 5 ? 13 : 9;
+    double tAcc[kNT];  // transition sums of this lane, one per transition in list order
+#pragma unroll
+    for (int i = 0; i < kNT; i++) tAcc[i] = 0.0;
+    double likelihood = 0.0;
+    uint8_t *mine = reinterpret_cast<uint8_t *>(lds + kLdsCubics + 40 + kLdsWeights + (kExpect ? kExpectCopies * 80 : 0)) +
+                    (size_t)g * pack_group_bytes(S, GW);
     double *rows = reinterpret_cast<double *>(mine);                                   // rolling buffers
     int4 *ebuf = reinterpret_cast<int4 *>(mine + pack_rows_bytes(S, GW));              // table entries of the chunk
     uint8_t *xwin = mine + pack_rows_bytes(S, GW) + 16 * kPackChunk, *ywin = xwin + kWin;  // symbols of the chunk
@@ -79,6 +93,7 @@ cpecan_pairhmm_packed(const KArgs a) {
         Candidate *cand = a.cand + sub * (size_t)a.geo.fbCells;
         double *cbuf = a.cbuf + sub * (size_t)a.geo.refreshCells, *mbuf = a.mbuf + sub * (size_t)a.geo.refreshCells;
         double *totals = a.totals + sub * (size_t)a.geo.maxRefresh;
+        double *bring = kExpect ? a.bring + sub * (size_t)a.geo.fbCells * S : nullptr;  // B of the segment's emitted cells
         int32_t *out = a.triples + 3 * rg.outOff;
         int count = 0;
 
@@ -98,7 +113,9 @@ cpecan_pairhmm_packed(const KArgs a) {
                 ebuf[i] = on ? *reinterpret_cast<const int4 *>(table + dd) : int4{0, 1, 0, 0};
             }
             // both ends of the chunk bound the coordinates in between (x and y never decrease with the diagonal)
-            const int dA = step > 0 ? first : first - (cnt - 1), dB = step > 0 ? first + (cnt - 1) : first;
+            int dA = step > 0 ? first : first - (cnt - 1), dB = step > 0 ? first + (cnt - 1) : first;
+            dA = dA < 0 ? 0 : dA;  // the entries above are clamped the same way (look-ahead below diagonal 0)
+            dB = dB > N ? N : dB;
             const CpkDiag eA = unpack(ebuf[step > 0 ? 0 : (cnt > 0 ? cnt - 1 : 0)]);
             const CpkDiag eB = unpack(ebuf[step > 0 ? (cnt > 0 ? cnt - 1 : 0) : 0]);
             const int xloA = (dA + eA.xmyL) >> 1, xloB = (dB + eB.xmyL) >> 1;
@@ -107,8 +124,8 @@ cpecan_pairhmm_packed(const KArgs a) {
             const int x1 = xloB + eB.width - 1 + shift, y1 = dB - xloB + shift;
             for (int i = c; i < kWin; i += GW) {
                 const int px = x0 + i, py = y0 + i;
-                xwin[i] = (on && cnt > 0 && px <= x1 && px <= rg.lX + 1) ? gx[px] : (uint8_t)CPK_SYM_N;
-                ywin[i] = (on && cnt > 0 && py <= y1 && py <= rg.lY + 1) ? gy[py] : (uint8_t)CPK_SYM_N;
+                xwin[i] = (on && cnt > 0 && px >= 0 && px <= x1 && px <= rg.lX + 1) ? gx[px] : (uint8_t)CPK_SYM_N;
+                ywin[i] = (on && cnt > 0 && py >= 0 && py <= y1 && py <= rg.lY + 1) ? gy[py] : (uint8_t)CPK_SYM_N;
             }
         };
 
@@ -183,6 +200,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                 nCand += n;
             };
             float lastMax = -__builtin_huge_valf();
+            const int bBase = (kExpect && segOn) ? table[sg.tbPrev + 1].cellOff : 0;
             int d2 = segOn ? sg.dTop : 0;
             CpkDiag eb{}, ea{};  // entries of d2+1, d2+2
             while (__ballot(segOn && d2 > sg.tbPrev)) {
@@ -245,7 +263,12 @@ cpecan_pairhmm_packed(const KArgs a) {
                     }
                     const double fbv = f0 + v[0][0];
                     if (feeds && on) mbuf[(size_t)c * J + jrNext] = fbv;
-                    {
+                    if (kExpect && emit && on) {  // kept for the expectation step
+                        double *bo = bring + (size_t)(e.cellOff - bBase + c) * S;
+#pragma unroll
+                        for (int s = 0; s < S; s++) bo[s] = v[0][s];
+                    }
+                    if (!kExpect) {
                         const float keepFrom = lastMax + logThr - kCandMargin;
                         const bool keep = on && emit && x > 0 && y > 0 && (float)fbv >= keepFrom;
                         const unsigned long long mask = __ballot(keep);
@@ -270,7 +293,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                             for (int s2 = 1; s2 < S; s2++)
                                 t = logadd(lg, t, ld_self(fsrc + SW::ringIdx(W, s2, c)) + v[0][s2]);
                             cbuf[(size_t)c * J + jr] = t;
-                            if (x > 0 && y > 0) fbf = (float)fbv;
+                            if (!kExpect && x > 0 && y > 0) fbf = (float)fbv;
                         }
                         const float diagMax = group_max_f32<GW>(fbf);
                         if (refresh) lastMax = fmaxf(diagMax, lastMax - 1.0f);
@@ -282,7 +305,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                     }
                 }
             }
-            if (__ballot(pend > 0)) flush(pend);
+            if (!kExpect && __ballot(pend > 0)) flush(pend);
             roll_fence<true>();  // candidate / cbuf / mbuf stores of the group's lanes are visible to each other
             // ---------------- totals at the refresh points (:636-653): lane c takes points c, c + GW, ... ----------------
             for (int j0 = 0; __ballot(segOn && j0 + c < J); j0 += GW) {
@@ -299,34 +322,123 @@ cpecan_pairhmm_packed(const KArgs a) {
                 }
             }
             roll_fence<true>();
-            // ---------------- thresholded posteriors from the candidates, walked backwards (:655-689) ----------------
-            if (segOn && c == 0) a.segStarts[rg.segOff + si] = count;
-            for (int top = nCand; __ballot(segOn && top > 0); top -= GW) {
-                const int i = top - 1 - c;
-                const bool valid = segOn && top > 0 && i >= 0;
-                double p = 0.0;
-                int x = 0, y = 0;
-                if (valid) {
-                    const double fbv = ld_self(&cand[i].fb);
-                    const long long xy = __hip_atomic_load(reinterpret_cast<const long long *>(&cand[i].x), __ATOMIC_RELAXED,
-                                                           __HIP_MEMORY_SCOPE_WAVEFRONT);
-                    x = (int)(xy & 0xffffffffll);
-                    y = (int)(xy >> 32);
-                    const double total = ld_self(totals + (sg.tbFrom - (x + y)) / CPK_REFRESH_PERIOD);
-                    p = exp(fbv - total);
-                }
-                const bool keep = valid && p >= thr;
-                const unsigned long long mask = __ballot(keep);
-                if (keep) {
-                    if (p > 1.0) p = 1.0;
-                    const int pos = count + __popcll(mask & belowMe);
-                    if (pos < rg.outCap) {
-                        out[3 * (size_t)pos + 0] = (int32_t)floor(p * (double)CPECAN_PROB_1);
-                        out[3 * (size_t)pos + 1] = x - 1;
-                        out[3 * (size_t)pos + 2] = y - 1;
+            if (kExpect) {
+                // ---------------- expectation step (:735-746, :418-432), see Sweep::expectations ----------------
+                // Per emitted diagonal d2 and cell: p = exp(F_nbr[from] + B[to] + (eP + tP) - total) for every transition
+                // into the cell, neighbours from F[d2-1] / F[d2-2] (the latter is gone at d2 == tbPrev+1, :843-845).
+                int e2d = segOn ? sg.tbFrom : 0;
+                while (__ballot(segOn && e2d > sg.tbPrev)) {
+                    const bool more = segOn && e2d > sg.tbPrev;
+                    // 62 diagonals per chunk: the two entries below each diagonal are staged with it
+                    const int cnt = more ? (e2d - sg.tbPrev < kPackChunk - 2 ? e2d - sg.tbPrev : kPackChunk - 2) : 0;
+                    int x0, y0;
+                    stage_chunk(more, e2d, -1, more ? cnt + 2 : 0, 0, x0, y0);
+                    for (int i = 0; i < kPackChunk - 2; i++) {
+                        if (!__ballot(i < cnt)) break;
+                        const bool act = i < cnt;
+                        const CpkDiag e = act ? unpack(ebuf[i]) : CpkDiag{0, 1, 0, 0};
+                        const CpkDiag g1 = unpack(ebuf[i + 1]), g2 = unpack(ebuf[i + 2]);  // entries of d2-1, d2-2
+                        const int W = e.width;
+                        const bool on = act && c < W;
+                        const bool haveM2 = e2d - 2 >= sg.tbPrev;
+                        const int xlo = (e2d + e.xmyL) >> 1;
+                        const int dl = (e.xmyL - 1 - g1.xmyL) >> 1, dm = (e.xmyL - g2.xmyL) >> 1;
+                        const int w1 = g1.width, w2 = haveM2 ? g2.width : 0;
+                        const int kL = c + dl, kU = c + dl + 1, kM = c + dm;
+                        const bool okL = (unsigned)kL < (unsigned)w1, okU = (unsigned)kU < (unsigned)w1,
+                                   okM = (unsigned)kM < (unsigned)w2;
+                        const int qL = okL ? kL : 0, qU = okU ? kU : 0, qM = okM ? kM : 0;
+                        if (on) {
+                            const double total = ld_self(totals + (sg.tbFrom - e2d) / CPK_REFRESH_PERIOD);
+                            if (c == 0) likelihood += total;  // once per diagonal (:743)
+                            const double *f1 = ringAt(g1), *f2 = ringAt(g2);
+                            const double *bo = bring + (size_t)(e.cellOff - bBase + c) * S;
+                            double v[S], fL[S], fU[S], fM[S];
+#pragma unroll
+                            for (int s = 0; s < S; s++) {
+                                const bool needL = S == 3 || s == 0 || s == 1 || s == 3, needU = S == 3 || s == 0 || s == 2 || s == 4;
+                                v[s] = ld_self(bo + s);
+                                fL[s] = (needL && okL) ? ld_self(f1 + SW::ringIdx(w1, s, qL)) : NEG_INF;
+                                fU[s] = (needU && okU) ? ld_self(f1 + SW::ringIdx(w1, s, qU)) : NEG_INF;
+                                fM[s] = okM ? ld_self(f2 + SW::ringIdx(w2, s, qM)) : NEG_INF;
+                            }
+                            const int x = xlo + c, y = e2d - x;
+                            const int cX = xwin[x - x0], cY = ywin[y - y0];
+                            constexpr int kWM = SW::kWM, kWG = SW::kWG;
+                            const double *wM = wt + (cX * 5 + cY) * kWM, *wX = wt + 25 * kWM + cX * kWG,
+                                         *wY = wt + 25 * kWM + 5 * kWG + cY * kWG;
+                            double eAcc[S];
+#pragma unroll
+                            for (int s = 0; s < S; s++) eAcc[s] = 0.0;
+                            auto event = [&](int ti, double from, int to, double w) {
+                                const double p = exp_1e7(from + v[to] + w - total);
+                                tAcc[ti] += p;
+                                eAcc[to] += p;
+                            };
+                            if (S == 5) {
+                                event(0, fL[0], 1, wX[0]);
+                                event(1, fL[1], 1, wX[1]);
+                                event(2, fL[0], 3, wX[2]);
+                                event(3, fL[3], 3, wX[3]);
+                                event(4, fM[0], 0, wM[0]);
+                                event(5, fM[1], 0, wM[1]);
+                                event(6, fM[2], 0, wM[2]);
+                                event(7, fM[3], 0, wM[3]);
+                                event(8, fM[4], 0, wM[4]);
+                                event(9, fU[0], 2, wY[0]);
+                                event(10, fU[2], 2, wY[1]);
+                                event(11, fU[0], 4, wY[2]);
+                                event(12, fU[4], 4, wY[3]);
+                            } else {
+                                event(0, fL[0], 1, wX[0]);
+                                event(1, fL[1], 1, wX[1]);
+                                event(2, fL[2], 1, wX[2]);
+                                event(3, fM[0], 0, wM[0]);
+                                event(4, fM[1], 0, wM[1]);
+                                event(5, fM[2], 0, wM[2]);
+                                event(6, fU[0], 2, wY[0]);
+                                event(7, fU[2], 2, wY[1]);
+                                event(8, fU[1], 2, wY[2]);
+                            }
+                            if (cX < CPK_SYM_N && cY < CPK_SYM_N) {  // emissions are counted for ACGT x ACGT cells only (:429)
+                                double *copy = eLds + (lane & (kExpectCopies - 1)) * 80;
+#pragma unroll
+                                for (int s = 0; s < S; s++) atomicAdd(&copy[s * 16 + cX * 4 + cY], eAcc[s]);
+                            }
+                        }
+                        if (act) e2d--;
                     }
                 }
-                count += __popcll(mask & groupBits);
+            } else {
+            // ---------------- thresholded posteriors from the candidates, walked backwards (:655-689) ----------------
+                if (segOn && c == 0) a.segStarts[rg.segOff + si] = count;
+                for (int top = nCand; __ballot(segOn && top > 0); top -= GW) {
+                    const int i = top - 1 - c;
+                    const bool valid = segOn && top > 0 && i >= 0;
+                    double p = 0.0;
+                    int x = 0, y = 0;
+                    if (valid) {
+                        const double fbv = ld_self(&cand[i].fb);
+                        const long long xy = __hip_atomic_load(reinterpret_cast<const long long *>(&cand[i].x), __ATOMIC_RELAXED,
+                                                               __HIP_MEMORY_SCOPE_WAVEFRONT);
+                        x = (int)(xy & 0xffffffffll);
+                        y = (int)(xy >> 32);
+                        const double total = ld_self(totals + (sg.tbFrom - (x + y)) / CPK_REFRESH_PERIOD);
+                        p = exp(fbv - total);
+                    }
+                    const bool keep = valid && p >= thr;
+                    const unsigned long long mask = __ballot(keep);
+                    if (keep) {
+                        if (p > 1.0) p = 1.0;
+                        const int pos = count + __popcll(mask & belowMe);
+                        if (pos < rg.outCap) {
+                            out[3 * (size_t)pos + 0] = (int32_t)floor(p * (double)CPECAN_PROB_1);
+                            out[3 * (size_t)pos + 1] = x - 1;
+                            out[3 * (size_t)pos + 2] = y - 1;
+                        }
+                    }
+                    count += __popcll(mask & groupBits);
+                }
             }
             // ---------------- the traceback used the rolling buffers: restore F[dTop-1], F[dTop] ----------------
             if (segOn && !sg.atEnd) {
@@ -344,5 +456,31 @@ cpecan_pairhmm_packed(const KArgs a) {
             }
         }
         if (have && c == 0) a.outCounts[r] = count;
+    }
+    if (kExpect) {
+        // one partial result per wave, as in the sweep kernel: [0,25) transitions [from*S+to], [25,105) emissions, [105] likelihood
+        __syncthreads();
+        double *dst = a.expectOut + (size_t)blockIdx.x * 128;
+        constexpr int kFrom5[13] = {0, 1, 0, 3, 0, 1, 2, 3, 4, 0, 2, 0, 4}, kTo5[13] = {1, 1, 3, 3, 0, 0, 0, 0, 0, 2, 2, 4, 4};
+        constexpr int kFrom3[9] = {0, 1, 2, 0, 1, 2, 0, 2, 1}, kTo3[9] = {1, 1, 1, 0, 0, 0, 2, 2, 2};
+        for (int i = lane; i < 25; i += CPK_WAVE) dst[i] = 0.0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kNT; i++) {
+            double v = tAcc[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            const int idx = S == 5 ? kFrom5[i] * 5 + kTo5[i] : kFrom3[i] * 3 + kTo3[i];
+            if (lane == 0) dst[idx] = v;
+        }
+        for (int i = lane; i < 80; i += CPK_WAVE) {
+            double e = 0.0;
+            for (int k = 0; k < kExpectCopies; k++) e += eLds[k * 80 + i];
+            dst[25 + i] = e;
+        }
+        double lk = likelihood;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) lk += __shfl_xor(lk, off);
+        if (lane == 0) dst[105] = lk;
     }
 }

@@ -503,3 +503,27 @@ def test_packed_kernel_output_overflow_rerun(force_packed):
     assert st.launches >= 2
     for (sx, sy, a), g in zip(problems, got):
         assert_pairs_match(g, ob.aligned_pairs(ob.model(0), sx, sy, a, ob.params(**kw)), threshold=1e-9)
+
+
+@pytest.mark.parametrize("mtype", [0, 2])
+def test_packed_kernel_expectations(force_packed, mtype):
+    """The EM E-step as cPecanRealign runs it (--outputExpectations, cPecanRealign.c:530-534): dense anchors, expansion 4,
+    ragged ends, split at 10 -- narrow bands, so the packed kernel computes the expectations."""
+    from cpecan_amd.workload import make_realign_batch
+    problems = make_realign_batch(6, 40, 100, 2600, 4) + [("ACGTNACGT", "ACGTACGT", [(1, 1, 4)]), ("A", "A", [])]
+    kw = dict(diagonalExpansion=4, splitMatrixBiggerThanThis=10)
+    p = api.pairwiseAlignmentBandingParameters_construct(**kw)
+    op = ob.params(**kw)
+    sM, om = _sm(mtype), ob.model(mtype)
+    got = api.hmm_constructEmpty(1e-12, mtype)
+    with api.Batch(sM, p, emit=api.EMIT_EXPECT) as b:
+        for sx, sy, a in problems:
+            b.add(sx, sy, a, True, True)
+        b.upload()
+        b.run()
+        b.download()
+        b.expectations(got)
+    want = ob.hmm(mtype, 1e-12)
+    for sx, sy, a in problems:
+        ob.expectations(om, want, sx, sy, a, op, True, True)
+    _assert_hmm_close(got, want, 5 if mtype < 2 else 3)

@@ -23,6 +23,8 @@ maxlen = int(os.environ.get("NARROW_MAXLEN", "5000"))
 run("config4-like (realign, E=4, split at 10)", workload.make_realign_batch(4, n4, 100, maxlen, 4), api.EMIT_MATCH, (True, True),
     diagonalExpansion=4, splitMatrixBiggerThanThis=10)
 if len(sys.argv) > 2:
+    run("config4-like, expectations (EM E-step on realign bands)", workload.make_realign_batch(4, n4, 100, maxlen, 4), api.EMIT_EXPECT,
+        (True, True), diagonalExpansion=4, splitMatrixBiggerThanThis=10)
     sys.exit(0)
 run("config5-like (E=10, expectations)", workload.make_batch(5, 2 * n4, 1000, 10), api.EMIT_EXPECT, (False, False), diagonalExpansion=10)
 run("config5-like (E=10, match)", workload.make_batch(5, 2 * n4, 1000, 10), api.EMIT_MATCH, (False, False), diagonalExpansion=10)
