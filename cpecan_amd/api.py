@@ -83,10 +83,11 @@ EXPORTS = [
     "cpecan_compute_forward_probability", "cpecan_free",
     "cpecan_batch_set_post", "cpecan_batch_scores", "cpecan_reweight_aligned_pairs", "cpecan_posterior_scores",
     "cpecan_mea_alignment", "cpecan_left_shift_alignment", "cpecan_get_shifted_mea_alignment",
-    "cpecan_anchors_from_alignment",
+    "cpecan_anchors_from_alignment", "cpecan_batch_set_match_gamma", "cpecan_batch_identity_scores",
+    "cpecan_identity_scores", "cpecan_filter_pairs_ordered",
 ]
 OP_MATCH, OP_INDEL_X, OP_INDEL_Y = 0, 1, 2
-POST_REWEIGHT, POST_MEA, POST_LEFT_SHIFT = 1, 2, 4
+POST_REWEIGHT, POST_MEA, POST_LEFT_SHIFT, POST_ORDERED = 1, 2, 4, 8
 
 _lib = None
 
@@ -145,6 +146,10 @@ def lib():
                                                 C.c_int64, C.c_char_p, C.c_int64, i64p]
     L.cpecan_batch_set_post.argtypes = [vp, C.c_int, C.c_double]
     L.cpecan_batch_scores.argtypes = [vp, C.c_int64, dp, dp, dp]
+    L.cpecan_batch_set_match_gamma.argtypes = [vp, C.c_float]
+    L.cpecan_batch_identity_scores.argtypes = [vp, C.c_int64, dp, dp]
+    L.cpecan_identity_scores.argtypes = [i32p, C.c_int64, C.c_char_p, C.c_char_p, dp, dp]
+    L.cpecan_filter_pairs_ordered.argtypes = [i32p, C.c_int64, C.c_int64, C.c_int64, C.c_float, C.POINTER(i32p), i64p]
     L.cpecan_reweight_aligned_pairs.argtypes = [i32p, C.c_int64, C.c_int64, C.c_int64, C.c_double]
     L.cpecan_posterior_scores.argtypes = [i32p, C.c_int64, C.c_int64, C.c_int64, dp, dp]
     L.cpecan_mea_alignment.argtypes = [i32p, C.c_int64, i32p, C.c_int64, i32p, C.c_int64, C.c_int64, C.c_int64, C.c_float,
@@ -309,10 +314,20 @@ class Batch:
             return np.zeros((0, 3), dtype=np.int32)
         return np.ctypeslib.as_array(ptr, shape=(n.value * 3,)).copy().reshape(n.value, 3)
 
-    def set_post(self, flags, gapGamma=0.0):
+    def set_post(self, flags, gapGamma=0.0, matchGamma=None):
         """Consumers applied on the device by download(): POST_REWEIGHT (reweightAlignedPairs2), POST_MEA
-        (getMaximalExpectedAccuracyPairwiseAlignment, result list 3), POST_MEA | POST_LEFT_SHIFT (getShiftedMEAAlignment)."""
+        (getMaximalExpectedAccuracyPairwiseAlignment, result list 3), POST_MEA | POST_LEFT_SHIFT (getShiftedMEAAlignment),
+        POST_ORDERED (filterPairwiseAlignmentToMakePairsOrdered with matchGamma, result list 3)."""
         _check(lib().cpecan_batch_set_post(self._h, int(flags), float(gapGamma)), "cpecan_batch_set_post")
+        if matchGamma is not None:
+            _check(lib().cpecan_batch_set_match_gamma(self._h, C.c_float(matchGamma)), "cpecan_batch_set_match_gamma")
+
+    def identity_scores(self, problem):
+        """(scoreByIdentity, scoreByIdentityIgnoringGaps) of a problem's final list."""
+        a, b = C.c_double(), C.c_double()
+        _check(lib().cpecan_batch_identity_scores(self._h, problem, C.byref(a), C.byref(b)),
+               "cpecan_batch_identity_scores")
+        return a.value, b.value
 
     def scores(self, problem):
         """(scoreByPosteriorProbability, scoreByPosteriorProbabilityIgnoringGaps, MEA alignment score) of a problem."""
@@ -427,6 +442,33 @@ def scoreByPosteriorProbability(lX, lY, alignedPairs):  # impl/pairwiseAligner.c
 
 def scoreByPosteriorProbabilityIgnoringGaps(alignedPairs):  # impl/pairwiseAligner.c:1591
     return _posterior_scores(alignedPairs, 0, 0)[1]
+
+
+def _identity_scores(alignedPairs, seqX, seqY):
+    a, pa, n = _i32_triples(alignedPairs)
+    s0, s1 = C.c_double(), C.c_double()
+    _check(lib().cpecan_identity_scores(pa, n, _bytes(seqX), _bytes(seqY), C.byref(s0), C.byref(s1)),
+           "cpecan_identity_scores")
+    return s0.value, s1.value
+
+
+def scoreByIdentity(subSeqX, subSeqY, lX, lY, alignedPairs):  # impl/pairwiseAligner.c:1572
+    return _identity_scores(alignedPairs, subSeqX, subSeqY)[0]
+
+
+def scoreByIdentityIgnoringGaps(subSeqX, subSeqY, alignedPairs):  # impl/pairwiseAligner.c:1577
+    return _identity_scores(alignedPairs, subSeqX, subSeqY)[1]
+
+
+def filterPairwiseAlignmentToMakePairsOrdered(alignedPairs, seqX, seqY, matchGamma):  # impl/multipleAligner.c:945
+    """The heaviest chain of the pairs with weight >= matchGamma, in the reference's output order (reverse input order);
+    the reference's random weight jitter (multipleAligner.c:145) is left out."""
+    a, pa, n = _i32_triples(alignedPairs)
+    out = C.POINTER(C.c_int32)()
+    cnt = C.c_int64()
+    _check(lib().cpecan_filter_pairs_ordered(pa, n, len(seqX), len(seqY), C.c_float(matchGamma), C.byref(out),
+                                             C.byref(cnt)), "cpecan_filter_pairs_ordered")
+    return _take_list(out, cnt.value)
 
 
 def getMaximalExpectedAccuracyPairwiseAlignment(alignedPairs, gapXPairs, gapYPairs, seqXLength, seqYLength, p=None,

@@ -376,6 +376,35 @@ double scoreByPosteriorProbabilityIgnoringGaps(stList *alignedPairs) {
     free(t);
     return s;
 }
+double scoreByIdentity(char *subSeqX, char *subSeqY, int64_t lX, int64_t lY, stList *alignedPairs) {
+    (void)lX; /* the reference's callers pass strlen of the two strings (cPecanRealign.c:560) */
+    (void)lY;
+    int64_t n;
+    int32_t *t = flatten_triples(alignedPairs, &n);
+    double s = 0.0;
+    check(cpecan_identity_scores(t, n, subSeqX, subSeqY, &s, NULL), "scoreByIdentity");
+    free(t);
+    return s;
+}
+double scoreByIdentityIgnoringGaps(char *subSeqX, char *subSeqY, stList *alignedPairs) {
+    int64_t n;
+    int32_t *t = flatten_triples(alignedPairs, &n);
+    double s = 0.0;
+    check(cpecan_identity_scores(t, n, subSeqX, subSeqY, NULL, &s), "scoreByIdentityIgnoringGaps");
+    free(t);
+    return s;
+}
+stList *filterPairwiseAlignmentToMakePairsOrdered(stList *alignedPairs, const char *seqX, const char *seqY, float matchGamma) {
+    int64_t n, cnt = 0;
+    int32_t *t = flatten_triples(alignedPairs, &n), *out = NULL;
+    check(cpecan_filter_pairs_ordered(t, n, (int64_t)strlen(seqX), (int64_t)strlen(seqY), matchGamma, &out, &cnt),
+          "filterPairwiseAlignmentToMakePairsOrdered");
+    stList *l = list_of(out, cnt);
+    cpecan_free(out);
+    free(t);
+    stList_destruct(alignedPairs); /* "Destroys input list of aligned pairs in process" (multipleAligner.c:943) */
+    return l;
+}
 stList *getMaximalExpectedAccuracyPairwiseAlignment(stList *alignedPairs, stList *gapXPairs, stList *gapYPairs,
                                                     int64_t seqXLength, int64_t seqYLength, double *alignmentScore,
                                                     PairwiseAlignmentParameters *p) {

@@ -375,7 +375,7 @@ typedef struct {
     int64_t nTriples[4];
     int64_t lX, lY;          /* of the whole problem */
     int64_t charX, charY;    /* raw upper-case sequences in cpecan_batch.chars */
-    double scores[3];        /* byPosterior, byPosteriorIgnoringGaps, MEA alignment score */
+    double scores[CPK_POST_SCORES]; /* byPosterior, byPosteriorIgnoringGaps, MEA alignment score, byIdentity, ...IgnoringGaps */
 } HostProblem;
 
 struct cpecan_batch {
@@ -408,6 +408,7 @@ struct cpecan_batch {
     int64_t nChars, capChars;
     int postFlags;    /* CPECAN_POST_* applied by download */
     double postGapGamma;
+    float postMatchGamma; /* ORDERED: matchGamma of cPecanRealign.c:355 */
     int32_t *postMea, *postShift;
     cpecan_stats stats;
 };
@@ -479,6 +480,7 @@ int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpe
     b->device = device;
     b->dev = NULL;
     b->nLists = emit == CPECAN_EMIT_INDEL ? 3 : 1;
+    b->postMatchGamma = 0.85f; /* cPecanRealign.c:355 */
     *out = b;
     return CPECAN_OK;
 }
@@ -1020,9 +1022,10 @@ static int run_post(cpecan_batch *b) {
     memset(&job, 0, sizeof job);
     job.flags = b->postFlags;
     job.gapGamma = b->postGapGamma;
+    job.matchGamma = (double)b->postMatchGamma; /* float widened, as the reference passes it (multipleAligner.c:945) */
     job.nProblems = b->nProblems;
     CpkPostProblem *pp = malloc(sizeof(CpkPostProblem) * (size_t)(b->nProblems ? b->nProblems : 1));
-    double *scores = malloc(sizeof(double) * 3 * (size_t)(b->nProblems ? b->nProblems : 1));
+    double *scores = malloc(sizeof(double) * CPK_POST_SCORES * (size_t)(b->nProblems ? b->nProblems : 1));
     int32_t *counts = malloc(sizeof(int32_t) * 2 * (size_t)(b->nProblems ? b->nProblems : 1));
     int rc = (pp && scores && counts) ? CPECAN_OK : CPECAN_ENOMEM;
     for (int64_t i = 0; rc == CPECAN_OK && i < b->nProblems; i++) {
@@ -1038,7 +1041,9 @@ static int run_post(cpecan_batch *b) {
         job.problems = pp;
         job.scores = scores;
         job.counts = counts;
-        if (job.flags & CPECAN_POST_MEA) {
+        job.chars = b->chars; /* identity scores, left shift */
+        job.nChars = b->nChars;
+        if (job.flags & (CPECAN_POST_MEA | CPECAN_POST_ORDERED)) {
             b->postMea = malloc(sizeof(int32_t) * 3 * (size_t)(job.meaCap ? job.meaCap : 1));
             job.mea = b->postMea;
             if (!b->postMea) rc = CPECAN_ENOMEM;
@@ -1046,19 +1051,17 @@ static int run_post(cpecan_batch *b) {
         if (rc == CPECAN_OK && (job.flags & CPECAN_POST_LEFT_SHIFT)) {
             b->postShift = malloc(sizeof(int32_t) * 3 * (size_t)(job.shiftCap ? job.shiftCap : 1));
             job.shift = b->postShift;
-            job.chars = b->chars;
-            job.nChars = b->nChars;
             if (!b->postShift) rc = CPECAN_ENOMEM;
         }
     }
     if (rc == CPECAN_OK) rc = cpk_device_post(b->dev, &job);
     for (int64_t i = 0; rc == CPECAN_OK && i < b->nProblems; i++) {
         HostProblem *pr = &b->problems[i];
-        for (int k = 0; k < 3; k++) pr->scores[k] = scores[3 * i + k];
+        for (int k = 0; k < CPK_POST_SCORES; k++) pr->scores[k] = scores[CPK_POST_SCORES * i + k];
         if (job.flags & CPECAN_POST_LEFT_SHIFT) {
             pr->triples[3] = b->postShift + 3 * pp[i].shiftOut;
             pr->nTriples[3] = counts[2 * i + 1];
-        } else if (job.flags & CPECAN_POST_MEA) {
+        } else if (job.flags & (CPECAN_POST_MEA | CPECAN_POST_ORDERED)) {
             pr->triples[3] = b->postMea + 3 * pp[i].meaOut;
             pr->nTriples[3] = counts[2 * i];
         }
@@ -1071,8 +1074,9 @@ static int run_post(cpecan_batch *b) {
 
 int cpecan_batch_set_post(cpecan_batch *b, int flags, double gapGamma) {
     if (!b) return CPECAN_EINVAL;
-    if (flags & ~(CPECAN_POST_REWEIGHT | CPECAN_POST_MEA | CPECAN_POST_LEFT_SHIFT)) return CPECAN_EINVAL;
+    if (flags & ~(CPECAN_POST_REWEIGHT | CPECAN_POST_MEA | CPECAN_POST_LEFT_SHIFT | CPECAN_POST_ORDERED)) return CPECAN_EINVAL;
     if ((flags & CPECAN_POST_LEFT_SHIFT) && !(flags & CPECAN_POST_MEA)) return CPECAN_EINVAL;
+    if ((flags & CPECAN_POST_ORDERED) && (flags & (CPECAN_POST_MEA | CPECAN_POST_LEFT_SHIFT))) return CPECAN_EINVAL;
     if ((flags & CPECAN_POST_MEA) && (flags & CPECAN_POST_REWEIGHT)) return CPECAN_EINVAL; /* alternatives in the reference */
     if ((flags & CPECAN_POST_MEA) && b->emit != CPECAN_EMIT_INDEL) {
         cpk_set_error("the MEA alignment needs the gap lists: create the batch with CPECAN_EMIT_INDEL");
@@ -1081,6 +1085,25 @@ int cpecan_batch_set_post(cpecan_batch *b, int flags, double gapGamma) {
     if (flags && (b->emit == CPECAN_EMIT_FORWARD || b->emit == CPECAN_EMIT_EXPECT)) return CPECAN_EINVAL;
     b->postFlags = flags;
     b->postGapGamma = gapGamma;
+    return CPECAN_OK;
+}
+
+int cpecan_batch_set_match_gamma(cpecan_batch *b, float matchGamma) {
+    if (!b || !(matchGamma >= 0.0f)) return CPECAN_EINVAL;
+    b->postMatchGamma = matchGamma;
+    return CPECAN_OK;
+}
+
+int cpecan_batch_identity_scores(const cpecan_batch *b, int64_t problem, double *byIdentity, double *byIdentityIgnoringGaps) {
+    if (!b || !b->downloaded) return CPECAN_ESTATE;
+    if (problem < 0 || problem >= b->nProblems || b->emit == CPECAN_EMIT_FORWARD || b->emit == CPECAN_EMIT_EXPECT)
+        return CPECAN_EINVAL;
+    if (!b->postFlags) {
+        cpk_set_error("identity scores are computed by the consumer stage: select one with cpecan_batch_set_post");
+        return CPECAN_ESTATE;
+    }
+    if (byIdentity) *byIdentity = b->problems[problem].scores[3];
+    if (byIdentityIgnoringGaps) *byIdentityIgnoringGaps = b->problems[problem].scores[4];
     return CPECAN_OK;
 }
 
@@ -1173,7 +1196,7 @@ int cpecan_batch_download(cpecan_batch *b) {
 int cpecan_batch_result(const cpecan_batch *b, int64_t problem, int which, const int32_t **triples, int64_t *n) {
     if (!b || !b->downloaded) return CPECAN_ESTATE;
     if (problem < 0 || problem >= b->nProblems || which < 0) return CPECAN_EINVAL;
-    if (which >= b->nLists && !(which == 3 && (b->postFlags & CPECAN_POST_MEA))) return CPECAN_EINVAL;
+    if (which >= b->nLists && !(which == 3 && (b->postFlags & (CPECAN_POST_MEA | CPECAN_POST_ORDERED)))) return CPECAN_EINVAL;
     *triples = b->problems[problem].triples[which];
     *n = b->problems[problem].nTriples[which];
     return CPECAN_OK;
@@ -1237,7 +1260,7 @@ typedef struct {
     CpkPostProblem pp;
     CpkPostJob job;
     uint8_t *chars;
-    double scores[3];
+    double scores[CPK_POST_SCORES];
     int32_t counts[2];
 } PostSingle;
 
@@ -1248,9 +1271,10 @@ static void post_single_free(PostSingle *ps) {
     free(ps->job.shift);
 }
 
-static int post_single_run(PostSingle *ps, int flags, double gapGamma, const int32_t *lists[3], const int64_t n[3],
-                           int64_t lX, int64_t lY, const char *sX, const char *sY) {
+static int post_single_run(PostSingle *ps, int flags, double gapGamma, double matchGamma, const int32_t *lists[3],
+                           const int64_t n[3], int64_t lX, int64_t lY, const char *sX, const char *sY) {
     memset(ps, 0, sizeof *ps);
+    ps->job.matchGamma = matchGamma;
     if (lX < 0 || lY < 0 || lX + lY >= (int64_t)1 << 30) return CPECAN_EINVAL;
     int64_t off[3], at = 0;
     for (int l = 0; l < 3; l++) {
@@ -1262,7 +1286,7 @@ static int post_single_run(PostSingle *ps, int flags, double gapGamma, const int
     ps->buf = malloc(sizeof(int32_t) * 3 * (size_t)(at ? at : 1));
     if (!ps->buf) return CPECAN_ENOMEM;
     for (int l = 0; l < 3; l++) {
-        for (int64_t i = 0; flags && i < n[l]; i++) { /* coordinates index the mass arrays and the sequences: check them */
+        for (int64_t i = 0; (flags || sX) && i < n[l]; i++) { /* coordinates index the mass arrays and the sequences: check them */
             const int32_t x = lists[l][3 * i + 1], y = lists[l][3 * i + 2];
             const int okX = x >= 0 && x < lX, okY = y >= 0 && y < lY;
             if ((l == 0 && !(okX && okY)) || (l == 1 && !okX) || (l == 2 && !okY)) return CPECAN_EINVAL;
@@ -1276,19 +1300,22 @@ static int post_single_run(PostSingle *ps, int flags, double gapGamma, const int
     ps->job.problems = &ps->pp;
     ps->job.scores = ps->scores;
     ps->job.counts = ps->counts;
-    if (flags & CPECAN_POST_MEA) {
+    if (flags & (CPECAN_POST_MEA | CPECAN_POST_ORDERED)) {
         ps->job.mea = malloc(sizeof(int32_t) * 3 * (size_t)(ps->job.meaCap ? ps->job.meaCap : 1));
         if (!ps->job.mea) return CPECAN_ENOMEM;
     }
-    if (flags & CPECAN_POST_LEFT_SHIFT) {
-        if (!sX || !sY) return CPECAN_EINVAL;
-        ps->job.shift = malloc(sizeof(int32_t) * 3 * (size_t)(ps->job.shiftCap ? ps->job.shiftCap : 1));
+    if ((flags & CPECAN_POST_LEFT_SHIFT) && (!sX || !sY)) return CPECAN_EINVAL;
+    if (sX && sY) {
         ps->chars = malloc((size_t)(lX + lY + 1));
-        if (!ps->job.shift || !ps->chars) return CPECAN_ENOMEM;
+        if (!ps->chars) return CPECAN_ENOMEM;
         for (int64_t i = 0; i < lX; i++) ps->chars[i] = (uint8_t)toupper((unsigned char)sX[i]);
         for (int64_t i = 0; i < lY; i++) ps->chars[lX + i] = (uint8_t)toupper((unsigned char)sY[i]);
         ps->job.chars = ps->chars;
         ps->job.nChars = lX + lY;
+    }
+    if (flags & CPECAN_POST_LEFT_SHIFT) {
+        ps->job.shift = malloc(sizeof(int32_t) * 3 * (size_t)(ps->job.shiftCap ? ps->job.shiftCap : 1));
+        if (!ps->job.shift) return CPECAN_ENOMEM;
     }
     return cpk_post_lists(0, ps->buf, ps->total, &ps->job);
 }
@@ -1306,7 +1333,7 @@ int cpecan_reweight_aligned_pairs(int32_t *triples, int64_t n, int64_t lX, int64
     const int32_t *lists[3] = {triples, NULL, NULL};
     const int64_t ns[3] = {n, 0, 0};
     PostSingle ps;
-    int rc = post_single_run(&ps, CPECAN_POST_REWEIGHT, gapGamma, lists, ns, lX, lY, NULL, NULL);
+    int rc = post_single_run(&ps, CPECAN_POST_REWEIGHT, gapGamma, 0.0, lists, ns, lX, lY, NULL, NULL);
     if (rc == CPECAN_OK && n) memcpy(triples, ps.buf, sizeof(int32_t) * 3 * (size_t)n);
     post_single_free(&ps);
     return rc;
@@ -1317,11 +1344,38 @@ int cpecan_posterior_scores(const int32_t *triples, int64_t n, int64_t lX, int64
     const int32_t *lists[3] = {triples, NULL, NULL};
     const int64_t ns[3] = {n, 0, 0};
     PostSingle ps;
-    int rc = post_single_run(&ps, 0, 0.0, lists, ns, lX, lY, NULL, NULL);
+    int rc = post_single_run(&ps, 0, 0.0, 0.0, lists, ns, lX, lY, NULL, NULL);
     if (rc == CPECAN_OK) {
         if (byPosterior) *byPosterior = ps.scores[0];
         if (byPosteriorIgnoringGaps) *byPosteriorIgnoringGaps = ps.scores[1];
     }
+    post_single_free(&ps);
+    return rc;
+}
+
+int cpecan_identity_scores(const int32_t *triples, int64_t n, const char *sX, const char *sY, double *byIdentity,
+                           double *byIdentityIgnoringGaps) {
+    if (!sX || !sY) return CPECAN_EINVAL;
+    const int32_t *lists[3] = {triples, NULL, NULL};
+    const int64_t ns[3] = {n, 0, 0};
+    PostSingle ps;
+    int rc = post_single_run(&ps, 0, 0.0, 0.0, lists, ns, (int64_t)strlen(sX), (int64_t)strlen(sY), sX, sY);
+    if (rc == CPECAN_OK) {
+        if (byIdentity) *byIdentity = ps.scores[3];
+        if (byIdentityIgnoringGaps) *byIdentityIgnoringGaps = ps.scores[4];
+    }
+    post_single_free(&ps);
+    return rc;
+}
+
+int cpecan_filter_pairs_ordered(const int32_t *pairs, int64_t n, int64_t lX, int64_t lY, float matchGamma, int32_t **out,
+                                int64_t *nOut) {
+    if (!out || !nOut || !(matchGamma >= 0.0f)) return CPECAN_EINVAL;
+    const int32_t *lists[3] = {pairs, NULL, NULL};
+    const int64_t ns[3] = {n, 0, 0};
+    PostSingle ps;
+    int rc = post_single_run(&ps, CPECAN_POST_ORDERED, 0.0, (double)matchGamma, lists, ns, lX, lY, NULL, NULL);
+    if (rc == CPECAN_OK) rc = take_list(ps.job.mea, ps.counts[0], out, nOut);
     post_single_free(&ps);
     return rc;
 }
@@ -1333,7 +1387,7 @@ int cpecan_mea_alignment(const int32_t *pairs, int64_t n, const int32_t *gapX, i
     const int32_t *lists[3] = {pairs, gapX, gapY};
     const int64_t ns[3] = {n, nGapX, nGapY};
     PostSingle ps;
-    int rc = post_single_run(&ps, CPECAN_POST_MEA, (double)gapGamma, lists, ns, lX, lY, NULL, NULL);
+    int rc = post_single_run(&ps, CPECAN_POST_MEA, (double)gapGamma, 0.0, lists, ns, lX, lY, NULL, NULL);
     if (rc == CPECAN_OK) rc = take_list(ps.job.mea, ps.counts[0], out, nOut);
     if (rc == CPECAN_OK && alignmentScore) *alignmentScore = ps.scores[2];
     post_single_free(&ps);
@@ -1347,7 +1401,7 @@ int cpecan_left_shift_alignment(const int32_t *pairs, int64_t n, const char *sX,
     const int32_t *lists[3] = {pairs, NULL, NULL};
     const int64_t ns[3] = {n, 0, 0};
     PostSingle ps;
-    int rc = post_single_run(&ps, CPECAN_POST_LEFT_SHIFT, 0.0, lists, ns, (int64_t)strlen(sX), (int64_t)strlen(sY), sX, sY);
+    int rc = post_single_run(&ps, CPECAN_POST_LEFT_SHIFT, 0.0, 0.0, lists, ns, (int64_t)strlen(sX), (int64_t)strlen(sY), sX, sY);
     if (rc == CPECAN_OK) rc = take_list(ps.job.shift, ps.counts[1], out, nOut);
     post_single_free(&ps);
     return rc;

@@ -146,17 +146,20 @@ typedef struct {
     int64_t shiftOut;        /* first of n[0] + min(lX, lY) + 1 output triples */
 } CpkPostProblem;
 
+#define CPK_POST_SCORES 5
 typedef struct {
     int flags;               /* CPECAN_POST_* */
     double gapGamma;
+    double matchGamma;       /* ORDERED: the float of cPecanRealign.c:355 widened to double */
     int64_t nProblems;
     const CpkPostProblem *problems;
-    const uint8_t *chars;    /* host: raw sequences, or NULL */
+    const uint8_t *chars;    /* host: raw upper-case sequences, or NULL (then no left shift, no identity scores) */
     int64_t nChars;
     int64_t seqSlots, chainSlots, meaCap, shiftCap; /* totals over the problems */
     /* outputs (host) */
-    double *scores;          /* [nProblems][3]: byPosterior, byPosteriorIgnoringGaps, MEA alignment score */
-    int32_t *counts;         /* [nProblems][2]: MEA pairs, left-shifted pairs */
+    double *scores;          /* [nProblems][CPK_POST_SCORES]: byPosterior, byPosteriorIgnoringGaps, MEA alignment score,
+                              * byIdentity, byIdentityIgnoringGaps (the last two only when chars are given) */
+    int32_t *counts;         /* [nProblems][2]: MEA or ordered pairs, left-shifted pairs */
     int32_t *mea;            /* [meaCap*3] or NULL */
     int32_t *shift;          /* [shiftCap*3] or NULL */
 } CpkPostJob;

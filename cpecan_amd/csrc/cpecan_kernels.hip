@@ -587,10 +587,10 @@ static int post_core(int32_t *dTriples, const CpkPostJob *job) {
     double *dScores = nullptr;
     int32_t *dCounts = nullptr;
     if (int rc = sc.alloc(&dProblems, (size_t)nP)) return rc;
-    if (int rc = sc.alloc(&dScores, (size_t)nP * 3)) return rc;
+    if (int rc = sc.alloc(&dScores, (size_t)nP * kPostScores)) return rc;
     if (int rc = sc.alloc(&dCounts, (size_t)nP * 2)) return rc;
     HIP_TRY(hipMemcpy(dProblems, job->problems, sizeof(CpkPostProblem) * (size_t)nP, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(dScores, 0, sizeof(double) * (size_t)nP * 3));
+    HIP_TRY(hipMemset(dScores, 0, sizeof(double) * (size_t)nP * kPostScores));
     HIP_TRY(hipMemset(dCounts, 0, sizeof(int32_t) * (size_t)nP * 2));
     {
         int32_t *dMass = nullptr;
@@ -601,9 +601,33 @@ static int post_core(int32_t *dTriples, const CpkPostJob *job) {
         HIP_TRY(hipGetLastError());
     }
     int32_t *dMea = nullptr, *dShift = nullptr;
+    uint8_t *dChars = nullptr;
     const unsigned laneBlocks = (unsigned)((nP + 63) / 64);
-    if (job->flags & (kPostMea | kPostLeftShift))
+    if (job->flags & (kPostMea | kPostLeftShift | kPostOrdered))
         if (int rc = sc.alloc(&dMea, (size_t)job->meaCap * 3)) return rc;
+    if (job->chars) {
+        if (int rc = sc.alloc(&dChars, (size_t)(job->nChars > 0 ? job->nChars : 1))) return rc;
+        if (job->nChars > 0) HIP_TRY(hipMemcpy(dChars, job->chars, (size_t)job->nChars, hipMemcpyHostToDevice));
+    }
+    if (job->flags & kPostOrdered) {
+        int32_t *dSeq = nullptr, *dPrev = nullptr, *dNext = nullptr;
+        double *dBest = nullptr;
+        uint8_t *dChosen = nullptr;
+        if (int rc = sc.alloc(&dSeq, (size_t)(job->seqSlots > 0 ? job->seqSlots : 1))) return rc;
+        if (int rc = sc.alloc(&dBest, (size_t)job->chainSlots)) return rc;
+        if (int rc = sc.alloc(&dPrev, (size_t)job->chainSlots)) return rc;
+        if (int rc = sc.alloc(&dNext, (size_t)job->chainSlots)) return rc;
+        if (int rc = sc.alloc(&dChosen, (size_t)job->chainSlots)) return rc;
+        hipLaunchKernelGGL(cpecan_post_ordered, dim3(laneBlocks), dim3(64), 0, nullptr, dProblems, nP, dTriples, dSeq,
+                           dBest, dPrev, dNext, dChosen, job->matchGamma, dMea, dCounts);
+        HIP_TRY(hipGetLastError());
+    }
+    if ((job->flags & kPostOrdered) || dChars) {
+        const int fromOut = (job->flags & kPostOrdered) ? 1 : 0;
+        hipLaunchKernelGGL(cpecan_post_list_scores, dim3((unsigned)nP), dim3(256), 0, nullptr, dProblems, dTriples, dMea,
+                           dCounts, fromOut, fromOut, dChars, dScores);
+        HIP_TRY(hipGetLastError());
+    }
     if (job->flags & kPostMea) {
         long long *dCum = nullptr;
         double *dBest = nullptr;
@@ -622,20 +646,18 @@ static int post_core(int32_t *dTriples, const CpkPostJob *job) {
         HIP_TRY(hipGetLastError());
     }
     if (job->flags & kPostLeftShift) {
-        uint8_t *dChars = nullptr;
-        if (!job->chars) {
+        if (!dChars) {
             cpk_set_error("left shift needs the raw sequences");
             return CPECAN_EINVAL;
         }
-        if (int rc = sc.alloc(&dChars, (size_t)job->nChars)) return rc;
         if (int rc = sc.alloc(&dShift, (size_t)job->shiftCap * 3)) return rc;
-        HIP_TRY(hipMemcpy(dChars, job->chars, (size_t)job->nChars, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(cpecan_post_left_shift, dim3(laneBlocks), dim3(64), 0, nullptr, dProblems, nP, dMea, dChars,
                            dShift, dCounts);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipDeviceSynchronize());
-    if (job->scores) HIP_TRY(hipMemcpy(job->scores, dScores, sizeof(double) * (size_t)nP * 3, hipMemcpyDeviceToHost));
+    if (job->scores)
+        HIP_TRY(hipMemcpy(job->scores, dScores, sizeof(double) * (size_t)nP * kPostScores, hipMemcpyDeviceToHost));
     if (job->counts) HIP_TRY(hipMemcpy(job->counts, dCounts, sizeof(int32_t) * (size_t)nP * 2, hipMemcpyDeviceToHost));
     if (job->mea && dMea) HIP_TRY(hipMemcpy(job->mea, dMea, sizeof(int32_t) * 3 * (size_t)job->meaCap, hipMemcpyDeviceToHost));
     if (job->shift && dShift)

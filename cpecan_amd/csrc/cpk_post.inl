@@ -4,7 +4,8 @@
 // ------------------------------------------------------------------------------------------------
 // Consumers of the posterior lists.  Integer / order-defined arithmetic: bit-exact.
 // ------------------------------------------------------------------------------------------------
-constexpr int kPostReweight = 1, kPostMea = 2, kPostLeftShift = 4;  // == CPECAN_POST_*
+constexpr int kPostReweight = 1, kPostMea = 2, kPostLeftShift = 4, kPostOrdered = 8;  // == CPECAN_POST_*
+constexpr int kPostScores = CPK_POST_SCORES;  // doubles per problem: see CpkPostJob.scores
 
 // reweightAlignedPairs2 (impl/pairwiseAligner.c:1519-1558) + scoreByPosteriorProbability[IgnoringGaps] (:1578-1597).
 // One workgroup per problem.  mass[] = PROB_1 minus the listed mass of every base of X then Y, floored at 0 when read
@@ -44,8 +45,8 @@ __global__ void __launch_bounds__(256) cpecan_post_reweight(const CpkPostProblem
     if (threadIdx.x == 0) {
         const double total = (double)partial[0];  // the reference adds int64 scores into a double: exact below 2^53
         const long long L = (long long)pb.lX + pb.lY;
-        scores[3 * blockIdx.x + 0] = 100.0 * (L == 0 ? 0 : (2.0 * total) / (double)(L * CPECAN_PROB_1));
-        scores[3 * blockIdx.x + 1] = 100.0 * total / ((double)n * CPECAN_PROB_1);
+        scores[kPostScores * blockIdx.x + 0] = 100.0 * (L == 0 ? 0 : (2.0 * total) / (double)(L * CPECAN_PROB_1));
+        scores[kPostScores * blockIdx.x + 1] = 100.0 * total / ((double)n * CPECAN_PROB_1);
     }
 }
 
@@ -123,7 +124,7 @@ __global__ void __launch_bounds__(64) cpecan_post_mea(const CpkPostProblem *prob
         out[3 * at + 2] = pairs[3 * i + 2];
     }
     counts[2 * p] = count;
-    scores[3 * p + 2] = top;
+    scores[kPostScores * p + 2] = top;
 }
 
 // LEFT_SHIFT without MEA: list 0 is the chain to shift; put it where the MEA stage would have put its alignment.
@@ -185,4 +186,121 @@ __global__ void __launch_bounds__(64) cpecan_post_left_shift(const CpkPostProble
             out[3 * b + f] = t;
         }
     counts[2 * p + 1] = count;
+}
+
+// filterPairwiseAlignmentToMakePairsOrdered (impl/multipleAligner.c:945-972), one lane per problem: the heaviest chain
+// of the pairs whose weight reaches matchGamma, as a filter of list 0.  With two sequences the reference's
+// pairwiseAlignColumns (:358-492) keeps a frontier of chain ends sorted by y with strictly increasing scores; the
+// predecessor it gives a pair (the frontier entry with the largest y below it, :397) is the processed pair that is
+// maximal under (score, then smaller y, then later column), because every other processed pair is dominated by a
+// frontier entry in exactly that order (:418-427).  That maximum is what the Fenwick tree over y holds here, so no
+// entry ever has to be deleted.  Pairs of one X column are all scored before any of them is inserted (:389-409).
+// The reference's st_random() * 0.00001 per weight (:145) is left out.
+struct OrderedCtx {
+    const int32_t *pairs;
+    const double *best;
+    __device__ __forceinline__ int pick(int a, int b) const {
+        if (a < 0) return b;
+        if (b < 0) return a;
+        const double sa = best[a], sb = best[b];
+        if (sa != sb) return sa > sb ? a : b;
+        const int ya = pairs[3 * a + 2], yb = pairs[3 * b + 2];
+        if (ya != yb) return ya < yb ? a : b;
+        return pairs[3 * a + 1] > pairs[3 * b + 1] ? a : b;
+    }
+};
+
+__global__ void __launch_bounds__(64) cpecan_post_ordered(const CpkPostProblem *problems, int64_t nProblems,
+                                                          const int32_t *triples, int32_t *seqScratch, double *best,
+                                                          int32_t *prev, int32_t *next, uint8_t *chosen, double matchGamma,
+                                                          int32_t *out, int32_t *counts) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= nProblems) return;
+    const CpkPostProblem pb = problems[p];
+    const int32_t *pairs = triples + 3 * pb.off[0];
+    const int n = pb.n[0], lX = pb.lX, lY = pb.lY;
+    int32_t *head = seqScratch + pb.seqOff, *tree = head + lX;  // pairs of each X column; Fenwick tree over y
+    double *bs = best + pb.chainOff;
+    int32_t *pv = prev + pb.chainOff, *nx = next + pb.chainOff;
+    uint8_t *ch = chosen + pb.chainOff;
+    for (int i = 0; i < lX + lY; i++) head[i] = -1;
+    for (int i = n - 1; i >= 0; i--) {
+        const int x = pairs[3 * i + 1];
+        nx[i] = head[x];
+        head[x] = i;
+        ch[i] = 0;
+    }
+    const OrderedCtx cx{pairs, bs};
+    for (int x = 0; x < lX; x++) {
+        for (int i = head[x]; i >= 0; i = nx[i]) {
+            const double w = (double)pairs[3 * i] / (double)CPECAN_PROB_1;
+            if (w >= matchGamma && w > 0.0) {  // :393
+                int from = -1;
+                for (int k = pairs[3 * i + 2]; k > 0; k -= k & -k) from = cx.pick(from, tree[k - 1]);  // y' < y
+                pv[i] = from;
+                bs[i] = (from < 0 ? 0.0 : bs[from]) + w * 1.0;  // :404
+                ch[i] = 2;
+            }
+        }
+        for (int i = head[x]; i >= 0; i = nx[i])
+            if (ch[i] == 2)
+                for (int k = pairs[3 * i + 2] + 1; k <= lY; k += k & -k) tree[k - 1] = cx.pick(tree[k - 1], i);
+    }
+    int last = -1;
+    for (int k = lY; k > 0; k -= k & -k) last = cx.pick(last, tree[k - 1]);
+    for (int i = last; i >= 0; i = pv[i]) ch[i] = 1;  // :437-475
+    int32_t *o = out + 3 * pb.meaOut;
+    int count = 0;
+    for (int i = n - 1; i >= 0; i--)  // the list conversions of :621-651 and :582 reverse the list three times
+        if (ch[i] == 1) {
+            o[3 * count] = pairs[3 * i];
+            o[3 * count + 1] = pairs[3 * i + 1];
+            o[3 * count + 2] = pairs[3 * i + 2];
+            count++;
+        }
+    counts[2 * p] = count;
+}
+
+// Scores of the final list (list 0, or the ordered alignment when fromOut): scoreByPosteriorProbability[IgnoringGaps]
+// (:1578-1597) when posterior != 0, scoreByIdentity[IgnoringGaps] (:1562-1580) when chars are given.  One workgroup per
+// problem.  chars are upper-case already.
+__global__ void __launch_bounds__(256) cpecan_post_list_scores(const CpkPostProblem *problems, const int32_t *triples,
+                                                               const int32_t *out, const int32_t *counts, int fromOut,
+                                                               int posterior, const uint8_t *chars, double *scores) {
+    const CpkPostProblem pb = problems[blockIdx.x];
+    const int32_t *t = fromOut ? out + 3 * pb.meaOut : triples + 3 * pb.off[0];
+    const int n = fromOut ? counts[2 * blockIdx.x] : pb.n[0];
+    __shared__ long long partial[2][256];
+    long long sum = 0, matches = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        sum += t[3 * i];
+        if (chars) {
+            const uint8_t a = chars[pb.charX + t[3 * i + 1]], b = chars[pb.charY + t[3 * i + 2]];
+            matches += (a == b) & (a != 'N');
+        }
+    }
+    partial[0][threadIdx.x] = sum;
+    partial[1][threadIdx.x] = matches;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) {
+            partial[0][threadIdx.x] += partial[0][threadIdx.x + off];
+            partial[1][threadIdx.x] += partial[1][threadIdx.x + off];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const long long L = (long long)pb.lX + pb.lY;
+        double *s = scores + kPostScores * blockIdx.x;
+        if (posterior) {
+            const double total = (double)partial[0][0];
+            s[0] = 100.0 * (L == 0 ? 0 : (2.0 * total) / (double)(L * CPECAN_PROB_1));
+            s[1] = 100.0 * total / ((double)n * CPECAN_PROB_1);
+        }
+        if (chars) {
+            const long long m = partial[1][0];
+            s[3] = 100.0 * (L == 0 ? 0 : (2.0 * (double)m) / (double)L);
+            s[4] = 100.0 * (double)m / (double)n;
+        }
+    }
 }

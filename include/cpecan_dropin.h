@@ -131,6 +131,11 @@ double computeForwardProbability(char *seqX, char *seqY, stList *anchorPairs, Pa
 stList *reweightAlignedPairs2(stList *alignedPairs, int64_t seqLengthX, int64_t seqLengthY, double gapGamma);
 double scoreByPosteriorProbability(int64_t lX, int64_t lY, stList *alignedPairs);
 double scoreByPosteriorProbabilityIgnoringGaps(stList *alignedPairs);
+double scoreByIdentity(char *subSeqX, char *subSeqY, int64_t lX, int64_t lY, stList *alignedPairs);
+double scoreByIdentityIgnoringGaps(char *subSeqX, char *subSeqY, stList *alignedPairs);
+/* inc/multipleAligner.h (impl/multipleAligner.c:945): consumes its input list.  The reference perturbs every weight by
+ * st_random() * 0.00001 before comparing (multipleAligner.c:145); this one does not. */
+stList *filterPairwiseAlignmentToMakePairsOrdered(stList *alignedPairs, const char *seqX, const char *seqY, float matchGamma);
 stList *getMaximalExpectedAccuracyPairwiseAlignment(stList *alignedPairs, stList *gapXPairs, stList *gapYPairs,
                                                     int64_t seqXLength, int64_t seqYLength, double *alignmentScore,
                                                     PairwiseAlignmentParameters *p);

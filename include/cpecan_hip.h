@@ -176,14 +176,25 @@ int cpecan_batch_stats(const cpecan_batch *b, cpecan_stats *s);
  *            is result list 3; gapGamma is used as the float of PairwiseAlignmentParameters
  * LEFT_SHIFT leftShiftAlignment (:1726) of the MEA alignment (list 3 then holds the shifted alignment): MEA | LEFT_SHIFT
  *            == getShiftedMEAAlignment (:1767)
- * REWEIGHT and MEA are alternatives in the reference's callers and exclude each other here. */
-enum { CPECAN_POST_REWEIGHT = 1, CPECAN_POST_MEA = 2, CPECAN_POST_LEFT_SHIFT = 4 };
+ * ORDERED    filterPairwiseAlignmentToMakePairsOrdered (impl/multipleAligner.c:945) on list 0 (after REWEIGHT, if set --
+ *            REWEIGHT | ORDERED is the realign step of cPecanRealign.c:552-553): the heaviest chain of the pairs whose
+ *            weight / PAIR_ALIGNMENT_PROB_1 reaches matchGamma, as result list 3, in the reference's output order
+ *            (reverse input order).  The reference adds st_random() * 0.00001 to every weight before it compares them
+ *            (multipleAligner.c:145); that jitter is left out here, so chains whose weights tie within it may differ.
+ * REWEIGHT and MEA are alternatives in the reference's callers and exclude each other here; so do ORDERED and MEA. */
+enum { CPECAN_POST_REWEIGHT = 1, CPECAN_POST_MEA = 2, CPECAN_POST_LEFT_SHIFT = 4, CPECAN_POST_ORDERED = 8 };
 /* Selects what cpecan_batch_download does to the lists before they leave the device. */
 int cpecan_batch_set_post(cpecan_batch *b, int flags, double gapGamma);
-/* After download: scoreByPosteriorProbability (:1587) and scoreByPosteriorProbabilityIgnoringGaps (:1591) of list 0 (as
- * downloaded, i.e. reweighted if REWEIGHT was set), and the MEA alignment score (0 without MEA). NULL = not wanted. */
+/* matchGamma of ORDERED (default 0.85f, cPecanRealign.c:355); a float, widened to double as the reference passes it. */
+int cpecan_batch_set_match_gamma(cpecan_batch *b, float matchGamma);
+/* After download: scoreByPosteriorProbability (:1587) and scoreByPosteriorProbabilityIgnoringGaps (:1591) of the final
+ * list -- list 0 as downloaded (reweighted if REWEIGHT was set), or the ordered alignment with ORDERED, as
+ * cPecanRealign.c:556-563 scores it -- and the MEA alignment score (0 without MEA). NULL = not wanted. */
 int cpecan_batch_scores(const cpecan_batch *b, int64_t problem, double *byPosterior, double *byPosteriorIgnoringGaps,
                         double *meaScore);
+/* scoreByIdentity (:1572) and scoreByIdentityIgnoringGaps (:1577) of the same final list; needs a consumer stage to
+ * have been selected (any flag). */
+int cpecan_batch_identity_scores(const cpecan_batch *b, int64_t problem, double *byIdentity, double *byIdentityIgnoringGaps);
 
 /* Debug / test hook: for single-region problem i, copies the per-cell forward+backward match sums
  * (fb[cell] = F.match + B.match at emit time) and the total log-probability used for each diagonal.
@@ -214,6 +225,13 @@ int cpecan_reweight_aligned_pairs(int32_t *triples, int64_t n, int64_t lX, int64
 /* scoreByPosteriorProbability / ...IgnoringGaps (:1587-1597). */
 int cpecan_posterior_scores(const int32_t *triples, int64_t n, int64_t lX, int64_t lY, double *byPosterior,
                             double *byPosteriorIgnoringGaps);
+/* scoreByIdentity / scoreByIdentityIgnoringGaps (:1572-1580). */
+int cpecan_identity_scores(const int32_t *triples, int64_t n, const char *sX, const char *sY, double *byIdentity,
+                           double *byIdentityIgnoringGaps);
+/* filterPairwiseAlignmentToMakePairsOrdered (impl/multipleAligner.c:945), without the reference's random jitter (see
+ * CPECAN_POST_ORDERED); the pairs must be distinct cells; *out is malloc'd (cpecan_free). */
+int cpecan_filter_pairs_ordered(const int32_t *pairs, int64_t n, int64_t lX, int64_t lY, float matchGamma, int32_t **out,
+                                int64_t *nOut);
 /* getMaximalExpectedAccuracyPairwiseAlignment (:1628): *out is malloc'd (cpecan_free). */
 int cpecan_mea_alignment(const int32_t *pairs, int64_t n, const int32_t *gapX, int64_t nGapX, const int32_t *gapY,
                          int64_t nGapY, int64_t lX, int64_t lY, float gapGamma, int32_t **out, int64_t *nOut,

@@ -1058,3 +1058,112 @@ int64_t orc_left_shift_alignment(const int64_t *pairs, int64_t n, const char *sX
         }
     return count;
 }
+
+/* ---- filterPairwiseAlignmentToMakePairsOrdered, impl/multipleAligner.c:945-972, and the identity scores ---- */
+
+/* getNumberOfMatchingAlignedPairs, impl/pairwiseAligner.c:1562-1570 */
+static int64_t matching_pairs(const char *sX, const char *sY, const int64_t *triples, int64_t n) {
+    int64_t matches = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const int cx = up(sX[triples[3 * i + 1]]), cy = up(sY[triples[3 * i + 2]]);
+        matches += cx == cy && cx != 'N';
+    }
+    return matches;
+}
+
+double orc_score_by_identity(const char *sX, const char *sY, int64_t lX, int64_t lY, const int64_t *triples, int64_t n) {
+    const int64_t matches = matching_pairs(sX, sY, triples, n); /* :1572-1575 */
+    return 100.0 * ((lX + lY) == 0 ? 0 : (2.0 * matches) / (lX + lY));
+}
+
+double orc_score_by_identity_ignoring_gaps(const char *sX, const char *sY, const int64_t *triples, int64_t n) {
+    return 100.0 * matching_pairs(sX, sY, triples, n) / (double)n; /* :1577-1580 */
+}
+
+typedef struct {
+    int64_t y, pair; /* pair: index of the aligned pair, -1 for the buffering first pair (multipleAligner.c:378) */
+    double score;
+} FrontierEntry;
+
+static const int64_t *g_sortPairs;
+static int cmp_pair_by_xy(const void *a, const void *b) {
+    const int64_t i = *(const int64_t *)a, j = *(const int64_t *)b;
+    const int64_t *p = g_sortPairs + 3 * i, *q = g_sortPairs + 3 * j;
+    if (p[1] != q[1]) return p[1] < q[1] ? -1 : 1;
+    if (p[2] != q[2]) return p[2] < q[2] ? -1 : 1;
+    return i < j ? -1 : (i > j ? 1 : 0);
+}
+
+int64_t orc_filter_pairs_ordered(const int64_t *pairs, int64_t n, int64_t lX, int64_t lY, double matchGamma, int64_t *out) {
+    /* With two sequences every column holds one base, every weight links one X base to one Y base with
+     * numberOfWeights == 1 (multipleAligner.c:140-147), both sequences carry the same number of weights so X stays X
+     * (:361-367), and getMultipleSequenceAlignmentProgressive makes the single call of pairwiseAlignColumns (:358-492)
+     * restated here.  The st_random() * 0.00001 added to every weight (:145) is left out. */
+    (void)lX;
+    int64_t *order = malloc(sizeof(int64_t) * (size_t)(n + 1));
+    int64_t *pred = malloc(sizeof(int64_t) * (size_t)(n + 1));
+    double *score = malloc(sizeof(double) * (size_t)(n + 1));
+    char *chosen = calloc((size_t)n + 1, 1);
+    FrontierEntry *f = malloc(sizeof(FrontierEntry) * (size_t)(n + 2)); /* bestScoringAlignments, sorted by y (:375) */
+    for (int64_t i = 0; i < n; i++) order[i] = i;
+    g_sortPairs = pairs;
+    qsort(order, (size_t)n, sizeof(int64_t), cmp_pair_by_xy); /* the adjacency lists: per X column, by Y position */
+    int64_t nf = 0;
+    f[nf++] = (FrontierEntry){-1, -1, 0.0};
+    f[nf++] = (FrontierEntry){lY, -2, (double)INT64_MAX}; /* :379 */
+    for (int64_t a = 0; a < n;) {
+        int64_t b = a;
+        while (b < n && pairs[3 * order[b] + 1] == pairs[3 * order[a] + 1]) b++;
+        /* all pairs of this X column are scored against the pairs of earlier columns (:389-409) ... */
+        for (int64_t k = a; k < b; k++) {
+            const int64_t i = order[k];
+            const double w = (double)pairs[3 * i] / ORC_PROB_1;
+            pred[i] = -3; /* not a candidate */
+            if (w >= matchGamma && w > 0.0) {
+                int64_t at = 0; /* searchLessThan: the entry with the largest y below this one */
+                while (f[at + 1].y < pairs[3 * i + 2]) at++;
+                pred[i] = f[at].pair;
+                score[i] = f[at].score + w * 1.0;
+            }
+        }
+        /* ... and then put into the frontier from the right (:412-433) */
+        for (int64_t k = b - 1; k >= a; k--) {
+            const int64_t i = order[k];
+            if (pred[i] == -3) continue;
+            const int64_t y = pairs[3 * i + 2];
+            int64_t at = 0; /* searchGreaterThanOrEqual */
+            while (f[at].y < y) at++;
+            if (score[i] >= f[at].score || f[at].y > y) {
+                int64_t end = at;
+                while (score[i] >= f[end].score) end++; /* entries at or right of y that score no better */
+                if (end == at) { /* make room */
+                    memmove(&f[at + 1], &f[at], sizeof(FrontierEntry) * (size_t)(nf - at));
+                    nf++;
+                } else if (end > at + 1) {
+                    memmove(&f[at + 1], &f[end], sizeof(FrontierEntry) * (size_t)(nf - end));
+                    nf -= end - at - 1;
+                }
+                f[at] = (FrontierEntry){y, i, score[i]};
+            }
+        }
+        a = b;
+    }
+    /* trace back from the right-most, i.e. best, entry (:437-475) */
+    for (int64_t i = f[nf - 2].pair; i >= 0; i = pred[i]) chosen[i] = 1;
+    /* filterMultipleAlignedPairs keeps the pairs whose bases share a column (:569-601); the three list conversions
+     * (:621-651, :582) pop from the back, which leaves the survivors in reverse input order */
+    int64_t count = 0;
+    for (int64_t i = n - 1; i >= 0; i--)
+        if (chosen[i]) {
+            out[3 * count] = pairs[3 * i];
+            out[3 * count + 1] = pairs[3 * i + 1];
+            out[3 * count + 2] = pairs[3 * i + 2];
+            count++;
+        }
+    free(order);
+    free(pred);
+    free(score);
+    free(chosen);
+    free(f);
+    return count;
+}

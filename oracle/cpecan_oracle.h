@@ -170,6 +170,16 @@ int64_t orc_mea_alignment(const int64_t *pairs, int64_t n, const int64_t *gapX, 
                           int64_t nGapY, int64_t lX, int64_t lY, float gapGamma, int64_t *out, double *alignmentScore);
 /* leftShiftAlignment, :1726-1762.  out holds n + min(lX, lY) + 1 triples; returns the number written. */
 int64_t orc_left_shift_alignment(const int64_t *pairs, int64_t n, const char *sX, const char *sY, int64_t *out);
+/* scoreByIdentity / scoreByIdentityIgnoringGaps, :1562-1580 */
+double orc_score_by_identity(const char *sX, const char *sY, int64_t lX, int64_t lY, const int64_t *triples, int64_t n);
+double orc_score_by_identity_ignoring_gaps(const char *sX, const char *sY, const int64_t *triples, int64_t n);
+/* filterPairwiseAlignmentToMakePairsOrdered, impl/multipleAligner.c:945-972 (the two-sequence case of
+ * pairwiseAlignColumns, :358-492): the heaviest chain of pairs with weight >= matchGamma, as a filter of the input list;
+ * the survivors come out in reverse input order.  The reference adds st_random() * 0.00001 to every weight (:145), so
+ * its own output is not a function of its input; this restatement leaves the jitter out -- PARITY UNPINNED (the
+ * reference's test of pairwiseAlignColumns, tests/multipleAlignerTest.c, checks properties only, which the tests here
+ * repeat).  The pairs must be distinct cells.  out holds n triples; returns the number written. */
+int64_t orc_filter_pairs_ordered(const int64_t *pairs, int64_t n, int64_t lX, int64_t lY, double matchGamma, int64_t *out);
 
 void orc_free(void *p);
 

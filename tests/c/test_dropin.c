@@ -178,6 +178,23 @@ static void test_consumers_gpu(void) {
     CHECK(stIntTuple_get(stList_get(l, 0), 0) == 3500000 && stIntTuple_get(stList_get(l, 1), 0) == -1000000);
     stList_destruct(l);
 
+    /* identity scores (:1562-1580) and the ordered filter (impl/multipleAligner.c:945) on a hand-checked case: the
+     * diagonal chain outweighs the heavy off-diagonal pair; the survivors come back in reverse input order */
+    stList *o = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    stList_append(o, stIntTuple_construct3(6000000, 0, 0));
+    stList_append(o, stIntTuple_construct3(9000000, 0, 2));
+    stList_append(o, stIntTuple_construct3(5000000, 1, 1));
+    stList_append(o, stIntTuple_construct3(4000000, 2, 2));
+    CHECK(fabs(scoreByIdentity("ACn", "AGN", 3, 3, o) - 100.0 * 2 * 1 / 6.0) < 1e-12);
+    CHECK(fabs(scoreByIdentityIgnoringGaps("ACn", "AGN", o) - 100.0 * 1 / 4.0) < 1e-12);
+    o = filterPairwiseAlignmentToMakePairsOrdered(o, "ACG", "ACG", 0.1f);
+    CHECK(stList_length(o) == 3);
+    if (stList_length(o) == 3) {
+        CHECK(stIntTuple_get(stList_get(o, 0), 1) == 2 && stIntTuple_get(stList_get(o, 0), 0) == 4000000);
+        CHECK(stIntTuple_get(stList_get(o, 1), 1) == 1 && stIntTuple_get(stList_get(o, 2), 1) == 0);
+    }
+    stList_destruct(o);
+
     /* MEA of two crossing pairs without gap mass keeps the heavier one; getShiftedMEAAlignment returns a chain */
     stList *a = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
     stList_append(a, stIntTuple_construct3(4000000, 1, 0));

@@ -122,6 +122,12 @@ def lib():
                                         i64p, dp]
         L.orc_left_shift_alignment.restype = C.c_int64
         L.orc_left_shift_alignment.argtypes = [i64p, C.c_int64, C.c_char_p, C.c_char_p, i64p]
+        L.orc_score_by_identity.restype = C.c_double
+        L.orc_score_by_identity.argtypes = [C.c_char_p, C.c_char_p, C.c_int64, C.c_int64, i64p, C.c_int64]
+        L.orc_score_by_identity_ignoring_gaps.restype = C.c_double
+        L.orc_score_by_identity_ignoring_gaps.argtypes = [C.c_char_p, C.c_char_p, i64p, C.c_int64]
+        L.orc_filter_pairs_ordered.restype = C.c_int64
+        L.orc_filter_pairs_ordered.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int64, C.c_double, i64p]
         L.orc_trace_free.argtypes = [C.POINTER(Trace)]
         L.orc_free.argtypes = [C.c_void_p]
         _lib = L
@@ -338,4 +344,24 @@ def left_shift_alignment(pairs, sx, sy):
     a, pa, n = _triples(pairs)
     out = np.zeros((n + min(len(sx), len(sy)) + 1, 3), dtype=np.int64)
     cnt = lib().orc_left_shift_alignment(pa, n, _b(sx), _b(sy), out.ctypes.data_as(C.POINTER(C.c_int64)))
+    return out[:cnt].copy()
+
+
+def score_by_identity(sx, sy, triples):
+    a, pa, n = _triples(triples)
+    return lib().orc_score_by_identity(_b(sx), _b(sy), len(sx), len(sy), pa, n)
+
+
+def score_by_identity_ignoring_gaps(sx, sy, triples):
+    a, pa, n = _triples(triples)
+    return lib().orc_score_by_identity_ignoring_gaps(_b(sx), _b(sy), pa, n)
+
+
+def filter_pairs_ordered(pairs, lX, lY, match_gamma):
+    """filterPairwiseAlignmentToMakePairsOrdered without the reference's random jitter; matchGamma is the float of
+    cPecanRealign.c:355 widened to double, as the reference passes it."""
+    a, pa, n = _triples(pairs)
+    out = np.zeros((max(n, 1), 3), dtype=np.int64)
+    cnt = lib().orc_filter_pairs_ordered(pa, n, lX, lY, float(np.float32(match_gamma)),
+                                         out.ctypes.data_as(C.POINTER(C.c_int64)))
     return out[:cnt].copy()

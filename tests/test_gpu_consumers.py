@@ -166,3 +166,78 @@ def test_realign_flow_end_to_end():
             # scores may differ by one unit before reweighting (device exp vs libm): reweight what the GPU produced
             plain = api.getAlignedPairsUsingAnchors(_sm(0), sx, sy, a, p, True, True)
             assert (got.astype(np.int64) == ob.reweight_aligned_pairs(plain, len(sx), len(sy), gamma)).all()
+
+
+def _as_tuples(a):
+    return [tuple(int(v) for v in r) for r in np.asarray(a).reshape(-1, 3)]
+
+
+def test_filter_pairs_ordered_vs_oracle():
+    """filterPairwiseAlignmentToMakePairsOrdered (impl/multipleAligner.c:945-972): the device's Fenwick-tree chain against
+    the oracle's frontier restatement of pairwiseAlignColumns, on random lists with many exact ties and on real posterior
+    lists; identical lists in identical order."""
+    rng = random.Random(23)
+    for trial in range(120):
+        lX, lY = rng.randrange(1, 60), rng.randrange(1, 60)
+        cells = list({(rng.randrange(lX), rng.randrange(lY)) for _ in range(rng.randrange(0, 200))})
+        rng.shuffle(cells)
+        coarse = trial % 2 == 0
+        pairs = [((rng.randrange(0, 11) * 1000000) if coarse else rng.randrange(-1000, 10000001), x, y) for x, y in cells]
+        gamma = rng.choice([0.0, 0.1, 0.5, 0.85])
+        got = api.filterPairwiseAlignmentToMakePairsOrdered(pairs, "A" * lX, "A" * lY, gamma)
+        want = ob.filter_pairs_ordered(pairs, lX, lY, gamma)
+        assert _as_tuples(got) == _as_tuples(want)
+    p = api.pairwiseAlignmentBandingParameters_construct(threshold=0.001)
+    for sx, sy, a in _problems(rng, 10, 60, 300):
+        pairs = api.getAlignedPairsUsingAnchors(_sm(0), sx, sy, a, p)
+        for gamma in (0.0, 0.3, 0.85):
+            got = api.filterPairwiseAlignmentToMakePairsOrdered(pairs, sx, sy, gamma)
+            want = ob.filter_pairs_ordered(pairs, len(sx), len(sy), gamma)
+            assert _as_tuples(got) == _as_tuples(want)
+            chain = sorted(_as_tuples(got), key=lambda t: t[1])
+            assert all(u[1] < v[1] and u[2] < v[2] for u, v in zip(chain, chain[1:]))  # checkAlignment's property
+
+
+def test_identity_scores_vs_oracle():
+    rng = random.Random(29)
+    p = api.pairwiseAlignmentBandingParameters_construct()
+    for sx, sy, a in _problems(rng, 10):
+        sx = "".join(c.lower() if rng.random() < 0.2 else ("N" if rng.random() < 0.05 else c) for c in sx)
+        pairs = api.getAlignedPairsUsingAnchors(_sm(0), sx, sy, a, p)
+        assert api.scoreByIdentity(sx, sy, len(sx), len(sy), pairs) == ob.score_by_identity(sx, sy, pairs)
+        if len(pairs):
+            assert api.scoreByIdentityIgnoringGaps(sx, sy, pairs) == ob.score_by_identity_ignoring_gaps(sx, sy, pairs)
+    assert api.scoreByIdentity("ACGT", "ACGT", 4, 4, []) == 0.0
+
+
+def test_batch_realign_step_reweight_then_ordered():
+    """cPecanRealign.c:552-563 as one consumer stage of the batch: reweightAlignedPairs2, then
+    filterPairwiseAlignmentToMakePairsOrdered, then the four scores of the ordered list."""
+    rng = random.Random(31)
+    probs = _problems(rng, 40, 30, 220)
+    p = api.pairwiseAlignmentBandingParameters_construct(splitMatrixBiggerThanThis=900)
+    gap_gamma, match_gamma = float(np.float32(0.5)), 0.6
+    with api.Batch(_sm(0), p) as b:
+        b.set_post(api.POST_REWEIGHT | api.POST_ORDERED, gap_gamma, match_gamma)
+        for sx, sy, a in probs:
+            b.add(sx, sy, a, True, True)
+        b.upload()
+        b.run()
+        b.download()
+        for i, (sx, sy, a) in enumerate(probs):
+            reweighted = b.result(i)  # list 0, as the device reweighted it
+            want = ob.filter_pairs_ordered(reweighted, len(sx), len(sy), match_gamma)
+            got = b.result(i, 3)
+            assert _as_tuples(got) == _as_tuples(want)
+            by_post, by_post_ig, _ = b.scores(i)
+            by_id, by_id_ig = b.identity_scores(i)
+            assert by_post == ob.score_by_posterior(len(sx), len(sy), want)
+            assert by_id == ob.score_by_identity(sx, sy, want)
+            if len(want):
+                assert by_post_ig == ob.score_by_posterior_ignoring_gaps(want)
+                assert by_id_ig == ob.score_by_identity_ignoring_gaps(sx, sy, want)
+            else:
+                assert np.isnan(by_post_ig) and np.isnan(by_id_ig)  # 0 / 0, as in the reference
+    with api.Batch(_sm(0), p, api.EMIT_INDEL) as b:
+        with pytest.raises(api.CpecanError):
+            b.set_post(api.POST_ORDERED | api.POST_MEA, 0.5)

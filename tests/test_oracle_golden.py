@@ -343,3 +343,64 @@ def test_mea_alignment_properties():
             best[i] = w + max([best[j] for j in range(len(pairs)) if pairs[j][1] < x and pairs[j][2] < y and j < i] + [0])
         assert score == max(best)
         assert sum(int(v) for v in got[:, 0]) == score
+
+
+def _heaviest_chain(pairs, gamma):
+    """Independent O(n^2) statement of what pairwiseAlignColumns maximises (multipleAligner.c:358-492)."""
+    g = float(np.float32(gamma))
+    cand = sorted((x, y, w / 1e7) for w, x, y in pairs if w / 1e7 >= g and w > 0)
+    best = []
+    for i, (x, y, w) in enumerate(cand):
+        best.append(w + max([best[j] for j in range(i) if cand[j][0] < x and cand[j][1] < y] + [0.0]))
+    return max(best + [0.0])
+
+
+def test_filter_pairs_ordered_by_hand():
+    """filterPairwiseAlignmentToMakePairsOrdered (multipleAligner.c:945-972), jitter-free: hand-worked cases, ties included."""
+    P = 10000000
+    # the diagonal chain (0,0),(1,1),(2,2) outweighs the single heavy off-diagonal pair; output is in reverse input order
+    pairs = [(int(.6 * P), 0, 0), (int(.9 * P), 0, 2), (int(.5 * P), 1, 1), (int(.4 * P), 2, 2), (int(.05 * P), 2, 0)]
+    got = ob.filter_pairs_ordered(pairs, 3, 3, 0.1)
+    assert [tuple(int(v) for v in r) for r in got] == [pairs[3], pairs[2], pairs[0]]
+    # raise matchGamma above the chain's weakest links: only the heavy pair is a candidate
+    got = ob.filter_pairs_ordered(pairs, 3, 3, 0.85)
+    assert [tuple(int(v) for v in r) for r in got] == [pairs[1]]
+    # equal-weight alternatives: the entry with the smaller y is the one the frontier keeps (:418-427)
+    pairs = [(int(.5 * P), 0, 1), (int(.5 * P), 1, 0)]
+    got = ob.filter_pairs_ordered(pairs, 2, 2, 0.0)
+    assert [tuple(int(v) for v in r) for r in got] == [pairs[1]]
+    # non-positive weights never enter (:393), even with matchGamma 0; an empty list stays empty
+    assert len(ob.filter_pairs_ordered([(0, 0, 0), (-5, 1, 1)], 2, 2, 0.0)) == 0
+    assert len(ob.filter_pairs_ordered([], 4, 4, 0.0)) == 0
+
+
+def test_filter_pairs_ordered_properties():
+    """As the reference's test of pairwiseAlignColumns (tests/multipleAlignerTest.c:124-148, checkAlignment): the kept
+    pairs are consistent (strictly increasing in both coordinates once sorted) and drawn from the input; and the chain is
+    the heaviest one among pairs of weight >= matchGamma."""
+    import random
+    rng = random.Random(11)
+    for trial in range(200):
+        lX, lY = rng.randrange(1, 25), rng.randrange(1, 25)
+        cells = list({(rng.randrange(lX), rng.randrange(lY)) for _ in range(rng.randrange(0, 60))})
+        rng.shuffle(cells)
+        coarse = trial % 2 == 0  # coarse weights make exact ties common
+        pairs = [((rng.randrange(0, 11) * 1000000) if coarse else rng.randrange(-1000, 10000001), x, y) for x, y in cells]
+        gamma = rng.choice([0.0, 0.1, 0.5, 0.85])
+        got = [tuple(int(v) for v in r) for r in ob.filter_pairs_ordered(pairs, lX, lY, gamma)]
+        assert set(got) <= set(pairs)
+        index = {p: i for i, p in enumerate(pairs)}
+        assert [index[p] for p in got] == sorted((index[p] for p in got), reverse=True)
+        chain = sorted(got, key=lambda p: p[1])
+        assert all(a[1] < b[1] and a[2] < b[2] for a, b in zip(chain, chain[1:]))
+        assert all(w / 1e7 >= float(np.float32(gamma)) and w > 0 for w, _, _ in got)
+        assert abs(sum(w for w, _, _ in got) / 1e7 - _heaviest_chain(pairs, gamma)) < 1e-9
+
+
+def test_identity_scores_by_hand():
+    """scoreByIdentity / scoreByIdentityIgnoringGaps (:1562-1580): N never matches, case is ignored."""
+    sx, sy = "ACgTN", "aCCTN"
+    pairs = [(1, 0, 0), (1, 1, 1), (1, 2, 2), (1, 3, 3), (1, 4, 4)]
+    assert ob.score_by_identity(sx, sy, pairs) == 100.0 * 2 * 3 / 10
+    assert ob.score_by_identity_ignoring_gaps(sx, sy, pairs) == 100.0 * 3 / 5
+    assert ob.score_by_identity("", "", []) == 0.0
