@@ -24,6 +24,13 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(L, name), name
     assert declared == set(api.EXPORTS)
+    # the realign front end (include/cpecan_realign.h)
+    from cpecan_amd import realign
+    header = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "cpecan_realign.h")).read(), flags=re.S)
+    declared = set(re.findall(r"\b(cpecan_[a-z_0-9]+)\s*\(", header))
+    for name in sorted(declared):
+        assert hasattr(L, name), name
+    assert declared == set(realign.EXPORTS)
     # the reference-named layer: every function include/cpecan_dropin.h declares is exported too
     dropin = open(os.path.join(ROOT, "include", "cpecan_dropin.h")).read()
     dropin = re.sub(r"/\*.*?\*/", "", dropin, flags=re.S)

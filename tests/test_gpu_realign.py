@@ -1,0 +1,250 @@
+"""GPU tests of the realign front end (include/cpecan_realign.h; cPecanRealign.c:509-600), one batch per call.
+
+What the reference's own tests of cPecanRealign check (cPecanRealignTest.py:20-113) is repeated on synthetic cigars:
+--rescoreOriginalAlignment gives the input alignment back, the default mode keeps the coordinates, every rescoring mode
+gives a score in [0, 100].  On top of that the loop is compared, cigar by cigar, with the same steps made one at a time
+through the single-problem GPU entry points and the cigar helpers (each of which has its own parity test)."""
+import os
+import random
+import subprocess
+
+import numpy as np
+import pytest
+
+from cpecan_amd import api
+from cpecan_amd.realign import Cigar, Realigner, realign_options
+
+pytestmark = pytest.mark.gpu
+
+M, DX, IY = api.OP_MATCH, api.OP_INDEL_X, api.OP_INDEL_Y
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+COMP = {"A": "T", "C": "G", "G": "C", "T": "A", "N": "N", "a": "t", "c": "g", "g": "c", "t": "a"}
+
+
+def _revcomp(s):
+    return "".join(COMP[c] for c in reversed(s))
+
+
+def _world(rng, n_seqs=6, n_cigars=40):
+    """Sequences by name and cigars over parts of them: a 'true' alignment as operations (first and last a match, no two
+    neighbours of one type), the aligned stretch of Y derived from X's with substitutions, either strand."""
+    seqs, cigars = {}, []
+    flank = lambda: "".join(rng.choice("ACGT") for _ in range(rng.randrange(0, 30)))
+    for k in range(n_cigars):
+        ops, last = [], None
+        n_ops = 2 * rng.randrange(0, 8) + 1
+        for i in range(n_ops):
+            t = M if i % 2 == 0 else rng.choice([DX, IY])
+            ops.append((t, rng.randrange(1, 40) if t == M else rng.choice([1, 1, 2, 3, 6, 15])))
+        sx, sy = [], []
+        for t, n in ops:
+            for _ in range(n):
+                b = rng.choice("ACGT")
+                if t != IY:
+                    sx.append(b if rng.random() > 0.03 else b.lower())
+                if t != DX:
+                    sy.append(b if t != M or rng.random() > 0.12 else rng.choice("ACGTN"))
+        sx, sy = "".join(sx), "".join(sy)
+        strand1, strand2 = rng.random() < 0.75, rng.random() < 0.6
+        lx, ly = flank(), flank()
+        name1, name2 = "X%d" % k, "Y%d" % k
+        seqs[name1] = lx + (sx if strand1 else _revcomp(sx)) + flank()
+        seqs[name2] = ly + (sy if strand2 else _revcomp(sy)) + flank()
+        a = (len(lx), len(lx) + len(sx)) if strand1 else (len(lx) + len(sx), len(lx))
+        b = (len(ly), len(ly) + len(sy)) if strand2 else (len(ly) + len(sy), len(ly))
+        cigars.append(Cigar(name1, a[0], a[1], strand1, name2, b[0], b[1], strand2, float(rng.randrange(1, 5000)), ops))
+    return seqs, cigars
+
+
+def _sub(seqs, c):
+    x = seqs[c.contig1][min(c.start1, c.end1):max(c.start1, c.end1)]
+    y = seqs[c.contig2][min(c.start2, c.end2):max(c.start2, c.end2)]
+    return (x if c.strand1 else _revcomp(x)), (y if c.strand2 else _revcomp(y))
+
+
+def _realigner(seqs, **opts):
+    r = Realigner(options=realign_options(**opts))
+    for name, s in seqs.items():
+        r.add_sequence(name + " a description", s)
+    return r
+
+
+def _stepwise(seqs, c, o):
+    """One cigar through cPecanRealign.c:511-581 with one GPU call per step."""
+    sx, sy = _sub(seqs, c)
+    p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=o.params.diagonalExpansion,
+                                                         splitMatrixBiggerThanThis=o.params.splitMatrixBiggerThanThis)
+    anchors = api.convertPairwiseForwardStrandAlignmentToAnchorPairs(c.ops, 0, 0, o.constraintDiagonalTrim,
+                                                                     o.params.diagonalExpansion, sx, sy)
+    pairs = api.getAlignedPairsUsingAnchors(api.stateMachine5_construct(), sx, sy, [tuple(a) for a in anchors.tolist()], p,
+                                            True, True)
+    pairs = api.reweightAlignedPairs2(pairs, len(sx), len(sy), float(np.float32(o.gapGamma)))
+    final = api.filterPairwiseAlignmentToMakePairsOrdered(pairs, sx, sy, o.matchGamma)
+    xy = sorted((int(x), int(y)) for _, x, y in final.tolist())
+    out = Cigar.from_aligned_pairs(c.contig1, c.contig2, c.score, len(sx), len(sy), xy)
+    for side in ("1", "2"):  # rebasePairwiseAlignmentCoordinates (:232) back to the input's frame
+        strand = getattr(c, "strand" + side)
+        lo = min(getattr(c, "start" + side), getattr(c, "end" + side))
+        s, e = getattr(out, "start" + side) + lo, getattr(out, "end" + side) + lo
+        if not strand:
+            s, e = e, s
+        setattr(out, "start" + side, s)
+        setattr(out, "end" + side, e)
+        setattr(out, "strand" + side, strand)
+    return out, final, (sx, sy)
+
+
+def test_rescore_original_alignment_returns_the_input():
+    """cPecanRealignTest.py:20-32 (testCPecanRealignDummy) and :76-103 (scores between 0 and 100)."""
+    rng = random.Random(41)
+    seqs, cigars = _world(rng)
+    with _realigner(seqs, rescoreOriginalAlignment=1) as r:
+        assert r.realign(cigars) == cigars
+    for flag in ("rescoreByIdentity", "rescoreByPosteriorProb", "rescoreByIdentityIgnoringGaps",
+                 "rescoreByPosteriorProbIgnoringGaps"):
+        with _realigner(seqs, rescoreOriginalAlignment=1, **{flag: 1}) as r:
+            got = r.realign(cigars)
+        for a, b in zip(got, cigars):
+            assert a.same_coordinates(b) and a.ops == b.ops
+            assert 0.0 <= a.score <= 100.0
+        if flag == "rescoreByIdentityIgnoringGaps":  # every aligned column of the input that is a true match
+            for a, c in zip(got, cigars):
+                sx, sy = _sub(seqs, c)
+                cols = [(int(x), int(y)) for x, y, _ in
+                        api.convertPairwiseForwardStrandAlignmentToAnchorPairs(c.ops, 0, 0, 0, 4).tolist()]
+                same = sum(sx[x].upper() == sy[y].upper() != "N" for x, y in cols)
+                assert a.score == 100.0 * same / len(cols)
+
+
+def test_realign_keeps_coordinates_and_matches_the_stepwise_flow():
+    """cPecanRealignTest.py:34-45 (testCPecanRealign: same coordinates), then every cigar against the stepwise flow."""
+    rng = random.Random(43)
+    seqs, cigars = _world(rng, n_cigars=60)
+    o = realign_options()
+    with _realigner(seqs) as r:
+        got = r.realign(cigars)
+    assert len(got) == len(cigars)
+    changed = 0
+    for a, c in zip(got, cigars):
+        assert a.same_coordinates(c) and a.score == c.score
+        want, _, _ = _stepwise(seqs, c, o)
+        assert a == want
+        assert Cigar.parse(a.format()) == a  # consistent (checkPairwiseAlignment, :582)
+        changed += a.ops != c.ops
+    assert changed > 5  # the realignment does move indels
+    # the four rescoring modes, scored on the final pairs (:556-564)
+    score_fns = {
+        "rescoreByPosteriorProb": lambda f, sx, sy: api.scoreByPosteriorProbability(len(sx), len(sy), f),
+        "rescoreByPosteriorProbIgnoringGaps": lambda f, sx, sy: api.scoreByPosteriorProbabilityIgnoringGaps(f),
+        "rescoreByIdentity": lambda f, sx, sy: api.scoreByIdentity(sx, sy, len(sx), len(sy), f),
+        "rescoreByIdentityIgnoringGaps": lambda f, sx, sy: api.scoreByIdentityIgnoringGaps(sx, sy, f),
+    }
+    for flag, fn in score_fns.items():
+        with _realigner(seqs, **{flag: 1}) as r:
+            rescored = r.realign(cigars[:20])
+        for a, c in zip(rescored, cigars):
+            _, final, (sx, sy) = _stepwise(seqs, c, o)
+            if len(final):
+                assert a.score == fn(final, sx, sy)
+                assert 0.0 <= a.score <= 100.0
+
+
+def test_realign_options_change_the_flow_consistently():
+    rng = random.Random(47)
+    seqs, cigars = _world(rng, n_cigars=25)
+    for opts in (dict(gapGamma=0.0, matchGamma=0.5), dict(constraintDiagonalTrim=2, diagonalExpansion=8),
+                 dict(splitMatrixBiggerThanThis=400, gapGamma=0.9, matchGamma=0.0)):
+        o = realign_options(**opts)
+        with _realigner(seqs, **opts) as r:
+            got = r.realign(cigars)
+        for a, c in zip(got, cigars):
+            assert a == _stepwise(seqs, c, o)[0]
+
+
+def test_split_indels_longer_than_this():
+    """--splitIndelsLongerThanThis (:584-591): the realigned cigar cut by splitPairwiseAlignment."""
+    rng = random.Random(53)
+    seqs, cigars = _world(rng, n_cigars=40)
+    with _realigner(seqs) as r:
+        whole = r.realign(cigars)
+    with _realigner(seqs, splitIndelsLongerThanThis=4) as r:
+        pieces = r.realign(cigars)
+    want = [p for c in whole for p in c.split(4)]
+    assert pieces == want and len(pieces) > len(whole)
+
+
+def test_expectations_mode_sums_the_single_problem_expectations():
+    """--outputExpectations (:530-534, :497): the batch's counts against getExpectationsUsingAnchors cigar by cigar."""
+    rng = random.Random(59)
+    seqs, cigars = _world(rng, n_cigars=30)
+    o = realign_options()
+    acc = api.hmm_constructEmpty(0.000000000001, api.fiveState)
+    with _realigner(seqs) as r:
+        r.expectations(cigars, acc)
+    want = api.hmm_constructEmpty(0.000000000001, api.fiveState)
+    p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=4, splitMatrixBiggerThanThis=10)
+    sm = api.stateMachine5_construct()
+    for c in cigars:
+        sx, sy = _sub(seqs, c)
+        anchors = api.convertPairwiseForwardStrandAlignmentToAnchorPairs(c.ops, 0, 0, 0, 4, sx, sy)
+        api.getExpectationsUsingAnchors(sm, want, sx, sy, [tuple(a) for a in anchors.tolist()], p, True, True)
+    np.testing.assert_allclose(list(acc.transitions), list(want.transitions), rtol=1e-9)
+    np.testing.assert_allclose(list(acc.emissions), list(want.emissions), rtol=1e-9)
+    np.testing.assert_allclose(acc.likelihood, want.likelihood, rtol=1e-9)
+
+
+def test_command_line_end_to_end(tmp_path):
+    """The cpecan_realign binary: fasta files + cigars on stdin -> cigars on stdout, identical to the library call; the
+    posterior-probability files of the last cigar; the expectations file loads back as an HMM (cPecanEm's loop)."""
+    exe = os.path.join(ROOT, "cpecan_amd", "cpecan_realign")
+    assert os.path.exists(exe), "build the command line with make -C cpecan_amd/csrc"
+    rng = random.Random(61)
+    seqs, cigars = _world(rng, n_cigars=30)
+    names = sorted(seqs)
+    fa1, fa2 = tmp_path / "a.fa", tmp_path / "b.fa"
+    for path, part in ((fa1, names[::2]), (fa2, names[1::2])):
+        with open(path, "w") as f:
+            for n in part:
+                f.write(">%s some words\n" % n)
+                for i in range(0, len(seqs[n]), 37):
+                    f.write(seqs[n][i:i + 37] + "\n")
+    text = "".join(c.format() + "\n" for c in cigars)
+    post, allp = tmp_path / "post.tsv", tmp_path / "all.tsv"
+
+    def run(*args):
+        res = subprocess.run([exe, *args, str(fa1), str(fa2)], input=text, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr
+        return [line for line in res.stdout.split("\n") if line]
+
+    with _realigner(seqs, rescoreByPosteriorProb=1) as r:
+        want = [c.format() for c in r.realign(cigars)]
+    # a batch size that does not divide the input: several batches, same output
+    got = run("--rescoreByPosteriorProb", "--batch", "7", "--outputPosteriorProbs", str(post), "--outputAllPosteriorProbs",
+              str(allp))
+    assert got == want
+    _, final, (sx, sy) = _stepwise(seqs, cigars[-1], realign_options())
+    c = cigars[-1]
+    rows = [line.split("\t") for line in open(post).read().split("\n") if line]
+    assert len(rows) == len(final)
+    for (x, y, pr), (w, fx, fy) in zip(rows, final.tolist()):
+        tx = min(c.start1, c.end1) + (fx if c.strand1 else len(sx) - 1 - fx)  # transformCoordinate (:283)
+        ty = min(c.start2, c.end2) + (fy if c.strand2 else len(sy) - 1 - fy)
+        assert (int(x), int(y)) == (tx, ty) and pr == "%f" % (w / 1e7)
+    assert len(open(allp).read().split("\n")) - 1 >= len(rows)
+    assert run("-x") == [c.format() for c in cigars]
+    hmm_path = tmp_path / "expectations.hmm"
+    assert run("--outputExpectations", str(hmm_path)) == []
+    loaded = api.hmm_loadFromFile(str(hmm_path))
+    acc = api.hmm_constructEmpty(0.000000000001, api.fiveState)
+    with _realigner(seqs) as r:
+        r.expectations(cigars, acc)
+    np.testing.assert_allclose(list(loaded.transitions), list(acc.transitions), rtol=1e-6, atol=1e-5)  # %f text
+    # --loadHmm: the expectations, normalised as cPecanEm.py does between iterations, are the next iteration's model
+    api.hmm_normalise(loaded)
+    model_path = tmp_path / "model.hmm"
+    api.hmm_write(loaded, str(model_path))
+    res = subprocess.run([exe, "--loadHmm", str(model_path), str(fa1), str(fa2)], input=text, capture_output=True, text=True,
+                         timeout=300)
+    assert res.returncode == 0 and len([l for l in res.stdout.split("\n") if l]) == len(cigars)
+    bad = subprocess.run([exe, str(fa1)], input=text, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "no sequence named" in bad.stderr
