@@ -10,6 +10,7 @@
 #include <ctype.h>
 #include <math.h>
 #include <stdio.h>
+#include <omp.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -405,6 +406,7 @@ struct cpecan_batch {
     double *forward; /* [nRegions] in device order, FORWARD emitter */
     int32_t *results; /* every emitted triple of the batch, list-ordered: [list][problem][triple] */
     uint8_t *chars;   /* raw upper-case sequences (leftShiftAlignment compares letters, not symbols) */
+    int64_t *rectScratch, capRectScratch; /* split rectangles of the problem being added */
     int64_t nChars, capChars;
     int postFlags;    /* CPECAN_POST_* applied by download */
     double postGapGamma;
@@ -438,7 +440,9 @@ int64_t cpecan_anchors_from_alignment(const int64_t *ops, int64_t nOps, int64_t 
                 const int64_t ax = x + l, ay = y + l;
                 if (filter) {
                     if (ax < 0 || ay < 0 || ax >= lX || ay >= lY) return CPECAN_EINVAL;
-                    const int cx = toupper((unsigned char)sX[ax]), cy = toupper((unsigned char)sY[ay]);
+                    int cx = (unsigned char)sX[ax], cy = (unsigned char)sY[ay]; /* toupper, "C" locale */
+                    cx -= (cx >= 'a' && cx <= 'z') ? 'a' - 'A' : 0;
+                    cy -= (cy >= 'a' && cy <= 'z') ? 'a' - 'A' : 0;
                     if (cx != cy || cx == 'N') continue; /* cPecanRealign.c:277-281 */
                 }
                 anchors[3 * n] = ax;
@@ -456,6 +460,8 @@ int64_t cpecan_anchors_from_alignment(const int64_t *ops, int64_t nOps, int64_t 
 int cpecan_device_count(void) { return cpk_device_count(); }
 const char *cpecan_last_error(void) { return cpk_last_error(); }
 
+static void init_byte_tables(void);
+
 int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpecan_params *params, int emit,
                         int device) {
     if (!out || !model || !params) return CPECAN_EINVAL;
@@ -472,6 +478,7 @@ int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpe
         return CPECAN_EINVAL;
     }
     /* The GPU is bound at upload time: adding problems and planning (bands, schedules) are host-only integer work. */
+    init_byte_tables();
     cpecan_batch *b = calloc(1, sizeof *b);
     if (!b) return CPECAN_ENOMEM;
     b->model = *model;
@@ -510,6 +517,7 @@ void cpecan_batch_destroy(cpecan_batch *b) {
     free(b->segs);
     free(b->forward);
     free(b->chars);
+    free(b->rectScratch);
     free(b);
 }
 
@@ -519,14 +527,17 @@ int cpecan_batch_set_debug(cpecan_batch *b, int on) {
     return CPECAN_OK;
 }
 
-static uint8_t to_symbol(char c) { /* symbol_convertCharToSymbol, pairwiseAligner.c:317-334 */
-    switch (c) {
-    case 'A': case 'a': return 0;
-    case 'C': case 'c': return 1;
-    case 'G': case 'g': return 2;
-    case 'T': case 't': return 3;
-    default: return CPK_SYM_N;
+/* symbol_convertCharToSymbol (pairwiseAligner.c:317-334) and toupper as byte tables: both run over every base added */
+static uint8_t g_symbolOf[256], g_upperOf[256];
+static void init_byte_tables(void) { /* idempotent: every caller writes the same values */
+    for (int c = 0; c < 256; c++) {
+        g_symbolOf[c] = CPK_SYM_N;
+        g_upperOf[c] = (uint8_t)((c >= 'a' && c <= 'z') ? c - 'a' + 'A' : c);
     }
+    g_symbolOf['A'] = g_symbolOf['a'] = 0;
+    g_symbolOf['C'] = g_symbolOf['c'] = 1;
+    g_symbolOf['G'] = g_symbolOf['g'] = 2;
+    g_symbolOf['T'] = g_symbolOf['t'] = 3;
 }
 
 /* Appends N + symbols + N (so that index x addresses base x-1 and x = 0 / x = l+1 read as N). */
@@ -535,7 +546,7 @@ static int64_t append_symbols(cpecan_batch *b, const char *s, int64_t l) {
     const int64_t off = b->nSymbols;
     uint8_t *dst = b->symbols + off;
     dst[0] = CPK_SYM_N;
-    for (int64_t i = 0; i < l; i++) dst[i + 1] = to_symbol(s[i]);
+    for (int64_t i = 0; i < l; i++) dst[i + 1] = g_symbolOf[(unsigned char)s[i]];
     dst[l + 1] = CPK_SYM_N;
     b->nSymbols += l + 2;
     return off;
@@ -553,8 +564,8 @@ int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char
         if (x < 0 || y < 0 || x >= lX || y >= lY) return CPECAN_EINVAL;
         if (i > 0 && (x <= anchors[3 * (i - 1)] || y <= anchors[3 * (i - 1) + 1])) return CPECAN_EINVAL;
     }
-    int64_t *rects = malloc(sizeof(int64_t) * 4 * (size_t)(nAnchors + 2));
-    if (!rects) return CPECAN_ENOMEM;
+    if (grow((void **)&b->rectScratch, &b->capRectScratch, 4 * (nAnchors + 2), sizeof(int64_t))) return CPECAN_ENOMEM;
+    int64_t *rects = b->rectScratch; /* reused from call to call */
     int64_t nRects;
     if (b->emit == CPECAN_EMIT_FORWARD) { /* computeForwardProbability never splits (pairwiseAligner.c:936-949) */
         nRects = 1;
@@ -567,17 +578,14 @@ int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char
                                      raggedRight, rects);
     }
     if (nRects < 0) {
-        free(rects);
         return CPECAN_EINVAL;
     }
     if (grow((void **)&b->problems, &b->capProblems, b->nProblems + 1, sizeof(HostProblem)) ||
         grow((void **)&b->regions, &b->capRegions, b->nRegions + nRects, sizeof(HostRegion)) ||
         grow((void **)&b->anchors, &b->capAnchorVals, b->nAnchorVals + 3 * nAnchors, sizeof(int64_t))) {
-        free(rects);
         return CPECAN_ENOMEM;
     }
     if (grow((void **)&b->chars, &b->capChars, b->nChars + lX + lY + 1, 1)) {
-        free(rects);
         return CPECAN_ENOMEM;
     }
     HostProblem *pr = &b->problems[b->nProblems];
@@ -587,9 +595,9 @@ int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char
     pr->lX = lX;
     pr->lY = lY;
     pr->charX = b->nChars;
-    for (int64_t i = 0; i < lX; i++) b->chars[b->nChars++] = (uint8_t)toupper((unsigned char)sX[i]);
+    for (int64_t i = 0; i < lX; i++) b->chars[b->nChars++] = g_upperOf[(unsigned char)sX[i]];
     pr->charY = b->nChars;
-    for (int64_t i = 0; i < lY; i++) b->chars[b->nChars++] = (uint8_t)toupper((unsigned char)sY[i]);
+    for (int64_t i = 0; i < lY; i++) b->chars[b->nChars++] = g_upperOf[(unsigned char)sY[i]];
     int64_t next = 0; /* anchors are handed to regions in order, pairwiseAligner.c:1296-1308 */
     for (int64_t i = 0; i < nRects; i++) {
         const int64_t x1 = rects[4 * i], y1 = rects[4 * i + 1], x2 = rects[4 * i + 2], y2 = rects[4 * i + 3];
@@ -605,8 +613,7 @@ int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char
         r->seqXOff = append_symbols(b, sX + x1, r->lX);
         r->seqYOff = append_symbols(b, sY + y1, r->lY);
         if (r->seqXOff < 0 || r->seqYOff < 0) {
-            free(rects);
-            return CPECAN_ENOMEM;
+                return CPECAN_ENOMEM;
         }
         r->anchorOff = b->nAnchorVals / 3;
         while (next < nAnchors && anchors[3 * next] + anchors[3 * next + 1] < x2 + y2) {
@@ -619,7 +626,6 @@ int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char
             next++;
         }
     }
-    free(rects);
     return b->nProblems++;
 }
 
@@ -645,6 +651,18 @@ static int64_t default_out_cap(const cpecan_batch *b, const HostRegion *r) {
     int64_t cap = 6 * (r->lX + r->lY) + 64;
     if (b->params.threshold <= 0.0 || cap > r->cells) cap = r->cells;
     return cap < 1 ? 1 : cap;
+}
+
+/* Threads for the host's parallel loops: OpenMP's default is every hardware thread of the machine, which on a shared
+ * multi-GPU host is far more than this process's share; 16 unless CPECAN_THREADS or a smaller OMP_NUM_THREADS says otherwise. */
+int cpk_host_threads(void) {
+    const char *env = getenv("CPECAN_THREADS");
+    int n = env ? atoi(env) : 0;
+    if (n < 1) {
+        n = omp_get_max_threads();
+        if (n > 16) n = 16;
+    }
+    return n < 1 ? 1 : n;
 }
 
 int cpecan_batch_upload(cpecan_batch *b) {
@@ -691,7 +709,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
     }
     const int dynamic = b->emit == CPECAN_EMIT_FORWARD ? 0 : p->dynamicAnchorExpansion; /* :894: forward uses the static band */
     int64_t badRegion = -1;
-#pragma omp parallel
+#pragma omp parallel num_threads(cpk_host_threads())
     {
         /* cell offsets of the last traceBackDiagonals + 3 diagonals: the schedule looks that far back */
         const int64_t K = p->traceBackDiagonals + 3;

@@ -172,6 +172,7 @@ int cpk_device_debug_fetch(CpkDevice *dev, double *fb, int64_t cells, double *to
 int64_t cpk_device_bytes(const CpkDevice *dev);
 int cpk_device_waves(const CpkDevice *dev);
 void cpk_set_error(const char *fmt, ...);
+int cpk_host_threads(void); /* threads of the host's parallel loops (cpecan_host.c) */
 
 #ifdef __cplusplus
 }

@@ -13,8 +13,15 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "cpecan_internal.h"
+
+static double now_ms(void) {
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return 1e3 * (double)t.tv_sec + 1e-6 * (double)t.tv_nsec;
+}
 
 /* ------------------------------------------------------------------------------------------------
  * cigars
@@ -576,11 +583,14 @@ static int item_prepare(const cpecan_realigner *r, const cpecan_cigar *pA, Item 
     int64_t matches = 0;
     for (int64_t i = 0; i < pA->nOps; i++)
         if (pA->ops[2 * i] == CPECAN_OP_MATCH) matches += pA->ops[2 * i + 1];
-    it->anchors = malloc(sizeof(int64_t) * 3 * (size_t)(matches ? matches : 1));
     it->filtered = malloc(sizeof(int64_t) * 3 * (size_t)(matches ? matches : 1));
-    if (!it->anchors || !it->filtered) return CPECAN_ENOMEM;
-    it->nAnchors = cpecan_anchors_from_alignment(pA->ops, pA->nOps, 0, 0, r->opt.constraintDiagonalTrim,
-                                                 r->opt.params.diagonalExpansion, NULL, 0, NULL, 0, it->anchors);
+    if (!it->filtered) return CPECAN_ENOMEM;
+    if (r->opt.rescoreOriginalAlignment) { /* scoreAnchorPairs looks the unfiltered anchors up (:548) */
+        it->anchors = malloc(sizeof(int64_t) * 3 * (size_t)(matches ? matches : 1));
+        if (!it->anchors) return CPECAN_ENOMEM;
+        it->nAnchors = cpecan_anchors_from_alignment(pA->ops, pA->nOps, 0, 0, r->opt.constraintDiagonalTrim,
+                                                     r->opt.params.diagonalExpansion, NULL, 0, NULL, 0, it->anchors);
+    }
     it->nFiltered = cpecan_anchors_from_alignment(pA->ops, pA->nOps, 0, 0, r->opt.constraintDiagonalTrim,
                                                   r->opt.params.diagonalExpansion, it->subX, it->lX, it->subY, it->lY,
                                                   it->filtered);
@@ -663,10 +673,135 @@ static void host_scores(const Item *it, const int32_t *t, int64_t n, double s[4]
     s[3] = 100.0 * matches / (double)n;
 }
 
+static double g_stage[3]; /* upload, run, download of the last run_batch (CPECAN_REALIGN_TIMING only) */
 static int run_batch(cpecan_batch *b) {
+    const double t0 = now_ms();
     int rc = cpecan_batch_upload(b);
+    const double t1 = now_ms();
     if (rc == CPECAN_OK) rc = cpecan_batch_run(b, NULL);
+    const double t2 = now_ms();
     if (rc == CPECAN_OK) rc = cpecan_batch_download(b);
+    g_stage[0] = t1 - t0;
+    g_stage[1] = t2 - t1;
+    g_stage[2] = now_ms() - t2;
+    return rc;
+}
+
+/* cPecanRealign.c:511-529 for every cigar, in parallel (the cigars are independent).  An error message belongs to the
+ * thread that set it, so the first failing cigar is prepared once more on the calling thread. */
+static int prepare_range(const cpecan_realigner *r, const cpecan_cigar *in, int64_t from, int64_t to, Item *items) {
+    int64_t firstBad = to;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(cpk_host_threads())
+    for (int64_t i = from; i < to; i++)
+        if (item_prepare(r, &in[i], &items[i]) != CPECAN_OK) {
+#pragma omp critical(cpk_realign)
+            if (i < firstBad) firstBad = i;
+        }
+    if (firstBad == to) return CPECAN_OK;
+    item_clear(&items[firstBad]);
+    const int rc = item_prepare(r, &in[firstBad], &items[firstBad]);
+    return rc != CPECAN_OK ? rc : CPECAN_ESTATE;
+}
+
+/* Prepares the cigars a slice at a time and adds each slice to the batch (both ends ragged, :537); the anchor lists of a
+ * slice are released as soon as the batch holds them, so the next slice reuses their memory. */
+static int prepare_and_add(const cpecan_realigner *r, const cpecan_cigar *in, int64_t n, Item *items, cpecan_batch *b) {
+    const int64_t slice = 2048;
+    for (int64_t from = 0; from < n; from += slice) {
+        const int64_t to = from + slice < n ? from + slice : n;
+        int rc = prepare_range(r, in, from, to, items);
+        for (int64_t i = from; rc == CPECAN_OK && i < to; i++) {
+            const int64_t idx = cpecan_batch_add(b, items[i].subX, items[i].lX, items[i].subY, items[i].lY, items[i].filtered,
+                                                 items[i].nFiltered, 1, 1);
+            rc = idx < 0 ? (int)idx : CPECAN_OK;
+            free(items[i].filtered);
+            items[i].filtered = NULL;
+        }
+        if (rc != CPECAN_OK) return rc;
+    }
+    return CPECAN_OK;
+}
+
+/* The list a cigar is rebuilt from, and its four scores: the ordered alignment with the scores of the batch's consumer
+ * stage, or -- rescoreOriginalAlignment -- the input's own columns as the aligner scored them (:547-564). */
+static int final_list(const cpecan_realigner *r, const cpecan_batch *b, const Item *it, int64_t i, const int32_t **list,
+                      int32_t **owned, int64_t *nList, double s[4]) {
+    *owned = NULL;
+    if (r->opt.rescoreOriginalAlignment) {
+        const int32_t *all;
+        int64_t nAll;
+        int rc = cpecan_batch_result(b, i, 0, &all, &nAll);
+        if (rc == CPECAN_OK) rc = score_anchor_pairs(it, all, nAll, owned, nList);
+        if (rc != CPECAN_OK) return rc;
+        *list = *owned;
+        host_scores(it, *list, *nList, s);
+        return CPECAN_OK;
+    }
+    int rc = cpecan_batch_result(b, i, 3, list, nList);
+    if (rc == CPECAN_OK) rc = cpecan_batch_scores(b, i, &s[0], &s[1], NULL);
+    if (rc == CPECAN_OK) rc = cpecan_batch_identity_scores(b, i, &s[2], &s[3]);
+    return rc;
+}
+
+typedef struct {
+    cpecan_cigar *pieces;
+    int64_t n, cap;
+} OutSlot;
+
+/* cPecanRealign.c:556-591 for one cigar: score, cigar from the sorted pairs, rebase, optional split */
+static int build_output(const cpecan_realigner *r, const cpecan_batch *b, const cpecan_cigar *pA, const Item *it, int64_t i,
+                        OutSlot *slot) {
+    const cpecan_realign_options *o = &r->opt;
+    const int32_t *list = NULL;
+    int32_t *owned = NULL;
+    int64_t nList = 0;
+    double s[4] = {0, 0, 0, 0};
+    int rc = final_list(r, b, it, i, &list, &owned, &nList, s);
+    if (rc != CPECAN_OK) return rc;
+    double score = pA->score; /* :556-564 */
+    if (o->rescoreByPosteriorProb) score = s[0];
+    else if (o->rescoreByPosteriorProbIgnoringGaps) score = s[1];
+    else if (o->rescoreByIdentity) score = s[2];
+    else if (o->rescoreByIdentityIgnoringGaps) score = s[3];
+    int64_t *xy = malloc(sizeof(int64_t) * 2 * (size_t)(nList ? nList : 1));
+    cpecan_cigar rPA;
+    memset(&rPA, 0, sizeof rPA);
+    if (!xy) rc = CPECAN_ENOMEM;
+    if (rc == CPECAN_OK) {
+        int sorted = 1;
+        for (int64_t k = 0; k < nList; k++) {
+            xy[2 * k] = list[3 * k + 1];
+            xy[2 * k + 1] = list[3 * k + 2];
+            if (k > 0 && cmp_xy(&xy[2 * k - 2], &xy[2 * k]) > 0) sorted = 0;
+        }
+        if (!sorted) qsort(xy, (size_t)nList, 2 * sizeof(int64_t), cmp_xy); /* :573 */
+        rc = cigar_from_pairs(&rPA, pA->contig1, pA->contig2, score, it->lX, it->lY, xy, nList);
+    }
+    free(xy);
+    free(owned);
+    if (rc == CPECAN_OK) {
+        rebase(&rPA.start1, &rPA.end1, &rPA.strand1, it->shift1, it->flip1); /* :578-581 */
+        rebase(&rPA.start2, &rPA.end2, &rPA.strand2, it->shift2, it->flip2);
+        if (!cigar_consistent(&rPA)) {
+            cpk_set_error("internal: realigned cigar is inconsistent");
+            rc = CPECAN_ESTATE;
+        }
+    }
+    if (rc == CPECAN_OK && o->splitIndelsLongerThanThis != -1) {
+        rc = cigar_split(&rPA, o->splitIndelsLongerThanThis, &slot->pieces, &slot->n, &slot->cap);
+        cpecan_cigar_clear(&rPA);
+    } else if (rc == CPECAN_OK) {
+        slot->pieces = malloc(sizeof(cpecan_cigar));
+        if (slot->pieces) {
+            slot->pieces[0] = rPA;
+            slot->n = slot->cap = 1;
+        } else {
+            rc = CPECAN_ENOMEM;
+            cpecan_cigar_clear(&rPA);
+        }
+    } else {
+        cpecan_cigar_clear(&rPA);
+    }
     return rc;
 }
 
@@ -676,92 +811,63 @@ int cpecan_realigner_realign(cpecan_realigner *r, const cpecan_cigar *in, int64_
     *nOut = 0;
     const cpecan_realign_options *o = &r->opt;
     Item *items = calloc((size_t)(n ? n : 1), sizeof(Item));
+    OutSlot *slots = calloc((size_t)(n ? n : 1), sizeof(OutSlot));
     cpecan_cigar *res = NULL;
-    int64_t nRes = 0, capRes = 0;
+    int64_t nRes = 0;
     cpecan_batch *b = NULL;
-    int rc = items ? CPECAN_OK : CPECAN_ENOMEM;
+    int rc = items && slots ? CPECAN_OK : CPECAN_ENOMEM;
+    const int timing = getenv("CPECAN_REALIGN_TIMING") != NULL; /* stage times of this call on stderr */
+    const double t0 = now_ms();
     if (rc == CPECAN_OK) rc = cpecan_batch_create(&b, &r->model, &o->params, CPECAN_EMIT_MATCH, r->device);
     if (rc == CPECAN_OK && !o->rescoreOriginalAlignment) { /* :552-553 as the batch's consumer stage */
         rc = cpecan_batch_set_post(b, CPECAN_POST_REWEIGHT | CPECAN_POST_ORDERED, (double)o->gapGamma);
         if (rc == CPECAN_OK) rc = cpecan_batch_set_match_gamma(b, o->matchGamma);
     }
-    for (int64_t i = 0; rc == CPECAN_OK && i < n; i++) {
-        rc = item_prepare(r, &in[i], &items[i]);
-        if (rc == CPECAN_OK) {
-            const int64_t idx = cpecan_batch_add(b, items[i].subX, items[i].lX, items[i].subY, items[i].lY, items[i].filtered,
-                                                 items[i].nFiltered, 1, 1); /* both ends ragged (:537) */
-            rc = idx < 0 ? (int)idx : CPECAN_OK;
+    if (rc == CPECAN_OK) rc = prepare_and_add(r, in, n, items, b);
+    const double t1 = now_ms();
+    if (rc == CPECAN_OK && n > 0) rc = run_batch(b);
+    const double t2 = now_ms();
+    if (rc == CPECAN_OK) {
+        int64_t firstBad = n;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(cpk_host_threads())
+        for (int64_t i = 0; i < n; i++)
+            if (build_output(r, b, &in[i], &items[i], i, &slots[i]) != CPECAN_OK) {
+#pragma omp critical(cpk_realign)
+                if (i < firstBad) firstBad = i;
+            }
+        if (firstBad < n) { /* once more on this thread, for its error message */
+            cpecan_cigars_free(slots[firstBad].pieces, slots[firstBad].n);
+            memset(&slots[firstBad], 0, sizeof(OutSlot));
+            rc = build_output(r, b, &in[firstBad], &items[firstBad], firstBad, &slots[firstBad]);
+            if (rc == CPECAN_OK) rc = CPECAN_ESTATE;
         }
     }
-    if (rc == CPECAN_OK && n > 0) rc = run_batch(b);
-    for (int64_t i = 0; rc == CPECAN_OK && i < n; i++) {
-        const Item *it = &items[i];
+    if (rc == CPECAN_OK) {
+        for (int64_t i = 0; i < n; i++) nRes += slots[i].n;
+        res = malloc(sizeof(cpecan_cigar) * (size_t)(nRes ? nRes : 1));
+        if (!res) rc = CPECAN_ENOMEM;
+        for (int64_t i = 0, at = 0; rc == CPECAN_OK && i < n; i++) { /* ownership of the pieces moves to res */
+            if (slots[i].n) memcpy(res + at, slots[i].pieces, sizeof(cpecan_cigar) * (size_t)slots[i].n);
+            at += slots[i].n;
+            free(slots[i].pieces);
+            memset(&slots[i], 0, sizeof(OutSlot));
+        }
+    }
+    if (rc == CPECAN_OK && n > 0 && r->finalPairsPath) { /* the last cigar's final pairs (:566-570) */
         const int32_t *list = NULL;
         int32_t *owned = NULL;
         int64_t nList = 0;
-        double s[4] = {0, 0, 0, 0};
-        if (o->rescoreOriginalAlignment) {
-            const int32_t *all;
-            int64_t nAll;
-            rc = cpecan_batch_result(b, i, 0, &all, &nAll);
-            if (rc == CPECAN_OK) rc = score_anchor_pairs(it, all, nAll, &owned, &nList);
-            if (rc != CPECAN_OK) break;
-            list = owned;
-            host_scores(it, list, nList, s);
-        } else {
-            rc = cpecan_batch_result(b, i, 3, &list, &nList);
-            if (rc == CPECAN_OK) rc = cpecan_batch_scores(b, i, &s[0], &s[1], NULL);
-            if (rc == CPECAN_OK) rc = cpecan_batch_identity_scores(b, i, &s[2], &s[3]);
-            if (rc != CPECAN_OK) break;
-        }
-        double score = in[i].score; /* :556-564 */
-        if (o->rescoreByPosteriorProb) score = s[0];
-        else if (o->rescoreByPosteriorProbIgnoringGaps) score = s[1];
-        else if (o->rescoreByIdentity) score = s[2];
-        else if (o->rescoreByIdentityIgnoringGaps) score = s[3];
-        if (i == n - 1 && r->finalPairsPath) rc = write_pairs(r->finalPairsPath, list, nList, it);
-        int64_t *xy = malloc(sizeof(int64_t) * 2 * (size_t)(nList ? nList : 1));
-        if (!xy) rc = CPECAN_ENOMEM;
-        cpecan_cigar rPA;
-        memset(&rPA, 0, sizeof rPA);
-        if (rc == CPECAN_OK) {
-            for (int64_t k = 0; k < nList; k++) {
-                xy[2 * k] = list[3 * k + 1];
-                xy[2 * k + 1] = list[3 * k + 2];
-            }
-            qsort(xy, (size_t)nList, 2 * sizeof(int64_t), cmp_xy); /* :573 */
-            rc = cigar_from_pairs(&rPA, in[i].contig1, in[i].contig2, score, it->lX, it->lY, xy, nList);
-        }
-        free(xy);
+        double s[4];
+        rc = final_list(r, b, &items[n - 1], n - 1, &list, &owned, &nList, s);
+        if (rc == CPECAN_OK) rc = write_pairs(r->finalPairsPath, list, nList, &items[n - 1]);
         free(owned);
-        if (rc == CPECAN_OK) {
-            rebase(&rPA.start1, &rPA.end1, &rPA.strand1, it->shift1, it->flip1); /* :578-581 */
-            rebase(&rPA.start2, &rPA.end2, &rPA.strand2, it->shift2, it->flip2);
-            if (!cigar_consistent(&rPA)) {
-                cpk_set_error("internal: realigned cigar is inconsistent");
-                rc = CPECAN_ESTATE;
-            }
-        }
-        if (rc == CPECAN_OK && o->splitIndelsLongerThanThis != -1) {
-            rc = cigar_split(&rPA, o->splitIndelsLongerThanThis, &res, &nRes, &capRes);
-            cpecan_cigar_clear(&rPA);
-        } else if (rc == CPECAN_OK) {
-            if (nRes == capRes) {
-                capRes = capRes ? 2 * capRes : 16;
-                cpecan_cigar *grown = realloc(res, sizeof(cpecan_cigar) * (size_t)capRes);
-                if (!grown) rc = CPECAN_ENOMEM;
-                else res = grown;
-            }
-            if (rc == CPECAN_OK) res[nRes++] = rPA;
-            else cpecan_cigar_clear(&rPA);
-        } else {
-            cpecan_cigar_clear(&rPA);
-        }
     }
     if (rc == CPECAN_OK && n > 0 && r->allPairsPath) { /* every pair of the last alignment, before reweighting (:541-545) */
         cpecan_batch *raw = NULL;
-        const Item *it = &items[n - 1];
-        rc = cpecan_batch_create(&raw, &r->model, &o->params, CPECAN_EMIT_MATCH, r->device);
+        Item *it = &items[n - 1];
+        item_clear(it);
+        rc = item_prepare(r, &in[n - 1], it);
+        if (rc == CPECAN_OK) rc = cpecan_batch_create(&raw, &r->model, &o->params, CPECAN_EMIT_MATCH, r->device);
         if (rc == CPECAN_OK) {
             const int64_t idx = cpecan_batch_add(raw, it->subX, it->lX, it->subY, it->lY, it->filtered, it->nFiltered, 1, 1);
             rc = idx < 0 ? (int)idx : run_batch(raw);
@@ -772,9 +878,21 @@ int cpecan_realigner_realign(cpecan_realigner *r, const cpecan_cigar *in, int64_
         if (rc == CPECAN_OK) rc = write_pairs(r->allPairsPath, all, nAll, it);
         cpecan_batch_destroy(raw);
     }
+    if (timing && rc == CPECAN_OK && n > 0) {
+        cpecan_stats st;
+        cpecan_batch_stats(b, &st);
+        fprintf(stderr,
+                "cpecan_realign: %lld cigars, %lld regions, %lld cells, %lld pairs: prepare+add %.1f ms, batch %.1f ms "
+                "(plan+upload %.1f [h2d copy %.1f], launch %.1f, wait+consumers+download %.1f [DP kernel %.1f, d2h copy %.1f]), "
+                "cigars %.1f ms\n",
+                (long long)n, (long long)st.regions, (long long)st.cells, (long long)st.pairs, t1 - t0, t2 - t1, g_stage[0],
+                st.h2dMs, g_stage[1], g_stage[2], st.kernelMs, st.d2hMs, now_ms() - t2);
+    }
     cpecan_batch_destroy(b);
     for (int64_t i = 0; items && i < n; i++) item_clear(&items[i]);
     free(items);
+    for (int64_t i = 0; slots && i < n; i++) cpecan_cigars_free(slots[i].pieces, slots[i].n);
+    free(slots);
     if (rc != CPECAN_OK) {
         cpecan_cigars_free(res, nRes);
         return rc;
