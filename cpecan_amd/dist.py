@@ -69,3 +69,49 @@ def expectation_step(sM, problems, p, pseudo=1e-12, device_index=0, reduce_devic
     for i in range(S * 16):
         acc.emissions[i] += pseudo
     return acc
+
+
+def cost_balanced_bounds(costs, rank, world_size):
+    """Contiguous shard [lo, hi) of items with the given costs such that every rank gets about the same total cost
+    (cut points at the multiples of total / world_size in the running sum).  Contiguous, so outputs concatenate in input
+    order; with equal costs it reduces to shard_bounds up to rounding."""
+    c = np.asarray(costs, dtype=np.float64)
+    if len(c) == 0:
+        return 0, 0
+    run = np.concatenate([[0.0], np.cumsum(np.maximum(c, 0.0) + 1e-9)])
+    cuts = [int(np.searchsorted(run, run[-1] * k / world_size, side="left")) for k in range(world_size + 1)]
+    cuts[0], cuts[-1] = 0, len(c)
+    for k in range(1, world_size + 1):
+        cuts[k] = max(cuts[k], cuts[k - 1])
+    return cuts[rank], cuts[rank + 1]
+
+
+def cigar_cost(c, expansion=4):
+    """Band cells a cigar costs the aligner, near enough: diagonals times band width."""
+    return (abs(c.end1 - c.start1) + abs(c.end2 - c.start2) + 1) * (expansion + 1)
+
+
+def realign_sharded(cigars, realign_fn, expansion=4):
+    """BASELINE config 4 across GPUs: every rank realigns one contiguous, cost-balanced shard of the cigars with
+    realign_fn (its own Realigner, bound to its own GPU) -- no data-path collective -- and rank 0 receives the realigned
+    cigars of all ranks in input order (a gather of the result objects; None on the other ranks)."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    lo, hi = cost_balanced_bounds([cigar_cost(c, expansion) for c in cigars], rank, world)
+    mine = realign_fn(cigars[lo:hi])
+    if world == 1:
+        return mine
+    parts = [None] * world if rank == 0 else None
+    dist.gather_object(mine, parts, dst=0)
+    return [c for part in parts for c in part] if rank == 0 else None
+
+
+def realign_expectations_sharded(cigars, expectations_fn, hmm, expansion=4, reduce_device=None):
+    """--outputExpectations across GPUs: per-rank counts of a contiguous shard, then the one all-reduce of the EM step."""
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank() if world > 1 else 0
+    lo, hi = cost_balanced_bounds([cigar_cost(c, expansion) for c in cigars], rank, world)
+    expectations_fn(cigars[lo:hi], hmm)
+    return allreduce_hmm(hmm, reduce_device)

@@ -81,3 +81,53 @@ def test_hmm_vector_round_trip():
     assert v.shape == (58,)
     g = cdist.vector_to_hmm(v, api.hmm_constructEmpty(0.0, api.threeState))
     assert list(g.transitions)[:9] == list(h.transitions)[:9] and g.likelihood == h.likelihood
+
+
+def test_cost_balanced_bounds():
+    import random
+    rng = random.Random(3)
+    for _ in range(200):
+        n, w = rng.randrange(0, 300), rng.choice([1, 2, 3, 8])
+        costs = [rng.choice([1, 5, 100, 2000]) for _ in range(n)]
+        spans = [cdist.cost_balanced_bounds(costs, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(b == c for (_, b), (c, _) in zip(spans, spans[1:])) and all(a <= b for a, b in spans)
+        if n:
+            share = sum(costs) / w
+            for a, b in spans:  # no shard exceeds its share by more than one item
+                assert sum(costs[a:b]) <= share + max(costs) + 1e-6
+    assert [cdist.cost_balanced_bounds([1] * 10, r, 2) for r in range(2)] == [(0, 5), (5, 10)]
+
+
+def _realign_worker(rank, world, port, out_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from cpecan_amd.realign import Cigar
+    cigars = [Cigar("t", 0, 10 * (i + 1), True, "q", 0, 10 * (i + 1), True, float(i), [(0, 10 * (i + 1))]) for i in range(23)]
+
+    def fake_realign(shard):  # stands in for Realigner.realign on this rank's GPU: tags every cigar with the rank
+        return [Cigar(c.contig1, c.start1, c.end1, True, c.contig2, c.start2, c.end2, True, c.score + 1000 * (rank + 1), c.ops)
+                for c in shard]
+
+    got = cdist.realign_sharded(cigars, fake_realign)
+    if rank == 0:
+        np.save(out_path, np.array([c.score for c in got]))
+    else:
+        assert got is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_realign_sharding_keeps_input_order(tmp_path):
+    out = str(tmp_path / "scores.npy")
+    mp.spawn(_realign_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    scores = np.load(out)
+    assert len(scores) == 23
+    assert [int(s) % 1000 for s in scores] == list(range(23))  # input order kept
+    ranks = [int(s) // 1000 for s in scores]
+    assert ranks == sorted(ranks) and set(ranks) == {1, 2}  # contiguous shards, both ranks worked
+    cut = ranks.index(2)
+    cost = [10 * (i + 1) for i in range(23)]
+    assert abs(sum(cost[:cut]) - sum(cost[cut:])) <= max(cost) * 2  # balanced by cost, not by count
+    assert cut > 23 // 2
