@@ -248,3 +248,44 @@ def test_command_line_end_to_end(tmp_path):
     assert res.returncode == 0 and len([l for l in res.stdout.split("\n") if l]) == len(cigars)
     bad = subprocess.run([exe, str(fa1)], input=text, capture_output=True, text=True, timeout=300)
     assert bad.returncode != 0 and "no sequence named" in bad.stderr
+
+
+def test_degenerate_cigars():
+    """Empty alignments, alignments of indels only, a matchGamma nothing reaches, one-base sequences: no pair survives and
+    the cigar falls back to the unaligned ends (convertAlignedPairsToPairwiseAlignment's end pair, :56-87)."""
+    seqs = {"a": "ACGTACGTAC", "b": "ACGTTCGTAC", "n": "NNNNNNNNNN", "one": "G"}
+    cigars = [
+        Cigar("a", 3, 3, True, "b", 5, 5, True, 7.0, []),                      # nothing aligned at all
+        Cigar("a", 0, 5, True, "b", 0, 3, True, 7.0, [(DX, 5), (IY, 3)]),      # indels only: no anchors, full matrix
+        Cigar("a", 0, 10, True, "n", 0, 10, True, 7.0, [(M, 10)]),             # every anchor filtered (N never matches)
+        Cigar("one", 0, 1, True, "one", 1, 0, False, 7.0, [(M, 1)]),           # one base against its reverse complement
+        Cigar("a", 0, 10, True, "b", 0, 10, True, 7.0, [(M, 10)]),
+    ]
+    o = realign_options()
+    with _realigner(seqs) as r:
+        got = r.realign(cigars)
+    assert len(got) == len(cigars)
+    for a, c in zip(got, cigars):
+        assert a.same_coordinates(c)
+        assert a == _stepwise(seqs, c, o)[0]
+    assert got[0].ops == []
+    assert got[4].ops == [(M, 10)]
+    with _realigner(seqs, matchGamma=1.5) as r:  # a posterior never reaches 1.5
+        none = r.realign(cigars)
+    assert none[4].ops == [(DX, 10), (IY, 10)] and none[1].ops == [(DX, 5), (IY, 3)]
+    with _realigner(seqs, rescoreOriginalAlignment=1, rescoreByPosteriorProb=1, constraintDiagonalTrim=2) as r:
+        trimmed = r.realign(cigars[4:])
+    # -x with a trim: only the untrimmed columns are anchors, the rest of the match run comes back as indels (:548)
+    assert trimmed[0].ops == [(DX, 2), (IY, 2), (M, 6), (DX, 2), (IY, 2)] and 0.0 <= trimmed[0].score <= 100.0
+    with _realigner(seqs, splitIndelsLongerThanThis=0) as r:
+        assert r.realign(cigars[:2]) == []  # nothing but indels: no piece survives the split
+    acc = api.hmm_constructEmpty(0.0, api.fiveState)
+    with _realigner(seqs) as r:
+        r.expectations(cigars, acc)
+    assert np.isfinite(list(acc.transitions)).all() and acc.likelihood != 0.0
+    with pytest.raises(api.CpecanError):
+        with _realigner(seqs) as r:
+            r.realign([Cigar("a", 0, 11, True, "b", 0, 11, True, 1.0, [(M, 11)])])  # beyond the end of the sequence
+    with pytest.raises(api.CpecanError):
+        with _realigner(seqs) as r:
+            r.realign([Cigar("a", 0, 5, True, "zz", 0, 5, True, 1.0, [(M, 5)])])  # unknown sequence
