@@ -285,6 +285,77 @@ static void check(int rc, const char *what) {
     if (rc != CPECAN_OK) die("cpecan_hip: %s failed (%d): %s", what, rc, cpecan_last_error());
 }
 
+/* pairwiseAlignmentParameters_jsonParse, impl/pairwiseAligner.c:1354-1408.  The reference tokenises with jsmn (through
+ * sonLib's stJson) and walks key/value token pairs of one flat object; the same here without the tokeniser. */
+static const char *json_skip(const char *s, const char *end) {
+    while (s < end && (*s == ' ' || *s == '\t' || *s == '\n' || *s == '\r' || *s == ',' || *s == ':')) s++;
+    return s;
+}
+PairwiseAlignmentParameters *pairwiseAlignmentParameters_jsonParse(char *buf, size_t r) {
+    PairwiseAlignmentParameters *p = pairwiseAlignmentBandingParameters_construct();
+    const char *s = buf, *end = buf + r;
+    s = json_skip(s, end);
+    if (s >= end || *s != '{') die("cpecan_hip: pairwise alignment parameters json: expected an object");
+    s++;
+    for (;;) {
+        s = json_skip(s, end);
+        if (s >= end) die("cpecan_hip: pairwise alignment parameters json: unterminated object");
+        if (*s == '}') break;
+        if (*s != '"') die("cpecan_hip: pairwise alignment parameters json: expected a key");
+        const char *key = ++s;
+        while (s < end && *s != '"') s++;
+        if (s >= end) die("cpecan_hip: pairwise alignment parameters json: unterminated key");
+        const size_t keyLen = (size_t)(s - key);
+        s = json_skip(s + 1, end);
+        char val[64];
+        size_t n = 0;
+        while (s < end && *s != ',' && *s != '}' && *s != ' ' && *s != '\n' && *s != '\r' && *s != '\t' && n + 1 < sizeof val)
+            val[n++] = *s++;
+        val[n] = 0;
+        if (n == 0) die("cpecan_hip: pairwise alignment parameters json: key without a value");
+#define KEY(name) (keyLen == strlen(name) && strncmp(key, name, keyLen) == 0)
+        const int truth = strcmp(val, "true") == 0 ? 1 : (strcmp(val, "false") == 0 ? 0 : (int)strtoll(val, NULL, 10) != 0);
+        if (KEY("threshold")) p->threshold = strtod(val, NULL);
+        else if (KEY("minDiagsBetweenTraceBack")) p->minDiagsBetweenTraceBack = strtoll(val, NULL, 10);
+        else if (KEY("traceBackDiagonals")) p->traceBackDiagonals = strtoll(val, NULL, 10);
+        else if (KEY("diagonalExpansion")) p->diagonalExpansion = strtoll(val, NULL, 10);
+        else if (KEY("constraintDiagonalTrim")) p->constraintDiagonalTrim = strtoll(val, NULL, 10);
+        else if (KEY("anchorMatrixBiggerThanThis")) p->anchorMatrixBiggerThanThis = strtoll(val, NULL, 10);
+        else if (KEY("repeatMaskMatrixBiggerThanThis")) p->repeatMaskMatrixBiggerThanThis = strtoll(val, NULL, 10);
+        else if (KEY("splitMatrixBiggerThanThis")) p->splitMatrixBiggerThanThis = strtoll(val, NULL, 10);
+        else if (KEY("alignAmbiguityCharacters")) p->alignAmbiguityCharacters = truth;
+        else if (KEY("gapGamma")) p->gapGamma = (float)strtod(val, NULL);
+        else if (KEY("dynamicAnchorExpansion")) p->dynamicAnchorExpansion = truth;
+        else die("cpecan_hip: ERROR: Unrecognised key in pairwise alignment parameters json: %.*s", (int)keyLen, key);
+#undef KEY
+    }
+    return p;
+}
+
+/* convertPairwiseForwardStrandAlignmentToAnchorPairs, impl/pairwiseAligner.c:979-1003 */
+stList *convertPairwiseForwardStrandAlignmentToAnchorPairs(struct PairwiseAlignment *pA, int64_t trim, int64_t diagonalExpansion) {
+    if (!pA || !pA->strand1 || !pA->strand2) die("cpecan_hip: the alignment must be on the forward strands (:981-982)");
+    const int64_t nOps = pA->operationList ? pA->operationList->length : 0;
+    int64_t *ops = malloc(sizeof(int64_t) * 2 * (size_t)(nOps ? nOps : 1)), matches = 0;
+    if (!ops) die("cpecan_hip: out of memory");
+    for (int64_t i = 0; i < nOps; i++) {
+        const struct AlignmentOperation *op = pA->operationList->list[i];
+        ops[2 * i] = op->opType == PAIRWISE_MATCH ? CPECAN_OP_MATCH : (op->opType == PAIRWISE_INDEL_X ? CPECAN_OP_INDEL_X : CPECAN_OP_INDEL_Y);
+        ops[2 * i + 1] = op->length;
+        if (op->opType == PAIRWISE_MATCH) matches += op->length;
+    }
+    int64_t *anchors = malloc(sizeof(int64_t) * 3 * (size_t)(matches ? matches : 1));
+    if (!anchors) die("cpecan_hip: out of memory");
+    const int64_t n = cpecan_anchors_from_alignment(ops, nOps, pA->start1, pA->start2, trim, diagonalExpansion, NULL, 0, NULL, 0,
+                                                    anchors);
+    if (n < 0) die("cpecan_hip: convertPairwiseForwardStrandAlignmentToAnchorPairs failed: %s", cpecan_last_error());
+    stList *l = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    for (int64_t i = 0; i < n; i++) stList_append(l, stIntTuple_construct3(anchors[3 * i], anchors[3 * i + 1], anchors[3 * i + 2]));
+    free(ops);
+    free(anchors);
+    return l;
+}
+
 /* ---------------- the path: impl/pairwiseAligner.c:1431-1513, :936 ---------------- */
 stList *getAlignedPairsUsingAnchors(StateMachine *sM, const char *sX, const char *sY, stList *anchorPairs,
                                     PairwiseAlignmentParameters *p, bool raggedLeft, bool raggedRight) {

@@ -112,6 +112,42 @@ typedef struct _pairwiseAlignmentBandingParameters {
 
 PairwiseAlignmentParameters *pairwiseAlignmentBandingParameters_construct(void);
 void pairwiseAlignmentBandingParameters_destruct(PairwiseAlignmentParameters *p);
+/* inc/pairwiseAligner.h:51 (impl/pairwiseAligner.c:1354-1408): a flat JSON object of the eleven field names; fields that
+ * are absent keep their defaults; an unknown key aborts, as st_errAbort does in the reference. */
+PairwiseAlignmentParameters *pairwiseAlignmentParameters_jsonParse(char *buf, size_t r);
+
+/* sonLib's pairwise alignment types (pairwiseAlignment.h, commonC.h), as far as the reference reads them
+ * (impl/pairwiseAligner.c:979-1003, cPecanRealign.c:49-96); define CPECAN_HAVE_SONLIB_ALIGNMENT to use sonLib's own. */
+#ifndef CPECAN_HAVE_SONLIB_ALIGNMENT
+#define PAIRWISE_MATCH 0
+#define PAIRWISE_INDEL_X 1
+#define PAIRWISE_INDEL_Y 2
+struct List {
+    int64_t length;
+    int64_t maxLength;
+    void **list;
+    void (*destructElement)(void *);
+};
+struct AlignmentOperation {
+    int64_t opType;
+    int64_t length;
+    float score;
+};
+struct PairwiseAlignment {
+    char *contig1;
+    int64_t start1;
+    int64_t end1;
+    int64_t strand1;
+    char *contig2;
+    int64_t start2;
+    int64_t end2;
+    int64_t strand2;
+    double score;
+    struct List *operationList;
+};
+#endif
+/* inc/pairwiseAligner.h:73 (impl/pairwiseAligner.c:979-1003): both strands must be forward (asserted there). */
+stList *convertPairwiseForwardStrandAlignmentToAnchorPairs(struct PairwiseAlignment *pA, int64_t trim, int64_t diagonalExpansion);
 
 stList *getAlignedPairsUsingAnchors(StateMachine *sM, const char *sX, const char *sY, stList *anchorPairs,
                                     PairwiseAlignmentParameters *p, bool alignmentHasRaggedLeftEnd,

@@ -115,6 +115,36 @@ static void test_models(void) {
     pairwiseAlignmentBandingParameters_destruct(p);
 }
 
+/* pairwiseAlignmentParameters_jsonParse (impl/pairwiseAligner.c:1354-1408) and
+ * convertPairwiseForwardStrandAlignmentToAnchorPairs (:979-1003) */
+static void test_params_json_and_anchor_conversion(void) {
+    char js[] = "{ \"threshold\": 0.2, \"diagonalExpansion\":6,\n \"gapGamma\" : 0.25, \"dynamicAnchorExpansion\": true,"
+                " \"splitMatrixBiggerThanThis\": 100 , \"alignAmbiguityCharacters\": false}";
+    PairwiseAlignmentParameters *p = pairwiseAlignmentParameters_jsonParse(js, strlen(js));
+    CHECK(p->threshold == 0.2 && p->diagonalExpansion == 6 && p->gapGamma == 0.25f && p->dynamicAnchorExpansion);
+    CHECK(p->splitMatrixBiggerThanThis == 100 && !p->alignAmbiguityCharacters);
+    CHECK(p->minDiagsBetweenTraceBack == 1000 && p->traceBackDiagonals == 40 && p->constraintDiagonalTrim == 14); /* defaults kept */
+    pairwiseAlignmentBandingParameters_destruct(p);
+    char empty[] = "{}";
+    p = pairwiseAlignmentParameters_jsonParse(empty, strlen(empty));
+    CHECK(p->threshold == 0.01 && p->diagonalExpansion == 20);
+    pairwiseAlignmentBandingParameters_destruct(p);
+
+    struct AlignmentOperation ops[4] = {{PAIRWISE_MATCH, 5, 0}, {PAIRWISE_INDEL_X, 2, 0}, {PAIRWISE_MATCH, 3, 0}, {PAIRWISE_INDEL_Y, 4, 0}};
+    void *opPtrs[4] = {&ops[0], &ops[1], &ops[2], &ops[3]};
+    struct List opList = {4, 4, opPtrs, NULL};
+    struct PairwiseAlignment pA = {"x", 10, 20, 1, "y", 100, 112, 1, 0.0, &opList};
+    stList *anchors = convertPairwiseForwardStrandAlignmentToAnchorPairs(&pA, 1, 8);
+    /* the first run keeps columns 1..3, the second (behind a 2-base gap in y... in x) its middle column */
+    const int64_t wantX[] = {11, 12, 13, 18}, wantY[] = {101, 102, 103, 106};
+    CHECK(stList_length(anchors) == 4);
+    for (int i = 0; i < 4 && i < stList_length(anchors); i++) {
+        stIntTuple *t = stList_get(anchors, i);
+        CHECK(stIntTuple_get(t, 0) == wantX[i] && stIntTuple_get(t, 1) == wantY[i] && stIntTuple_get(t, 2) == 8);
+    }
+    stList_destruct(anchors);
+}
+
 static void test_known_answers_gpu(void) {
     StateMachine *sM5 = stateMachine5_construct(fiveState), *sM3 = stateMachine3_construct(threeState);
     PairwiseAlignmentParameters *p = pairwiseAlignmentBandingParameters_construct();
@@ -223,6 +253,7 @@ int main(int argc, char **argv) {
     const int gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
     test_bands();
     test_split_points();
+    test_params_json_and_anchor_conversion();
     test_hmm(fiveState);
     test_hmm(fiveStateAsymmetric);
     test_hmm(threeState);
