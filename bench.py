@@ -97,6 +97,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
+    torch.zeros(1, device="cuda")  # create the HIP context now: a once-per-process cost, not part of any upload
+    torch.cuda.synchronize()
     cfg = dict(workload.CONFIGS[args.config])
     n_pairs = args.pairs or cfg["n_pairs"]
     # weak scaling: rank r aligns pairs [r*n, (r+1)*n) of the same seeded stream -- independent objects, no exchange
