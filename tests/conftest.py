@@ -9,8 +9,23 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, p)
 
 
+def _ensure_built():
+    """The built libraries normally travel with the tree (they are git-ignored, not gpurun-ignored); a fresh checkout has
+    none, so build what is missing (gcc + hipcc, the same recipe as __graft_entry__.build())."""
+    import subprocess
+    wanted = {
+        os.path.join(ROOT, "cpecan_amd", "csrc"): [os.path.join(ROOT, "cpecan_amd", "libcpecan_hip.so"),
+                                                   os.path.join(ROOT, "cpecan_amd", "cpecan_realign")],
+        os.path.join(ROOT, "oracle"): [os.path.join(ROOT, "oracle", "liboracle.so")],
+    }
+    for makedir, products in wanted.items():
+        if not all(os.path.exists(f) for f in products):
+            subprocess.check_call(["make", "-C", makedir], stdout=subprocess.DEVNULL)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    _ensure_built()
 
 
 def _has_gpu():
