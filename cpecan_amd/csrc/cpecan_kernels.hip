@@ -311,6 +311,37 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     const int64_t pRing[3] = {geo->pRingCells[0] * S, geo->pRingCells[1] * S, geo->pRingCells[2] * S};
     const int64_t pRefresh[3] = {(int64_t)8 * geo->pMaxRefresh[0], (int64_t)16 * geo->pMaxRefresh[1], (int64_t)32 * geo->pMaxRefresh[2]};
     const int64_t pTotals[3] = {geo->pMaxRefresh[0], geo->pMaxRefresh[1], geo->pMaxRefresh[2]};
+    // Every resident wave of the sweep kernel owns scratch sized for the batch's LARGEST wide region (forward ring of one
+    // traceback segment, candidates, refresh series).  One unanchored 3000 x 3000 region (a single segment: 360 MB of
+    // ring) would ask for that 2000 times over: keep as many waves as fit in what the device has free and let the rest
+    // of the regions queue behind them.
+    if (nWide > 0) {
+        const int nCandLists = geo->emit == CPECAN_EMIT_INDEL ? 3 : 1;
+        const double perSlot = 8.0 * geo->ringCells * S + (double)sizeof(Candidate) * geo->fbCells * nCandLists +
+                               16.0 * geo->refreshCells + 8.0 * geo->maxRefresh +
+                               (geo->useGlobalRoll ? 8.0 * geo->rollDoubles : 0.0) +
+                               (geo->emit == CPECAN_EMIT_EXPECT ? 8.0 * geo->fbCells * S : 0.0);
+        double fixed = (double)sizeof(CpkRegion) * geo->nRegions + (double)sizeof(CpkDiag) * nDiags +
+                       (double)sizeof(CpkSegment) * nSegs + (double)nSymbolBytes + 24.0 * nAnchors +
+                       2.0 * 12.0 * nLists * outTriplesPerList /* the triples and their compact copy */;
+        for (int k = 0; k < 3; k++)
+            fixed += (double)subSlots[k] * (8.0 * pRing[k] + (double)sizeof(Candidate) * geo->pFbCells[k] + 16.0 * pRefresh[k] +
+                                            8.0 * pTotals[k] + (geo->emit == CPECAN_EMIT_EXPECT ? 8.0 * geo->pFbCells[k] * S : 0.0));
+        size_t freeB = 0, totalB = 0;
+        HIP_TRY(hipMemGetInfo(&freeB, &totalB));
+        double budget = 0.9 * (double)freeB;
+        if (const char *mb = getenv("CPECAN_MEM_BUDGET_MB")) budget = 1048576.0 * atof(mb);  // test / diagnostic knob
+        if (fixed + perSlot * (double)slots > budget) {
+            const double fit = (budget - fixed) / (perSlot > 0 ? perSlot : 1.0);
+            if (fit < 1.0) {
+                cpk_set_error("out of device memory: the batch needs %.0f MB plus %.0f MB per resident wave, %.0f MB are free",
+                              fixed / 1048576.0, perSlot / 1048576.0, budget / 1048576.0);
+                return CPECAN_ENOMEM;
+            }
+            slots = (int64_t)fit;
+            d->slots = (int)slots;
+        }
+    }
 
     if (int rc = dev_alloc(d, &d->dRegions, (size_t)geo->nRegions)) return rc;
     if (int rc = dev_alloc(d, &d->dDiags, (size_t)nDiags)) return rc;

@@ -203,6 +203,23 @@ def test_output_overflow_triggers_exact_rerun():
     assert_pairs_match(got[0], want, threshold=1e-9)
 
 
+def test_memory_budget_caps_resident_waves(monkeypatch):
+    """Every resident wave owns scratch sized for the batch's largest region; when that does not fit in device memory the
+    batch runs with fewer waves (the other regions queue) and gives the same lists.  CPECAN_MEM_BUDGET_MB stands in for
+    a nearly full device; a budget below one wave's scratch is an error, not a crash."""
+    problems = make_batch(21, 300, 400, 40)
+    free, st_free = _run_batch(0, problems, diagonalExpansion=40)
+    monkeypatch.setenv("CPECAN_MEM_BUDGET_MB", "120")
+    capped, st_capped = _run_batch(0, problems, diagonalExpansion=40)
+    assert 1 <= st_capped.wavesPerLaunch < st_free.wavesPerLaunch
+    for t1, t2 in zip(free, capped):
+        assert np.array_equal(t1, t2)
+    monkeypatch.setenv("CPECAN_MEM_BUDGET_MB", "1")
+    with pytest.raises(api.CpecanError) as e:
+        _run_batch(0, problems, diagonalExpansion=40)
+    assert "out of device memory" in str(e.value)
+
+
 def test_full_size_properties_config_B_slice():
     """Size-independent properties at BASELINE's full per-pair size: scores in (0, 1e7], coordinates unique and
     in range, per-row posterior mass <= 1 (+ logAdd slack), and results independent of batch composition."""
