@@ -814,6 +814,15 @@ int cpecan_batch_upload(cpecan_batch *b) {
                 perClass[k + 1] += perClass[k];
                 perClass[k] = 0;
             }
+        /* the wide regions by the LDS their rolling buffers and symbol strings need (classes 3..6; the last one keeps
+         * both in global memory): a launch per class, each with its own occupancy and per-wave scratch */
+        for (int64_t i = 0; i < b->nRegions; i++) {
+            if (keys[i].cls != 3) continue;
+            const int64_t w = plan[i].maxW;
+            const size_t lds = sizeof(double) * (size_t)(544 + 768 + (2 * S + 1) * (w + 1)) +
+                               (size_t)((b->regions[i].lX + 3) / 2 + (b->regions[i].lY + 3) / 2) + 16;
+            keys[i].cls = 3 + (lds > 64 * 1024 ? 3 : (w <= 128 ? 0 : (w <= 256 ? 1 : 2)));
+        }
     }
     qsort(keys, (size_t)b->nRegions, sizeof(CostKey), by_cost_desc);
 
@@ -868,10 +877,13 @@ int cpecan_batch_upload(cpecan_batch *b) {
             geo.pRingCells[k] = imax(geo.pRingCells[k], pl->liveMax + pl->maxW);
             geo.pFbCells[k] = imax(geo.pFbCells[k], pl->fbMax);
         } else {
-            geo.maxWidth = g->maxWidth > geo.maxWidth ? g->maxWidth : geo.maxWidth;
-            geo.maxRefresh = pl->refreshMax > geo.maxRefresh ? (int32_t)pl->refreshMax : geo.maxRefresh;
-            geo.ringCells = imax(geo.ringCells, pl->liveMax + pl->maxW);
-            geo.fbCells = imax(geo.fbCells, pl->fbMax);
+            const int k = keys[di].cls - 3;
+            geo.nWide[k]++;
+            geo.wMaxWidth[k] = g->maxWidth > geo.wMaxWidth[k] ? g->maxWidth : geo.wMaxWidth[k];
+            geo.wMaxRefresh[k] = pl->refreshMax > geo.wMaxRefresh[k] ? (int32_t)pl->refreshMax : geo.wMaxRefresh[k];
+            geo.wRingCells[k] = imax(geo.wRingCells[k], pl->liveMax + pl->maxW);
+            geo.wFbCells[k] = imax(geo.wFbCells[k], pl->fbMax);
+            geo.wSeqLdsBytes[k] = (int32_t)imax(geo.wSeqLdsBytes[k], imin((r->lX + 3) / 2 + (r->lY + 3) / 2, (int64_t)1 << 30));
         }
     }
     for (int k = 0; k < 3; k++)
@@ -880,27 +892,18 @@ int cpecan_batch_upload(cpecan_batch *b) {
             if (geo.pRingCells[k] < 1) geo.pRingCells[k] = 1;
             if (geo.pFbCells[k] < 1) geo.pFbCells[k] = 1;
         }
-    if (b->emit == CPECAN_EMIT_FORWARD) { /* no traceback: nothing is kept of the forward matrix */
-        geo.ringCells = 1;
-        geo.fbCells = 1;
-    }
-    if (geo.maxRefresh < 1) geo.maxRefresh = 1;
-    if (geo.ringCells < 1) geo.ringCells = 1;
-    if (geo.fbCells < 1) geo.fbCells = 1;
-    geo.rollStride = geo.maxWidth + 1;
-    {
-        int64_t seqMax = 0;
-        for (int64_t di = geo.nPacked[0] + geo.nPacked[1] + geo.nPacked[2]; di < b->nRegions; di++) { /* wide regions: two symbols per byte in LDS */
-            const HostRegion *r = &b->regions[keys[di].index];
-            seqMax = imax(seqMax, (r->lX + 3) / 2 + (r->lY + 3) / 2);
+    for (int k = 0; k < CPK_WIDE_CLASSES; k++)
+        if (geo.nWide[k]) {
+            if (b->emit == CPECAN_EMIT_FORWARD) { /* no traceback: nothing is kept of the forward matrix */
+                geo.wRingCells[k] = 1;
+                geo.wFbCells[k] = 1;
+            }
+            if (geo.wMaxRefresh[k] < 1) geo.wMaxRefresh[k] = 1;
+            if (geo.wRingCells[k] < 1) geo.wRingCells[k] = 1;
+            if (geo.wFbCells[k] < 1) geo.wFbCells[k] = 1;
         }
-        geo.seqLdsBytes = (int32_t)imin(seqMax, (int64_t)1 << 30);
-    }
-    geo.refreshCells = (int64_t)geo.maxWidth * geo.maxRefresh;
-    if (geo.refreshCells < 1) geo.refreshCells = 1;
-    geo.rollDoubles = (int64_t)(2 * S + 1) * geo.rollStride;
-    /* LDS budget: beyond 64 KiB per wave (rolling buffers + symbol strings) the batch takes the global-memory path */
-    geo.useGlobalRoll = (sizeof(double) * (size_t)(544 + 768 + geo.rollDoubles) + (size_t)geo.seqLdsBytes + 16 > 64 * 1024);
+    /* the scalar geometry (maxWidth, rollStride, ringCells, ..., useGlobalRoll) is filled per launch from the class
+     * arrays by the device side (cpk_class_geometry) */
     b->geo = geo;
     b->segs = segs;
     b->nSegs = nSegs;

@@ -74,6 +74,7 @@ typedef struct {
     double threshold;
 } CpkModel;
 
+#define CPK_WIDE_CLASSES 4
 /* Per-launch geometry computed on the host. */
 typedef struct {
     int32_t nRegions;
@@ -95,6 +96,13 @@ typedef struct {
     int32_t nPacked[3];
     int32_t pMaxRefresh[3];
     int64_t pRingCells[3], pFbCells[3];
+    /* The wide regions follow, again by class: widest diagonal at most 128 / 256 / CPK_LDS_MAX_WIDTH cells, or wider
+     * (global-memory rolling buffers).  Every class is one launch of the sweep kernel with LDS and per-wave scratch sized
+     * for ITS largest region, so that one very wide region neither takes the LDS that decides how many waves the others
+     * get nor multiplies everybody's scratch.  The scalar fields above are filled per launch from these. */
+    int32_t nWide[CPK_WIDE_CLASSES];
+    int32_t wMaxWidth[CPK_WIDE_CLASSES], wMaxRefresh[CPK_WIDE_CLASSES], wSeqLdsBytes[CPK_WIDE_CLASSES];
+    int64_t wRingCells[CPK_WIDE_CLASSES], wFbCells[CPK_WIDE_CLASSES];
 } CpkGeometry;
 
 /* One run of consecutive triples to move into the compact, list-ordered result buffer: the triples of one traceback

@@ -67,6 +67,27 @@ extern "C" const char *cpk_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------------
 // host side of the HIP TU: memory, launch, timing
 // ------------------------------------------------------------------------------------------------
+using KernelFn = void (*)(const KArgs);
+constexpr int kMaxClasses = CPK_WIDE_CLASSES + 3;
+
+// One kernel launch of a run: the regions [regionBase, regionBase + regionCount) of the device order, which share one
+// size class, with LDS, occupancy and per-wave scratch sized for the largest of THEM.
+struct LaunchClass {
+    bool packed = false;
+    int k = 0;           // class index within its kind (wide 0..3, packed 0..2)
+    KernelFn fn = nullptr;
+    CpkGeometry geo{};   // what the kernel reads: the scalar fields describe this class
+    int waves = 0;
+    int64_t subSlots = 0;  // scratch slots: one per wave (sweep) or one per region group of a wave (packed)
+    size_t ldsBytes = 0;
+    int regionBase = 0, regionCount = 0;
+    int64_t ringEl = 0, candEl = 0, refEl = 0, totEl = 0, bringEl = 0, grollEl = 0;  // elements per scratch slot
+    int64_t oRing = 0, oCand = 0, oRef = 0, oTot = 0, oBring = 0, oGroll = 0, oExpect = 0;  // element offsets of the class
+    double slotBytes() const {
+        return 8.0 * ringEl + (double)sizeof(Candidate) * candEl + 16.0 * refEl + 8.0 * totEl + 8.0 * bringEl + 8.0 * grollEl;
+    }
+};
+
 struct CpkDevice {
     int device = 0;
     int numCUs = 0;
@@ -76,10 +97,8 @@ struct CpkDevice {
     int64_t nSegs = 0, nDiags = 0;
     int64_t outTriplesPerList = 0;
     int64_t dbgCells = 0, dbgDiags = 0;
-    int slots = 0;        // waves of the sweep kernel (wide regions)
-    size_t ldsBytes = 0;
-    int pSlots[3] = {0, 0, 0};  // waves of the packed kernel per class (groups of 8 / 16 / 32 lanes)
-    size_t pLdsBytes[3] = {0, 0, 0};
+    std::vector<LaunchClass> classes;  // one launch each: the wide classes (sweep kernel), then the narrow ones (packed)
+    int totalWaves = 0;
     // device buffers
     CpkRegion *dRegions = nullptr;
     CpkDiag *dDiags = nullptr;
@@ -94,10 +113,9 @@ struct CpkDevice {
     int64_t bytes = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     hipStream_t lastStream = nullptr;
-    // the packed classes run beside the sweep kernel on streams of their own (fork / join around cpk_device_run)
-    hipStream_t sideStream[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t sideDone[3] = {nullptr, nullptr, nullptr};
-    int64_t subBase[3] = {0, 0, 0};  // first scratch sub-slot of each packed class (behind the sweep kernel's slots)
+    // every class but the first runs beside it on a stream of its own (fork / join around cpk_device_run)
+    hipStream_t sideStream[kMaxClasses] = {};
+    hipEvent_t sideDone[kMaxClasses] = {};
     bool ran = false;
 };
 
@@ -121,7 +139,7 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
     d->numCUs = prop.multiProcessorCount;
     HIP_TRY(hipEventCreate(&d->evStart));
     HIP_TRY(hipEventCreate(&d->evStop));
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < kMaxClasses; k++) {
         HIP_TRY(hipStreamCreateWithFlags(&d->sideStream[k], hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&d->sideDone[k], hipEventDisableTiming));
     }
@@ -153,7 +171,7 @@ extern "C" void cpk_device_destroy(CpkDevice *d) {
     free_all(d);
     if (d->evStart) (void)hipEventDestroy(d->evStart);
     if (d->evStop) (void)hipEventDestroy(d->evStop);
-    for (int k = 0; k < 3; k++) {
+    for (int k = 0; k < kMaxClasses; k++) {
         if (d->sideStream[k]) (void)hipStreamDestroy(d->sideStream[k]);
         if (d->sideDone[k]) (void)hipEventDestroy(d->sideDone[k]);
     }
@@ -168,8 +186,6 @@ static int dev_alloc(CpkDevice *d, T **p, size_t count) {
     d->bytes += (int64_t)bytes;
     return CPECAN_OK;
 }
-
-using KernelFn = void (*)(const KArgs);
 
 static KernelFn pick_packed_kernel(const CpkGeometry &g, int cls) {  // class k: groups of 8 << k lanes
     const bool five = g.nStates == 5;
@@ -221,126 +237,196 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     d->ran = false;
     const int S = geo->nStates;
 
-    // LDS: 40 doubles of emission tables + (fast path) three rolling buffers + both padded symbol strings
-    d->ldsBytes = sizeof(double) * (lds_header_doubles(geo->emit) + lds_stage_doubles(geo->emit));
-    if (!geo->useGlobalRoll)
-        d->ldsBytes += sizeof(double) * (size_t)(2 * S + 1) * geo->rollStride + (size_t)((geo->seqLdsBytes + 15) / 16 * 16);
-    KernelFn fn = pick_kernel(*geo);
-    if (!fn) {
-        cpk_set_error("no kernel for emitter %d", geo->emit);
-        return CPECAN_EINVAL;
-    }
-    if (d->ldsBytes > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d->ldsBytes));
-    }
-    // Resident single-wave workgroups per CU.  hipOccupancyMaxActiveBlocksPerMultiprocessor answers 3 for this
-    // 64-thread kernel (it reports waves per SIMD), so the bound is computed from the register file and LDS
+    // ---- the launches of a run: one per size class that has regions ----
+    d->classes.clear();
+    // Resident single-wave workgroups per CU.  hipOccupancyMaxActiveBlocksPerMultiprocessor answers 3 for these
+    // 64-thread kernels (it reports waves per SIMD), so the bound is computed from the register file and LDS
     // directly (MI355X_MICROARCH.md: 512 VGPRs per lane per SIMD in granules of 8, 4 SIMDs, 32 waves, 160 KiB LDS).
     // Over-estimating is harmless: surplus workgroups simply queue, every wave exits when the work queue is empty.
-    hipFuncAttributes attr;
-    HIP_TRY(hipFuncGetAttributes(&attr, (const void *)fn));
-    const int vgprAlloc = ((attr.numRegs > 0 ? attr.numRegs : 128) + 7) / 8 * 8;
-    int wavesPerSimd = 512 / vgprAlloc;
-    if (wavesPerSimd > 8) wavesPerSimd = 8;
-    if (wavesPerSimd < 1) wavesPerSimd = 1;
-    int perCU = 4 * wavesPerSimd;
-    const size_t ldsTotal = d->ldsBytes + (size_t)attr.sharedSizeBytes;
-    const int byLds = (int)((160 * 1024) / (ldsTotal ? ldsTotal : 1));
-    if (byLds < perCU) perCU = byLds;
-    if (perCU > 32) perCU = 32;
-    if (const char *cap = getenv("CPECAN_MAX_WAVES_PER_CU")) {  // tuning/diagnostic knob
-        const int c = atoi(cap);
-        if (c >= 1 && c < perCU) perCU = c;
-    }
-    if (perCU < 1) {
-        cpk_set_error("kernel does not fit on a CU (LDS %zu bytes)", d->ldsBytes);
-        return CPECAN_EHIP;
-    }
-    const int64_t nWide = geo->nRegions - geo->nPacked[0] - geo->nPacked[1] - geo->nPacked[2];
-    int64_t slots = (int64_t)perCU * d->numCUs;
-    if (slots > nWide) slots = nWide;
-    if (slots < 1) slots = 1;
-    if (nWide > 0) {
-        // Even out the rounds: with R = ceil(regions / slots) rounds, ceil(regions / R) waves do the same work in the
-        // same number of rounds with fewer waves competing per SIMD (10 000 equal pairs: 1667 waves x 6 pairs instead
-        // of 1792 waves of which 1044 do 6 and 748 do 5).
-        const int64_t rounds = (nWide + slots - 1) / slots;
-        const int64_t even = (nWide + rounds - 1) / rounds;
-        if (even >= 1 && even < slots) slots = even;
-    }
-    d->slots = (int)slots;
-    // the packed kernel's waves per class (narrow regions, 64 / GW per wave) and their scratch sub-slots
-    int64_t subSlots[3] = {0, 0, 0};
-    for (int k = 0; k < 3; k++) {
-        d->pSlots[k] = 0;
+    auto wavesPerCU = [&](KernelFn fn, size_t ldsBytes, int *out) -> int {
+        hipFuncAttributes attr;
+        HIP_TRY(hipFuncGetAttributes(&attr, (const void *)fn));
+        const int vgprAlloc = ((attr.numRegs > 0 ? attr.numRegs : 128) + 7) / 8 * 8;
+        int perSimd = 512 / vgprAlloc;
+        if (perSimd > 8) perSimd = 8;
+        if (perSimd < 1) perSimd = 1;
+        int perCU = 4 * perSimd;
+        const size_t ldsTotal = ldsBytes + (size_t)attr.sharedSizeBytes;
+        const int byLds = (int)((160 * 1024) / (ldsTotal ? ldsTotal : 1));
+        if (byLds < perCU) perCU = byLds;
+        if (perCU > 32) perCU = 32;
+        if (const char *cap = getenv("CPECAN_MAX_WAVES_PER_CU")) {  // tuning/diagnostic knob
+            const int c = atoi(cap);
+            if (c >= 1 && c < perCU) perCU = c;
+        }
+        *out = perCU;
+        return CPECAN_OK;
+    };
+    const int nCandLists = geo->emit == CPECAN_EMIT_INDEL ? 3 : 1;
+    const bool expect = geo->emit == CPECAN_EMIT_EXPECT;
+    int regionAt = 0;
+    for (int k = 0; k < 3; k++) {  // narrow regions come first in the device order: the packed kernel, 64 / GW to a wave
         if (geo->nPacked[k] <= 0) continue;
-        KernelFn pfn = pick_packed_kernel(*geo, k);
-        if (!pfn) {
+        LaunchClass c;
+        c.packed = true;
+        c.k = k;
+        c.fn = pick_packed_kernel(*geo, k);
+        if (!c.fn) {
             cpk_set_error("no packed kernel for emitter %d", geo->emit);
             return CPECAN_EINVAL;
         }
         const int GW = 8 << k, G = CPK_WAVE / GW;
-        d->pLdsBytes[k] = sizeof(double) * (size_t)(kLdsCubics + 40 + kLdsWeights + (geo->emit == CPECAN_EMIT_EXPECT ? kExpectCopies * 80 : 0)) +
-                          (size_t)G * pack_group_bytes(S, GW);
-        hipFuncAttributes pattr;
-        HIP_TRY(hipFuncGetAttributes(&pattr, (const void *)pfn));
-        const int pv = ((pattr.numRegs > 0 ? pattr.numRegs : 128) + 7) / 8 * 8;
-        int pPerSimd = 512 / pv;
-        if (pPerSimd > 8) pPerSimd = 8;
-        if (pPerSimd < 1) pPerSimd = 1;
-        int pPerCU = 4 * pPerSimd;
-        const int pByLds = (int)((160 * 1024) / (d->pLdsBytes[k] + (size_t)pattr.sharedSizeBytes));
-        if (pByLds < pPerCU) pPerCU = pByLds;
-        if (const char *cap = getenv("CPECAN_MAX_WAVES_PER_CU")) {
-            const int c = atoi(cap);
-            if (c >= 1 && c < pPerCU) pPerCU = c;
-        }
-        int64_t pSlots = (int64_t)pPerCU * d->numCUs;
+        c.geo = *geo;
+        c.geo.ringCells = geo->pRingCells[k];
+        c.geo.fbCells = geo->pFbCells[k];
+        c.geo.maxRefresh = geo->pMaxRefresh[k];
+        c.geo.refreshCells = (int64_t)GW * geo->pMaxRefresh[k];
+        c.ldsBytes = sizeof(double) * (size_t)(kLdsCubics + 40 + kLdsWeights + (expect ? kExpectCopies * 80 : 0)) +
+                     (size_t)G * pack_group_bytes(S, GW);
+        int perCU = 0;
+        if (int rc = wavesPerCU(c.fn, c.ldsBytes, &perCU)) return rc;
+        int64_t waves = (int64_t)perCU * d->numCUs;
         const int64_t wavesNeeded = (geo->nPacked[k] + G - 1) / G;
-        if (pSlots > wavesNeeded) pSlots = wavesNeeded;
-        d->pSlots[k] = (int)pSlots;
-        subSlots[k] = pSlots * G;
+        if (waves > wavesNeeded) waves = wavesNeeded;
+        c.waves = (int)waves;
+        c.subSlots = waves * G;
+        c.regionBase = regionAt;
+        c.regionCount = geo->nPacked[k];
+        regionAt += geo->nPacked[k];
+        c.ringEl = c.geo.ringCells * S;
+        c.candEl = c.geo.fbCells;
+        c.refEl = c.geo.refreshCells;
+        c.totEl = c.geo.maxRefresh;
+        c.bringEl = expect ? c.geo.fbCells * S : 0;
+        d->classes.push_back(c);
     }
-    // scratch per slot: the launches run side by side, each class has its own part of every buffer behind the sweep's
-    auto scratch = [&](int64_t wide, const int64_t (&packed)[3]) {
-        int64_t all = nWide > 0 ? slots * wide : 0;
-        for (int k = 0; k < 3; k++) all += subSlots[k] * packed[k];
-        return (size_t)all;
-    };
-    for (int k = 0; k < 3; k++) d->subBase[k] = subSlots[k];  // sub-slot counts, turned into element offsets at launch
-    const int64_t pRing[3] = {geo->pRingCells[0] * S, geo->pRingCells[1] * S, geo->pRingCells[2] * S};
-    const int64_t pRefresh[3] = {(int64_t)8 * geo->pMaxRefresh[0], (int64_t)16 * geo->pMaxRefresh[1], (int64_t)32 * geo->pMaxRefresh[2]};
-    const int64_t pTotals[3] = {geo->pMaxRefresh[0], geo->pMaxRefresh[1], geo->pMaxRefresh[2]};
-    // Every resident wave of the sweep kernel owns scratch sized for the batch's LARGEST wide region (forward ring of one
-    // traceback segment, candidates, refresh series).  One unanchored 3000 x 3000 region (a single segment: 360 MB of
-    // ring) would ask for that 2000 times over: keep as many waves as fit in what the device has free and let the rest
-    // of the regions queue behind them.
-    if (nWide > 0) {
-        const int nCandLists = geo->emit == CPECAN_EMIT_INDEL ? 3 : 1;
-        const double perSlot = 8.0 * geo->ringCells * S + (double)sizeof(Candidate) * geo->fbCells * nCandLists +
-                               16.0 * geo->refreshCells + 8.0 * geo->maxRefresh +
-                               (geo->useGlobalRoll ? 8.0 * geo->rollDoubles : 0.0) +
-                               (geo->emit == CPECAN_EMIT_EXPECT ? 8.0 * geo->fbCells * S : 0.0);
+    for (int k = 0; k < CPK_WIDE_CLASSES; k++) {  // then the wide ones: the sweep kernel, one region per wave at a time
+        if (geo->nWide[k] <= 0) continue;
+        LaunchClass c;
+        c.k = k;
+        c.geo = *geo;
+        c.geo.maxWidth = geo->wMaxWidth[k];
+        c.geo.maxRefresh = geo->wMaxRefresh[k];
+        c.geo.ringCells = geo->wRingCells[k];
+        c.geo.fbCells = geo->wFbCells[k];
+        c.geo.seqLdsBytes = geo->wSeqLdsBytes[k];
+        c.geo.rollStride = c.geo.maxWidth + 1;
+        c.geo.refreshCells = (int64_t)c.geo.maxWidth * c.geo.maxRefresh;
+        if (c.geo.refreshCells < 1) c.geo.refreshCells = 1;
+        c.geo.rollDoubles = (int64_t)(2 * S + 1) * c.geo.rollStride;
+        // LDS budget: beyond 64 KiB per wave (rolling buffers + symbol strings) the class takes the global-memory path
+        const size_t header = sizeof(double) * (lds_header_doubles(geo->emit) + lds_stage_doubles(geo->emit));
+        const size_t fastLds = header + sizeof(double) * (size_t)c.geo.rollDoubles + (size_t)((c.geo.seqLdsBytes + 15) / 16 * 16);
+        c.geo.useGlobalRoll = fastLds + 16 > 64 * 1024;
+        c.ldsBytes = c.geo.useGlobalRoll ? header : fastLds;
+        c.fn = pick_kernel(c.geo);
+        if (!c.fn) {
+            cpk_set_error("no kernel for emitter %d", geo->emit);
+            return CPECAN_EINVAL;
+        }
+        int perCU = 0;
+        if (int rc = wavesPerCU(c.fn, c.ldsBytes, &perCU)) return rc;
+        if (perCU < 1) {
+            cpk_set_error("kernel does not fit on a CU (LDS %zu bytes)", c.ldsBytes);
+            return CPECAN_EHIP;
+        }
+        const int64_t n = geo->nWide[k];
+        int64_t waves = (int64_t)perCU * d->numCUs;
+        if (waves > n) waves = n;
+        {
+            // Even out the rounds: with R = ceil(regions / waves) rounds, ceil(regions / R) waves do the same work in the
+            // same number of rounds with fewer waves competing per SIMD (10 000 equal pairs: 1667 waves x 6 pairs instead
+            // of 1792 waves of which 1044 do 6 and 748 do 5).
+            const int64_t rounds = (n + waves - 1) / waves;
+            const int64_t even = (n + rounds - 1) / rounds;
+            if (even >= 1 && even < waves) waves = even;
+        }
+        c.waves = (int)waves;
+        c.subSlots = waves;
+        c.regionBase = regionAt;
+        c.regionCount = geo->nWide[k];
+        regionAt += geo->nWide[k];
+        c.ringEl = c.geo.ringCells * S;
+        c.candEl = c.geo.fbCells * nCandLists;
+        c.refEl = c.geo.refreshCells;
+        c.totEl = c.geo.maxRefresh;
+        c.bringEl = expect ? c.geo.fbCells * S : 0;
+        c.grollEl = c.geo.useGlobalRoll ? c.geo.rollDoubles : 0;
+        d->classes.push_back(c);
+    }
+    if ((int)d->classes.size() > kMaxClasses || regionAt != geo->nRegions) {
+        cpk_set_error("internal: the size classes do not cover the regions (%d of %d)", regionAt, geo->nRegions);
+        return CPECAN_ESTATE;
+    }
+    // Every resident wave owns scratch sized for its class's LARGEST region (forward ring of one traceback segment,
+    // candidates, refresh series).  One unanchored 3000 x 3000 region (a single segment: 360 MB of ring) in a class of
+    // its own is one wave's worth; where a class still asks for more than the device has free, it keeps as many
+    // waves as fit and the rest of its regions queue behind them.
+    {
         double fixed = (double)sizeof(CpkRegion) * geo->nRegions + (double)sizeof(CpkDiag) * nDiags +
                        (double)sizeof(CpkSegment) * nSegs + (double)nSymbolBytes + 24.0 * nAnchors +
                        2.0 * 12.0 * nLists * outTriplesPerList /* the triples and their compact copy */;
-        for (int k = 0; k < 3; k++)
-            fixed += (double)subSlots[k] * (8.0 * pRing[k] + (double)sizeof(Candidate) * geo->pFbCells[k] + 16.0 * pRefresh[k] +
-                                            8.0 * pTotals[k] + (geo->emit == CPECAN_EMIT_EXPECT ? 8.0 * geo->pFbCells[k] * S : 0.0));
         size_t freeB = 0, totalB = 0;
         HIP_TRY(hipMemGetInfo(&freeB, &totalB));
         double budget = 0.9 * (double)freeB;
         if (const char *mb = getenv("CPECAN_MEM_BUDGET_MB")) budget = 1048576.0 * atof(mb);  // test / diagnostic knob
-        if (fixed + perSlot * (double)slots > budget) {
-            const double fit = (budget - fixed) / (perSlot > 0 ? perSlot : 1.0);
-            if (fit < 1.0) {
-                cpk_set_error("out of device memory: the batch needs %.0f MB plus %.0f MB per resident wave, %.0f MB are free",
-                              fixed / 1048576.0, perSlot / 1048576.0, budget / 1048576.0);
-                return CPECAN_ENOMEM;
-            }
-            slots = (int64_t)fit;
-            d->slots = (int)slots;
+        double need = fixed, floorNeed = fixed;
+        for (const LaunchClass &c : d->classes) {
+            need += c.slotBytes() * (double)c.subSlots;
+            floorNeed += c.slotBytes() * (double)(c.subSlots / (c.waves > 0 ? c.waves : 1));  // one wave each
         }
+        if (floorNeed > budget) {
+            cpk_set_error("out of device memory: the batch needs %.0f MB with one resident wave per size class, %.0f MB are free",
+                          floorNeed / 1048576.0, budget / 1048576.0);
+            return CPECAN_ENOMEM;
+        }
+        if (need > budget) {
+            // the narrow and less wide classes first: they hold most of the regions
+            double left = budget - floorNeed;
+            for (LaunchClass &c : d->classes) {
+                const int64_t perWave = c.subSlots / c.waves;
+                const double waveBytes = c.slotBytes() * (double)perWave;
+                int64_t extra = waveBytes > 0 ? (int64_t)(left / waveBytes) : c.waves - 1;
+                if (extra > c.waves - 1) extra = c.waves - 1;
+                if (extra < 0) extra = 0;
+                left -= waveBytes * (double)extra;
+                c.waves = (int)(1 + extra);
+                c.subSlots = perWave * c.waves;
+            }
+        }
+    }
+    d->totalWaves = 0;
+    {
+        int64_t oRing = 0, oCand = 0, oRef = 0, oTot = 0, oBring = 0, oGroll = 0, oExpect = 0;
+        for (LaunchClass &c : d->classes) {
+            c.oRing = oRing;
+            c.oCand = oCand;
+            c.oRef = oRef;
+            c.oTot = oTot;
+            c.oBring = oBring;
+            c.oGroll = oGroll;
+            c.oExpect = oExpect;
+            oRing += c.subSlots * c.ringEl;
+            oCand += c.subSlots * c.candEl;
+            oRef += c.subSlots * c.refEl;
+            oTot += c.subSlots * c.totEl;
+            oBring += c.subSlots * c.bringEl;
+            oGroll += c.subSlots * c.grollEl;
+            oExpect += (int64_t)c.waves * 128;
+            d->totalWaves += c.waves;
+            if (c.ldsBytes > 64 * 1024)
+                HIP_TRY(hipFuncSetAttribute((const void *)c.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.ldsBytes));
+        }
+        if (int rc = dev_alloc(d, &d->dRing, (size_t)oRing)) return rc;
+        if (int rc = dev_alloc(d, &d->dCand, (size_t)oCand)) return rc;
+        if (int rc = dev_alloc(d, &d->dC, (size_t)oRef)) return rc;
+        if (int rc = dev_alloc(d, &d->dM, (size_t)oRef)) return rc;
+        if (int rc = dev_alloc(d, &d->dTotals, (size_t)oTot)) return rc;
+        if (oGroll > 0)
+            if (int rc = dev_alloc(d, &d->dGroll, (size_t)oGroll)) return rc;
+        if (expect)
+            if (int rc = dev_alloc(d, &d->dBring, (size_t)oBring)) return rc;
+        if (int rc = dev_alloc(d, &d->dExpect, (size_t)(oExpect > 0 ? oExpect : 128))) return rc;
     }
 
     if (int rc = dev_alloc(d, &d->dRegions, (size_t)geo->nRegions)) return rc;
@@ -348,23 +434,11 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (int rc = dev_alloc(d, &d->dSegs, (size_t)nSegs)) return rc;
     if (int rc = dev_alloc(d, &d->dSymbols, (size_t)nSymbolBytes)) return rc;
     if (int rc = dev_alloc(d, &d->dModel, 1)) return rc;
-    if (int rc = dev_alloc(d, &d->dRing, scratch(geo->ringCells * S, pRing))) return rc;
-    if (int rc = dev_alloc(d, &d->dCand, scratch(geo->fbCells * (geo->emit == CPECAN_EMIT_INDEL ? 3 : 1), geo->pFbCells))) return rc;
     if (int rc = dev_alloc(d, &d->dForward, (size_t)geo->nRegions)) return rc;
-    if (int rc = dev_alloc(d, &d->dExpect, (size_t)(slots + d->pSlots[0] + d->pSlots[1] + d->pSlots[2]) * 128)) return rc;
-    if (int rc = dev_alloc(d, &d->dC, scratch(geo->refreshCells, pRefresh))) return rc;
-    if (int rc = dev_alloc(d, &d->dM, scratch(geo->refreshCells, pRefresh))) return rc;
-    if (int rc = dev_alloc(d, &d->dTotals, scratch(geo->maxRefresh, pTotals))) return rc;
-    if (geo->useGlobalRoll)
-        if (int rc = dev_alloc(d, &d->dGroll, (size_t)slots * geo->rollDoubles)) return rc;
     if (int rc = dev_alloc(d, &d->dCounts, (size_t)nLists * geo->nRegions)) return rc;
     if (int rc = dev_alloc(d, &d->dSegStarts, (size_t)nLists * nSegs)) return rc;
     if (int rc = dev_alloc(d, &d->dTriples, (size_t)nLists * outTriplesPerList * 3)) return rc;
-    if (geo->emit == CPECAN_EMIT_EXPECT) {
-        const int64_t pB[3] = {geo->pFbCells[0] * S, geo->pFbCells[1] * S, geo->pFbCells[2] * S};
-        if (int rc = dev_alloc(d, &d->dBring, scratch(geo->fbCells * S, pB))) return rc;
-    }
-    if (int rc = dev_alloc(d, &d->dQueue, 4)) return rc;
+    if (int rc = dev_alloc(d, &d->dQueue, (size_t)kMaxClasses)) return rc;
     HIP_TRY(hipMemset(d->dCounts, 0, sizeof(int32_t) * (size_t)nLists * geo->nRegions));
     HIP_TRY(hipMemset(d->dSegStarts, 0, sizeof(int32_t) * (size_t)nLists * (nSegs ? nSegs : 1)));
     if (geo->debug) {
@@ -450,60 +524,38 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.expectOut = d->dExpect;
     a.dbgFb = d->dDbgFb;
     a.dbgTotals = d->dDbgTotals;
-    HIP_TRY(hipMemsetAsync(d->dQueue, 0, 4 * sizeof(unsigned int), st));
-    KernelFn fn = pick_kernel(d->geo);
-    HIP_TRY(hipEventRecord(d->evStart, st));
-    int base = 0;
-    const int64_t nWideRun = d->geo.nRegions - d->geo.nPacked[0] - d->geo.nPacked[1] - d->geo.nPacked[2];
-    const int SS = d->geo.nStates;
-    // element offsets of each class's scratch inside the shared buffers: [sweep slots][class 0][class 1][class 2]
-    int64_t oRing = nWideRun > 0 ? (int64_t)d->slots * d->geo.ringCells * SS : 0;
-    int64_t oCand = nWideRun > 0 ? (int64_t)d->slots * d->geo.fbCells * (d->geo.emit == CPECAN_EMIT_INDEL ? 3 : 1) : 0;
-    int64_t oRef = nWideRun > 0 ? (int64_t)d->slots * d->geo.refreshCells : 0;
-    int64_t oTot = nWideRun > 0 ? (int64_t)d->slots * d->geo.maxRefresh : 0;
-    int64_t oBring = nWideRun > 0 ? (int64_t)d->slots * d->geo.fbCells * SS : 0;
-    int64_t oExpect = (int64_t)d->slots * 128;  // the sweep kernel's waves come first in the partial-sum array
+    HIP_TRY(hipMemsetAsync(d->dQueue, 0, kMaxClasses * sizeof(unsigned int), st));
     if (d->geo.emit == CPECAN_EMIT_EXPECT)
-        HIP_TRY(hipMemsetAsync(d->dExpect, 0, sizeof(double) * 128 * (size_t)(d->slots + d->pSlots[0] + d->pSlots[1] + d->pSlots[2]), st));
-    for (int k = 0; k < 3; k++) {  // narrow regions, class by class: several to a wave, on a stream of their own
-        if (d->geo.nPacked[k] <= 0) continue;
+        HIP_TRY(hipMemsetAsync(d->dExpect, 0, sizeof(double) * 128 * (size_t)(d->totalWaves > 0 ? d->totalWaves : 1), st));
+    HIP_TRY(hipEventRecord(d->evStart, st));
+    // one launch per size class, side by side: the last class (the widest regions, usually the bulk of the work) on the
+    // caller's stream, the others on streams of their own, joined below
+    const int nClasses = (int)d->classes.size();
+    for (int i = 0; i < nClasses; i++) {
+        const LaunchClass &c = d->classes[i];
         KArgs p = a;
-        p.regionBase = base;
-        p.regionCount = d->geo.nPacked[k];
-        p.geo.ringCells = d->geo.pRingCells[k];
-        p.geo.fbCells = d->geo.pFbCells[k];
-        p.geo.refreshCells = (int64_t)(8 << k) * d->geo.pMaxRefresh[k];
-        p.geo.maxRefresh = d->geo.pMaxRefresh[k];
-        p.ring = d->dRing + oRing;
-        p.cand = d->dCand + oCand;
-        p.cbuf = d->dC + oRef;
-        p.mbuf = d->dM + oRef;
-        p.totals = d->dTotals + oTot;
-        p.bring = d->dBring ? d->dBring + oBring : nullptr;
-        p.expectOut = d->dExpect + oExpect;
-        p.queue = d->dQueue + 1 + k;
-        HIP_TRY(hipStreamWaitEvent(d->sideStream[k], d->evStart, 0));
-        hipLaunchKernelGGL(pick_packed_kernel(d->geo, k), dim3((unsigned)d->pSlots[k]), dim3(CPK_WAVE), d->pLdsBytes[k],
-                           d->sideStream[k], p);
+        p.geo = c.geo;
+        p.geo.debug = a.geo.debug;
+        p.regionBase = c.regionBase;
+        p.regionCount = c.regionCount;
+        p.ring = d->dRing + c.oRing;
+        p.cand = d->dCand + c.oCand;
+        p.cbuf = d->dC + c.oRef;
+        p.mbuf = d->dM + c.oRef;
+        p.totals = d->dTotals + c.oTot;
+        p.groll = d->dGroll ? d->dGroll + c.oGroll : nullptr;
+        p.bring = d->dBring ? d->dBring + c.oBring : nullptr;
+        p.expectOut = d->dExpect + c.oExpect;
+        p.queue = d->dQueue + i;
+        const bool onCaller = i == nClasses - 1;
+        hipStream_t cs = onCaller ? st : d->sideStream[i];
+        if (!onCaller) HIP_TRY(hipStreamWaitEvent(cs, d->evStart, 0));
+        hipLaunchKernelGGL(c.fn, dim3((unsigned)c.waves), dim3(CPK_WAVE), c.ldsBytes, cs, p);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventRecord(d->sideDone[k], d->sideStream[k]));
-        const int64_t subs = d->subBase[k];
-        oRing += subs * p.geo.ringCells * SS;
-        oCand += subs * p.geo.fbCells;
-        oRef += subs * p.geo.refreshCells;
-        oTot += subs * p.geo.maxRefresh;
-        oBring += subs * p.geo.fbCells * SS;
-        oExpect += (int64_t)d->pSlots[k] * 128;
-        base += d->geo.nPacked[k];
+        if (!onCaller) HIP_TRY(hipEventRecord(d->sideDone[i], cs));
     }
-    a.regionBase = base;
-    a.regionCount = d->geo.nRegions - base;
-    if (a.regionCount > 0) {
-        hipLaunchKernelGGL(fn, dim3((unsigned)d->slots), dim3(CPK_WAVE), d->ldsBytes, st, a);
-        HIP_TRY(hipGetLastError());
-    }
-    for (int k = 0; k < 3; k++)  // join: the caller's stream continues when every class is done
-        if (d->geo.nPacked[k] > 0) HIP_TRY(hipStreamWaitEvent(st, d->sideDone[k], 0));
+    for (int i = 0; i + 1 < nClasses; i++)  // join: the caller's stream continues when every class is done
+        HIP_TRY(hipStreamWaitEvent(st, d->sideDone[i], 0));
     HIP_TRY(hipEventRecord(d->evStop, st));
     d->lastStream = st;
     d->ran = true;
@@ -537,7 +589,7 @@ extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segSt
         HIP_TRY(hipMemcpy(expect, d->dForward, sizeof(double) * (size_t)d->geo.nRegions, hipMemcpyDeviceToHost));
     if (expect && d->geo.emit == CPECAN_EMIT_EXPECT) {
         // sum the per-wave partials (every launched wave wrote its 106 values, zeros included)
-        const int nWaves = d->slots + d->pSlots[0] + d->pSlots[1] + d->pSlots[2];
+        const int nWaves = d->totalWaves;
         std::vector<double> part((size_t)nWaves * 128);
         HIP_TRY(hipMemcpy(part.data(), d->dExpect, sizeof(double) * part.size(), hipMemcpyDeviceToHost));
         for (int i = 0; i < 106; i++) expect[i] = 0.0;
@@ -738,4 +790,4 @@ extern "C" int cpk_device_debug_fetch(CpkDevice *d, double *fb, int64_t cells, d
 }
 
 extern "C" int64_t cpk_device_bytes(const CpkDevice *d) { return d->bytes; }
-extern "C" int cpk_device_waves(const CpkDevice *d) { return d->slots + d->pSlots[0] + d->pSlots[1] + d->pSlots[2]; }
+extern "C" int cpk_device_waves(const CpkDevice *d) { return d->totalWaves; }

@@ -196,6 +196,45 @@ def test_wide_band_uses_global_rolling_buffers():
     _check_batch(0, [(sx, sy, ())], diagonalExpansion=20)
 
 
+@pytest.mark.parametrize("mtype,emit", [(0, "match"), (2, "match"), (0, "expect")])
+def test_mixed_widths_run_in_size_classes(mtype, emit):
+    """One batch with regions of every wide class -- banded at 41-81 cells, unanchored 150 x 150 (151 cells), 300 x 300
+    (301), and 900 x 900 (901 cells: rolling buffers in global memory) -- runs as one launch per class, each with LDS
+    and scratch for its own largest region, and gives what each problem gives alone."""
+    probs = [make_pair(31, i, 400, 40) for i in range(40)]                       # <= 128 cells
+    probs += [make_pair(32, i, 150, 0)[:2] + ((),) for i in range(6)]            # <= 256
+    probs += [make_pair(33, i, 300, 0)[:2] + ((),) for i in range(4)]            # fits the LDS
+    probs += [make_pair(34, 0, 900, 0)[:2] + ((),)]                              # does not
+    probs += [make_pair(35, i, 200, 40) for i in range(80)]                      # more of the first class, behind the wide ones
+    pkw = dict(diagonalExpansion=40)
+    if emit == "match":
+        worst, st = _check_batch(mtype, probs, **pkw)
+        assert st.regions == len(probs)
+        # the batch composition does not change a result
+        alone, _ = _run_batch(mtype, probs[46:51], **pkw)
+        together, _ = _run_batch(mtype, probs, **pkw)
+        for t1, t2 in zip(alone, together[46:51]):
+            assert np.array_equal(t1, t2)
+    else:
+        p = api.pairwiseAlignmentBandingParameters_construct(**pkw)
+        acc = api.hmm_constructEmpty(0.0, mtype)
+        with api.Batch(_sm(mtype), p, emit=api.EMIT_EXPECT) as b:
+            for sx, sy, a in probs:
+                b.add(sx, sy, a, False, False)
+            b.upload()
+            b.run()
+            b.download()
+            b.expectations(acc)
+        oacc = ob.hmm(mtype, 0.0)
+        om, op = ob.model(mtype), ob.params(**pkw)
+        for sx, sy, a in probs:
+            ob.expectations(om, oacc, sx, sy, a, op, False, False)
+        S = acc.stateNumber
+        np.testing.assert_allclose(list(acc.transitions)[:S * S], list(oacc.T)[:S * S], rtol=1e-5)
+        np.testing.assert_allclose(list(acc.emissions)[:S * 16], list(oacc.E)[:S * 16], rtol=1e-5, atol=1e-12)
+        np.testing.assert_allclose(acc.likelihood, oacc.likelihood, rtol=1e-9)
+
+
 def test_output_overflow_triggers_exact_rerun():
     sx, sy, a = make_pair(8, 0, 300, 40)
     got, st = _run_batch(0, [(sx, sy, a)], diagonalExpansion=40, threshold=1e-9)
