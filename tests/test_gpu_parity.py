@@ -98,6 +98,116 @@ def test_random_banded_property_like_reference():
         _check_batch(0, [(sx, sy, _rand_anchors(rng, len(sx), len(sy)))], **kw)
 
 
+@pytest.mark.parametrize("seed", [101, 102, 103, 104])
+def test_fuzz_batches_all_paths(seed):
+    """Random batches that mix everything a batch can hold: lengths 0-600, dense / sparse / no anchors (bands from a few
+    cells to whole rectangles), ragged ends, splitting by large gaps, short and long traceback schedules, thresholds down
+    to 0, all four model types -- so that packed classes, wide classes, multi-segment tracebacks and split regions meet
+    in one launch.  Every problem against the oracle."""
+    rng = random.Random(seed)
+    for _ in range(3):
+        mtype = rng.choice([0, 1, 2, 3])
+        tbd = rng.choice([1, 3, 10, 40])
+        pkw = dict(traceBackDiagonals=tbd, minDiagsBetweenTraceBack=tbd + rng.choice([2, 7, 60, 960]),
+                   diagonalExpansion=2 * rng.choice([0, 2, 3, 5, 10, 20, 40]), threshold=rng.choice([0.0, 0.01, 0.2]),
+                   splitMatrixBiggerThanThis=rng.choice([10, 900, 10 ** 12]))
+        probs, raggeds = [], []
+        for _ in range(rng.randrange(30, 90)):
+            sx = _rand_seq(rng, rng.choice([0, 1, 5, 40, 150, 300, 600]))
+            sy = _evolve(rng, sx) if sx and rng.random() > 0.1 else _rand_seq(rng, rng.randrange(0, 80))
+            kind = rng.random()
+            anchors = []
+            if kind < 0.6 and sx and sy:  # along the main diagonal, dense or sparse
+                step = rng.choice([1, 7, 30, 120])
+                x = y = rng.randrange(0, 5)
+                while x < len(sx) and y < len(sy):
+                    anchors.append((x, y, pkw["diagonalExpansion"]))
+                    x += step + rng.randrange(0, 3)
+                    y += step + rng.randrange(0, 3)
+            elif kind < 0.8:
+                anchors = [(x, y, pkw["diagonalExpansion"]) for x, y, _ in _rand_anchors(rng, len(sx), len(sy))]
+            probs.append((sx, sy, anchors))
+            raggeds.append((rng.random() > 0.5, rng.random() > 0.5))
+        if mtype in (1, 3):  # the asymmetric types only come from a loaded HMM (hmm_getStateMachine)
+            ph, oh = api.hmm_constructEmpty(0.0, mtype), ob.hmm(mtype, 0.0)
+            S = ph.stateNumber
+            for i in range(S * S):
+                ph.transitions[i] = oh.T[i] = 0.05 + rng.random()
+            for i in range(S * 16):
+                ph.emissions[i] = oh.E[i] = 0.05 + rng.random()
+            api.hmm_normalise(ph)
+            ob.lib().orc_hmm_normalise(oh)
+            sm, om = api.hmm_getStateMachine(ph), ob.model_from_hmm(oh)
+        else:
+            sm, om = _sm(mtype), ob.model(mtype)
+        p = api.pairwiseAlignmentBandingParameters_construct(**pkw)
+        op = ob.params(**pkw)
+        with api.Batch(sm, p) as b:
+            for (sx, sy, a), (rl, rr) in zip(probs, raggeds):
+                b.add(sx, sy, a, rl, rr)
+            b.upload()
+            b.run()
+            b.download()
+            for i, ((sx, sy, a), (rl, rr)) in enumerate(zip(probs, raggeds)):
+                want = ob.aligned_pairs(om, sx, sy, a, op, rl, rr)
+                assert_pairs_match(b.result(i), want, threshold=op.threshold)
+
+
+def _fuzz_problems(rng, n, expansion):
+    probs, raggeds = [], []
+    for _ in range(n):
+        sx = _rand_seq(rng, rng.choice([0, 1, 5, 40, 150, 300]))
+        sy = _evolve(rng, sx) if sx and rng.random() > 0.1 else _rand_seq(rng, rng.randrange(0, 80))
+        anchors = []
+        if rng.random() < 0.7 and sx and sy:
+            step = rng.choice([1, 7, 30, 120])
+            x = y = rng.randrange(0, 5)
+            while x < len(sx) and y < len(sy):
+                anchors.append((x, y, expansion))
+                x += step + rng.randrange(0, 3)
+                y += step + rng.randrange(0, 3)
+        probs.append((sx, sy, anchors))
+        raggeds.append((rng.random() > 0.5, rng.random() > 0.5))
+    return probs, raggeds
+
+
+@pytest.mark.parametrize("seed", [201, 202])
+def test_fuzz_batches_indel_and_expectation_emitters(seed):
+    """The same kind of mixed batch through the other two emitters: three lists per problem (:691-733) against the oracle,
+    and the batch's expectation counts (:735-746) against the oracle's sum over the problems (1e-5)."""
+    rng = random.Random(seed)
+    for mtype in (0, 2):
+        tbd = rng.choice([1, 5, 40])
+        pkw = dict(traceBackDiagonals=tbd, minDiagsBetweenTraceBack=tbd + rng.choice([2, 50, 960]),
+                   diagonalExpansion=2 * rng.choice([2, 5, 10, 30]), splitMatrixBiggerThanThis=rng.choice([10, 10 ** 12]))
+        probs, raggeds = _fuzz_problems(rng, 40, pkw["diagonalExpansion"])
+        p, op, om = api.pairwiseAlignmentBandingParameters_construct(**pkw), ob.params(**pkw), ob.model(mtype)
+        with api.Batch(_sm(mtype), p, emit=api.EMIT_INDEL) as b:
+            for (sx, sy, a), (rl, rr) in zip(probs, raggeds):
+                b.add(sx, sy, a, rl, rr)
+            b.upload()
+            b.run()
+            b.download()
+            for i, ((sx, sy, a), (rl, rr)) in enumerate(zip(probs, raggeds)):
+                want = ob.aligned_pairs_with_indels(om, sx, sy, a, op, rl, rr)
+                for which in range(3):
+                    assert_pairs_match(b.result(i, which), want[which], threshold=op.threshold)
+        acc, oacc = api.hmm_constructEmpty(0.0, mtype), ob.hmm(mtype, 0.0)
+        with api.Batch(_sm(mtype), p, emit=api.EMIT_EXPECT) as b:
+            for (sx, sy, a), (rl, rr) in zip(probs, raggeds):
+                b.add(sx, sy, a, rl, rr)
+            b.upload()
+            b.run()
+            b.download()
+            b.expectations(acc)
+        for (sx, sy, a), (rl, rr) in zip(probs, raggeds):
+            ob.expectations(om, oacc, sx, sy, a, op, rl, rr)
+        S = acc.stateNumber
+        np.testing.assert_allclose(list(acc.transitions)[:S * S], list(oacc.T)[:S * S], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(list(acc.emissions)[:S * 16], list(oacc.E)[:S * 16], rtol=1e-5, atol=1e-9)
+        np.testing.assert_allclose(acc.likelihood, oacc.likelihood, rtol=1e-9)
+
+
 @pytest.mark.parametrize("mtype", [0, 3])
 def test_random_wide_bands_stream_groups(mtype):
     """Diagonals of 65-250 cells with per-anchor expansions: two to four groups of 64 per diagonal, leftover cells
