@@ -19,7 +19,8 @@ static void usage(void) {
             "-x --rescoreOriginalAlignment  -i --rescoreByIdentity  -j --rescoreByPosteriorProb\n"
             "-k --rescoreByIdentityIgnoringGaps  -m --rescoreByPosteriorProbIgnoringGaps  -s --splitIndelsLongerThanThis N\n"
             "-u --outputPosteriorProbs FILE  -z --outputAllPosteriorProbs FILE  -v --outputExpectations FILE\n"
-            "-y --loadHmm FILE  -a --logLevel L (ignored)  -b --batch N (alignments per GPU batch, default 4096)\n"
+            "-y --loadHmm FILE  -a --logLevel L (ignored)  -b --batch N (most alignments per GPU batch, default 32768;\n"
+            "a batch also closes at 64 Mbp of aligned sequence)\n"
             "-g --device N  -h --help\n");
 }
 
@@ -33,7 +34,8 @@ int main(int argc, char **argv) {
     cpecan_realign_options o;
     cpecan_realign_options_default(&o);
     const char *posteriorFile = NULL, *allPosteriorFile = NULL, *expectationsFile = NULL, *hmmFile = NULL;
-    long long batch = 4096, device = 0, v;
+    long long batch = 32768, device = 0, v;
+    const long long batchBases = 64ll << 20; /* a batch also closes here: ~1.5 GB of anchors on the host */
     static struct option longOpts[] = {{"logLevel", required_argument, 0, 'a'},
                                        {"help", no_argument, 0, 'h'},
                                        {"gapGamma", required_argument, 0, 'l'},
@@ -106,7 +108,8 @@ int main(int argc, char **argv) {
     int status = in ? 0 : 1;
     for (int done = 0; !done && status == 0;) {
         int64_t n = 0;
-        while (n < batch) {
+        long long bases = 0;
+        while (n < batch && bases < batchBases) {
             if (getline(&line, &lineCap, stdin) < 0) {
                 done = 1;
                 break;
@@ -116,6 +119,7 @@ int main(int argc, char **argv) {
                 status = fail("cigar");
                 break;
             }
+            bases += llabs((long long)(in[n].end1 - in[n].start1));
             n++;
         }
         if (status == 0 && n > 0) {

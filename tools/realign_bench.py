@@ -90,6 +90,14 @@ def main():
         print("%s: %d cigars (%d aligned X bases) in %.2f s wall = %.0f cigars/s  [process start, HIP init, fasta + cigar "
               "text included]" % (label, n_cigars, bases, dt, n_cigars / dt))
         print("   " + res.stderr.strip().replace("\n", "\n   "))
+    for batch in (1024, 4096, 16384):  # smaller batches: more launches and uploads for the same cigars
+        t0 = time.time()
+        with open(cig) as fin:
+            res = subprocess.run([exe, "--batch", str(batch), os.path.join(d, "seqs.fa")], stdin=fin, capture_output=True,
+                                 text=True)
+        dt = time.time() - t0
+        assert res.returncode == 0 and [l for l in res.stdout.split("\n") if l] == out
+        print("--batch %d: %.2f s wall = %.0f cigars/s, same output" % (batch, dt, n_cigars / dt))
     same = sum(a.split()[10:] == b.split()[10:] for a, b in zip(lines, out))
     print("cigars whose operations are unchanged by the realignment: %d of %d" % (same, n_cigars))
 
