@@ -29,6 +29,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "cpecan_internal.h"
@@ -88,6 +89,86 @@ struct LaunchClass {
     }
 };
 
+// ------------------------------------------------------------------------------------------------
+// Device memory and device shells are recycled: a batch of one small problem (the single-call entry points, a caller's
+// loop over alignments) would otherwise spend ~40 ms in hipMalloc / hipFree / stream creation around a 1 ms kernel.
+// Freed blocks up to a bounded total wait in a per-device list and serve later requests of about their size; what
+// the list will not hold goes back to the driver.  Blocks are only recycled after the device has gone idle.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct CachedBlock {
+    void *ptr;
+    size_t bytes;
+};
+struct BlockCache {
+    std::vector<CachedBlock> blocks;
+    size_t bytes = 0;
+};
+constexpr int kMaxDevices = 64;
+constexpr size_t kCacheMaxBytes = (size_t)2 << 30, kCacheMaxBlock = (size_t)512 << 20;
+constexpr int kCacheMaxBlocks = 512;
+std::mutex g_cacheMutex;
+BlockCache g_blockCache[kMaxDevices];
+
+size_t round_alloc(size_t bytes) {  // coarser sizes make blocks fit later requests
+    const size_t g = bytes <= (64u << 10) ? 4096 : (bytes <= (16u << 20) ? (64u << 10) : (1u << 20));
+    return (bytes + g - 1) / g * g;
+}
+
+// the current device is `device`
+hipError_t cache_alloc(int device, void **out, size_t bytes) {
+    bytes = round_alloc(bytes ? bytes : 1);
+    if (device >= 0 && device < kMaxDevices) {
+        std::lock_guard<std::mutex> lock(g_cacheMutex);
+        BlockCache &c = g_blockCache[device];
+        int best = -1;
+        for (int i = 0; i < (int)c.blocks.size(); i++)
+            if (c.blocks[i].bytes >= bytes && c.blocks[i].bytes <= 2 * bytes + (1u << 20) &&
+                (best < 0 || c.blocks[i].bytes < c.blocks[best].bytes))
+                best = i;
+        if (best >= 0) {
+            *out = c.blocks[best].ptr;
+            c.bytes -= c.blocks[best].bytes;
+            c.blocks[best] = c.blocks.back();
+            c.blocks.pop_back();
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && device >= 0 && device < kMaxDevices) {  // give the cached blocks back and try once more
+        std::vector<CachedBlock> drop;
+        {
+            std::lock_guard<std::mutex> lock(g_cacheMutex);
+            drop.swap(g_blockCache[device].blocks);
+            g_blockCache[device].bytes = 0;
+        }
+        for (const CachedBlock &b : drop) (void)hipFree(b.ptr);
+        (void)hipGetLastError();
+        e = hipMalloc(out, bytes);
+    }
+    return e;
+}
+
+// the device must be idle with respect to this block (callers synchronise first)
+void cache_free(int device, void *ptr, size_t bytes) {
+    if (!ptr) return;
+    bytes = round_alloc(bytes ? bytes : 1);
+    if (device >= 0 && device < kMaxDevices && bytes <= kCacheMaxBlock) {
+        std::lock_guard<std::mutex> lock(g_cacheMutex);
+        BlockCache &c = g_blockCache[device];
+        if (c.bytes + bytes <= kCacheMaxBytes && (int)c.blocks.size() < kCacheMaxBlocks) {
+            c.blocks.push_back({ptr, bytes});
+            c.bytes += bytes;
+            return;
+        }
+    }
+    (void)hipFree(ptr);
+}
+}  // namespace
+
+struct CpkDevice;
+static std::vector<CpkDevice *> g_shells[kMaxDevices];  // idle device shells (guarded by g_cacheMutex)
+
 struct CpkDevice {
     int device = 0;
     int numCUs = 0;
@@ -111,6 +192,8 @@ struct CpkDevice {
     unsigned int *dQueue = nullptr;
     double *dDbgFb = nullptr, *dDbgTotals = nullptr;
     int64_t bytes = 0;
+    std::vector<CachedBlock> allocs;  // every device block this batch holds, with its size (for the block cache)
+    size_t compactBytes = 0, chunkBytes = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     hipStream_t lastStream = nullptr;
     // every class but the first runs beside it on a stream of its own (fork / join around cpk_device_run)
@@ -132,6 +215,14 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
         return CPECAN_ENODEVICE;
     }
     HIP_TRY(hipSetDevice(device));
+    if (device < kMaxDevices) {  // an idle shell of an earlier batch: its streams and events are ready
+        std::lock_guard<std::mutex> lock(g_cacheMutex);
+        if (!g_shells[device].empty()) {
+            *out = g_shells[device].back();
+            g_shells[device].pop_back();
+            return CPECAN_OK;
+        }
+    }
     CpkDevice *d = new CpkDevice();
     d->device = device;
     hipDeviceProp_t prop;
@@ -148,11 +239,12 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
 }
 
 static void free_all(CpkDevice *d) {
-    void *ptrs[] = {d->dRegions, d->dDiags, d->dSegs, d->dSymbols, d->dModel, d->dRing, d->dCand, d->dC, d->dM,
-                    d->dTotals, d->dGroll, d->dBring, d->dCounts, d->dSegStarts, d->dTriples, d->dQueue, d->dDbgFb, d->dDbgTotals, d->dForward, d->dExpect,
-                    d->dCompact, d->dChunks};
-    for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+    if (!d->allocs.empty() || d->dCompact || d->dChunks) (void)hipDeviceSynchronize();  // nothing in flight uses them
+    for (const CachedBlock &b : d->allocs) cache_free(d->device, b.ptr, b.bytes);
+    d->allocs.clear();
+    cache_free(d->device, d->dCompact, d->compactBytes);
+    cache_free(d->device, d->dChunks, d->chunkBytes);
+    d->compactBytes = d->chunkBytes = 0;
     d->dRegions = nullptr; d->dDiags = nullptr; d->dSegs = nullptr; d->dSymbols = nullptr; d->dModel = nullptr;
     d->dRing = d->dC = d->dM = d->dTotals = d->dGroll = d->dBring = nullptr;
     d->dCand = nullptr;
@@ -169,6 +261,16 @@ extern "C" void cpk_device_destroy(CpkDevice *d) {
     if (!d) return;
     (void)hipSetDevice(d->device);
     free_all(d);
+    if (d->device < kMaxDevices) {  // keep the shell (streams, events) for the next batch on this device
+        d->classes.clear();
+        d->ran = false;
+        d->lastStream = nullptr;
+        std::lock_guard<std::mutex> lock(g_cacheMutex);
+        if (g_shells[d->device].size() < 16) {
+            g_shells[d->device].push_back(d);
+            return;
+        }
+    }
     if (d->evStart) (void)hipEventDestroy(d->evStart);
     if (d->evStop) (void)hipEventDestroy(d->evStop);
     for (int k = 0; k < kMaxClasses; k++) {
@@ -182,9 +284,21 @@ template <typename T>
 static int dev_alloc(CpkDevice *d, T **p, size_t count) {
     size_t bytes = count * sizeof(T);
     if (bytes == 0) bytes = sizeof(T);
-    HIP_TRY(hipMalloc((void **)p, bytes));
+    HIP_TRY(cache_alloc(d->device, (void **)p, bytes));
+    d->allocs.push_back({(void *)*p, bytes});
     d->bytes += (int64_t)bytes;
     return CPECAN_OK;
+}
+// gives one block of the batch back (the device is idle)
+static void dev_release(CpkDevice *d, void *p) {
+    for (size_t i = 0; i < d->allocs.size(); i++)
+        if (d->allocs[i].ptr == p) {
+            cache_free(d->device, p, d->allocs[i].bytes);
+            d->bytes -= (int64_t)d->allocs[i].bytes;
+            d->allocs[i] = d->allocs.back();
+            d->allocs.pop_back();
+            return;
+        }
 }
 
 static KernelFn pick_packed_kernel(const CpkGeometry &g, int cls) {  // class k: groups of 8 << k lanes
@@ -456,14 +570,15 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     {
         // anchors -> per-diagonal table, on the device (the anchors are only needed for this)
         int64_t *dAnchors = nullptr;
-        HIP_TRY(hipMalloc((void **)&dAnchors, sizeof(int64_t) * 3 * (size_t)(nAnchors > 0 ? nAnchors : 1)));
+        const size_t anchorBytes = sizeof(int64_t) * 3 * (size_t)(nAnchors > 0 ? nAnchors : 1);
+        HIP_TRY(cache_alloc(d->device, (void **)&dAnchors, anchorBytes));
         if (nAnchors > 0)
             HIP_TRY(hipMemcpy(dAnchors, anchors, sizeof(int64_t) * 3 * (size_t)nAnchors, hipMemcpyHostToDevice));
         hipLaunchKernelGGL(cpecan_build_diag_table, dim3((unsigned)((geo->nRegions + 63) / 64)), dim3(64), 0, nullptr,
                            d->dRegions, geo->nRegions, dAnchors, d->dDiags, expansion, dynamic);
         const hipError_t launched = hipGetLastError();
         const hipError_t done = hipDeviceSynchronize();
-        (void)hipFree(dAnchors);
+        cache_free(d->device, dAnchors, anchorBytes);  // after the synchronise above
         HIP_TRY(launched);
         HIP_TRY(done);
     }
@@ -484,8 +599,8 @@ extern "C" int cpk_device_update_regions(CpkDevice *d, const CpkRegion *regions,
     HIP_TRY(hipSetDevice(d->device));
     if (outTriplesPerList != d->outTriplesPerList) {
         if (d->dTriples) {
-            (void)hipFree(d->dTriples);
-            d->bytes -= (int64_t)sizeof(int32_t) * d->nLists * d->outTriplesPerList * 3;
+            HIP_TRY(hipDeviceSynchronize());  // the run that overflowed has finished with it
+            dev_release(d, d->dTriples);
             d->dTriples = nullptr;
         }
         d->outTriplesPerList = outTriplesPerList;
@@ -602,16 +717,19 @@ extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segSt
 extern "C" int cpk_device_gather(CpkDevice *d, const CpkChunk *chunks, int64_t nChunks, int64_t total) {
     HIP_TRY(hipSetDevice(d->device));
     if (nChunks <= 0 || total <= 0) return CPECAN_OK;
+    if (nChunks > d->chunkCap || total > d->compactCap) HIP_TRY(hipDeviceSynchronize());  // before blocks are recycled
     if (nChunks > d->chunkCap) {
-        if (d->dChunks) (void)hipFree(d->dChunks);
+        cache_free(d->device, d->dChunks, d->chunkBytes);
         d->dChunks = nullptr;
-        HIP_TRY(hipMalloc((void **)&d->dChunks, sizeof(CpkChunk) * (size_t)nChunks));
+        d->chunkBytes = sizeof(CpkChunk) * (size_t)nChunks;
+        HIP_TRY(cache_alloc(d->device, (void **)&d->dChunks, d->chunkBytes));
         d->chunkCap = nChunks;
     }
     if (total > d->compactCap) {
-        if (d->dCompact) (void)hipFree(d->dCompact);
+        cache_free(d->device, d->dCompact, d->compactBytes);
         d->dCompact = nullptr;
-        HIP_TRY(hipMalloc((void **)&d->dCompact, sizeof(int32_t) * 3 * (size_t)total));
+        d->compactBytes = sizeof(int32_t) * 3 * (size_t)total;
+        HIP_TRY(cache_alloc(d->device, (void **)&d->dCompact, d->compactBytes));
         d->compactCap = total;
     }
     HIP_TRY(hipMemcpy(d->dChunks, chunks, sizeof(CpkChunk) * (size_t)nChunks, hipMemcpyHostToDevice));
@@ -642,20 +760,23 @@ extern "C" int cpk_device_fetch(CpkDevice *d, int32_t *hostOut, int64_t total, d
 
 // The consumers on a device-resident triple buffer.  Scratch lives for the duration of the call.
 namespace {
-struct PostScratch {
-    std::vector<void *> ptrs;
+struct PostScratch {  // device blocks of one consumer stage, on the current device
+    std::vector<CachedBlock> blocks;
+    int device = 0;
+    PostScratch() { (void)hipGetDevice(&device); }
     ~PostScratch() {
-        for (void *p : ptrs)
-            if (p) (void)hipFree(p);
+        if (!blocks.empty()) (void)hipDeviceSynchronize();  // the stage's kernels are done with them
+        for (const CachedBlock &b : blocks) cache_free(device, b.ptr, b.bytes);
     }
     template <typename T>
     int alloc(T **out, size_t count) {
         void *p = nullptr;
-        if (hipMalloc(&p, (count ? count : 1) * sizeof(T)) != hipSuccess) {
+        const size_t bytes = (count ? count : 1) * sizeof(T);
+        if (cache_alloc(device, &p, bytes) != hipSuccess) {
             cpk_set_error("out of device memory in the list consumers");
             return CPECAN_ENOMEM;
         }
-        ptrs.push_back(p);
+        blocks.push_back({p, bytes});
         *out = static_cast<T *>(p);
         return CPECAN_OK;
     }
@@ -752,7 +873,8 @@ extern "C" int cpk_device_post(CpkDevice *d, const CpkPostJob *job) {
     HIP_TRY(hipSetDevice(d->device));
     if (!d->dCompact && job->nProblems > 0) {
         // every list is empty: the consumers still need a valid base pointer
-        HIP_TRY(hipMalloc((void **)&d->dCompact, sizeof(int32_t) * 3));
+        d->compactBytes = sizeof(int32_t) * 3;
+        HIP_TRY(cache_alloc(d->device, (void **)&d->dCompact, d->compactBytes));
         d->compactCap = 1;
     }
     return post_core(d->dCompact, job);
