@@ -199,14 +199,53 @@ __global__ void __launch_bounds__(64) cpecan_post_left_shift(const CpkPostProble
 struct OrderedCtx {
     const int32_t *pairs;
     const double *best;
-    __device__ __forceinline__ int pick(int a, int b) const {
+    // the better chain end of a (score sa) and b (score sb): higher score, then smaller y, then the later column
+    __device__ __forceinline__ int pick(int a, double sa, int b, double sb) const {
         if (a < 0) return b;
         if (b < 0) return a;
-        const double sa = best[a], sb = best[b];
         if (sa != sb) return sa > sb ? a : b;
         const int ya = pairs[3 * a + 2], yb = pairs[3 * b + 2];
         if (ya != yb) return ya < yb ? a : b;
         return pairs[3 * a + 1] > pairs[3 * b + 1] ? a : b;
+    }
+    __device__ __forceinline__ double score(int i) const { return i >= 0 ? best[i] : -__builtin_huge_val(); }
+    // Fenwick prefix maximum over y' < y.  The nodes of a query are known from y alone: four nodes, then their four
+    // scores, are loaded side by side -- two dependent round trips per four nodes instead of eight (one lane per
+    // problem: this walk is pure memory latency).
+    __device__ __forceinline__ int query(const int32_t *tree, int y) const {
+        int from = -1;
+        double sFrom = -__builtin_huge_val();
+        for (int k = y; k > 0;) {
+            const int k0 = k, k1 = k0 - (k0 & -k0), k2 = k1 - (k1 & -k1), k3 = k2 - (k2 & -k2);  // 0 stays 0
+            const int i0 = tree[k0 - 1], i1 = k1 > 0 ? tree[k1 - 1] : -1, i2 = k2 > 0 ? tree[k2 - 1] : -1,
+                      i3 = k3 > 0 ? tree[k3 - 1] : -1;
+            const double s0 = score(i0), s1 = score(i1), s2 = score(i2), s3 = score(i3);
+            int a = pick(i0, s0, i1, s1);
+            const double sa = a == i0 ? s0 : s1;
+            int b = pick(i2, s2, i3, s3);
+            const double sb = b == i2 ? s2 : s3;
+            a = pick(a, sa, b, sb);
+            const double sab = a == b ? sb : sa;
+            const int f = pick(from, sFrom, a, sab);
+            sFrom = f == from ? sFrom : sab;
+            from = f;
+            k = k3 - (k3 & -k3);
+        }
+        return from;
+    }
+    // pair i (score si) becomes a candidate end for every prefix that contains y
+    __device__ __forceinline__ void update(int32_t *tree, int lY, int y, int i, double si) const {
+        for (int k = y + 1; k <= lY;) {
+            const int k0 = k, k1 = k0 + (k0 & -k0), k2 = k1 + (k1 & -k1), k3 = k2 + (k2 & -k2);
+            const bool v1 = k1 <= lY, v2 = k2 <= lY, v3 = k3 <= lY;
+            const int i0 = tree[k0 - 1], i1 = v1 ? tree[k1 - 1] : -1, i2 = v2 ? tree[k2 - 1] : -1, i3 = v3 ? tree[k3 - 1] : -1;
+            const double s0 = score(i0), s1 = score(i1), s2 = score(i2), s3 = score(i3);
+            if (pick(i0, s0, i, si) == i) tree[k0 - 1] = i;
+            if (v1 && pick(i1, s1, i, si) == i) tree[k1 - 1] = i;
+            if (v2 && pick(i2, s2, i, si) == i) tree[k2 - 1] = i;
+            if (v3 && pick(i3, s3, i, si) == i) tree[k3 - 1] = i;
+            k = v3 ? k3 + (k3 & -k3) : lY + 1;
+        }
     }
 };
 
@@ -235,19 +274,16 @@ __global__ void __launch_bounds__(64) cpecan_post_ordered(const CpkPostProblem *
         for (int i = head[x]; i >= 0; i = nx[i]) {
             const double w = (double)pairs[3 * i] / (double)CPECAN_PROB_1;
             if (w >= matchGamma && w > 0.0) {  // :393
-                int from = -1;
-                for (int k = pairs[3 * i + 2]; k > 0; k -= k & -k) from = cx.pick(from, tree[k - 1]);  // y' < y
+                const int from = cx.query(tree, pairs[3 * i + 2]);  // y' < y
                 pv[i] = from;
                 bs[i] = (from < 0 ? 0.0 : bs[from]) + w * 1.0;  // :404
                 ch[i] = 2;
             }
         }
         for (int i = head[x]; i >= 0; i = nx[i])
-            if (ch[i] == 2)
-                for (int k = pairs[3 * i + 2] + 1; k <= lY; k += k & -k) tree[k - 1] = cx.pick(tree[k - 1], i);
+            if (ch[i] == 2) cx.update(tree, lY, pairs[3 * i + 2], i, bs[i]);
     }
-    int last = -1;
-    for (int k = lY; k > 0; k -= k & -k) last = cx.pick(last, tree[k - 1]);
+    const int last = cx.query(tree, lY);
     for (int i = last; i >= 0; i = pv[i]) ch[i] = 1;  // :437-475
     int32_t *o = out + 3 * pb.meaOut;
     int count = 0;
