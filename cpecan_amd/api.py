@@ -63,6 +63,13 @@ class PairwiseAlignmentParameters(C.Structure):
     ]
 
 
+class Problem(C.Structure):
+    """cpecan_problem: one element of cpecan_batch_add_many."""
+    _fields_ = [("sX", C.c_char_p), ("lX", C.c_int64), ("sY", C.c_char_p), ("lY", C.c_int64),
+                ("anchors", C.POINTER(C.c_int64)), ("nAnchors", C.c_int64),
+                ("raggedLeft", C.c_int32), ("raggedRight", C.c_int32)]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("problems", C.c_int64), ("regions", C.c_int64), ("cells", C.c_int64), ("diagonals", C.c_int64),
@@ -84,7 +91,7 @@ EXPORTS = [
     "cpecan_batch_set_post", "cpecan_batch_scores", "cpecan_reweight_aligned_pairs", "cpecan_posterior_scores",
     "cpecan_mea_alignment", "cpecan_left_shift_alignment", "cpecan_get_shifted_mea_alignment",
     "cpecan_anchors_from_alignment", "cpecan_batch_set_match_gamma", "cpecan_batch_identity_scores",
-    "cpecan_identity_scores", "cpecan_filter_pairs_ordered",
+    "cpecan_identity_scores", "cpecan_filter_pairs_ordered", "cpecan_batch_add_many",
 ]
 OP_MATCH, OP_INDEL_X, OP_INDEL_Y = 0, 1, 2
 POST_REWEIGHT, POST_MEA, POST_LEFT_SHIFT, POST_ORDERED = 1, 2, 4, 8
@@ -146,6 +153,8 @@ def lib():
                                                 C.c_int64, C.c_char_p, C.c_int64, i64p]
     L.cpecan_batch_set_post.argtypes = [vp, C.c_int, C.c_double]
     L.cpecan_batch_scores.argtypes = [vp, C.c_int64, dp, dp, dp]
+    L.cpecan_batch_add_many.argtypes = [vp, C.POINTER(Problem), C.c_int64]
+    L.cpecan_batch_add_many.restype = C.c_int64
     L.cpecan_batch_set_match_gamma.argtypes = [vp, C.c_float]
     L.cpecan_batch_identity_scores.argtypes = [vp, C.c_int64, dp, dp]
     L.cpecan_identity_scores.argtypes = [i32p, C.c_int64, C.c_char_p, C.c_char_p, dp, dp]
@@ -296,6 +305,24 @@ class Batch:
                                             int(raggedRight)), "cpecan_batch_add")
         self.n += 1
         return idx
+
+    def add_many(self, problems):
+        """problems: iterable of (sX, sY, anchorPairs[, raggedLeft, raggedRight]); cut, converted and copied in parallel
+        by cpecan_batch_add_many.  Returns the index of the first."""
+        problems = list(problems)
+        arr = (Problem * max(1, len(problems)))()
+        keep = []
+        for i, pr in enumerate(problems):
+            sx, sy = _bytes(pr[0]), _bytes(pr[1])
+            a, ptr, n = _anchor_array(pr[2] if len(pr) > 2 else ())
+            keep.append((sx, sy, a))
+            arr[i].sX, arr[i].lX, arr[i].sY, arr[i].lY = sx, len(sx), sy, len(sy)
+            arr[i].anchors, arr[i].nAnchors = ptr, n
+            arr[i].raggedLeft = int(pr[3]) if len(pr) > 3 else 0
+            arr[i].raggedRight = int(pr[4]) if len(pr) > 4 else 0
+        first = _check(lib().cpecan_batch_add_many(self._h, arr, len(problems)), "cpecan_batch_add_many")
+        self.n += len(problems)
+        return first
 
     def upload(self):
         _check(lib().cpecan_batch_upload(self._h), "cpecan_batch_upload")

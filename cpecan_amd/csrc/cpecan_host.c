@@ -406,7 +406,6 @@ struct cpecan_batch {
     double *forward; /* [nRegions] in device order, FORWARD emitter */
     int32_t *results; /* every emitted triple of the batch, list-ordered: [list][problem][triple] */
     uint8_t *chars;   /* raw upper-case sequences (leftShiftAlignment compares letters, not symbols) */
-    int64_t *rectScratch, capRectScratch; /* split rectangles of the problem being added */
     int64_t nChars, capChars;
     int postFlags;    /* CPECAN_POST_* applied by download */
     double postGapGamma;
@@ -517,7 +516,6 @@ void cpecan_batch_destroy(cpecan_batch *b) {
     free(b->segs);
     free(b->forward);
     free(b->chars);
-    free(b->rectScratch);
     free(b);
 }
 
@@ -540,93 +538,186 @@ static void init_byte_tables(void) { /* idempotent: every caller writes the same
     g_symbolOf['T'] = g_symbolOf['t'] = 3;
 }
 
-/* Appends N + symbols + N (so that index x addresses base x-1 and x = 0 / x = l+1 read as N). */
-static int64_t append_symbols(cpecan_batch *b, const char *s, int64_t l) {
-    if (grow((void **)&b->symbols, &b->capSymbols, b->nSymbols + l + 2, 1)) return -1;
-    const int64_t off = b->nSymbols;
-    uint8_t *dst = b->symbols + off;
-    dst[0] = CPK_SYM_N;
-    for (int64_t i = 0; i < l; i++) dst[i + 1] = g_symbolOf[(unsigned char)s[i]];
-    dst[l + 1] = CPK_SYM_N;
-    b->nSymbols += l + 2;
-    return off;
+/* Writes N + symbols + N at dst[at..] (so that index x addresses base x-1 and x = 0 / x = l+1 read as N); returns the
+ * offset behind them. */
+static int64_t put_symbols(uint8_t *dst, int64_t at, const char *s, int64_t l) {
+    dst[at] = CPK_SYM_N;
+    for (int64_t i = 0; i < l; i++) dst[at + 1 + i] = g_symbolOf[(unsigned char)s[i]];
+    dst[at + l + 1] = CPK_SYM_N;
+    return at + l + 2;
+}
+
+/* What one problem adds to the batch's arrays; filled by the counting pass of cpecan_batch_add_many. */
+typedef struct {
+    int64_t nRects, symbolBytes, nAnchorsKept;
+} AddCount;
+
+/* The split rectangles of one problem (getSplitPoints semantics, pairwiseAligner.c:1230-1271) into *rects, grown as
+ * needed.  Returns their number or < 0. */
+static int64_t problem_rects(const cpecan_batch *b, const cpecan_problem *it, int64_t **rects, int64_t *cap) {
+    if (grow((void **)rects, cap, 4 * (it->nAnchors + 2), sizeof(int64_t))) return CPECAN_ENOMEM;
+    if (b->emit == CPECAN_EMIT_FORWARD) { /* computeForwardProbability never splits (pairwiseAligner.c:936-949) */
+        (*rects)[0] = 0;
+        (*rects)[1] = 0;
+        (*rects)[2] = it->lX;
+        (*rects)[3] = it->lY;
+        return 1;
+    }
+    return cpecan_split_points(it->anchors, it->nAnchors, it->lX, it->lY, b->params.splitMatrixBiggerThanThis, it->raggedLeft,
+                               it->raggedRight, *rects);
+}
+
+static int problem_valid(const cpecan_problem *it) {
+    if (it->lX < 0 || it->lY < 0 || it->nAnchors < 0 || (it->lX > 0 && !it->sX) || (it->lY > 0 && !it->sY) ||
+        (it->nAnchors > 0 && !it->anchors))
+        return 0;
+    if (it->lX + it->lY >= (int64_t)1 << 30) return 0;
+    /* anchors must be strictly increasing in both coordinates (pairwiseAligner.c:159-164) */
+    for (int64_t i = 0; i < it->nAnchors; i++) {
+        const int64_t x = it->anchors[3 * i], y = it->anchors[3 * i + 1];
+        if (x < 0 || y < 0 || x >= it->lX || y >= it->lY) return 0;
+        if (i > 0 && (x <= it->anchors[3 * (i - 1)] || y <= it->anchors[3 * (i - 1) + 1])) return 0;
+    }
+    return 1;
+}
+
+int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *items, int64_t n) {
+    if (!b || b->frozen) return CPECAN_ESTATE;
+    if (n < 0 || (n > 0 && !items)) return CPECAN_EINVAL;
+    if (n == 0) return b->nProblems;
+    AddCount *cnt = malloc(sizeof(AddCount) * (size_t)n);
+    int64_t *offs = malloc(sizeof(int64_t) * 4 * (size_t)n); /* first region, symbol byte, anchor triple, char of each */
+    if (!cnt || !offs) {
+        free(cnt);
+        free(offs);
+        return CPECAN_ENOMEM;
+    }
+    /* pass 1: what every problem needs (the problems are independent: OpenMP when there are enough of them) */
+    int64_t firstBad = n;
+    int bad = CPECAN_OK;
+#pragma omp parallel num_threads(cpk_host_threads()) if (n >= 64)
+    {
+        int64_t *rects = NULL, cap = 0;
+#pragma omp for schedule(dynamic, 32)
+        for (int64_t i = 0; i < n; i++) {
+            const cpecan_problem *it = &items[i];
+            int64_t nRects = problem_valid(it) ? problem_rects(b, it, &rects, &cap) : CPECAN_EINVAL;
+            if (nRects < 0) {
+#pragma omp critical(cpk_add)
+                if (i < firstBad) {
+                    firstBad = i;
+                    bad = nRects == CPECAN_ENOMEM ? CPECAN_ENOMEM : CPECAN_EINVAL;
+                }
+                cnt[i].nRects = cnt[i].symbolBytes = cnt[i].nAnchorsKept = 0;
+                continue;
+            }
+            int64_t sym = 0, kept = 0;
+            for (int64_t k = 0; k < nRects; k++) {
+                sym += (rects[4 * k + 2] - rects[4 * k]) + (rects[4 * k + 3] - rects[4 * k + 1]) + 4; /* N + bases + N, twice */
+                while (kept < it->nAnchors && it->anchors[3 * kept] + it->anchors[3 * kept + 1] < rects[4 * k + 2] + rects[4 * k + 3]) kept++;
+            }
+            cnt[i].nRects = nRects;
+            cnt[i].symbolBytes = sym;
+            cnt[i].nAnchorsKept = kept;
+        }
+        free(rects);
+    }
+    if (firstBad < n) {
+        free(cnt);
+        free(offs);
+        if (bad == CPECAN_EINVAL) cpk_set_error("problem %lld of the call: bad lengths or anchors", (long long)firstBad);
+        return bad;
+    }
+    int64_t nRegions = b->nRegions, nSymbols = b->nSymbols, nAnchorVals = b->nAnchorVals, nChars = b->nChars;
+    for (int64_t i = 0; i < n; i++) {
+        offs[4 * i] = nRegions;
+        offs[4 * i + 1] = nSymbols;
+        offs[4 * i + 2] = nAnchorVals;
+        offs[4 * i + 3] = nChars;
+        nRegions += cnt[i].nRects;
+        nSymbols += cnt[i].symbolBytes;
+        nAnchorVals += 3 * cnt[i].nAnchorsKept;
+        nChars += items[i].lX + items[i].lY;
+    }
+    if (grow((void **)&b->problems, &b->capProblems, b->nProblems + n, sizeof(HostProblem)) ||
+        grow((void **)&b->regions, &b->capRegions, nRegions, sizeof(HostRegion)) ||
+        grow((void **)&b->anchors, &b->capAnchorVals, nAnchorVals, sizeof(int64_t)) ||
+        grow((void **)&b->symbols, &b->capSymbols, nSymbols, 1) || grow((void **)&b->chars, &b->capChars, nChars + 1, 1)) {
+        free(cnt);
+        free(offs);
+        return CPECAN_ENOMEM;
+    }
+    /* pass 2: every problem writes its own slices */
+    const int64_t firstProblem = b->nProblems;
+    int oom = 0;
+#pragma omp parallel num_threads(cpk_host_threads()) if (n >= 64)
+    {
+        int64_t *rects = NULL, cap = 0;
+#pragma omp for schedule(dynamic, 32)
+        for (int64_t i = 0; i < n; i++) {
+            const cpecan_problem *it = &items[i];
+            const int64_t nRects = problem_rects(b, it, &rects, &cap);
+            if (nRects != cnt[i].nRects) { /* only an allocation failure can change the answer */
+#pragma omp atomic write
+                oom = 1;
+                continue;
+            }
+            HostProblem *pr = &b->problems[firstProblem + i];
+            memset(pr, 0, sizeof *pr);
+            pr->firstRegion = offs[4 * i];
+            pr->nRegions = nRects;
+            pr->lX = it->lX;
+            pr->lY = it->lY;
+            uint8_t *ch = b->chars + offs[4 * i + 3];
+            pr->charX = offs[4 * i + 3];
+            for (int64_t k = 0; k < it->lX; k++) ch[k] = g_upperOf[(unsigned char)it->sX[k]];
+            pr->charY = pr->charX + it->lX;
+            for (int64_t k = 0; k < it->lY; k++) ch[it->lX + k] = g_upperOf[(unsigned char)it->sY[k]];
+            int64_t next = 0, symAt = offs[4 * i + 1], anchorAt = offs[4 * i + 2]; /* anchors go to regions in order, :1296-1308 */
+            for (int64_t k = 0; k < nRects; k++) {
+                const int64_t x1 = rects[4 * k], y1 = rects[4 * k + 1], x2 = rects[4 * k + 2], y2 = rects[4 * k + 3];
+                HostRegion *r = &b->regions[offs[4 * i] + k];
+                memset(r, 0, sizeof *r);
+                r->problem = firstProblem + i;
+                r->x1 = x1;
+                r->y1 = y1;
+                r->lX = x2 - x1;
+                r->lY = y2 - y1;
+                r->raggedLeft = (it->raggedLeft || k > 0) ? 1 : 0;
+                r->raggedRight = (it->raggedRight || k < nRects - 1) ? 1 : 0;
+                r->seqXOff = symAt;
+                symAt = put_symbols(b->symbols, symAt, it->sX + x1, r->lX);
+                r->seqYOff = symAt;
+                symAt = put_symbols(b->symbols, symAt, it->sY + y1, r->lY);
+                r->anchorOff = anchorAt / 3;
+                while (next < it->nAnchors && it->anchors[3 * next] + it->anchors[3 * next + 1] < x2 + y2) {
+                    int64_t *a = b->anchors + anchorAt;
+                    a[0] = it->anchors[3 * next] - x1;
+                    a[1] = it->anchors[3 * next + 1] - y1;
+                    a[2] = it->anchors[3 * next + 2];
+                    anchorAt += 3;
+                    r->nAnchors++;
+                    next++;
+                }
+            }
+        }
+        free(rects);
+    }
+    free(cnt);
+    free(offs);
+    if (oom) return CPECAN_ENOMEM;
+    b->nProblems += n;
+    b->nRegions = nRegions;
+    b->nSymbols = nSymbols;
+    b->nAnchorVals = nAnchorVals;
+    b->nChars = nChars;
+    return firstProblem;
 }
 
 int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char *sY, int64_t lY,
                          const int64_t *anchors, int64_t nAnchors, int raggedLeft, int raggedRight) {
-    if (!b || b->frozen) return CPECAN_ESTATE;
-    if (lX < 0 || lY < 0 || nAnchors < 0 || (lX > 0 && !sX) || (lY > 0 && !sY) || (nAnchors > 0 && !anchors))
-        return CPECAN_EINVAL;
-    if (lX + lY >= (int64_t)1 << 30) return CPECAN_EINVAL;
-    /* anchors must be strictly increasing in both coordinates (pairwiseAligner.c:159-164) */
-    for (int64_t i = 0; i < nAnchors; i++) {
-        const int64_t x = anchors[3 * i], y = anchors[3 * i + 1];
-        if (x < 0 || y < 0 || x >= lX || y >= lY) return CPECAN_EINVAL;
-        if (i > 0 && (x <= anchors[3 * (i - 1)] || y <= anchors[3 * (i - 1) + 1])) return CPECAN_EINVAL;
-    }
-    if (grow((void **)&b->rectScratch, &b->capRectScratch, 4 * (nAnchors + 2), sizeof(int64_t))) return CPECAN_ENOMEM;
-    int64_t *rects = b->rectScratch; /* reused from call to call */
-    int64_t nRects;
-    if (b->emit == CPECAN_EMIT_FORWARD) { /* computeForwardProbability never splits (pairwiseAligner.c:936-949) */
-        nRects = 1;
-        rects[0] = 0;
-        rects[1] = 0;
-        rects[2] = lX;
-        rects[3] = lY;
-    } else {
-        nRects = cpecan_split_points(anchors, nAnchors, lX, lY, b->params.splitMatrixBiggerThanThis, raggedLeft,
-                                     raggedRight, rects);
-    }
-    if (nRects < 0) {
-        return CPECAN_EINVAL;
-    }
-    if (grow((void **)&b->problems, &b->capProblems, b->nProblems + 1, sizeof(HostProblem)) ||
-        grow((void **)&b->regions, &b->capRegions, b->nRegions + nRects, sizeof(HostRegion)) ||
-        grow((void **)&b->anchors, &b->capAnchorVals, b->nAnchorVals + 3 * nAnchors, sizeof(int64_t))) {
-        return CPECAN_ENOMEM;
-    }
-    if (grow((void **)&b->chars, &b->capChars, b->nChars + lX + lY + 1, 1)) {
-        return CPECAN_ENOMEM;
-    }
-    HostProblem *pr = &b->problems[b->nProblems];
-    memset(pr, 0, sizeof *pr);
-    pr->firstRegion = b->nRegions;
-    pr->nRegions = nRects;
-    pr->lX = lX;
-    pr->lY = lY;
-    pr->charX = b->nChars;
-    for (int64_t i = 0; i < lX; i++) b->chars[b->nChars++] = g_upperOf[(unsigned char)sX[i]];
-    pr->charY = b->nChars;
-    for (int64_t i = 0; i < lY; i++) b->chars[b->nChars++] = g_upperOf[(unsigned char)sY[i]];
-    int64_t next = 0; /* anchors are handed to regions in order, pairwiseAligner.c:1296-1308 */
-    for (int64_t i = 0; i < nRects; i++) {
-        const int64_t x1 = rects[4 * i], y1 = rects[4 * i + 1], x2 = rects[4 * i + 2], y2 = rects[4 * i + 3];
-        HostRegion *r = &b->regions[b->nRegions++];
-        memset(r, 0, sizeof *r);
-        r->problem = b->nProblems;
-        r->x1 = x1;
-        r->y1 = y1;
-        r->lX = x2 - x1;
-        r->lY = y2 - y1;
-        r->raggedLeft = (raggedLeft || i > 0) ? 1 : 0;
-        r->raggedRight = (raggedRight || i < nRects - 1) ? 1 : 0;
-        r->seqXOff = append_symbols(b, sX + x1, r->lX);
-        r->seqYOff = append_symbols(b, sY + y1, r->lY);
-        if (r->seqXOff < 0 || r->seqYOff < 0) {
-                return CPECAN_ENOMEM;
-        }
-        r->anchorOff = b->nAnchorVals / 3;
-        while (next < nAnchors && anchors[3 * next] + anchors[3 * next + 1] < x2 + y2) {
-            int64_t *a = b->anchors + b->nAnchorVals;
-            a[0] = anchors[3 * next] - x1;
-            a[1] = anchors[3 * next + 1] - y1;
-            a[2] = anchors[3 * next + 2];
-            b->nAnchorVals += 3;
-            r->nAnchors++;
-            next++;
-        }
-    }
-    return b->nProblems++;
+    const cpecan_problem it = {sX, lX, sY, lY, anchors, nAnchors, raggedLeft ? 1 : 0, raggedRight ? 1 : 0};
+    return cpecan_batch_add_many(b, &it, 1);
 }
 
 typedef struct {

@@ -10,6 +10,7 @@
 #include "cpecan_realign.h"
 
 #include <ctype.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -64,13 +65,17 @@ static size_t next_token(const char **s, const char **tok) {
 }
 
 static int parse_i64(const char *tok, size_t n, int64_t *v) {
-    char buf[32];
-    if (n == 0 || n >= sizeof buf) return 0;
-    memcpy(buf, tok, n);
-    buf[n] = 0;
-    char *end;
-    *v = strtoll(buf, &end, 10);
-    return *end == 0;
+    size_t i = 0;
+    const int neg = n > 0 && tok[0] == '-';
+    if (neg || (n > 0 && tok[0] == '+')) i++;
+    if (i >= n || n - i > 18) return 0; /* 18 digits always fit */
+    int64_t acc = 0;
+    for (; i < n; i++) {
+        if (tok[i] < '0' || tok[i] > '9') return 0;
+        acc = acc * 10 + (tok[i] - '0');
+    }
+    *v = neg ? -acc : acc;
+    return 1;
 }
 
 /* checkPairwiseAlignment (sonLib): strands and coordinates agree, the operations add up to the two spans */
@@ -169,23 +174,42 @@ int cpecan_cigar_parse(const char *line, cpecan_cigar *out) {
     return CPECAN_OK;
 }
 
+/* decimal text of v at dst (room for 21 bytes); returns the length */
+static int put_i64(char *dst, int64_t v) {
+    char tmp[24];
+    int n = 0, neg = v < 0;
+    uint64_t u = neg ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+    do {
+        tmp[n++] = (char)('0' + u % 10);
+        u /= 10;
+    } while (u);
+    int at = 0;
+    if (neg) dst[at++] = '-';
+    while (n) dst[at++] = tmp[--n];
+    return at;
+}
+
 int64_t cpecan_cigar_format(const cpecan_cigar *c, char *buf, int64_t cap) {
     if (!c || !c->contig1 || !c->contig2 || cap < 0) return CPECAN_EINVAL;
     static const char opChar[3] = {'M', 'D', 'I'};
-    int64_t at = 0;
     char *dst = cap > 0 ? buf : NULL;
-    int w = snprintf(dst, dst ? (size_t)cap : 0, "cigar: %s %lld %lld %c %s %lld %lld %c %f", c->contig2, (long long)c->start2,
-                     (long long)c->end2, c->strand2 ? '+' : '-', c->contig1, (long long)c->start1, (long long)c->end1,
-                     c->strand1 ? '+' : '-', c->score);
+    const int w = snprintf(dst, dst ? (size_t)cap : 0, "cigar: %s %lld %lld %c %s %lld %lld %c %f", c->contig2,
+                           (long long)c->start2, (long long)c->end2, c->strand2 ? '+' : '-', c->contig1, (long long)c->start1,
+                           (long long)c->end1, c->strand1 ? '+' : '-', c->score);
     if (w < 0) return CPECAN_EINVAL;
-    at = w;
-    for (int64_t i = 0; i < c->nOps; i++) {
-        const int64_t room = cap - at;
-        w = snprintf(room > 0 ? buf + at : NULL, room > 0 ? (size_t)room : 0, " %c %lld", opChar[c->ops[2 * i]],
-                     (long long)c->ops[2 * i + 1]);
-        if (w < 0) return CPECAN_EINVAL;
-        at += w;
+    int64_t at = w;
+    for (int64_t i = 0; i < c->nOps; i++) { /* " <op> <length>": by hand, an alignment has hundreds of these */
+        char piece[32];
+        int n = 0;
+        piece[n++] = ' ';
+        piece[n++] = opChar[c->ops[2 * i]];
+        piece[n++] = ' ';
+        n += put_i64(piece + n, c->ops[2 * i + 1]);
+        if (at + n < cap) memcpy(buf + at, piece, (size_t)n);
+        else if (at < cap - 1) memcpy(buf + at, piece, (size_t)(cap - 1 - at));
+        at += n;
     }
+    if (cap > 0) buf[at < cap ? at : cap - 1] = 0;
     return at;
 }
 
@@ -706,14 +730,23 @@ static int prepare_range(const cpecan_realigner *r, const cpecan_cigar *in, int6
 /* Prepares the cigars a slice at a time and adds each slice to the batch (both ends ragged, :537); the anchor lists of a
  * slice are released as soon as the batch holds them, so the next slice reuses their memory. */
 static int prepare_and_add(const cpecan_realigner *r, const cpecan_cigar *in, int64_t n, Item *items, cpecan_batch *b) {
-    const int64_t slice = 2048;
+    const int64_t slice = 4096;
     for (int64_t from = 0; from < n; from += slice) {
         const int64_t to = from + slice < n ? from + slice : n;
         int rc = prepare_range(r, in, from, to, items);
+        cpecan_problem *probs = rc == CPECAN_OK ? malloc(sizeof(cpecan_problem) * (size_t)(to - from)) : NULL;
+        if (rc == CPECAN_OK && !probs) rc = CPECAN_ENOMEM;
         for (int64_t i = from; rc == CPECAN_OK && i < to; i++) {
-            const int64_t idx = cpecan_batch_add(b, items[i].subX, items[i].lX, items[i].subY, items[i].lY, items[i].filtered,
-                                                 items[i].nFiltered, 1, 1);
-            rc = idx < 0 ? (int)idx : CPECAN_OK;
+            const cpecan_problem p = {items[i].subX, items[i].lX, items[i].subY, items[i].lY, items[i].filtered,
+                                      items[i].nFiltered, 1, 1};
+            probs[i - from] = p;
+        }
+        if (rc == CPECAN_OK) {
+            const int64_t first = cpecan_batch_add_many(b, probs, to - from);
+            rc = first < 0 ? (int)first : CPECAN_OK;
+        }
+        free(probs);
+        for (int64_t i = from; i < to; i++) {
             free(items[i].filtered);
             items[i].filtered = NULL;
         }

@@ -144,6 +144,18 @@ void cpecan_batch_destroy(cpecan_batch *b);
 int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char *sY, int64_t lY,
                          const int64_t *anchors, int64_t nAnchors, int raggedLeft, int raggedRight);
 
+/* The same for n problems at once: they are cut, converted and copied in parallel.  Returns the index of the first. */
+typedef struct cpecan_problem {
+    const char *sX;
+    int64_t lX;
+    const char *sY;
+    int64_t lY;
+    const int64_t *anchors; /* nAnchors triples (x, y, expansion) */
+    int64_t nAnchors;
+    int32_t raggedLeft, raggedRight;
+} cpecan_problem;
+int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *problems, int64_t n);
+
 /* Freezes the batch: builds band tables and traceback schedules on the host, allocates device
  * memory and copies the packed inputs to the GPU. */
 int cpecan_batch_upload(cpecan_batch *b);

@@ -251,3 +251,41 @@ def test_anchors_from_alignment():
     assert [tuple(r[:2]) for r in got.tolist()] == want and want == [(0, 0), (1, 1), (2, 4)]
     with pytest.raises(api.CpecanError):
         api.convertPairwiseForwardStrandAlignmentToAnchorPairs([(7, 1)], 0, 0, 0, 0)
+
+
+def test_add_many_matches_one_by_one_planning():
+    """cpecan_batch_add_many (two parallel passes over the problems) lays the batch out exactly as repeated
+    cpecan_batch_add does: same regions, same cell counts per problem, same errors."""
+    import random as _r
+    rng = _r.Random(9)
+    probs = []
+    for i in range(150):
+        lX, lY = rng.randrange(0, 400), rng.randrange(0, 400)
+        sx = "".join(rng.choice("ACGTNacgt") for _ in range(lX))
+        sy = "".join(rng.choice("ACGTNacgt") for _ in range(lY))
+        anchors, x, y = [], -1, -1
+        while rng.random() < 0.8:
+            x += rng.randrange(1, 90)
+            y += rng.randrange(1, 90)
+            if x >= lX or y >= lY:
+                break
+            anchors.append((x, y, 10))
+        probs.append((sx, sy, anchors, rng.random() < 0.5, rng.random() < 0.5))
+    p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=10, splitMatrixBiggerThanThis=2500)
+    with api.Batch(api.stateMachine5_construct(), p) as one, api.Batch(api.stateMachine5_construct(), p) as many:
+        for pr in probs:
+            one.add(*pr)
+        assert many.add_many(probs[:100]) == 0
+        assert many.add_many(probs[100:]) == 100
+        assert many.add_many([]) == 150
+        L = api.lib()
+        for b in (one, many):  # the upload fails for want of a GPU, after the planning has been checked by the host code
+            if L.cpecan_device_count() <= 0:
+                with pytest.raises(api.CpecanError):
+                    b.upload()
+        s1, s2 = one.stats(), many.stats()
+        assert (s1.problems, s1.regions) == (s2.problems, s2.regions) or L.cpecan_device_count() <= 0
+    with api.Batch(api.stateMachine5_construct(), p) as b:
+        with pytest.raises(api.CpecanError):
+            b.add_many([("ACGT", "ACGT", [(1, 1, 0)]), ("ACGT", "ACGT", [(2, 2, 0), (1, 3, 0)])])  # anchors not increasing
+        assert b.add_many([("ACGT", "ACGT", [(1, 1, 0)])]) == 0  # the failed call left the batch untouched

@@ -208,6 +208,24 @@ def test_fuzz_batches_indel_and_expectation_emitters(seed):
         np.testing.assert_allclose(acc.likelihood, oacc.likelihood, rtol=1e-9)
 
 
+def test_add_many_gives_the_same_results():
+    """cpecan_batch_add_many (parallel, two passes) against cpecan_batch_add one problem at a time: identical lists."""
+    rng = random.Random(301)
+    pkw = dict(diagonalExpansion=10, splitMatrixBiggerThanThis=900)
+    probs, raggeds = _fuzz_problems(rng, 200, 10)
+    one, st1 = _run_batch(0, probs, raggeds, **pkw)
+    p = api.pairwiseAlignmentBandingParameters_construct(**pkw)
+    with api.Batch(_sm(0), p) as b:
+        assert b.add_many([(sx, sy, a, rl, rr) for (sx, sy, a), (rl, rr) in zip(probs, raggeds)]) == 0
+        b.upload()
+        b.run()
+        b.download()
+        st2 = b.stats()
+        for i in range(len(probs)):
+            assert np.array_equal(b.result(i), one[i])
+    assert (st1.problems, st1.regions, st1.cells) == (st2.problems, st2.regions, st2.cells)
+
+
 @pytest.mark.parametrize("mtype", [0, 3])
 def test_random_wide_bands_stream_groups(mtype):
     """Diagonals of 65-250 cells with per-anchor expansions: two to four groups of 64 per diagonal, leftover cells
