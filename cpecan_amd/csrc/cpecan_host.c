@@ -723,7 +723,7 @@ int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char
 typedef struct {
     int64_t cells;
     int64_t index;
-    int cls; /* 0, 1, 2: narrow, at most 8 / 16 / 32 cells per diagonal (packed kernel); 3: wide */
+    int cls; /* 0, 1, 2: narrow, at most 8 / 16 / 32 cells per diagonal (packed kernel); 3 ..: the wide classes */
 } CostKey;
 
 /* what planning keeps of a region's band walk */
@@ -905,14 +905,17 @@ int cpecan_batch_upload(cpecan_batch *b) {
                 perClass[k + 1] += perClass[k];
                 perClass[k] = 0;
             }
-        /* the wide regions by the LDS their rolling buffers and symbol strings need (classes 3..6; the last one keeps
+        /* the wide regions by the LDS their rolling buffers and symbol strings need (classes 3..9; the last one keeps
          * both in global memory): a launch per class, each with its own occupancy and per-wave scratch */
         for (int64_t i = 0; i < b->nRegions; i++) {
             if (keys[i].cls != 3) continue;
             const int64_t w = plan[i].maxW;
             const size_t lds = sizeof(double) * (size_t)(544 + 768 + (2 * S + 1) * (w + 1)) +
                                (size_t)((b->regions[i].lX + 3) / 2 + (b->regions[i].lY + 3) / 2) + 16;
-            keys[i].cls = 3 + (lds > 64 * 1024 ? 3 : (w <= 128 ? 0 : (w <= 256 ? 1 : 2)));
+            static const int64_t edge[CPK_WIDE_CLASSES - 2] = {128, 192, 256, 384, 512};
+            int k = 0;
+            while (k < CPK_WIDE_CLASSES - 2 && w > edge[k]) k++; /* CPK_WIDE_CLASSES - 2: wider, but its LDS still fits */
+            keys[i].cls = 3 + (lds > 64 * 1024 ? CPK_WIDE_CLASSES - 1 : k);
         }
     }
     qsort(keys, (size_t)b->nRegions, sizeof(CostKey), by_cost_desc);

@@ -74,7 +74,7 @@ typedef struct {
     double threshold;
 } CpkModel;
 
-#define CPK_WIDE_CLASSES 4
+#define CPK_WIDE_CLASSES 7
 /* Per-launch geometry computed on the host. */
 typedef struct {
     int32_t nRegions;
@@ -96,8 +96,8 @@ typedef struct {
     int32_t nPacked[3];
     int32_t pMaxRefresh[3];
     int64_t pRingCells[3], pFbCells[3];
-    /* The wide regions follow, again by class: widest diagonal at most 128 / 256 / CPK_LDS_MAX_WIDTH cells, or wider
-     * (global-memory rolling buffers).  Every class is one launch of the sweep kernel with LDS and per-wave scratch sized
+    /* The wide regions follow, again by class: widest diagonal at most 128 / 192 / 256 / 384 / 512 cells, wider but
+     * still inside the 64 KiB LDS budget, or wider still (global-memory rolling buffers).  Every class is one launch of the sweep kernel with LDS and per-wave scratch sized
      * for ITS largest region, so that one very wide region neither takes the LDS that decides how many waves the others
      * get nor multiplies everybody's scratch.  The scalar fields above are filled per launch from these. */
     int32_t nWide[CPK_WIDE_CLASSES];
