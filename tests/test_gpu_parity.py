@@ -226,6 +226,39 @@ def test_add_many_gives_the_same_results():
     assert (st1.problems, st1.regions, st1.cells) == (st2.problems, st2.regions, st2.cells)
 
 
+def test_concurrent_batches_from_host_threads():
+    """Batches are independent objects: four host threads running their own small batches on the same device at the same
+    time (recycled device blocks and shells behind one mutex, one error slot per thread) get what a single thread gets."""
+    import threading
+    rng = random.Random(401)
+    pkw = dict(diagonalExpansion=10, splitMatrixBiggerThanThis=900)
+    jobs = []
+    for _ in range(24):
+        probs, raggeds = _fuzz_problems(rng, rng.randrange(1, 12), 10)
+        jobs.append((probs, raggeds))
+    serial = [_run_batch(0, probs, raggeds, **pkw)[0] for probs, raggeds in jobs]
+    results, errors = [None] * len(jobs), []
+
+    def worker(tid):
+        try:
+            for j in range(tid, len(jobs), 4):
+                for _ in range(3):  # the same job several times: blocks are recycled in between
+                    results[j] = _run_batch(0, jobs[j][0], jobs[j][1], **pkw)[0]
+        except Exception as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for got, want in zip(results, serial):
+        assert len(got) == len(want)
+        for a, b in zip(got, want):
+            assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("mtype", [0, 3])
 def test_random_wide_bands_stream_groups(mtype):
     """Diagonals of 65-250 cells with per-anchor expansions: two to four groups of 64 per diagonal, leftover cells
