@@ -476,6 +476,34 @@ stList *filterPairwiseAlignmentToMakePairsOrdered(stList *alignedPairs, const ch
     stList_destruct(alignedPairs); /* "Destroys input list of aligned pairs in process" (multipleAligner.c:943) */
     return l;
 }
+/* getBlastPairsForPairwiseAlignmentParameters (:1162-1166) up to the size at which the reference turns to lastz */
+static stList *no_anchors_or_die(const char *sX, const char *sY, const PairwiseAlignmentParameters *p, const char *what) {
+    const int64_t lX = (int64_t)strlen(sX), lY = (int64_t)strlen(sY);
+    if (lX * lY > p->anchorMatrixBiggerThanThis)
+        die("cpecan_hip: %s on a %lld x %lld matrix needs lastz anchors (anchorMatrixBiggerThanThis = %lld), which this "
+            "library does not compute: use the *UsingAnchors entry point",
+            what, (long long)lX, (long long)lY, (long long)p->anchorMatrixBiggerThanThis);
+    return stList_construct();
+}
+stList *getAlignedPairs(StateMachine *sM, const char *sX, const char *sY, PairwiseAlignmentParameters *p, bool raggedLeft,
+                        bool raggedRight) {
+    stList *anchors = no_anchors_or_die(sX, sY, p, "getAlignedPairs");
+    stList *l = getAlignedPairsUsingAnchors(sM, sX, sY, anchors, p, raggedLeft, raggedRight);
+    stList_destruct(anchors);
+    return l;
+}
+void getAlignedPairsWithIndels(StateMachine *sM, const char *sX, const char *sY, PairwiseAlignmentParameters *p,
+                               stList **alignedPairs, stList **gapXPairs, stList **gapYPairs, bool raggedLeft, bool raggedRight) {
+    stList *anchors = no_anchors_or_die(sX, sY, p, "getAlignedPairsWithIndels");
+    getAlignedPairsWithIndelsUsingAnchors(sM, sX, sY, anchors, p, alignedPairs, gapXPairs, gapYPairs, raggedLeft, raggedRight);
+    stList_destruct(anchors);
+}
+void getExpectations(StateMachine *sM, Hmm *hmmExpectations, const char *sX, const char *sY, PairwiseAlignmentParameters *p,
+                     bool raggedLeft, bool raggedRight) {
+    stList *anchors = no_anchors_or_die(sX, sY, p, "getExpectations");
+    getExpectationsUsingAnchors(sM, hmmExpectations, sX, sY, anchors, p, raggedLeft, raggedRight);
+    stList_destruct(anchors);
+}
 stList *getMaximalExpectedAccuracyPairwiseAlignment(stList *alignedPairs, stList *gapXPairs, stList *gapYPairs,
                                                     int64_t seqXLength, int64_t seqYLength, double *alignmentScore,
                                                     PairwiseAlignmentParameters *p) {

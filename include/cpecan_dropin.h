@@ -161,6 +161,17 @@ void getExpectationsUsingAnchors(StateMachine *sM, Hmm *hmmExpectations, const c
                                  bool alignmentHasRaggedRightEnd);
 double computeForwardProbability(char *seqX, char *seqY, stList *anchorPairs, PairwiseAlignmentParameters *p,
                                  StateMachine *sM, bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
+/* The entry points that find their own anchors (impl/pairwiseAligner.c:1481-1513).  The reference anchors with lastz only
+ * when lX * lY > p->anchorMatrixBiggerThanThis (:1164); up to that size these are the functions above with no anchors,
+ * and that is what is provided.  Beyond it they abort: the lastz anchoring (:959-1196) is not part of this library --
+ * pass anchors to the *UsingAnchors functions. */
+stList *getAlignedPairs(StateMachine *sM, const char *sX, const char *sY, PairwiseAlignmentParameters *p,
+                        bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
+void getAlignedPairsWithIndels(StateMachine *sM, const char *sX, const char *sY, PairwiseAlignmentParameters *p,
+                               stList **alignedPairs, stList **gapXPairs, stList **gapYPairs, bool alignmentHasRaggedLeftEnd,
+                               bool alignmentHasRaggedRightEnd);
+void getExpectations(StateMachine *sM, Hmm *hmmExpectations, const char *sX, const char *sY, PairwiseAlignmentParameters *p,
+                     bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd);
 
 /* Consumers of the posterior lists, evaluated on the GPU (inc/pairwiseAligner.h:86-98, :272-290;
  * impl/pairwiseAligner.c:1519-1790).  reweightAlignedPairs2 consumes its input list unless gapGamma <= 0. */

@@ -177,6 +177,14 @@ static void test_known_answers_gpu(void) {
     stList_destruct(anchors);
     pairwiseAlignmentBandingParameters_destruct(p);
     stateMachine_destruct(sM5);
+    /* the anchorless entry point is the same call with no anchors up to anchorMatrixBiggerThanThis (:1164) */
+    PairwiseAlignmentParameters *q = pairwiseAlignmentBandingParameters_construct();
+    q->threshold = 0.2;
+    stList *viaShort = getAlignedPairs(sM5, "AGCG", "AGTTCG", q, 0, 0);
+    CHECK(stList_length(viaShort) == 4);
+    if (stList_length(viaShort) == 4) CHECK(stIntTuple_get(stList_get(viaShort, 2), 0) == 8665179);
+    stList_destruct(viaShort);
+    pairwiseAlignmentBandingParameters_destruct(q);
     stateMachine_destruct(sM3);
 }
 
