@@ -92,6 +92,7 @@ EXPORTS = [
     "cpecan_mea_alignment", "cpecan_left_shift_alignment", "cpecan_get_shifted_mea_alignment",
     "cpecan_anchors_from_alignment", "cpecan_batch_set_match_gamma", "cpecan_batch_identity_scores",
     "cpecan_identity_scores", "cpecan_filter_pairs_ordered", "cpecan_batch_add_many",
+    "cpecan_filter_to_remove_overlap",
 ]
 OP_MATCH, OP_INDEL_X, OP_INDEL_Y = 0, 1, 2
 POST_REWEIGHT, POST_MEA, POST_LEFT_SHIFT, POST_ORDERED = 1, 2, 4, 8
@@ -153,6 +154,8 @@ def lib():
                                                 C.c_int64, C.c_char_p, C.c_int64, i64p]
     L.cpecan_batch_set_post.argtypes = [vp, C.c_int, C.c_double]
     L.cpecan_batch_scores.argtypes = [vp, C.c_int64, dp, dp, dp]
+    L.cpecan_filter_to_remove_overlap.argtypes = [i64p, C.c_int64, i64p]
+    L.cpecan_filter_to_remove_overlap.restype = C.c_int64
     L.cpecan_batch_add_many.argtypes = [vp, C.POINTER(Problem), C.c_int64]
     L.cpecan_batch_add_many.restype = C.c_int64
     L.cpecan_batch_set_match_gamma.argtypes = [vp, C.c_float]
@@ -549,3 +552,12 @@ def convertPairwiseForwardStrandAlignmentToAnchorPairs(ops, start1, start2, trim
                                             out.ctypes.data_as(C.POINTER(C.c_int64)))
     _check(n, "cpecan_anchors_from_alignment")
     return out[:n].copy()
+
+
+def filterToRemoveOverlap(sortedOverlappingPairs):  # impl/pairwiseAligner.c:1095
+    """Pairs (x, y, expansion) sorted by x, then y -> the ones that overlap no other pair, int64[n,3]."""
+    a, ptr, n = _anchor_array(sortedOverlappingPairs)
+    out = np.zeros((max(n, 1), 3), dtype=np.int64)
+    cnt = _check(lib().cpecan_filter_to_remove_overlap(ptr, n, out.ctypes.data_as(C.POINTER(C.c_int64))),
+                 "filterToRemoveOverlap")
+    return out[:cnt].copy()

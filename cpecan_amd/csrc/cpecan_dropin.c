@@ -356,6 +356,20 @@ stList *convertPairwiseForwardStrandAlignmentToAnchorPairs(struct PairwiseAlignm
     return l;
 }
 
+stList *filterToRemoveOverlap(stList *sortedOverlappingPairs) {
+    int64_t n;
+    int64_t *in = flatten_anchors(sortedOverlappingPairs, &n);
+    int64_t *out = malloc(sizeof(int64_t) * 3 * (size_t)(n ? n : 1));
+    if (!out) die("cpecan_hip: out of memory");
+    const int64_t kept = cpecan_filter_to_remove_overlap(in, n, out);
+    if (kept < 0) die("cpecan_hip: filterToRemoveOverlap failed: %s", cpecan_last_error());
+    stList *l = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    for (int64_t i = 0; i < kept; i++) stList_append(l, stIntTuple_construct3(out[3 * i], out[3 * i + 1], out[3 * i + 2]));
+    free(in);
+    free(out);
+    return l;
+}
+
 /* ---------------- the path: impl/pairwiseAligner.c:1431-1513, :936 ---------------- */
 stList *getAlignedPairsUsingAnchors(StateMachine *sM, const char *sX, const char *sY, stList *anchorPairs,
                                     PairwiseAlignmentParameters *p, bool raggedLeft, bool raggedRight) {

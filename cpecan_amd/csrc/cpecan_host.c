@@ -456,6 +456,41 @@ int64_t cpecan_anchors_from_alignment(const int64_t *ops, int64_t nOps, int64_t 
     return n;
 }
 
+/* filterToRemoveOverlap (impl/pairwiseAligner.c:1095-1135): one backward and one forward pass over the sorted pairs */
+int64_t cpecan_filter_to_remove_overlap(const int64_t *pairs, int64_t n, int64_t *out) {
+    if (n < 0 || (n > 0 && (!pairs || !out))) return CPECAN_EINVAL;
+    uint8_t *below = malloc((size_t)(n ? n : 1)); /* strictly below every later pair in both coordinates */
+    if (!below) return CPECAN_ENOMEM;
+    int64_t mX = INT64_MAX, mY = INT64_MAX;
+    for (int64_t i = n - 1; i >= 0; i--) {
+        const int64_t x = pairs[3 * i], y = pairs[3 * i + 1];
+        below[i] = x < mX && y < mY;
+        mX = x < mX ? x : mX;
+        mY = y < mY ? y : mY;
+        if (i > 0 && (pairs[3 * i - 3] > x || (pairs[3 * i - 3] == x && pairs[3 * i - 2] > y))) { /* asserted sorted, :1124-1127 */
+            free(below);
+            cpk_set_error("filterToRemoveOverlap: the pairs are not sorted by x, then y");
+            return CPECAN_EINVAL;
+        }
+    }
+    int64_t count = 0;
+    mX = INT64_MIN;
+    mY = INT64_MIN;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t x = pairs[3 * i], y = pairs[3 * i + 1];
+        if (below[i] && x > mX && y > mY) {
+            out[3 * count] = x;
+            out[3 * count + 1] = y;
+            out[3 * count + 2] = pairs[3 * i + 2];
+            count++;
+        }
+        mX = x > mX ? x : mX;
+        mY = y > mY ? y : mY;
+    }
+    free(below);
+    return count;
+}
+
 int cpecan_device_count(void) { return cpk_device_count(); }
 const char *cpecan_last_error(void) { return cpk_last_error(); }
 

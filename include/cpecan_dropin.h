@@ -148,6 +148,8 @@ struct PairwiseAlignment {
 #endif
 /* inc/pairwiseAligner.h:73 (impl/pairwiseAligner.c:979-1003): both strands must be forward (asserted there). */
 stList *convertPairwiseForwardStrandAlignmentToAnchorPairs(struct PairwiseAlignment *pA, int64_t trim, int64_t diagonalExpansion);
+/* inc/pairwiseAligner.h (impl/pairwiseAligner.c:1095-1135): a new list; the input is left alone, as in the reference */
+stList *filterToRemoveOverlap(stList *sortedOverlappingPairs);
 
 stList *getAlignedPairsUsingAnchors(StateMachine *sM, const char *sX, const char *sY, stList *anchorPairs,
                                     PairwiseAlignmentParameters *p, bool alignmentHasRaggedLeftEnd,

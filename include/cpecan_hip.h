@@ -127,6 +127,11 @@ int64_t cpecan_anchors_from_alignment(const int64_t *ops, int64_t nOps, int64_t 
                                       int64_t expansion, const char *sX, int64_t lX, const char *sY, int64_t lY,
                                       int64_t *anchors);
 
+/* filterToRemoveOverlap (pairwiseAligner.c:1095-1135), the step between a sorted list of blast / lastz pairs and an
+ * anchor list: a pair (x, y, expansion) is kept when every earlier pair is strictly smaller and every later pair strictly
+ * larger in both coordinates.  pairs: n triples sorted by x, then y; out: room for n triples.  Returns the number kept. */
+int64_t cpecan_filter_to_remove_overlap(const int64_t *pairs, int64_t n, int64_t *out);
+
 /* ---- device ---- */
 int cpecan_device_count(void);
 const char *cpecan_last_error(void);

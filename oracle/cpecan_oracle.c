@@ -1167,3 +1167,33 @@ int64_t orc_filter_pairs_ordered(const int64_t *pairs, int64_t n, int64_t lX, in
     free(f);
     return count;
 }
+
+/* filterToRemoveOverlap, impl/pairwiseAligner.c:1095-1135: pairs sorted by (x, y, expansion); a pair survives when it is
+ * strictly below every later pair in both coordinates (the backward pass, :1101-1110) and strictly above every earlier
+ * one (the forward pass, :1116-1131).  out holds n triples; returns the number kept. */
+int64_t orc_filter_to_remove_overlap(const int64_t *pairs, int64_t n, int64_t *out) {
+    char *inSet = calloc((size_t)n + 1, 1);
+    int64_t pX = INT64_MAX, pY = INT64_MAX;
+    for (int64_t i = n - 1; i >= 0; i--) {
+        const int64_t x = pairs[3 * i], y = pairs[3 * i + 1];
+        if (x < pX && y < pY) inSet[i] = 1;
+        pX = x < pX ? x : pX;
+        pY = y < pY ? y : pY;
+    }
+    int64_t count = 0;
+    pX = INT64_MIN;
+    pY = INT64_MIN;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t x = pairs[3 * i], y = pairs[3 * i + 1];
+        if (x > pX && y > pY && inSet[i]) {
+            out[3 * count] = x;
+            out[3 * count + 1] = y;
+            out[3 * count + 2] = pairs[3 * i + 2];
+            count++;
+        }
+        pX = x > pX ? x : pX;
+        pY = y > pY ? y : pY;
+    }
+    free(inSet);
+    return count;
+}

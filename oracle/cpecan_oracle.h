@@ -180,6 +180,8 @@ double orc_score_by_identity_ignoring_gaps(const char *sX, const char *sY, const
  * reference's test of pairwiseAlignColumns, tests/multipleAlignerTest.c, checks properties only, which the tests here
  * repeat).  The pairs must be distinct cells.  out holds n triples; returns the number written. */
 int64_t orc_filter_pairs_ordered(const int64_t *pairs, int64_t n, int64_t lX, int64_t lY, double matchGamma, int64_t *out);
+/* filterToRemoveOverlap, impl/pairwiseAligner.c:1095-1135 (input sorted by x, then y); out holds n triples */
+int64_t orc_filter_to_remove_overlap(const int64_t *pairs, int64_t n, int64_t *out);
 
 void orc_free(void *p);
 

@@ -128,6 +128,8 @@ def lib():
         L.orc_score_by_identity_ignoring_gaps.argtypes = [C.c_char_p, C.c_char_p, i64p, C.c_int64]
         L.orc_filter_pairs_ordered.restype = C.c_int64
         L.orc_filter_pairs_ordered.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int64, C.c_double, i64p]
+        L.orc_filter_to_remove_overlap.restype = C.c_int64
+        L.orc_filter_to_remove_overlap.argtypes = [i64p, C.c_int64, i64p]
         L.orc_trace_free.argtypes = [C.POINTER(Trace)]
         L.orc_free.argtypes = [C.c_void_p]
         _lib = L
@@ -364,4 +366,11 @@ def filter_pairs_ordered(pairs, lX, lY, match_gamma):
     out = np.zeros((max(n, 1), 3), dtype=np.int64)
     cnt = lib().orc_filter_pairs_ordered(pa, n, lX, lY, float(np.float32(match_gamma)),
                                          out.ctypes.data_as(C.POINTER(C.c_int64)))
+    return out[:cnt].copy()
+
+
+def filter_to_remove_overlap(pairs):
+    a, pa, n = _triples(pairs)
+    out = np.zeros((max(n, 1), 3), dtype=np.int64)
+    cnt = lib().orc_filter_to_remove_overlap(pa, n, out.ctypes.data_as(C.POINTER(C.c_int64)))
     return out[:cnt].copy()

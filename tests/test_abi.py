@@ -289,3 +289,32 @@ def test_add_many_matches_one_by_one_planning():
         with pytest.raises(api.CpecanError):
             b.add_many([("ACGT", "ACGT", [(1, 1, 0)]), ("ACGT", "ACGT", [(2, 2, 0), (1, 3, 0)])])  # anchors not increasing
         assert b.add_many([("ACGT", "ACGT", [(1, 1, 0)])]) == 0  # the failed call left the batch untouched
+
+
+def test_filter_to_remove_overlap():
+    """filterToRemoveOverlap (impl/pairwiseAligner.c:1095-1135) as tests/pairwiseAlignerTest.c:496-553 tests it: random
+    subsets of a grid, sorted; the survivors are strictly increasing in both coordinates and are exactly the pairs that
+    no OTHER pair overlaps (the reference's own check compares every pair with itself too, which only an empty result
+    satisfies); the product against the oracle's two-pass restatement, expansions carried through."""
+    rng = random.Random(12)
+    some_kept = 0
+    for trial in range(150):
+        lX, lY = rng.randrange(0, 40), rng.randrange(0, 40)
+        accept = rng.random() ** 3  # mostly sparse grids: dense ones keep nothing
+        e = 2 * rng.randrange(0, 5)
+        pairs = [(x, y, e) for x in range(lX) for y in range(lY) if rng.random() < accept]
+        if trial % 2 and lX and lY:  # a handful of cells: the case in which pairs do survive
+            pairs = sorted({(rng.randrange(lX), rng.randrange(lY), e) for _ in range(rng.randrange(0, 7))})
+        got = [tuple(int(v) for v in r) for r in api.filterToRemoveOverlap(pairs)]
+        want = [tuple(int(v) for v in r) for r in ob.filter_to_remove_overlap(pairs)]
+        assert got == want
+        assert all(a[0] < b[0] and a[1] < b[1] for a, b in zip(got, got[1:]))
+        brute = [p for i, p in enumerate(pairs)
+                 if not any(j != i and ((q[0] <= p[0] and q[1] >= p[1]) or (q[0] >= p[0] and q[1] <= p[1]))
+                            for j, q in enumerate(pairs))]
+        assert got == brute
+        some_kept += bool(got)
+    assert some_kept > 30
+    assert api.filterToRemoveOverlap([]).shape == (0, 3)
+    with pytest.raises(api.CpecanError):
+        api.filterToRemoveOverlap([(5, 5, 0), (4, 9, 0)])  # not sorted (asserted in the reference, :1124)
