@@ -98,7 +98,17 @@ def test_random_banded_property_like_reference():
         _check_batch(0, [(sx, sy, _rand_anchors(rng, len(sx), len(sy)))], **kw)
 
 
-@pytest.mark.parametrize("seed", [101, 102, 103, 104])
+def _fuzz_seeds(default):
+    """CPECAN_FUZZ_SEEDS=lo:hi widens the fuzz tests for a soak run on the GPU box."""
+    import os
+    spec = os.environ.get("CPECAN_FUZZ_SEEDS")
+    if not spec:
+        return default
+    lo, hi = (int(v) for v in spec.split(":"))
+    return list(range(lo, hi))
+
+
+@pytest.mark.parametrize("seed", _fuzz_seeds([101, 102, 103, 104]))
 def test_fuzz_batches_all_paths(seed):
     """Random batches that mix everything a batch can hold: lengths 0-600, dense / sparse / no anchors (bands from a few
     cells to whole rectangles), ragged ends, splitting by large gaps, short and long traceback schedules, thresholds down
@@ -171,7 +181,7 @@ def _fuzz_problems(rng, n, expansion):
     return probs, raggeds
 
 
-@pytest.mark.parametrize("seed", [201, 202])
+@pytest.mark.parametrize("seed", _fuzz_seeds([201, 202]))
 def test_fuzz_batches_indel_and_expectation_emitters(seed):
     """The same kind of mixed batch through the other two emitters: three lists per problem (:691-733) against the oracle,
     and the batch's expectation counts (:735-746) against the oracle's sum over the problems (1e-5)."""
