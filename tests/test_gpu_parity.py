@@ -120,7 +120,8 @@ def test_fuzz_batches_all_paths(seed):
         tbd = rng.choice([1, 3, 10, 40])
         pkw = dict(traceBackDiagonals=tbd, minDiagsBetweenTraceBack=tbd + rng.choice([2, 7, 60, 960]),
                    diagonalExpansion=2 * rng.choice([0, 2, 3, 5, 10, 20, 40]), threshold=rng.choice([0.0, 0.01, 0.2]),
-                   splitMatrixBiggerThanThis=rng.choice([10, 900, 10 ** 12]))
+                   splitMatrixBiggerThanThis=rng.choice([10, 900, 10 ** 12]),
+                   dynamicAnchorExpansion=int(rng.random() < 0.3))  # then every anchor brings its own expansion
         probs, raggeds = [], []
         for _ in range(rng.randrange(30, 90)):
             sx = _rand_seq(rng, rng.choice([0, 1, 5, 40, 150, 300, 600]))
@@ -131,11 +132,12 @@ def test_fuzz_batches_all_paths(seed):
                 step = rng.choice([1, 7, 30, 120])
                 x = y = rng.randrange(0, 5)
                 while x < len(sx) and y < len(sy):
-                    anchors.append((x, y, pkw["diagonalExpansion"]))
+                    anchors.append((x, y, 2 * rng.randrange(0, 25) if pkw["dynamicAnchorExpansion"] else pkw["diagonalExpansion"]))
                     x += step + rng.randrange(0, 3)
                     y += step + rng.randrange(0, 3)
             elif kind < 0.8:
-                anchors = [(x, y, pkw["diagonalExpansion"]) for x, y, _ in _rand_anchors(rng, len(sx), len(sy))]
+                anchors = [(x, y, e if pkw["dynamicAnchorExpansion"] else pkw["diagonalExpansion"])
+                           for x, y, e in _rand_anchors(rng, len(sx), len(sy))]
             probs.append((sx, sy, anchors))
             raggeds.append((rng.random() > 0.5, rng.random() > 0.5))
         if mtype in (1, 3):  # the asymmetric types only come from a loaded HMM (hmm_getStateMachine)
