@@ -290,3 +290,29 @@ def test_degenerate_cigars():
     with pytest.raises(api.CpecanError):
         with _realigner(seqs) as r:
             r.realign([Cigar("a", 0, 5, True, "zz", 0, 5, True, 1.0, [(M, 5)])])  # unknown sequence
+
+
+def test_nothing_but_empty_problems():
+    """Batches and realign calls whose every problem is empty (or that hold no problem at all): nothing to launch, empty
+    lists, the cigar of an empty alignment comes back as it went in."""
+    p = api.pairwiseAlignmentBandingParameters_construct()
+    with api.Batch(api.stateMachine5_construct(), p) as b:
+        b.set_post(api.POST_REWEIGHT | api.POST_ORDERED, 0.5)
+        b.add("", "", ())
+        b.upload()
+        b.run()
+        b.download()
+        assert b.result(0).shape == (0, 3) and b.result(0, 3).shape == (0, 3)
+        assert b.scores(0)[0] == 0.0 and np.isnan(b.scores(0)[1])
+    with api.Batch(api.stateMachine5_construct(), p) as b:
+        b.upload()
+        b.run()
+        b.download()
+    empty = Cigar("a", 2, 2, True, "b", 1, 1, True, 3.0, [])
+    with Realigner() as r:
+        r.add_sequence("a", "ACGT")
+        r.add_sequence("b", "ACGT")
+        assert r.realign([empty]) == [empty]
+        acc = api.hmm_constructEmpty(0.0, api.fiveState)
+        r.expectations([empty], acc)
+        assert acc.likelihood == 0.0
