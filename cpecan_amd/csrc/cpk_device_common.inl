@@ -228,6 +228,9 @@ struct DiagCache {
     }
 };
 
+#ifndef CPK_SWEEP_WAVES
+#define CPK_SWEEP_WAVES 2  // waves per SIMD the sweep kernel's registers are allocated for
+#endif
 constexpr int kLdsCubics = 16;  // 4 rows x 4 coefficients
 // doubles of LDS in front of the rolling rows: cubics + emissions (+ expectation sums for that emitter only)
 constexpr int kExpectCopies = 4;  // emission-expectation sums are kept in 4 LDS copies (lane & 3): fewer atomic collisions

@@ -953,7 +953,7 @@ __device__ __forceinline__ void fill_weights(double *wt, const CpkModel &m, cons
 constexpr int kEmitForward = 3;
 
 template <int S, bool FAST, int EMIT>
-__global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(CPK_SWEEP_WAVES, CPK_SWEEP_WAVES)))
 cpecan_pairhmm_sweep(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
