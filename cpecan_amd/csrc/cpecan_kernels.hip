@@ -61,6 +61,7 @@ extern "C" const char *cpk_last_error(void) { return g_err; }
 
 #include "cpk_device_common.inl"
 #include "cpk_sweep.inl"
+#include "cpk_team.inl"
 #include "cpk_table_gather.inl"
 #include "cpk_packed.inl"
 #include "cpk_post.inl"
@@ -78,7 +79,8 @@ struct LaunchClass {
     int k = 0;           // class index within its kind (wide 0..3, packed 0..2)
     KernelFn fn = nullptr;
     CpkGeometry geo{};   // what the kernel reads: the scalar fields describe this class
-    int waves = 0;
+    int waves = 0;       // workgroups of the launch
+    int threads = CPK_WAVE;  // threads per workgroup: one wave, or the waves of a team
     int64_t subSlots = 0;  // scratch slots: one per wave (sweep) or one per region group of a wave (packed)
     size_t ldsBytes = 0;
     int regionBase = 0, regionCount = 0;
@@ -439,7 +441,30 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             return CPECAN_EINVAL;
         }
         int perCU = 0;
-        if (int rc = wavesPerCU(c.fn, c.ldsBytes, &perCU)) return rc;
+        // Bands of several hundred cells: a team of kTeamWaves waves per region (cpk_team.inl) instead of one wave
+        constexpr int kTeamWaves = 4;
+        const size_t teamLds = sizeof(double) * ((size_t)team_header_doubles() + (size_t)3 * S * c.geo.rollStride) +
+                               (size_t)((c.geo.seqLdsBytes + 15) / 16 * 16);
+        const char *teamEnv = getenv("CPECAN_TEAM");
+        const int teamFrom = teamEnv ? atoi(teamEnv) : 0;  // widest diagonal from which a class goes to teams; 0: never
+        if (teamFrom > 0 && geo->emit == CPECAN_EMIT_MATCH && !geo->debug && c.geo.maxWidth >= teamFrom &&
+            c.geo.maxWidth <= CPK_WAVE * kTeamWaves * kTeamGroups && teamLds <= 160 * 1024) {
+            c.fn = S == 5 ? cpecan_pairhmm_team<5, kTeamWaves> : cpecan_pairhmm_team<3, kTeamWaves>;
+            c.threads = CPK_WAVE * kTeamWaves;
+            c.geo.useGlobalRoll = 0;
+            c.ldsBytes = teamLds;
+            c.grollEl = 0;
+            hipFuncAttributes attr;
+            HIP_TRY(hipFuncGetAttributes(&attr, (const void *)c.fn));
+            const int vgprAlloc = ((attr.numRegs > 0 ? attr.numRegs : 128) + 7) / 8 * 8;
+            int perSimd = 512 / vgprAlloc;  // a team puts one wave on every SIMD
+            if (perSimd > 8) perSimd = 8;
+            const int byLds = (int)((160 * 1024) / (teamLds + (size_t)attr.sharedSizeBytes));
+            perCU = perSimd < byLds ? perSimd : byLds;
+            if (perCU < 1) perCU = 1;
+        } else if (int rc = wavesPerCU(c.fn, c.ldsBytes, &perCU)) {
+            return rc;
+        }
         if (perCU < 1) {
             cpk_set_error("kernel does not fit on a CU (LDS %zu bytes)", c.ldsBytes);
             return CPECAN_EHIP;
@@ -465,7 +490,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         c.refEl = c.geo.refreshCells;
         c.totEl = c.geo.maxRefresh;
         c.bringEl = expect ? c.geo.fbCells * S : 0;
-        c.grollEl = c.geo.useGlobalRoll ? c.geo.rollDoubles : 0;
+        c.grollEl = (c.geo.useGlobalRoll && c.threads == CPK_WAVE) ? c.geo.rollDoubles : 0;
         d->classes.push_back(c);
     }
     if ((int)d->classes.size() > kMaxClasses || regionAt != geo->nRegions) {
@@ -527,7 +552,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             oBring += c.subSlots * c.bringEl;
             oGroll += c.subSlots * c.grollEl;
             oExpect += (int64_t)c.waves * 128;
-            d->totalWaves += c.waves;
+            d->totalWaves += c.waves * (c.threads / CPK_WAVE);
             if (c.ldsBytes > 64 * 1024)
                 HIP_TRY(hipFuncSetAttribute((const void *)c.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.ldsBytes));
         }
@@ -665,7 +690,7 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
         const bool onCaller = i == nClasses - 1;
         hipStream_t cs = onCaller ? st : d->sideStream[i];
         if (!onCaller) HIP_TRY(hipStreamWaitEvent(cs, d->evStart, 0));
-        hipLaunchKernelGGL(c.fn, dim3((unsigned)c.waves), dim3(CPK_WAVE), c.ldsBytes, cs, p);
+        hipLaunchKernelGGL(c.fn, dim3((unsigned)c.waves), dim3((unsigned)c.threads), c.ldsBytes, cs, p);
         HIP_TRY(hipGetLastError());
         if (!onCaller) HIP_TRY(hipEventRecord(d->sideDone[i], cs));
     }

@@ -1,7 +1,9 @@
 // cpk_sweep.inl -- the sweep kernel: one wave per DP region (forward stream, traceback, expectation step, totals, emission).
 // Part of the single HIP translation unit cpecan_kernels.hip (included there, in this order); not compiled on its own.
 
-template <int S, bool FAST>
+// ROWS: rows of the rolling buffers per position (2S+1 for one wave per region; the team kernel keeps three forward
+// diagonals, 3S rows)
+template <int S, bool FAST, int ROWS = 2 * S + 1>
 struct Sweep {
     const KArgs &a;
     const KConsts &m;  // kernarg-resident constants
@@ -41,7 +43,7 @@ struct Sweep {
     //  backward layout: match row in a ring of three, B[d].match = row (d mod 3); the other states in two alternating
     //                   groups, B[d][s] = row 3 + (d&1)*(S-1) + (s-1) for s >= 1
     //  fbuf1/bM1/bG1 return the row pointer at position 1 (cell 0); bG1(d)[s + kR] is state s >= 1 of cell k
-    static constexpr int R = 2 * S + 1;
+    static constexpr int R = ROWS;
     // Cell k of a diagonal lives at position k+1, i.e. at element offset k*R from a row pointer that already points at
     // position 1 (fbuf1/bM1/bG1 below).  Cell indices are kept premultiplied by R ("kR"): lane*R is computed once per
     // kernel and everything added to it per diagonal / per group is wave-uniform, so no per-access multiply is left.

@@ -1,0 +1,350 @@
+// cpk_team.inl -- the team sweep kernel: T waves of one workgroup share one wide DP region (match emitter, LDS rows).
+// Part of the single HIP translation unit cpecan_kernels.hip (included there, after cpk_sweep.inl); not compiled on its own.
+//
+// A band of a few hundred cells per diagonal needs tens of KB of LDS for its rolling rows: with one wave per region a CU
+// holds three such regions, i.e. three waves, and every diagonal is a serial chain of up to a dozen 64-cell groups on one
+// wave.  Here the T waves of a workgroup own ONE region: the tables, the symbol strings and the rolling rows are in LDS
+// once, every wave takes a contiguous range of the diagonal's cells (whole groups of 64), and the waves meet at one
+// barrier per diagonal.  The cell arithmetic is Sweep's (fwdCells / bwdCells: their contexts are row pointers and shifts);
+// what differs from cpk_sweep.inl:
+//   * three forward diagonals rotate through the rows (3S rows per position): a team cannot overwrite F[d-2] in place,
+//     the single wave's direction trick does not carry over; the traceback uses rows 0..2S of the same buffer;
+//   * candidates: every wave keeps the candidates of its cells of the current diagonal in registers; at the barrier the
+//     waves exchange their counts through LDS, and each writes its run behind the runs of the waves before it -- the
+//     segment's candidate list comes out in the single-wave order (diagonal descending, x-y ascending), so the totals
+//     fold and the emission are Sweep's, run by wave 0;
+//   * the candidate bound (lastMax) is the maximum over the waves' maxima on refresh diagonals, exchanged the same way;
+//   * F rows are read from the forward ring where they are used (the other waves of the team cover the latency).
+constexpr int kTeamGroups = 4;  // 64-cell groups a wave handles per diagonal at most: bands up to 64 * T * kTeamGroups cells
+constexpr int kTeamXchg = 32;   // doubles of LDS for the exchange area (counts, maxima, the region ticket)
+
+__host__ __device__ constexpr int team_header_doubles() { return kLdsCubics + 40 + kLdsWeights + kTeamXchg; }
+
+template <int S, int T>
+__global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    constexpr int R = 3 * S;
+    using SweepT = Sweep<S, true, R>;
+    const int tid = threadIdx.x, wave = tid / CPK_WAVE, lane = tid & (CPK_WAVE - 1);
+    const CpkModel &m = *a.model;
+    const int stride = a.geo.rollStride;
+
+    // LDS (doubles): logAdd cubics | emissions | weights | exchange area | rolling rows | symbol strings
+    if (wave == 0) {
+        fill_cubics(lds);
+        double *em0 = lds + kLdsCubics;
+        if (lane < 25) em0[lane] = m.matchEm[lane];
+        if (lane < 5) {
+            em0[25 + lane] = m.gapXEm[lane];
+            em0[30 + lane] = m.gapYEm[lane];
+        }
+        fill_weights<S>(lds + kLdsCubics + 40, m, a.kc, lane);
+    }
+    const Cubic *lg = reinterpret_cast<const Cubic *>(lds);
+    double *em = lds + kLdsCubics;
+    double *wt = lds + kLdsCubics + 40;
+    int *xi = reinterpret_cast<int *>(lds + kLdsCubics + 40 + kLdsWeights);  // [0]: ticket, [8 + parity * T + w]: counts
+    float *xf = reinterpret_cast<float *>(xi + 8 + 2 * T);                   // [parity * T + w]: maxima
+    double *roll = lds + team_header_doubles();
+    uint8_t *seqLds = reinterpret_cast<uint8_t *>(roll + (size_t)R * stride);
+    for (int i = tid; i < R * stride; i += CPK_WAVE * T) roll[i] = NEG_INF;  // position 0 of every row stays the guard
+    __syncthreads();
+
+    // forward diagonal d (d >= -1), state s of cell k: frow(d)[s + k * R]
+    auto frow = [&](int d) { return roll + R + ((d + 3) % 3) * S; };
+    const size_t slot = blockIdx.x;
+    const float logThr = (float)log(m.threshold);
+    for (;;) {
+        if (wave == 0) {  // wave-uniform test; inside, every lane takes part (see the note in cpecan_pairhmm_sweep)
+            const unsigned int ticket = atomicAdd(a.queue, lane == 0 ? 1u : 0u);
+            const int tk0 = __builtin_amdgcn_readfirstlane((int)ticket);
+            if (lane == 0) xi[0] = tk0;
+        }
+        __syncthreads();
+        const int tk = xi[0];
+        __syncthreads();  // everyone has read the ticket before the next one overwrites it
+        if (tk >= a.regionCount) break;
+        const int r = a.regionBase + tk;
+        const CpkRegion &rg = a.regions[r];
+        const int lX = rg.lX, lY = rg.lY, N = lX + lY;
+        const uint8_t *gx = a.symbols + rg.seqXOff, *gy = a.symbols + rg.seqYOff;
+        {
+            const int bx = (lX + 3) >> 1, by = (lY + 3) >> 1;
+            for (int i = tid; i < bx; i += CPK_WAVE * T) {
+                const int lo4 = gx[2 * i], hi4 = 2 * i + 1 < lX + 2 ? gx[2 * i + 1] : CPK_SYM_N;
+                seqLds[i] = (uint8_t)(lo4 | (hi4 << 4));
+            }
+            for (int i = tid; i < by; i += CPK_WAVE * T) {
+                const int lo4 = gy[2 * i], hi4 = 2 * i + 1 < lY + 2 ? gy[2 * i + 1] : CPK_SYM_N;
+                seqLds[bx + i] = (uint8_t)(lo4 | (hi4 << 4));
+            }
+        }
+        const CpkDiag *table = a.diags + rg.diagOff;
+        SweepT sw{a,
+                  a.kc,
+                  DiagCache{table, N, 0, lane, 0, 0, 0, 0},
+                  seqLds,
+                  seqLds + ((lX + 3) >> 1),
+                  roll,
+                  em,
+                  wt,
+                  lg,
+                  a.ring + slot * (size_t)a.geo.ringCells * S,
+                  a.cand + slot * (size_t)a.geo.fbCells,
+                  nullptr,
+                  a.cbuf + slot * (size_t)a.geo.refreshCells,
+                  a.mbuf + slot * (size_t)a.geo.refreshCells,
+                  a.totals + slot * (size_t)a.geo.maxRefresh,
+                  stride,
+                  lane,
+                  lane * R,
+                  N,
+                  CpkDiag{},
+                  CpkDiag{}};
+        __syncthreads();  // symbols staged
+        int count = 0;
+        if (a.geo.debug & 4) {  // diagnostic (CPECAN_DEBUG_SKIP=4): regions are fetched and staged, nothing is computed
+            if (tid == 0) a.outCounts[r] = 0;
+            continue;
+        }
+        if (N > 0) {
+            sw.dc.load(0);
+            const double *startPrior = rg.raggedLeft ? m.raggedStart : m.start;
+            CpkDiag f1 = sw.dc.get(0, false), f2 = f1;  // table entries of the two previous forward diagonals
+            if (tid < S) {
+                frow(0)[tid] = startPrior[tid];
+                sw.ringAt(f1)[tid] = startPrior[tid];
+            }
+            __syncthreads();
+            // this wave's range of a diagonal of W cells: whole groups of 64, contiguous, in wave order
+            auto range = [&](int W, int &lo, int &hi) {
+                const int groups = (W + CPK_WAVE - 1) / CPK_WAVE, per = (groups + T - 1) / T;
+                lo = wave * per * CPK_WAVE;
+                hi = lo + per * CPK_WAVE;
+                lo = lo < W ? lo : W;
+                hi = hi < W ? hi : W;
+            };
+            int d = 1;
+            int emitSeg = 0, emitFrom = a.segs[rg.segOff].tbFrom;
+            for (int si = 0; si < rg.nSeg; si++) {
+                const CpkSegment sg = a.segs[rg.segOff + si];
+                // ---- forward sweep up to dTop (pairwiseAligner.c:609-629) ----
+                while (d <= sg.dTop) {
+                    sw.dc.load(d);
+                    const int dEnd = d + CPK_WAVE - 1 < sg.dTop ? d + CPK_WAVE - 1 : sg.dTop;
+                    for (; d <= dEnd; d++) {
+                        while (d > emitFrom) emitFrom = a.segs[rg.segOff + ++emitSeg].tbFrom;
+                        const bool all = (emitFrom - d) % CPK_REFRESH_PERIOD == 0 || d >= sg.dTop - 1;
+                        const CpkDiag g = sw.dc.at(d - sw.dc.base);
+                        const int W = g.width;
+                        typename SweepT::FwdCtx c;
+                        c.d = d;
+                        c.xlo = (d + g.xmyL) >> 1;
+                        c.dlR = ((g.xmyL - 1 - f1.xmyL) >> 1) * R;
+                        c.w1R = f1.width * R;
+                        c.dmR = ((g.xmyL - f2.xmyL) >> 1) * R;
+                        c.w2R = d >= 2 ? f2.width * R : 0;
+                        c.p1 = frow(d - 1);
+                        c.p2 = frow(d - 2);
+                        double *cur = frow(d);
+                        double *out = sw.ringAt(g);
+                        int lo, hi;
+                        range(W, lo, hi);
+                        for (int kb = lo; kb < hi; kb += CPK_WAVE) {
+                            const int k0 = kb + lane;
+                            if (k0 < hi) {
+                                const int kk[1] = {k0};
+                                const int kkR[1] = {kb * R + lane * R};
+                                double v[1][S];
+                                sw.template fwdCells<1>(c, kk, kkR, v);
+#pragma unroll
+                                for (int s = 0; s < S; s++) cur[s + kkR[0]] = v[0][s];
+                                out[SweepT::ringIdx(W, 0, k0)] = v[0][0];
+                                if (all) {
+#pragma unroll
+                                    for (int s = 1; s < S; s++) out[SweepT::ringIdx(W, s, k0)] = v[0][s];
+                                }
+                            }
+                        }
+                        __syncthreads();
+                        f2 = f1;
+                        f1 = g;
+                    }
+                }
+                if (a.geo.debug & 2) continue;  // diagnostic (CPECAN_DEBUG_SKIP=2): the forward sweep alone, no output
+                // ---- traceback of the segment (pairwiseAligner.c:796-862) ----
+                const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
+                double ep[S];
+#pragma unroll
+                for (int s = 0; s < S; s++) ep[s] = endPrior[s];
+                const int J = sg.nRefresh;
+                float lastMax = -__builtin_huge_valf();
+                int nCand = 0;
+                int untilRefresh = sg.dTop - sg.tbFrom, jr = 0;
+                CpkDiag gb{}, ga{};
+                CpkDiag g = sw.dc.get(sg.dTop, true);
+                for (int d2 = sg.dTop; d2 > sg.tbPrev;) {
+                    sw.dc.load(d2 - 1 - (CPK_WAVE - 1));  // entries of the 64 diagonals ending at d2-1
+                    for (int ci = CPK_WAVE - 1; ci >= 0 && d2 > sg.tbPrev; ci--, d2--) {
+                        const bool seeded = d2 == sg.dTop;
+                        const int W = g.width;
+                        const bool emit = d2 <= sg.tbFrom;
+                        const bool refresh = untilRefresh == 0;
+                        const bool feeds = untilRefresh == 1 && d2 - 1 > sg.tbPrev;
+                        const CpkDiag gnext = sw.dc.at(ci);  // entry of d2-1 (of diagonal 0 when d2 < 1: not used then)
+                        double *curM = sw.bM1(d2), *curG = sw.bG1(d2);
+                        const double *fsrc = sw.ringAt(g);
+                        const int xlo = (d2 + g.xmyL) >> 1;
+                        typename SweepT::BwdCtx c;
+                        c.d2 = d2;
+                        c.xlo = xlo;
+                        c.dbR = ((g.xmyL - 1 - gb.xmyL) >> 1) * R;
+                        c.wBR = seeded ? 0 : gb.width * R;
+                        c.daR = ((g.xmyL - ga.xmyL) >> 1) * R;
+                        c.wAR = (!seeded && d2 + 2 <= sg.dTop) ? ga.width * R : 0;
+                        c.pb = sw.bG1(d2 + 1);
+                        c.pa = sw.bM1(d2 + 2);
+                        const float keepFrom = lastMax + logThr - kCandMargin;
+                        int lo, hi;
+                        range(W, lo, hi);
+                        // this wave's candidates of the diagonal wait in registers for the other waves' counts
+                        double pfb[kTeamGroups];
+                        int px[kTeamGroups];
+                        unsigned long long pmask[kTeamGroups];
+                        int myCount = 0;
+                        float myMax = -__builtin_huge_valf();
+#pragma unroll
+                        for (int gi = 0; gi < kTeamGroups; gi++) {
+                            pmask[gi] = 0;
+                            pfb[gi] = 0.0;
+                            px[gi] = 0;
+                            const int kb = lo + gi * CPK_WAVE;
+                            if (kb < hi) {  // wave-uniform
+                                const int k0 = kb + lane;
+                                const bool on = k0 < hi;
+                                const int kc = on ? k0 : hi - 1;
+                                const int kR0 = kc * R;
+                                double v[1][S];
+                                if (seeded) {
+#pragma unroll
+                                    for (int s = 0; s < S; s++) v[0][s] = ep[s];
+                                } else {
+                                    const int kk[1] = {kc};
+                                    const int kkR[1] = {kR0};
+                                    sw.template bwdCells<1>(c, kk, kkR, v);
+                                }
+                                if (on) {
+                                    curM[kR0] = v[0][0];
+#pragma unroll
+                                    for (int s = 1; s < S; s++) curG[s + kR0] = v[0][s];
+                                }
+                                const int x = xlo + kc, y = d2 - x;
+                                if (emit || feeds) {
+                                    const double f0 = ld_self(fsrc + SweepT::ringIdx(W, 0, kc));
+                                    const double fb = f0 + v[0][0];
+                                    if (feeds && on) sw.mbuf[(size_t)k0 * J + jr] = fb;  // series of the refresh point below (:647)
+                                    if (emit) {
+                                        const bool keep = on && x > 0 && y > 0 && (float)fb >= keepFrom;
+                                        pmask[gi] = __ballot(keep);
+                                        pfb[gi] = fb;
+                                        px[gi] = x;
+                                        myCount += __popcll(pmask[gi]);
+                                        if (refresh) {
+                                            // cell dot product over the states (pairwiseAligner.c:402-408) and this wave's
+                                            // share of the diagonal's largest F.m + B.m
+                                            float fbf = -__builtin_huge_valf();
+                                            if (on) {
+                                                double t = fb;
+#pragma unroll
+                                                for (int s2 = 1; s2 < S; s2++)
+                                                    t = logadd(lg, t, ld_self(fsrc + SweepT::ringIdx(W, s2, kc)) + v[0][s2]);
+                                                sw.cbuf[(size_t)k0 * J + jr] = t;
+                                                if (x > 0 && y > 0) fbf = (float)fb;
+                                            }
+                                            myMax = fmaxf(myMax, wave_max_f32(fbf));
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                        // ---- the waves meet: the diagonal is complete, counts and maxima are exchanged ----
+                        const int par = d2 & 1;
+                        if (lane == 0) {
+                            xi[8 + par * T + wave] = myCount;
+                            xf[par * T + wave] = myMax;
+                        }
+                        __syncthreads();
+                        int before = 0, total = 0;
+                        float dmax = -__builtin_huge_valf();
+#pragma unroll
+                        for (int w = 0; w < T; w++) {
+                            const int cw = xi[8 + par * T + w];
+                            before += w < wave ? cw : 0;
+                            total += cw;
+                            dmax = fmaxf(dmax, xf[par * T + w]);
+                        }
+                        if (emit) {
+                            int at = nCand + before;
+#pragma unroll
+                            for (int gi = 0; gi < kTeamGroups; gi++) {
+                                const unsigned long long mk = pmask[gi];
+                                if (mk) {  // wave-uniform
+                                    if ((mk >> lane) & 1ull) {
+                                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
+                                        Candidate cd;
+                                        cd.fb = pfb[gi];
+                                        cd.x = px[gi];
+                                        cd.y = d2 - px[gi];
+                                        sw.cand[at + rank] = cd;
+                                    }
+                                    at += __popcll(mk);
+                                }
+                            }
+                            nCand += total;
+                        }
+                        if (refresh) lastMax = fmaxf(dmax, lastMax - 1.0f);
+                        ga = gb;
+                        gb = g;
+                        g = gnext;
+                        if (refresh) {
+                            untilRefresh = CPK_REFRESH_PERIOD - 1;
+                            jr++;
+                        } else {
+                            untilRefresh--;
+                        }
+                    }
+                }
+                __threadfence_block();
+                __syncthreads();  // every candidate and refresh series is written
+                // every wave folds the totals (the same values; foldTotals ends in a workgroup barrier, so all must call
+                // it), wave 0 emits
+                sw.foldTotals(sg, table);
+                if (wave == 0) {
+                    if (lane == 0) a.segStarts[(size_t)rg.segOff + si] = count;
+                    count = sw.emitMatches(sg, sw.cand, nCand, a.triples + 3 * (size_t)rg.outOff, rg.outCap, count);
+                }
+                if (!sg.atEnd) {
+                    // the traceback reused the rows: put F[dTop-1] and F[dTop] back for the forward sweep
+                    const CpkDiag gTopM1 = sw.dc.get(sg.dTop - 1, false);
+                    const CpkDiag gTop = sw.dc.get(sg.dTop, false);
+                    __syncthreads();  // nobody still reads backward rows
+                    for (int which = 0; which < 2; which++) {
+                        const CpkDiag &gd = which ? gTop : gTopM1;
+                        const int dd = which ? sg.dTop : sg.dTop - 1;
+                        double *cur = frow(dd);
+                        const double *src = sw.ringAt(gd);
+                        for (int k = tid; k < gd.width; k += CPK_WAVE * T) {
+#pragma unroll
+                            for (int s = 0; s < S; s++) cur[s + k * R] = ld_self(src + SweepT::ringIdx(gd.width, s, k));
+                        }
+                    }
+                    f2 = gTopM1;
+                    f1 = gTop;
+                }
+                __syncthreads();
+            }
+        }
+        if (tid == 0) a.outCounts[r] = count;
+        // count lives in wave 0 only: tid 0 is lane 0 of wave 0
+    }
+}
