@@ -446,7 +446,9 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         const size_t teamLds = sizeof(double) * ((size_t)team_header_doubles() + (size_t)3 * S * c.geo.rollStride) +
                                (size_t)((c.geo.seqLdsBytes + 15) / 16 * 16);
         const char *teamEnv = getenv("CPECAN_TEAM");
-        const int teamFrom = teamEnv ? atoi(teamEnv) : 0;  // widest diagonal from which a class goes to teams; 0: never
+        // widest diagonal from which a class goes to teams (measured crossover: one wave per region wins up to ~350-cell
+        // bands, the team from ~450); CPECAN_TEAM=0: never
+        const int teamFrom = teamEnv ? atoi(teamEnv) : 385;
         if (teamFrom > 0 && geo->emit == CPECAN_EMIT_MATCH && !geo->debug && c.geo.maxWidth >= teamFrom &&
             c.geo.maxWidth <= CPK_WAVE * kTeamWaves * kTeamGroups && teamLds <= 160 * 1024) {
             c.fn = S == 5 ? cpecan_pairhmm_team<5, kTeamWaves> : cpecan_pairhmm_team<3, kTeamWaves>;

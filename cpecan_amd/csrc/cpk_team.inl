@@ -15,7 +15,7 @@
 //     fold and the emission are Sweep's, run by wave 0;
 //   * the candidate bound (lastMax) is the maximum over the waves' maxima on refresh diagonals, exchanged the same way;
 //   * F rows are read from the forward ring where they are used (the other waves of the team cover the latency).
-constexpr int kTeamGroups = 4;  // 64-cell groups a wave handles per diagonal at most: bands up to 64 * T * kTeamGroups cells
+constexpr int kTeamGroups = 5;  // 64-cell groups a wave handles per diagonal at most: bands up to 64 * T * kTeamGroups cells
 constexpr int kTeamXchg = 32;   // doubles of LDS for the exchange area (counts, maxima, the region ticket)
 
 __host__ __device__ constexpr int team_header_doubles() { return kLdsCubics + 40 + kLdsWeights + kTeamXchg; }
@@ -183,6 +183,20 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                 int untilRefresh = sg.dTop - sg.tbFrom, jr = 0;
                 CpkDiag gb{}, ga{};
                 CpkDiag g = sw.dc.get(sg.dTop, true);
+                // F.match of this wave's cells, one diagonal ahead of its use (the ring is in HBM): group gi of the range
+                auto loadF = [&](const CpkDiag &gd, double (&dst)[kTeamGroups]) {
+                    int flo, fhi;
+                    range(gd.width, flo, fhi);
+                    const double *src = sw.ringAt(gd);
+#pragma unroll
+                    for (int gi = 0; gi < kTeamGroups; gi++) {
+                        int k = flo + gi * CPK_WAVE + lane;
+                        k = k < gd.width ? k : gd.width - 1;
+                        dst[gi] = ld_self(src + SweepT::ringIdx(gd.width, 0, k > 0 ? k : 0));
+                    }
+                };
+                double fCur[kTeamGroups];
+                loadF(g, fCur);
                 for (int d2 = sg.dTop; d2 > sg.tbPrev;) {
                     sw.dc.load(d2 - 1 - (CPK_WAVE - 1));  // entries of the 64 diagonals ending at d2-1
                     for (int ci = CPK_WAVE - 1; ci >= 0 && d2 > sg.tbPrev; ci--, d2--) {
@@ -192,6 +206,8 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                         const bool refresh = untilRefresh == 0;
                         const bool feeds = untilRefresh == 1 && d2 - 1 > sg.tbPrev;
                         const CpkDiag gnext = sw.dc.at(ci);  // entry of d2-1 (of diagonal 0 when d2 < 1: not used then)
+                        double fNext[kTeamGroups];
+                        loadF(gnext, fNext);
                         double *curM = sw.bM1(d2), *curG = sw.bG1(d2);
                         const double *fsrc = sw.ringAt(g);
                         const int xlo = (d2 + g.xmyL) >> 1;
@@ -240,7 +256,7 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                                 }
                                 const int x = xlo + kc, y = d2 - x;
                                 if (emit || feeds) {
-                                    const double f0 = ld_self(fsrc + SweepT::ringIdx(W, 0, kc));
+                                    const double f0 = fCur[gi];
                                     const double fb = f0 + v[0][0];
                                     if (feeds && on) sw.mbuf[(size_t)k0 * J + jr] = fb;  // series of the refresh point below (:647)
                                     if (emit) {
@@ -306,6 +322,11 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                         ga = gb;
                         gb = g;
                         g = gnext;
+#pragma unroll
+                        for (int gi = 0; gi < kTeamGroups; gi++) {
+                            asm volatile("" : "+v"(fNext[gi]));  // waited for here, a diagonal after the loads were issued
+                            fCur[gi] = fNext[gi];
+                        }
                         if (refresh) {
                             untilRefresh = CPK_REFRESH_PERIOD - 1;
                             jr++;
