@@ -451,16 +451,20 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         const int teamFrom = teamEnv ? atoi(teamEnv) : 385;
         if (teamFrom > 0 && geo->emit == CPECAN_EMIT_MATCH && !geo->debug && c.geo.maxWidth >= teamFrom &&
             c.geo.maxWidth <= CPK_WAVE * kTeamWaves * kTeamGroups && teamLds <= 160 * 1024) {
-            c.fn = S == 5 ? cpecan_pairhmm_team<5, kTeamWaves> : cpecan_pairhmm_team<3, kTeamWaves>;
-            c.threads = CPK_WAVE * kTeamWaves;
+            // one workgroup per CU is all the LDS allows from ~660 cells: then eight waves share the region
+            const bool big = 2 * teamLds > 160 * 1024;
+            c.fn = S == 5 ? (big ? cpecan_pairhmm_team<5, 2 * kTeamWaves> : cpecan_pairhmm_team<5, kTeamWaves>)
+                          : (big ? cpecan_pairhmm_team<3, 2 * kTeamWaves> : cpecan_pairhmm_team<3, kTeamWaves>);
+            c.threads = CPK_WAVE * kTeamWaves * (big ? 2 : 1);
             c.geo.useGlobalRoll = 0;
             c.ldsBytes = teamLds;
             c.grollEl = 0;
             hipFuncAttributes attr;
             HIP_TRY(hipFuncGetAttributes(&attr, (const void *)c.fn));
             const int vgprAlloc = ((attr.numRegs > 0 ? attr.numRegs : 128) + 7) / 8 * 8;
-            int perSimd = 512 / vgprAlloc;  // a team puts one wave on every SIMD
+            int perSimd = 512 / vgprAlloc;  // a team of four puts one wave on every SIMD, a team of eight two
             if (perSimd > 8) perSimd = 8;
+            if (big) perSimd /= 2;
             const int byLds = (int)((160 * 1024) / (teamLds + (size_t)attr.sharedSizeBytes));
             perCU = perSimd < byLds ? perSimd : byLds;
             if (perCU < 1) perCU = 1;
