@@ -449,10 +449,10 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         // widest diagonal from which a class goes to teams (measured crossover: one wave per region wins up to ~350-cell
         // bands, the team from ~450); CPECAN_TEAM=0: never
         const int teamFrom = teamEnv ? atoi(teamEnv) : 385;
+        // one workgroup per CU is all the LDS allows from ~660 cells: then eight waves share the region
+        const bool big = 2 * teamLds > 160 * 1024;
         if (teamFrom > 0 && geo->emit == CPECAN_EMIT_MATCH && !geo->debug && c.geo.maxWidth >= teamFrom &&
-            c.geo.maxWidth <= CPK_WAVE * kTeamWaves * kTeamGroups && teamLds <= 160 * 1024) {
-            // one workgroup per CU is all the LDS allows from ~660 cells: then eight waves share the region
-            const bool big = 2 * teamLds > 160 * 1024;
+            c.geo.maxWidth <= CPK_WAVE * kTeamWaves * (big ? 2 : 1) * kTeamGroups && teamLds <= 160 * 1024) {
             c.fn = S == 5 ? (big ? cpecan_pairhmm_team<5, 2 * kTeamWaves> : cpecan_pairhmm_team<5, kTeamWaves>)
                           : (big ? cpecan_pairhmm_team<3, 2 * kTeamWaves> : cpecan_pairhmm_team<3, kTeamWaves>);
             c.threads = CPK_WAVE * kTeamWaves * (big ? 2 : 1);

@@ -15,7 +15,7 @@
 //     fold and the emission are Sweep's, run by wave 0;
 //   * the candidate bound (lastMax) is the maximum over the waves' maxima on refresh diagonals, exchanged the same way;
 //   * F rows are read from the forward ring where they are used (the other waves of the team cover the latency).
-constexpr int kTeamGroups = 5;  // 64-cell groups a wave handles per diagonal at most: bands up to 64 * T * kTeamGroups cells
+constexpr int kTeamGroups = 3;  // 64-cell groups a wave handles per diagonal at most: bands up to 64 * T * kTeamGroups cells
 constexpr int kTeamXchg = 32;   // doubles of LDS for the exchange area (counts, maxima, the region ticket)
 
 __host__ __device__ constexpr int team_header_doubles() { return kLdsCubics + 40 + kLdsWeights + kTeamXchg; }
