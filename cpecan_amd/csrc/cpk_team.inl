@@ -229,6 +229,18 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                         unsigned long long pmask[kTeamGroups];
                         int myCount = 0;
                         float myMax = -__builtin_huge_valf();
+                        // refresh diagonals need the other states of F as well (cell dot products): their loads go out
+                        // here, ahead of the diagonal's arithmetic
+                        double rf[kTeamGroups][S];
+                        if (refresh) {
+#pragma unroll
+                            for (int gi = 0; gi < kTeamGroups; gi++) {
+                                int k = lo + gi * CPK_WAVE + lane;
+                                k = k < W ? k : W - 1;
+#pragma unroll
+                                for (int s2 = 1; s2 < S; s2++) rf[gi][s2] = ld_self(fsrc + SweepT::ringIdx(W, s2, k > 0 ? k : 0));
+                            }
+                        }
 #pragma unroll
                         for (int gi = 0; gi < kTeamGroups; gi++) {
                             pmask[gi] = 0;
@@ -273,7 +285,7 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                                                 double t = fb;
 #pragma unroll
                                                 for (int s2 = 1; s2 < S; s2++)
-                                                    t = logadd(lg, t, ld_self(fsrc + SweepT::ringIdx(W, s2, kc)) + v[0][s2]);
+                                                    t = logadd(lg, t, rf[gi][s2] + v[0][s2]);
                                                 sw.cbuf[(size_t)k0 * J + jr] = t;
                                                 if (x > 0 && y > 0) fbf = (float)fb;
                                             }
