@@ -854,6 +854,8 @@ struct Sweep {
 
     // ---- total probability at every refresh point of the segment: one lane per refresh point, each doing the
     // reference's sequential folds (dpDiagonal_dotProduct :513-523, then the straddle term :649).
+    // TEAM: called by one wave of a multi-wave workgroup (no workgroup barrier at the end, a wave-level fence instead)
+    template <bool TEAM = false>
     __device__ void foldTotals(const CpkSegment &sg, const CpkDiag *table) {
         const int J = sg.nRefresh;
         for (int j0 = 0; j0 < J; j0 += CPK_WAVE) {
@@ -885,7 +887,7 @@ struct Sweep {
                 totals[j] = total;
             }
         }
-        roll_fence<true>();
+        roll_fence<!TEAM>();
     }
 
     // ---- thresholded posteriors (pairwiseAligner.c:655-689) from the candidate list, walked backwards so that the

@@ -12,7 +12,7 @@
 //   * candidates: every wave keeps the candidates of its cells of the current diagonal in registers; at the barrier the
 //     waves exchange their counts through LDS, and each writes its run behind the runs of the waves before it -- the
 //     segment's candidate list comes out in the single-wave order (diagonal descending, x-y ascending), so the totals
-//     fold and the emission are Sweep's, run by wave 0;
+//     fold and the emission are Sweep's, run by wave 0 while the other waves restore the forward rows;
 //   * the candidate bound (lastMax) is the maximum over the waves' maxima on refresh diagonals, exchanged the same way;
 //   * F rows are read from the forward ring where they are used (the other waves of the team cover the latency).
 constexpr int kTeamGroups = 3;  // 64-cell groups a wave handles per diagonal at most: bands up to 64 * T * kTeamGroups cells
@@ -349,10 +349,9 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                 }
                 __threadfence_block();
                 __syncthreads();  // every candidate and refresh series is written
-                // every wave folds the totals (the same values; foldTotals ends in a workgroup barrier, so all must call
-                // it), wave 0 emits
-                sw.foldTotals(sg, table);
+                // wave 0 folds the totals and emits while the others already put the forward rows back
                 if (wave == 0) {
+                    sw.template foldTotals<true>(sg, table);
                     if (lane == 0) a.segStarts[(size_t)rg.segOff + si] = count;
                     count = sw.emitMatches(sg, sw.cand, nCand, a.triples + 3 * (size_t)rg.outOff, rg.outCap, count);
                 }
@@ -360,13 +359,14 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                     // the traceback reused the rows: put F[dTop-1] and F[dTop] back for the forward sweep
                     const CpkDiag gTopM1 = sw.dc.get(sg.dTop - 1, false);
                     const CpkDiag gTop = sw.dc.get(sg.dTop, false);
-                    __syncthreads();  // nobody still reads backward rows
-                    for (int which = 0; which < 2; which++) {
+                    // (nobody reads backward rows any more: the barrier above came after the last diagonal; wave 0 is
+                    // busy with the totals and the emission, the other waves do this)
+                    for (int which = 0; which < 2 && wave > 0; which++) {
                         const CpkDiag &gd = which ? gTop : gTopM1;
                         const int dd = which ? sg.dTop : sg.dTop - 1;
                         double *cur = frow(dd);
                         const double *src = sw.ringAt(gd);
-                        for (int k = tid; k < gd.width; k += CPK_WAVE * T) {
+                        for (int k = tid - CPK_WAVE; k < gd.width; k += CPK_WAVE * (T - 1)) {
 #pragma unroll
                             for (int s = 0; s < S; s++) cur[s + k * R] = ld_self(src + SweepT::ringIdx(gd.width, s, k));
                         }
