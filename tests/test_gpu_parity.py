@@ -372,21 +372,23 @@ def test_wide_band_uses_global_rolling_buffers():
 @pytest.mark.parametrize("mtype,emit", [(0, "match"), (2, "match"), (0, "expect")])
 def test_mixed_widths_run_in_size_classes(mtype, emit):
     """One batch with regions of every wide class -- banded at 41-81 cells, unanchored 150 x 150 (151 cells), 300 x 300
-    (301), and 900 x 900 (901 cells: rolling buffers in global memory) -- runs as one launch per class, each with LDS
-    and scratch for its own largest region, and gives what each problem gives alone."""
+    (301), 500 x 500 (501) and 900 x 900 (901 cells: rolling buffers in global memory for one wave; the match emitter
+    runs the last two on the team kernel) -- runs as one launch per class, each with LDS and scratch for its own largest
+    region, and gives what each problem gives alone."""
     probs = [make_pair(31, i, 400, 40) for i in range(40)]                       # <= 128 cells
     probs += [make_pair(32, i, 150, 0)[:2] + ((),) for i in range(6)]            # <= 256
     probs += [make_pair(33, i, 300, 0)[:2] + ((),) for i in range(4)]            # fits the LDS
-    probs += [make_pair(34, 0, 900, 0)[:2] + ((),)]                              # does not
+    probs += [make_pair(36, i, 500, 0)[:2] + ((),) for i in range(2)]            # 501 cells: a team of four waves (match emitter)
+    probs += [make_pair(34, 0, 900, 0)[:2] + ((),)]                              # 901: does not fit one wave's LDS; a team of eight
     probs += [make_pair(35, i, 200, 40) for i in range(80)]                      # more of the first class, behind the wide ones
     pkw = dict(diagonalExpansion=40)
     if emit == "match":
         worst, st = _check_batch(mtype, probs, **pkw)
         assert st.regions == len(probs)
         # the batch composition does not change a result
-        alone, _ = _run_batch(mtype, probs[46:51], **pkw)
+        alone, _ = _run_batch(mtype, probs[46:53], **pkw)
         together, _ = _run_batch(mtype, probs, **pkw)
-        for t1, t2 in zip(alone, together[46:51]):
+        for t1, t2 in zip(alone, together[46:53]):
             assert np.array_equal(t1, t2)
     else:
         p = api.pairwiseAlignmentBandingParameters_construct(**pkw)
