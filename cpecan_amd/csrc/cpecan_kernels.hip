@@ -17,8 +17,12 @@
  *     per-diagonal total is transposed (one lane per refresh point); posteriors are thresholded and compacted with
  *     wave ballots straight into the output list order;
  *   - packed kernel (cpk_packed.inl): narrow bands, 64/GW regions per wave, the same cell functions;
+ *   - team kernel (cpk_team.inl): bands of several hundred cells, four or eight waves of a workgroup per region, one
+ *     barrier per diagonal, the same cell functions;
+ *   - every launch of a run is one size class of regions (narrow 8/16/32, wide 128 ... LDS-sized, global) with LDS,
+ *     occupancy and scratch for its own largest region (LaunchClass below);
  *   - cpk_table_gather.inl: the per-diagonal band table from the anchors, the lists' re-ordering;
- *   - cpk_post.inl: reweighting, posterior scores, MEA chain, left shift on the device.
+ *   - cpk_post.inl: reweighting, posterior and identity scores, ordered chain, MEA chain, left shift on the device.
  * No MFMA: an fp64 stencil bounded by vector-instruction issue (HBM traffic is ~1/3 of the algorithmic figure).
  *
  * Built with -ffp-contract=off: the reference's polynomial is separately rounded mul/add.
