@@ -449,13 +449,17 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         constexpr int kTeamWaves = 4;
         const size_t teamLds = sizeof(double) * ((size_t)team_header_doubles() + (size_t)3 * S * c.geo.rollStride) +
                                (size_t)((c.geo.seqLdsBytes + 15) / 16 * 16);
+        // A class goes to teams where one wave per region is down to three waves per CU or fewer (measured: at four per
+        // CU, ~400-cell bands, the single wave still wins by 13 %; at three, ~450 cells, the team wins by 30 %), or on
+        // the global-memory variant.  CPECAN_TEAM=<cells> (tests, diagnostics): from that band width instead; 0: never.
         const char *teamEnv = getenv("CPECAN_TEAM");
-        // widest diagonal from which a class goes to teams (measured crossover: one wave per region wins up to ~350-cell
-        // bands, the team from ~450); CPECAN_TEAM=0: never
-        const int teamFrom = teamEnv ? atoi(teamEnv) : 385;
+        int soloPerCU = 0;
+        if (int rc = wavesPerCU(c.fn, c.ldsBytes, &soloPerCU)) return rc;
+        const bool wanted = teamEnv ? (atoi(teamEnv) > 0 && c.geo.maxWidth >= atoi(teamEnv))
+                                    : (c.geo.maxWidth > 256 && (soloPerCU <= 3 || c.geo.useGlobalRoll));
         // one workgroup per CU is all the LDS allows from ~660 cells: then eight waves share the region
         const bool big = 2 * teamLds > 160 * 1024;
-        if (teamFrom > 0 && geo->emit == CPECAN_EMIT_MATCH && !geo->debug && c.geo.maxWidth >= teamFrom &&
+        if (wanted && geo->emit == CPECAN_EMIT_MATCH && !geo->debug &&
             c.geo.maxWidth <= CPK_WAVE * kTeamWaves * (big ? 2 : 1) * kTeamGroups && teamLds <= 160 * 1024) {
             c.fn = S == 5 ? (big ? cpecan_pairhmm_team<5, 2 * kTeamWaves> : cpecan_pairhmm_team<5, kTeamWaves>)
                           : (big ? cpecan_pairhmm_team<3, 2 * kTeamWaves> : cpecan_pairhmm_team<3, kTeamWaves>);
@@ -472,8 +476,8 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             const int byLds = (int)((160 * 1024) / (teamLds + (size_t)attr.sharedSizeBytes));
             perCU = perSimd < byLds ? perSimd : byLds;
             if (perCU < 1) perCU = 1;
-        } else if (int rc = wavesPerCU(c.fn, c.ldsBytes, &perCU)) {
-            return rc;
+        } else {
+            perCU = soloPerCU;
         }
         if (perCU < 1) {
             cpk_set_error("kernel does not fit on a CU (LDS %zu bytes)", c.ldsBytes);
