@@ -697,7 +697,7 @@ static void host_scores(const Item *it, const int32_t *t, int64_t n, double s[4]
     s[3] = 100.0 * matches / (double)n;
 }
 
-static double g_stage[3]; /* upload, run, download of the last run_batch (CPECAN_REALIGN_TIMING only) */
+static __thread double g_stage[3]; /* upload, run, download of the last run_batch (CPECAN_REALIGN_TIMING only) */
 static int run_batch(cpecan_batch *b) {
     const double t0 = now_ms();
     int rc = cpecan_batch_upload(b);
