@@ -25,7 +25,8 @@
  *   - cpk_post.inl: reweighting, posterior and identity scores, ordered chain, MEA chain, left shift on the device.
  * No MFMA: an fp64 stencil bounded by vector-instruction issue (HBM traffic is ~1/3 of the algorithmic figure).
  *
- * Built with -ffp-contract=off: the reference's polynomial is separately rounded mul/add.
+ * Built with -ffp-contract=off; the logAdd cubic's three FMAs are explicit (cpk_device_common.inl: what the shipped
+ * build changes against the reference's operation sequence, and the EXACT=1 diagnostic build that does not).
  */
 #include <hip/hip_runtime.h>
 
@@ -660,7 +661,9 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.symbols = d->dSymbols;
     a.model = d->dModel;
     a.geo = d->geo;
-    if (const char *skip = getenv("CPECAN_DEBUG_SKIP")) a.geo.debug |= (atoi(skip) & 6);  // diagnostic phase bisection
+#ifdef CPK_DIAGNOSTICS  // tools/ab_build.sh <tag> -DCPK_DIAGNOSTICS: phase bisection for timing runs; never in the shipped library
+    if (const char *skip = getenv("CPECAN_DEBUG_SKIP")) a.geo.debug |= (atoi(skip) & 6);
+#endif
     a.ring = d->dRing;
     a.cand = d->dCand;
     a.cbuf = d->dC;

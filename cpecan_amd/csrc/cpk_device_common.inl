@@ -47,23 +47,36 @@ struct KArgs {
     double *dbgTotals;
 };
 
-// logAdd, impl/pairwiseAligner.c:287-307.  hi/lo form: with d = hi - lo the reference returns hi when
-// lo == -inf or d >= 7.5, else lo + P(d).  d is +inf when only lo is -inf and NaN when both are, and
-// both fail (d < 7.5), so one comparison covers the reference's two tests.  The cubic's coefficients are
-// float literals in the reference, i.e. float32 values widened to double; Horner with separate mul/add.
-// The four cubics live in a 128-byte LDS table [segment][c3,c2,c1,c0] read with two ds_read_b128: selecting
-// four 64-bit coefficients with v_cndmask cost 24 VALU instructions per logAdd (47 % of the forward loop).
+// logAdd, impl/pairwiseAligner.c:287-307: with hi = max(x, y), lo = min(x, y), d = hi - lo the reference returns hi when
+// lo == -inf or d >= 7.5, else lo + P(d), P one of four cubics chosen by d <= 1.0 / <= 2.5 / <= 4.5 / else, evaluated in
+// Horner form with separately rounded multiplies and adds.  The coefficients are float literals in the reference, i.e.
+// float32 values widened to double.
+//
+// Two builds of the same function:
+//  * CPK_LOGADD_EXACT=1 (diagnostic build, `make EXACT=1`): the reference's operations one for one -- 11 fp64 + 9 integer
+//    vector instructions.  Bit-identical to the oracle; used to tell a rounding difference from a logic error.
+//  * default: 7 fp64 + 5 integer vector instructions, the kernel's largest single saving (16 logAdds per cell).
+//      r = hi + Q(dc),  dc = min(|x - y|, 8),  Q(d) = P(d) - d  (the same cubic with c1 - 1), three FMAs,
+//      and a FIFTH all-zero table row for dc >= 7.5, so that "return hi" needs no compare and no select:
+//      lo + P(d) = hi - d + P(d) = hi + Q(d).  |x - y| is +inf when one operand is -inf and NaN when both are; the
+//      IEEE minimum with 8 turns both into 8 (row 4, Q = 0), so -inf operands give exactly the reference's result.
+//    Differences from the reference's arithmetic: the rounding of d is not cancelled exactly (<= 1 ulp of d), Horner is
+//    fused, and c1 - 1 is rounded once: |delta| <= ~1e-15 per logAdd against values of 1e3..1e4 that both sides round
+//    at 2e-13..2e-12 anyway.  Measured against the oracle: see tests/parity.py (log-space values agree to < 1e-9 over
+//    4000-diagonal sweeps; posteriors to ~1e-10 relative; the gate is 1e-5).  A value of d equal to a threshold to
+//    the last bit takes the upper cubic here and the lower one in the reference (the cubics differ by ~1e-4 there);
+//    such a d has probability ~2^-50 per logAdd.
+// The cubics live in an LDS table [row][c3, c2, c1, c0] of 32-byte rows read with two ds_read_b128: selecting four
+// 64-bit coefficients with v_cndmask cost 24 VALU instructions per logAdd (47 % of the forward loop).  Rows 0..4 span
+// 160 bytes, fewer than the 64 banks x 4 bytes: conflict-free for every combination of rows.
 struct __attribute__((aligned(16))) Cubic {
     double c3, c2, c1, c0;
 };
 
-// The segment of d = hi - lo is found without fp64 compares.  For d >= 0 the IEEE bit pattern is monotone; the three
-// thresholds (1.0, 2.5, 4.5) have a zero low dword and high dwords that are multiples of 2^17, so the segment is a
-// function of the bucket  b = ((bits(d) + 2^49 - 1) >> 49) - (bits(1.0) >> 49), saturated at 0:
-// b == 0 -> d <= 1;  1..10 -> (1, 2.5];  11..17 -> (2.5, 4.5];  18.. -> above, i.e. segment = number of set bits of
-// {0, 10, 17} below position b.  Exact for every double, thresholds included.  NaN / +inf / d >= 8 may pick any
-// segment: the result is `hi` then.  The table keeps 4 rows of 32 bytes (conflict-free for ds_read_b128); a 26-row
-// table indexed by bucket measured 100x the LDS bank conflicts.
+#ifndef CPK_LOGADD_EXACT
+#define CPK_LOGADD_EXACT 0
+#endif
+
 __device__ __forceinline__ void fill_cubics(double *t) {
     const float c[16] = {-0.009350833524763f, 0.130659527668286f, 0.498799810682272f, 0.693203116424741f,
                          -0.014532321752540f, 0.139942324101744f, 0.495635523139337f, 0.692140569840976f,
@@ -74,10 +87,21 @@ __device__ __forceinline__ void fill_cubics(double *t) {
         float v = c[0];
 #pragma unroll
         for (int i = 1; i < 16; i++) v = l == i ? c[i] : v;
-        t[l] = (double)v;
+        double w = (double)v;
+        if (!CPK_LOGADD_EXACT && (l & 3) == 2) w = w - 1.0;  // Q(d) = P(d) - d
+        t[l] = w;
+    } else if (l < 20) {
+        t[l] = 0.0;  // row 4: d >= 7.5, the result is hi
     }
 }
 
+#if CPK_LOGADD_EXACT
+// The segment of d = hi - lo is found without fp64 compares.  For d >= 0 the IEEE bit pattern is monotone; the three
+// thresholds (1.0, 2.5, 4.5) have a zero low dword and high dwords that are multiples of 2^17, so the segment is a
+// function of the bucket  b = ((bits(d) + 2^49 - 1) >> 49) - (bits(1.0) >> 49), saturated at 0:
+// b == 0 -> d <= 1;  1..10 -> (1, 2.5];  11..17 -> (2.5, 4.5];  18.. -> above, i.e. segment = number of set bits of
+// {0, 10, 17} below position b.  Exact for every double, thresholds included.  NaN / +inf / d >= 8 may pick any
+// segment: the result is `hi` then.
 __device__ __forceinline__ int cubic_row(double d) {
     // bits(d) > bits(T)  <=>  bits(d) + 2^49 - 1 >= bits(T) + 2^49 for the three thresholds (multiples of 2^49), so the
     // bucket is the high part of one 64-bit add; the saturating subtract sends every d <= 1 (d == 0 included) to
@@ -91,7 +115,7 @@ __device__ __forceinline__ int cubic_row(double d) {
 __device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
     const double hi = __builtin_fmax(x, y);
     const double lo = __builtin_fmin(x, y);
-    const double d = hi - lo;
+    const double d = hi - lo;  // +inf / NaN exactly when the reference's LOG_ZERO tests fire: both fail d < 7.5
     const Cubic q = tab[cubic_row(d)];
     double r = q.c3 * d;
     r = r + q.c2;
@@ -102,6 +126,26 @@ __device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
     r = r + lo;
     return (d < 7.5) ? r : hi;
 }
+#else
+// Row of dc in [0, 8]: the number of thresholds T in {1.0, 2.5, 4.5, 7.5} with dc >= T.  Their bit patterns are
+// multiples of 2^49, so with hs = bits(dc) >> 49 and b = max(hs - (bits(1.0) >> 49) + 1, 0) (at most 25 for dc <= 8)
+// the row is the number of set bits of {0, 10, 17, 23} below position b: shift, saturating subtract, v_bfe, v_bcnt.
+__device__ __forceinline__ int cubic_row(double dc) {
+    const unsigned hs = (unsigned)((unsigned long long)__double_as_longlong(dc) >> 32) >> 17;
+    const unsigned b = __builtin_elementwise_sub_sat(hs, (0x3FF00000u >> 17) - 1u);
+    return __builtin_popcount(__builtin_amdgcn_ubfe((1u << 0) | (1u << 10) | (1u << 17) | (1u << 23), 0u, b));
+}
+
+__device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
+    const double hi = __builtin_fmax(x, y);
+    const double dc = __builtin_fmin(__builtin_fabs(x - y), 8.0);
+    const Cubic q = tab[cubic_row(dc)];
+    double r = __builtin_fma(q.c3, dc, q.c2);
+    r = __builtin_fma(r, dc, q.c1);
+    r = __builtin_fma(r, dc, q.c0);
+    return hi + r;
+}
+#endif
 
 // exp(x) to a relative error of ~1e-7 for x <= ~1 (probabilities): 2^(x log2 e) with the integer part split off in
 // double, the fraction through v_exp_f32, and the scaling by v_ldexp_f64 -- 8 instructions instead of the ~35 of the
@@ -119,6 +163,7 @@ __device__ __forceinline__ double exp_1e7(double x) {
 // table fetches are in flight together instead of one fetch + wait per logAdd.  acc[i] = logAdd(acc[i], t[i]).
 template <int N>
 __device__ __forceinline__ void logadd_n(const Cubic *tab, double (&acc)[N], const double (&t)[N]) {
+#if CPK_LOGADD_EXACT
     double hi[N], lo[N], d[N];
     Cubic q[N];
 #pragma unroll
@@ -146,6 +191,26 @@ __device__ __forceinline__ void logadd_n(const Cubic *tab, double (&acc)[N], con
     for (int i = 0; i < N; i++) r[i] = r[i] + lo[i];
 #pragma unroll
     for (int i = 0; i < N; i++) acc[i] = (d[i] < 7.5) ? r[i] : hi[i];
+#else
+    double hi[N], dc[N];
+    Cubic q[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        hi[i] = __builtin_fmax(acc[i], t[i]);
+        dc[i] = __builtin_fmin(__builtin_fabs(acc[i] - t[i]), 8.0);
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) q[i] = tab[cubic_row(dc[i])];
+    double r[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = __builtin_fma(q[i].c3, dc[i], q[i].c2);
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = __builtin_fma(r[i], dc[i], q[i].c1);
+#pragma unroll
+    for (int i = 0; i < N; i++) r[i] = __builtin_fma(r[i], dc[i], q[i].c0);
+#pragma unroll
+    for (int i = 0; i < N; i++) acc[i] = hi[i] + r[i];
+#endif
 }
 
 // Row position of neighbour cell i of a diagonal that has `w` cells (w = 0: the diagonal does not exist):
@@ -231,7 +296,7 @@ struct DiagCache {
 #ifndef CPK_SWEEP_WAVES
 #define CPK_SWEEP_WAVES 2  // waves per SIMD the sweep kernel's registers are allocated for
 #endif
-constexpr int kLdsCubics = 16;  // 4 rows x 4 coefficients
+constexpr int kLdsCubics = 24;  // 5 rows x 4 coefficients (4 cubics + the all-zero row), padded to 64 bytes
 // doubles of LDS in front of the rolling rows: cubics + emissions (+ expectation sums for that emitter only)
 constexpr int kExpectCopies = 4;  // emission-expectation sums are kept in 4 LDS copies (lane & 3): fewer atomic collisions
 constexpr int kLdsWeights = 168;  // (emission + transition) sums, see Sweep::wt: 25*5 + 5*4 + 5*4 = 165, padded

@@ -103,10 +103,12 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                   CpkDiag{}};
         __syncthreads();  // symbols staged
         int count = 0;
-        if (a.geo.debug & 4) {  // diagnostic (CPECAN_DEBUG_SKIP=4): regions are fetched and staged, nothing is computed
+#ifdef CPK_DIAGNOSTICS
+        if (a.geo.debug & 4) {  // diagnostic build (CPECAN_DEBUG_SKIP=4): regions are fetched and staged, nothing is computed
             if (tid == 0) a.outCounts[r] = 0;
             continue;
         }
+#endif
         if (N > 0) {
             sw.dc.load(0);
             const double *startPrior = rg.raggedLeft ? m.raggedStart : m.start;
@@ -171,7 +173,9 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                         f1 = g;
                     }
                 }
+#ifdef CPK_DIAGNOSTICS
                 if (a.geo.debug & 2) continue;  // diagnostic (CPECAN_DEBUG_SKIP=2): the forward sweep alone, no output
+#endif
                 // ---- traceback of the segment (pairwiseAligner.c:796-862) ----
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
                 double ep[S];

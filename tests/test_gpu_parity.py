@@ -8,7 +8,7 @@ import pytest
 import oracle_binding as ob
 from cpecan_amd import api
 from cpecan_amd.workload import make_batch, make_pair
-from parity import assert_pairs_match
+from parity import assert_pairs_match, assert_log_close
 
 pytestmark = pytest.mark.gpu
 
@@ -518,13 +518,13 @@ def test_forward_probability_matches_oracle_and_reference_properties():
         b.download()
         for i, (sx, sy, rl, rr) in enumerate(cases):
             lp, lpi = b.forward_prob(2 * i), b.forward_prob(2 * i + 1)
-            assert lp == ob.forward_prob(om, sx, sy, (), op, rl, rr)  # pure logAdd arithmetic: bit-identical
-            assert lpi == ob.forward_prob(om, sx, sx, (), op, rl, rr)
+            assert_log_close(lp, ob.forward_prob(om, sx, sy, (), op, rl, rr))  # pure logAdd arithmetic
+            assert_log_close(lpi, ob.forward_prob(om, sx, sx, (), op, rl, rr))
             assert float("-inf") < lp <= 0.0 and lp <= lpi
     sx, sy, a = make_pair(10, 0, 1500, 40)
     p5 = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=40, dynamicAnchorExpansion=1)
     got = api.computeForwardProbability(sx, sy, a, p5, api.stateMachine5_construct())
-    assert got == ob.forward_prob(ob.model(0), sx, sy, a, ob.params(diagonalExpansion=40, dynamicAnchorExpansion=1))
+    assert_log_close(got, ob.forward_prob(ob.model(0), sx, sy, a, ob.params(diagonalExpansion=40, dynamicAnchorExpansion=1)))
 
 
 # ---- expectation emitter (diagonalCalculationExpectations, pairwiseAligner.c:735-746) ----
@@ -758,3 +758,49 @@ def test_packed_kernel_expectations(force_packed, mtype):
     for sx, sy, a in problems:
         ob.expectations(om, want, sx, sy, a, op, True, True)
     _assert_hmm_close(got, want, 5 if mtype < 2 else 3)
+
+
+# ---- per-cell log-space values: sharper than any posterior (they see every logAdd of both sweeps) ----
+@pytest.mark.parametrize("case", ["tiny5", "tiny3", "full200", "A_1kb", "B_2kb", "short_tracebacks", "asym_ragged"])
+def test_cell_values_and_totals_match_oracle(case):
+    """F.match + B.match of every emitted cell and the total probability used on every emitted diagonal (the debug
+    buffers of the sweep kernel) against the oracle's trace of the same problem: equal to LOG_TOL (tests/parity.py), i.e.
+    ~1e-12 relative -- seven orders inside the north star's 1e-5.  Multi-segment tracebacks, both state counts, ragged ends."""
+    from parity import LOG_TOL
+    rl = rr = False
+    if case == "tiny5":
+        mtype, (sx, sy, a), pkw = 0, ("AGCG", "AGTTCG", ()), dict(threshold=0.2)
+    elif case == "tiny3":
+        mtype, (sx, sy, a), pkw = 2, ("AGCG", "AGTTCG", ()), dict(threshold=0.2)
+    elif case == "full200":
+        mtype, (sx, sy, a), pkw = 0, make_pair(1, 0, 200, 0), dict(diagonalExpansion=20)
+        a = ()
+    elif case == "A_1kb":
+        mtype, (sx, sy, a), pkw = 2, make_pair(2, 0, 1000, 50), dict(diagonalExpansion=50)
+    elif case == "B_2kb":
+        mtype, (sx, sy, a), pkw = 0, make_pair(3, 0, 2000, 100), dict(diagonalExpansion=100)
+    elif case == "short_tracebacks":
+        mtype, (sx, sy, a), pkw = 0, make_pair(3, 1, 600, 10), dict(diagonalExpansion=10, minDiagsBetweenTraceBack=50,
+                                                                  traceBackDiagonals=7)
+    else:
+        mtype, (sx, sy, a), pkw = 1, make_pair(3, 2, 1500, 30), dict(diagonalExpansion=30)
+        rl = rr = True
+    p = api.pairwiseAlignmentBandingParameters_construct(**pkw)
+    want, tr = ob.aligned_pairs_traced(ob.model(mtype), sx, sy, a, ob.params(**pkw), rl, rr)
+    with api.Batch(_sm(mtype), p, debug=True) as b:
+        b.add(sx, sy, a, rl, rr)
+        b.upload()
+        b.run()
+        b.download()
+        got = b.result(0)
+        fb, tot = b.debug_fetch(0, tr["n_cells"], tr["n_diagonals"])
+    assert_pairs_match(got, want, threshold=p.threshold)
+    ofb, otot = tr["fb_match"], tr["total_used"]
+    m = ~np.isnan(ofb)
+    inf = np.isinf(ofb[m])
+    assert np.array_equal(np.isinf(fb[m]), inf) and np.array_equal(fb[m][inf], ofb[m][inf])
+    scale = np.maximum(1.0, np.abs(ofb[m][~inf]))
+    assert np.all(np.abs(fb[m][~inf] - ofb[m][~inf]) <= LOG_TOL * scale), float(np.max(np.abs(fb[m][~inf] - ofb[m][~inf])))
+    mt = ~np.isnan(otot)
+    assert mt.any()
+    assert np.all(np.abs(tot[mt] - otot[mt]) <= LOG_TOL * np.maximum(1.0, np.abs(otot[mt]))), float(np.max(np.abs(tot[mt] - otot[mt])))
