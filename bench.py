@@ -1,17 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- band DP cells/s of the banded pair-HMM forward+backward+posterior path on MI355X.
 
-A "step" is one pass of the hot path (one launch of the fused sweep kernel) over one batch of synthetic
-sequence pairs that is already resident in HBM.  Default workload = BASELINE.json configs[2] ("B"):
-10 000 pairs, 2 kb x 2 kb, stateMachine5, diagonalExpansion (band) 100, anchors every 50 bp.
-With --gpus N (launched by torch.distributed.run, one rank per GPU) every rank runs its own 10 000 pairs
-(weak scaling, no data-path collective); value = cells of all ranks / max-over-ranks time.
+A "step" is one pass of the hot path (one run of the batch's sweep kernels) over one batch of synthetic sequence
+pairs that is already resident in HBM.  Default workload = BASELINE.json configs[2] ("B"): 10 000 pairs,
+2 kb x 2 kb, stateMachine5, diagonalExpansion (band) 100, anchors every 50 bp.  --config A | 4 | 5 | plumbing select
+the other BASELINE configs (4: cPecanRealign mode, 50 000 mixed-length pairs, expansion 4, split at 10, ragged ends;
+5: the EM expectation step on 100 000 pairs, its count all-reduce inside the step when N > 1).
+
+--gpus N: one process per GPU.  Started by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE in the environment)
+the process is one rank; started plainly with N > 1 it launches the N ranks itself -- as child processes, before
+anything touches the GPU -- and exits with their code.  --scaling strong (default for N > 1): the config's pairs are
+dealt out to the ranks longest-first by band cells, no data-path collective; --scaling weak: every rank
+runs the whole config's number of pairs.  value = cells of all ranks / max-over-ranks time.
+
+Besides the kernel-only `value` the line carries `value_e2e` (SURVEY 8d's wall clock: problems in host memory ->
+result lists in host memory; steady state of a pipeline two batches deep, every stage of every batch inside the clock)
+and `e2e` with the unpipelined stages and the pipeline's fill and drain.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -21,51 +33,108 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+KERNEL_SOURCES = ["cpecan_kernels.hip", "cpk_device_common.inl", "cpk_sweep.inl", "cpk_team.inl", "cpk_packed.inl",
+                  "cpk_table_gather.inl", "cpk_post.inl", "cpecan_band.inl", "cpecan_internal.h"]
 
 
-def measured_traffic(config, n_pairs):
-    """HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/*_traffic.json: FETCH_SIZE and
-    WRITE_SIZE collected in separate runs of this very command, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    for gfx950).  Counters cannot be read from inside bench.py, so the figure is only quoted for the exact workload it
-    was measured on (config B, 10 000 pairs); otherwise null."""
+def kernel_source_hash():
+    """Identifies the device code a profile was taken on: sha256 over the HIP translation unit's files."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "cpecan_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def committed_profile(kind, config, n_pairs):
+    """A figure that cannot be measured from inside bench.py (PMC counters need rocprofv3 around the process): read from
+    the newest profiles/r*_<kind>.json whose recorded kernel-source hash, config and pair count are THIS build's and this
+    run's; otherwise None (a stale number is worse than none)."""
     import glob
-    if config != "B" or n_pairs != 10000:
-        return None
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")),
-                   key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])  # r01_v9 < r01_v10
-    if not files:
-        return None
-    try:
-        return json.load(open(files[-1]))["hbm_bytes_per_launch"]
-    except Exception:
-        return None
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s.json" % kind)),
+                   key=lambda f: [int(t) for t in re.findall(r"\d+", os.path.basename(f))])
+    src = kernel_source_hash()
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:  # noqa: BLE001
+            continue
+        if d.get("kernel_source_hash") == src and d.get("config") == config and d.get("pairs") == n_pairs:
+            return d
+    return None
 
 
-def build_batch(api, workload, cfg, n_pairs, first, device):
+def self_launch(args):
+    """python bench.py --gpus N without a launcher: start the N ranks as children (nothing here has touched the GPU)."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def model_and_params(api, cfg):
     mtype = api.fiveState if cfg["model"] == "fiveState" else api.threeState
     sm = api.stateMachine5_construct(mtype) if mtype == api.fiveState else api.stateMachine3_construct(mtype)
     p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=cfg["expansion"],
-                                                         splitMatrixBiggerThanThis=10 ** 15)
-    problems = workload.make_batch(cfg["seed"], n_pairs, cfg["length"], cfg["expansion"], first=first)
-    b = api.Batch(sm, p, device=device)
-    for sx, sy, a in problems:
-        b.add(sx, sy, a if cfg["anchors"] else ())
-    t0 = time.time()
-    b.upload()
-    return b, problems, p, mtype, time.time() - t0
+                                                         splitMatrixBiggerThanThis=cfg.get("split", 10 ** 15))
+    return sm, p, mtype
 
 
-def cpu_baseline(cfg, problems, threads):
-    """The CPU oracle (a port of the reference algorithm, see oracle/) on a bounded sample, host cores only."""
+def cpu_baseline(cfg, problems, threads, reps=3):
+    """The CPU oracle (a port of the reference algorithm, see oracle/) on a bounded sample of the same workload; median
+    of `reps` repetitions."""
     import oracle_binding as ob
     mtype = ob.FIVE_STATE if cfg["model"] == "fiveState" else ob.THREE_STATE
-    op = ob.params(diagonalExpansion=cfg["expansion"], splitMatrixBiggerThanThis=10 ** 15)
-    sample = problems if cfg["anchors"] else [(sx, sy, ()) for sx, sy, _ in problems]
-    t0 = time.time()
-    _, cells = ob.batch_aligned_pairs(ob.model(mtype), sample, op, threads=threads)
-    dt = time.time() - t0
-    return cells / dt, cells, dt
+    op = ob.params(diagonalExpansion=cfg["expansion"], splitMatrixBiggerThanThis=cfg.get("split", 10 ** 15))
+    rates, cells, dts = [], 0, []
+    rg = bool(cfg.get("ragged"))
+    for _ in range(reps):
+        t0 = time.time()
+        if cfg.get("emit") == "expect":
+            acc = ob.hmm(mtype, 0.0)
+            cells = ob.batch_expectations(ob.model(mtype), problems, op, acc, rg, rg, threads=threads)
+        else:
+            _, cells = ob.batch_aligned_pairs(ob.model(mtype), problems, op, rg, rg, threads=threads)
+        dts.append(time.time() - t0)
+        rates.append(cells / dts[-1])
+    rates.sort()
+    return rates[len(rates) // 2], cells, sorted(dts)[len(dts) // 2]
+
+
+def usable_cores():
+    """Cores this process may actually use: the affinity mask, cut to the cgroup's CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) or os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
@@ -73,36 +142,94 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="B", choices=["A", "B", "plumbing"])
-    ap.add_argument("--pairs", type=int, default=0, help="override the number of pairs per GPU (debug)")
+    ap.add_argument("--config", default="B", choices=["A", "B", "4", "5", "plumbing"])
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="default: strong when --gpus > 1 (the config's batch dealt out over the ranks)")
+    ap.add_argument("--pairs", type=int, default=0, help="override the config's number of pairs (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host to host) measurements")
+    ap.add_argument("--e2e-batches", type=int, default=6, help="batches pushed through the two-deep pipeline")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend: nccl is RCCL; gloo only for the CPU dry run of the launcher (tests)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU work: partition the batch, run the rendezvous and the reductions, print the line "
+                         "(value null) -- checks the N > 1 launch path where there is no GPU")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(self_launch(args))
+
+    import numpy as np
     import torch
     from cpecan_amd import api, workload
+    from cpecan_amd import dist as cdist
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    if not torch.cuda.is_available() or api.device_count() < 1:
-        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    dry = args.dry_run
+    if not dry:
+        if not torch.cuda.is_available() or api.device_count() < 1:
+            raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+        torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl" and not dry:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
+    red_dev = torch.device("cuda", local_rank) if (not dry and (world == 1 or args.backend == "nccl")) else torch.device("cpu")
+
+    cfg = dict(workload.CONFIGS[args.config])
+    n_total = args.pairs or cfg["n_pairs"]
+    # ---- which pairs this rank aligns: independent objects, no exchange on the data path ----
+    if scaling == "strong":
+        mine = cdist.lpt_assign(workload.pair_costs(args.config, n_total), world)[rank]  # the SAME batch over N ranks
+    else:
+        mine = np.arange(rank * n_total, (rank + 1) * n_total)                            # every rank its own batch
+    expect = cfg.get("emit") == "expect"
+
+    if dry:
+        cells, kernel_ms, elapsed = int(workload.pair_costs(args.config, n_total)[mine % n_total].sum()), None, 1.0
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c = torch.tensor([cells, len(mine)], dtype=torch.int64)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+            total_cells, total_pairs = int(c[0]), int(c[1])
+        else:
+            total_cells, total_pairs = cells, len(mine)
+        if rank == 0:
+            print(json.dumps({"metric": "band DP cells/s (banded fwd+bwd+posterior)", "value": None, "unit": "cells/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "scaling": scaling,
+                              "dry_run": True, "config": {"workload": "config %s" % args.config, "pairs_total": total_pairs,
+                                                          "estimated_cells_total": total_cells,
+                                                          "world_size": world, "backend": "gloo"}}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
 
     torch.zeros(1, device="cuda")  # create the HIP context now: a once-per-process cost, not part of any upload
     torch.cuda.synchronize()
-    cfg = dict(workload.CONFIGS[args.config])
-    n_pairs = args.pairs or cfg["n_pairs"]
-    # weak scaling: rank r aligns pairs [r*n, (r+1)*n) of the same seeded stream -- independent objects, no exchange
-    batch, problems, params, mtype, upload_s = build_batch(api, workload, cfg, n_pairs, rank * n_pairs, local_rank)
+    sm, params, mtype = model_and_params(api, cfg)
+    emit = api.EMIT_EXPECT if expect else api.EMIT_MATCH
+    problems = workload.config_problems(args.config, mine)
+    prepared, n_prepared, _keep = api.Batch.prepare_problems(problems)  # the C-ABI array a C caller would hold
+
+    def make_batch():
+        b = api.Batch(sm, params, emit=emit, device=local_rank)
+        b.add_prepared(prepared, n_prepared)
+        b.upload()
+        return b
+
+    t0 = time.perf_counter()
+    batch = make_batch()
+    upload_s = time.perf_counter() - t0
     st = batch.stats()
     cells = st.cells
     stream = torch.cuda.current_stream()
@@ -113,38 +240,124 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def step():
         batch.run(stream.cuda_stream)
+        if expect:
+            # the E-step ends with the counts on the host and, across ranks, summed: cPecanEm.py:184-188
+            batch.download()
+            acc = api.hmm_constructEmpty(0.0, mtype)
+            batch.expectations(acc)
+            if world > 1:
+                cdist.allreduce_hmm(acc, red_dev)
+
+    for _ in range(args.warmup):
+        step()
     barrier()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    kernel_ms_sum = 0.0
     t0 = time.perf_counter()
     ev0.record(stream)
     for _ in range(args.steps):
-        batch.run(stream.cuda_stream)
+        step()
+        if expect:
+            kernel_ms_sum += batch.stats().kernelMs
     ev1.record(stream)
     barrier()
     elapsed = time.perf_counter() - t0
-    kernel_ms = ev0.elapsed_time(ev1) / max(1, args.steps)  # HIP events on the launch stream: avg launch duration
+    # average launch duration of the sweep kernels from HIP events on the launch stream (the expectation step's host part
+    # sits between its launches: there the library's own start/stop events around each run are summed instead)
+    kernel_ms = (kernel_ms_sum if expect else ev0.elapsed_time(ev1)) / max(1, args.steps)
 
-    total_cells = cells
+    total_cells, total_pairs = cells, len(mine)
+    per_rank_cells = [cells]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        c = torch.tensor([cells], dtype=torch.int64, device="cuda")
+        c = torch.zeros(world, dtype=torch.int64, device=red_dev)
+        c[rank] = cells
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
-        total_cells = int(c.item())
+        per_rank_cells = [int(v) for v in c.tolist()]
+        total_cells = sum(per_rank_cells)
+        n = torch.tensor([len(mine)], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM)
+        total_pairs = int(n.item())
 
-    # results back on the host once (not part of the timed region): PCIe + list assembly, and a parity spot check
+    # ---- results back on the host once: PCIe + list assembly (not in `value`), and a parity spot check below ----
     t1 = time.perf_counter()
     batch.download()
     d2h_s = time.perf_counter() - t1
     st = batch.stats()
 
+    # ---- SURVEY 8d's wall clock: problems resident in host memory -> result lists materialised in host memory ----
+    e2e = {"plan_upload_s": upload_s, "download_and_assemble_s": d2h_s, "pairs_emitted": int(st.pairs),
+           "device_bytes": int(st.deviceBytes), "waves": int(st.wavesPerLaunch)}
+    value_e2e = None
+    if not args.no_e2e:
+        barrier()
+        # (a) one batch after the other: create + pack + plan + upload + run + gather + download, nothing overlapped
+        t0 = time.perf_counter()
+        b = make_batch()
+        b.run(stream.cuda_stream)
+        b.download()
+        e2e["serial_s_per_batch"] = time.perf_counter() - t0
+        b.close()
+        # (b) two batches in flight from ONE host thread: while the sweep of batch k runs, batch k+1 is packed, planned and
+        # uploaded and batch k-1 is gathered and downloaded (every batch works on streams and events of its own)
+        nb = max(3, args.e2e_batches)
+        barrier()
+        t0 = time.perf_counter()
+        prev = make_batch()
+        prev.run(stream.cuda_stream)
+        pairs_out, t_first = 0, None
+        for _ in range(1, nb):
+            cur = make_batch()
+            cur.run(stream.cuda_stream)
+            prev.download()
+            if t_first is None:
+                t_first = time.perf_counter()  # the first batch's lists are on the host: the pipeline is full from here
+            pairs_out += int(prev.stats().pairs)
+            prev.close()
+            prev = cur
+        prev.download()
+        t_last = time.perf_counter()
+        pairs_out += int(prev.stats().pairs)
+        prev.close()
+        pipe_s, steady_s = t_last - t0, (t_last - t_first) / (nb - 1)
+        if world > 1:
+            t = torch.tensor([pipe_s, steady_s], dtype=torch.float64, device=red_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            pipe_s, steady_s = float(t[0]), float(t[1])
+        e2e["pipelined_batches"] = nb
+        e2e["pipelined_total_s_per_batch"] = pipe_s / nb    # fill and drain of the pipeline included
+        e2e["pipelined_steady_s_per_batch"] = steady_s      # lists of batch k on the host -> lists of batch k+1 on the host
+        value_e2e = total_cells / steady_s
+
     if rank == 0:
         S = 5 if cfg["model"] == "fiveState" else 3
         bytes_per_cell = 16 * S + 8  # F written once + read once (2*S*8 B) + one posterior word
         achieved = cells * bytes_per_cell / (kernel_ms * 1e-3) / 1e9
+        traffic = committed_profile("traffic", args.config, len(mine))
+        compute = committed_profile("compute", args.config, len(mine))
+        kname = "cpecan_pairhmm_%s<%d, ...>" % ("packed" if cfg.get("realign") else "sweep", S)
+        roofline = {
+            # the contract's figures: ALGORITHMIC bytes per launch / average launch duration, against the HBM peak
+            "bound": "hbm", "kernel": kname, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic["hbm_bytes_per_launch"] if traffic else None,
+            "algorithmic_bytes_per_cell": bytes_per_cell, "kernel_ms": kernel_ms,
+            # what the counters say moves: far fewer bytes than the algorithmic figure, so HBM is NOT what limits it
+            "measured_hbm_gbs": (traffic["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9) if traffic else None,
+            "limiter": "per-wave dependency chains at 2 waves/SIMD, then the LDS array and fp64 VALU issue "
+                       "(DESIGN.md section 5); HBM traffic is ~1/3 of the algorithmic bytes",
+        }
+        if compute:
+            # vector-instruction ceiling: VALU instructions per 64-cell group (PMC) x issue cycles measured per class
+            # (profiles/r02_valu_rate.txt) -> cells/s with every SIMD issuing back to back
+            roofline["compute"] = {"ceiling_cells_per_s": compute["ceiling_cells_per_s"],
+                                   "frac": (cells / (kernel_ms * 1e-3)) / compute["ceiling_cells_per_s"],
+                                   "valu_cycles_per_64_cells": compute["valu_cycles_per_64_cells"],
+                                   "source": compute.get("source")}
         out = {
             "metric": "band DP cells/s (banded fwd+bwd+posterior)",
             "value": total_cells * args.steps / elapsed,
@@ -154,52 +367,56 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "config %s: %d pairs/GPU, %d x ~%d bp, %s, diagonalExpansion=%d, anchors every 50 bp, "
-                            "threshold=0.01, traceback 1000/40" % (args.config, n_pairs, cfg["length"], cfg["length"],
-                                                                   cfg["model"], cfg["expansion"]),
-                "pairs_per_gpu": n_pairs,
-                "cells_per_gpu": cells,
-                "parallelism": "pairs sharded over %d GPU(s), no collective" % world,
+                "workload": "config %s: %d pairs%s, %s, %s, diagonalExpansion=%d, %s, threshold=0.01, traceback 1000/40%s"
+                            % (args.config, n_total, " per GPU" if scaling == "weak" and world > 1 else " in all",
+                               ("%d-%d bp" % (cfg["min_len"], cfg["max_len"])) if cfg.get("realign")
+                               else "%d x ~%d bp" % (cfg["length"], cfg["length"]),
+                               cfg["model"], cfg["expansion"],
+                               "anchors on every matching column, split at gaps of %d, ragged ends" % cfg["split"]
+                               if cfg.get("realign") else ("anchors every 50 bp" if cfg["anchors"] else "no anchors"),
+                               ", expectation emitter%s" % (" + all-reduce of %d counts" % (S * S + S * 16 + 1) if world > 1 else "")
+                               if expect else ""),
+                "pairs_total": total_pairs,
+                "cells_total": total_cells,
+                "cells_per_rank": per_rank_cells,
+                "world_size": world,
+                "parallelism": "pairs dealt longest-first over %d GPU(s), no data-path collective" % world
+                               if scaling == "strong" else "every GPU its own batch, no data-path collective",
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "cpecan_pairhmm_sweep<%d, true, 0>" % S,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(args.config, n_pairs),
-                "bytes_per_cell": bytes_per_cell,
-                "kernel_ms": kernel_ms,
-            },
-            "e2e": {"upload_s": upload_s, "download_and_assemble_s": d2h_s, "pairs_emitted": int(st.pairs),
-                    "device_bytes": int(st.deviceBytes), "waves": int(st.wavesPerLaunch)},
+            "roofline": roofline,
+            "value_e2e": value_e2e,
+            "e2e": e2e,
         }
         if not args.no_cpu_baseline and world == 1:
-            # (rank 0, N=1 only) the GPU box gives one GPU a 16-core share of its host CPUs; do not oversubscribe it
-            threads = int(os.environ.get("CPECAN_BENCH_CPU_THREADS", min(os.cpu_count() or 1, 16)))
-            sample = problems[:min(len(problems), 64 * threads)]
+            # (rank 0, N=1 only) every core the box gives this process: its affinity mask cut to its cgroup CPU quota (a
+            # one-GPU box hands out a 16-core share of one socket; BASELINE.md section 3 asks for a whole socket's cores)
+            threads = int(os.environ.get("CPECAN_BENCH_CPU_THREADS", usable_cores()))
+            per_thread = 64 if not cfg.get("realign") else 256
+            sample = problems[:min(len(problems), per_thread * threads)]
             v, ccells, dt = cpu_baseline(cfg, sample, threads)
             out["cpu_baseline"] = {
-                "value": v, "unit": "cells/s", "cores": threads, "kind": "port",
-                "sample": "first %d pairs of the same workload (%d cells), oracle C restatement, OpenMP over pairs, "
-                          "%.1f s" % (len(sample), ccells, dt),
+                "value": v, "unit": "cells/s", "cores": threads, "kind": "port", "cpu": cpu_model_name(),
+                "sample": "first %d pairs of the same workload (%d cells), the oracle's C restatement with OpenMP over pairs "
+                          "on %d threads (every core this process may use: affinity cut to the cgroup quota), median of 3 runs of %.1f s; the oracle does "
+                          "~6.8e6 cells/s/core where the survey measured 4.6e6 for the reference itself: it flatters the CPU"
+                          % (len(sample), ccells, threads, dt),
             }
             # parity spot check of the timed batch against the oracle (first 4 pairs)
             import oracle_binding as ob
             from parity import assert_pairs_match
             om = ob.model(ob.FIVE_STATE if cfg["model"] == "fiveState" else ob.THREE_STATE)
-            op = ob.params(diagonalExpansion=cfg["expansion"], splitMatrixBiggerThanThis=10 ** 15)
-            for i in range(min(4, len(problems))):
-                sx, sy, a = problems[i]
-                want = ob.aligned_pairs(om, sx, sy, a if cfg["anchors"] else (), op)
-                assert_pairs_match(batch.result(i), want, threshold=params.threshold)
-            out["parity_spot_check"] = "4 pairs match the oracle"
+            op = ob.params(diagonalExpansion=cfg["expansion"], splitMatrixBiggerThanThis=cfg.get("split", 10 ** 15))
+            if not expect:
+                for i in range(min(4, len(problems))):
+                    sx, sy, a, rl, rr = problems[i]
+                    want = ob.aligned_pairs(om, sx, sy, a, op, rl, rr)
+                    assert_pairs_match(batch.result(i), want, threshold=params.threshold)
+                out["parity_spot_check"] = "4 pairs match the oracle"
         print(json.dumps(out), flush=True)
     batch.close()
     if world > 1:

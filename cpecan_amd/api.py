@@ -309,9 +309,10 @@ class Batch:
         self.n += 1
         return idx
 
-    def add_many(self, problems):
-        """problems: iterable of (sX, sY, anchorPairs[, raggedLeft, raggedRight]); cut, converted and copied in parallel
-        by cpecan_batch_add_many.  Returns the index of the first."""
+    @staticmethod
+    def prepare_problems(problems):
+        """The C-ABI form of a list of problems -- (sX, sY, anchorPairs[, raggedLeft, raggedRight]) -- as one
+        cpecan_problem array: what a C caller holds anyway.  Returns (array, n, keepalive)."""
         problems = list(problems)
         arr = (Problem * max(1, len(problems)))()
         keep = []
@@ -323,9 +324,18 @@ class Batch:
             arr[i].anchors, arr[i].nAnchors = ptr, n
             arr[i].raggedLeft = int(pr[3]) if len(pr) > 3 else 0
             arr[i].raggedRight = int(pr[4]) if len(pr) > 4 else 0
-        first = _check(lib().cpecan_batch_add_many(self._h, arr, len(problems)), "cpecan_batch_add_many")
-        self.n += len(problems)
+        return arr, len(problems), keep
+
+    def add_prepared(self, arr, n):
+        first = _check(lib().cpecan_batch_add_many(self._h, arr, n), "cpecan_batch_add_many")
+        self.n += n
         return first
+
+    def add_many(self, problems):
+        """problems: iterable of (sX, sY, anchorPairs[, raggedLeft, raggedRight]); cut, converted and copied in parallel
+        by cpecan_batch_add_many.  Returns the index of the first."""
+        arr, n, _keep = self.prepare_problems(problems)
+        return self.add_prepared(arr, n)
 
     def upload(self):
         _check(lib().cpecan_batch_upload(self._h), "cpecan_batch_upload")

@@ -80,6 +80,7 @@ int cpecan_hmm_normalise(cpecan_hmm *h) { /* stateMachine.c:88-112 */
 }
 
 int cpecan_hmm_write(const cpecan_hmm *h, const char *path) { /* stateMachine.c:133-143 */
+    if (!h || !path) return CPECAN_EINVAL;
     FILE *f = fopen(path, "w");
     if (!f) return CPECAN_EINVAL;
     const int S = h->stateNumber;
@@ -93,6 +94,7 @@ int cpecan_hmm_write(const cpecan_hmm *h, const char *path) { /* stateMachine.c:
 }
 
 int cpecan_hmm_load(cpecan_hmm *h, const char *path) { /* stateMachine.c:145-202 */
+    if (!h || !path) return CPECAN_EINVAL;
     FILE *f = fopen(path, "r");
     if (!f) return CPECAN_EINVAL;
     int type = -1, rc = CPECAN_EINVAL;
@@ -1318,7 +1320,7 @@ int cpecan_batch_download(cpecan_batch *b) {
         b->outTriples = outAt;
         rc = cpk_device_update_regions(b->dev, b->devRegions, b->outTriples);
         if (rc != CPECAN_OK) break;
-        rc = cpk_device_run(b->dev, NULL);
+        rc = cpk_device_rerun(b->dev); /* same stream as the run that overflowed */
         if (rc != CPECAN_OK) break;
         b->stats.launches++;
         if (attempt == 2) {
@@ -1467,7 +1469,7 @@ static int post_single_run(PostSingle *ps, int flags, double gapGamma, double ma
         ps->job.shift = malloc(sizeof(int32_t) * 3 * (size_t)(ps->job.shiftCap ? ps->job.shiftCap : 1));
         if (!ps->job.shift) return CPECAN_ENOMEM;
     }
-    return cpk_post_lists(0, ps->buf, ps->total, &ps->job);
+    return cpk_post_lists(cpk_current_device(), ps->buf, ps->total, &ps->job); /* the caller's current device */
 }
 
 static int take_list(const int32_t *src, int64_t n, int32_t **out, int64_t *nOut) {
@@ -1562,7 +1564,7 @@ int cpecan_get_shifted_mea_alignment(const cpecan_model *m, const char *sX, cons
                                      int raggedRight, int32_t **out, int64_t *nOut, double *alignmentScore) {
     if (!m || !sX || !sY || !p || !out || !nOut) return CPECAN_EINVAL;
     cpecan_batch *b = NULL;
-    int rc = cpecan_batch_create(&b, m, p, CPECAN_EMIT_INDEL, 0);
+    int rc = cpecan_batch_create(&b, m, p, CPECAN_EMIT_INDEL, cpk_current_device());
     if (rc != CPECAN_OK) return rc;
     rc = cpecan_batch_set_post(b, CPECAN_POST_MEA | CPECAN_POST_LEFT_SHIFT, (double)gapGamma);
     if (rc == CPECAN_OK) {
@@ -1586,7 +1588,7 @@ static int run_single(cpecan_batch **out, const cpecan_model *m, const char *sX,
                       int64_t nAnchors, const cpecan_params *p, int raggedLeft, int raggedRight, int emit) {
     if (!m || !sX || !sY || !p) return CPECAN_EINVAL;
     cpecan_batch *b = NULL;
-    int rc = cpecan_batch_create(&b, m, p, emit, 0);
+    int rc = cpecan_batch_create(&b, m, p, emit, cpk_current_device()); /* single-problem calls: the caller's current device */
     if (rc != CPECAN_OK) return rc;
     int64_t idx = cpecan_batch_add(b, sX, (int64_t)strlen(sX), sY, (int64_t)strlen(sY), anchors, nAnchors, raggedLeft,
                                    raggedRight);

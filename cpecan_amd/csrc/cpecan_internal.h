@@ -120,6 +120,7 @@ typedef struct CpkDevice CpkDevice;
 
 /* ---- implemented in cpecan_kernels.hip ---- */
 int cpk_device_count(void);
+int cpk_current_device(void); /* the calling thread's current HIP device (0 when there is none) */
 const char *cpk_last_error(void);
 int cpk_device_create(CpkDevice **out, int device);
 void cpk_device_destroy(CpkDevice *dev);
@@ -131,6 +132,8 @@ int cpk_device_upload(CpkDevice *dev, const CpkGeometry *geo, const CpkModel *mo
                       int64_t outTriplesPerList, int nLists, int64_t dbgCells, int64_t dbgDiags, double *h2dMs);
 int cpk_device_update_regions(CpkDevice *dev, const CpkRegion *regions, int64_t outTriplesPerList);
 int cpk_device_run(CpkDevice *dev, void *stream);
+/* Once more on the stream of the last run (after an output overflow); kernel times of a batch's launches add up. */
+int cpk_device_rerun(CpkDevice *dev);
 /* Blocks until the run is complete and copies back the per-region counts and per-segment start offsets (and the
  * expectation sums / forward probabilities). The triples stay on the device: see cpk_device_gather. */
 int cpk_device_download(CpkDevice *dev, int32_t *counts /* [nLists][nRegions] */,

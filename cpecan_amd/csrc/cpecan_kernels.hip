@@ -98,9 +98,12 @@ struct LaunchClass {
 
 // ------------------------------------------------------------------------------------------------
 // Device memory and device shells are recycled: a batch of one small problem (the single-call entry points, a caller's
-// loop over alignments) would otherwise spend ~40 ms in hipMalloc / hipFree / stream creation around a 1 ms kernel.
-// Freed blocks up to a bounded total wait in a per-device list and serve later requests of about their size; what
-// the list will not hold goes back to the driver.  Blocks are only recycled after the device has gone idle.
+// loop over alignments) would otherwise spend ~40 ms in hipMalloc / hipFree / stream creation around a 1 ms kernel, and
+// a pipeline of large batches cannot afford hipFree at all: it waits for the whole device, i.e. for the other batch's
+// sweep kernel.  Freed blocks up to a bounded total (CPECAN_CACHE_MB, default 128 GiB of the 288 GB a MI355X has; two
+// config-B batches in flight hold 36 GB) wait in a per-device list and serve later requests of about their size; what
+// the list will not hold goes back to the driver, and all of it does when an allocation fails.  A block is recycled
+// only after its batch's own streams and events have completed.
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct CachedBlock {
@@ -112,8 +115,15 @@ struct BlockCache {
     size_t bytes = 0;
 };
 constexpr int kMaxDevices = 64;
-constexpr size_t kCacheMaxBytes = (size_t)2 << 30, kCacheMaxBlock = (size_t)512 << 20;
+constexpr size_t kCacheMaxBlock = (size_t)64 << 30;
 constexpr int kCacheMaxBlocks = 512;
+size_t cache_max_bytes() {
+    static const size_t v = [] {
+        const char *mb = getenv("CPECAN_CACHE_MB");
+        return mb ? (size_t)(atof(mb) * 1048576.0) : ((size_t)128 << 30);
+    }();
+    return v;
+}
 std::mutex g_cacheMutex;
 BlockCache g_blockCache[kMaxDevices];
 
@@ -157,13 +167,19 @@ hipError_t cache_alloc(int device, void **out, size_t bytes) {
 }
 
 // the device must be idle with respect to this block (callers synchronise first)
+size_t cache_bytes(int device) {
+    if (device < 0 || device >= kMaxDevices) return 0;
+    std::lock_guard<std::mutex> lock(g_cacheMutex);
+    return g_blockCache[device].bytes;
+}
+
 void cache_free(int device, void *ptr, size_t bytes) {
     if (!ptr) return;
     bytes = round_alloc(bytes ? bytes : 1);
     if (device >= 0 && device < kMaxDevices && bytes <= kCacheMaxBlock) {
         std::lock_guard<std::mutex> lock(g_cacheMutex);
         BlockCache &c = g_blockCache[device];
-        if (c.bytes + bytes <= kCacheMaxBytes && (int)c.blocks.size() < kCacheMaxBlocks) {
+        if (c.bytes + bytes <= cache_max_bytes() && (int)c.blocks.size() < kCacheMaxBlocks) {
             c.blocks.push_back({ptr, bytes});
             c.bytes += bytes;
             return;
@@ -172,6 +188,25 @@ void cache_free(int device, void *ptr, size_t bytes) {
     (void)hipFree(ptr);
 }
 }  // namespace
+
+// Every entry point works on its batch's device and leaves the calling thread's current device as it found it: in a
+// one-process-per-GPU job (torch.distributed, RCCL) the caller's allocations and collectives follow hipGetDevice().
+namespace {
+struct DeviceGuard {
+    int prev = -1, dev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) : dev(device) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) err = hipSetDevice(dev);
+    }
+    ~DeviceGuard() {
+        if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+    }
+};
+}  // namespace
+#define CPK_ON_DEVICE(dev)        \
+    DeviceGuard guard_(dev);      \
+    HIP_TRY(guard_.err)
 
 struct CpkDevice;
 static std::vector<CpkDevice *> g_shells[kMaxDevices];  // idle device shells (guarded by g_cacheMutex)
@@ -202,7 +237,14 @@ struct CpkDevice {
     std::vector<CachedBlock> allocs;  // every device block this batch holds, with its size (for the block cache)
     size_t compactBytes = 0, chunkBytes = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
+    hipEvent_t evA = nullptr, evB = nullptr;  // copy timing (owned by the shell: nothing to leak on an error path)
     hipStream_t lastStream = nullptr;
+    // Copies, memsets and the small kernels around the sweep (table build, list gather, consumers) run on this
+    // non-blocking stream of the batch's own, never on the null stream, and the batch waits on ITS events and streams,
+    // never on the device: batch k+1 is planned and uploaded and batch k-1 is gathered and downloaded while the sweep
+    // kernel of batch k runs (a pipeline of batches from one host thread, or batches on several host threads).
+    hipStream_t io = nullptr;
+    double kernelMsAccum = 0.0;  // launches before the last one (an overflow re-run)
     // every class but the first runs beside it on a stream of its own (fork / join around cpk_device_run)
     hipStream_t sideStream[kMaxClasses] = {};
     hipEvent_t sideDone[kMaxClasses] = {};
@@ -215,13 +257,49 @@ extern "C" int cpk_device_count(void) {
     return n;
 }
 
+extern "C" int cpk_current_device(void) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    return dev;
+}
+
+static void shell_delete(CpkDevice *d) {  // the shell's device is current
+    if (d->evStart) (void)hipEventDestroy(d->evStart);
+    if (d->evStop) (void)hipEventDestroy(d->evStop);
+    if (d->evA) (void)hipEventDestroy(d->evA);
+    if (d->evB) (void)hipEventDestroy(d->evB);
+    if (d->io) (void)hipStreamDestroy(d->io);
+    for (int k = 0; k < kMaxClasses; k++) {
+        if (d->sideStream[k]) (void)hipStreamDestroy(d->sideStream[k]);
+        if (d->sideDone[k]) (void)hipEventDestroy(d->sideDone[k]);
+    }
+    delete d;
+}
+
+static int shell_init(CpkDevice *d, int device) {
+    d->device = device;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    d->numCUs = prop.multiProcessorCount;
+    HIP_TRY(hipEventCreate(&d->evStart));
+    HIP_TRY(hipEventCreate(&d->evStop));
+    HIP_TRY(hipEventCreate(&d->evA));
+    HIP_TRY(hipEventCreate(&d->evB));
+    HIP_TRY(hipStreamCreateWithFlags(&d->io, hipStreamNonBlocking));
+    for (int k = 0; k < kMaxClasses; k++) {
+        HIP_TRY(hipStreamCreateWithFlags(&d->sideStream[k], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&d->sideDone[k], hipEventDisableTiming));
+    }
+    return CPECAN_OK;
+}
+
 extern "C" int cpk_device_create(CpkDevice **out, int device) {
     int n = cpk_device_count();
     if (n <= 0 || device < 0 || device >= n) {
         cpk_set_error("no usable HIP device (count=%d, requested=%d): the HIP path has no CPU fallback", n, device);
         return CPECAN_ENODEVICE;
     }
-    HIP_TRY(hipSetDevice(device));
+    CPK_ON_DEVICE(device);
     if (device < kMaxDevices) {  // an idle shell of an earlier batch: its streams and events are ready
         std::lock_guard<std::mutex> lock(g_cacheMutex);
         if (!g_shells[device].empty()) {
@@ -231,22 +309,24 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
         }
     }
     CpkDevice *d = new CpkDevice();
-    d->device = device;
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    d->numCUs = prop.multiProcessorCount;
-    HIP_TRY(hipEventCreate(&d->evStart));
-    HIP_TRY(hipEventCreate(&d->evStop));
-    for (int k = 0; k < kMaxClasses; k++) {
-        HIP_TRY(hipStreamCreateWithFlags(&d->sideStream[k], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&d->sideDone[k], hipEventDisableTiming));
+    if (int rc = shell_init(d, device)) {
+        shell_delete(d);  // whatever was created before the failure
+        return rc;
     }
     *out = d;
     return CPECAN_OK;
 }
 
+// Waits for everything this batch has in flight: its sweep launches (the stop event on the caller's stream) and its own
+// stream.  Nothing else ever touches the batch's blocks, so they may be recycled afterwards -- without draining the
+// device, which may be busy with another batch.
+static void batch_quiesce(CpkDevice *d) {
+    if (d->ran) (void)hipEventSynchronize(d->evStop);
+    if (d->io) (void)hipStreamSynchronize(d->io);
+}
+
 static void free_all(CpkDevice *d) {
-    if (!d->allocs.empty() || d->dCompact || d->dChunks) (void)hipDeviceSynchronize();  // nothing in flight uses them
+    if (!d->allocs.empty() || d->dCompact || d->dChunks) batch_quiesce(d);  // nothing in flight uses them
     for (const CachedBlock &b : d->allocs) cache_free(d->device, b.ptr, b.bytes);
     d->allocs.clear();
     cache_free(d->device, d->dCompact, d->compactBytes);
@@ -266,7 +346,7 @@ static void free_all(CpkDevice *d) {
 
 extern "C" void cpk_device_destroy(CpkDevice *d) {
     if (!d) return;
-    (void)hipSetDevice(d->device);
+    DeviceGuard guard(d->device);
     free_all(d);
     if (d->device < kMaxDevices) {  // keep the shell (streams, events) for the next batch on this device
         d->classes.clear();
@@ -278,13 +358,7 @@ extern "C" void cpk_device_destroy(CpkDevice *d) {
             return;
         }
     }
-    if (d->evStart) (void)hipEventDestroy(d->evStart);
-    if (d->evStop) (void)hipEventDestroy(d->evStop);
-    for (int k = 0; k < kMaxClasses; k++) {
-        if (d->sideStream[k]) (void)hipStreamDestroy(d->sideStream[k]);
-        if (d->sideDone[k]) (void)hipEventDestroy(d->sideDone[k]);
-    }
-    delete d;
+    shell_delete(d);
 }
 
 template <typename T>
@@ -342,8 +416,9 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                                  const CpkSegment *segs, int64_t nSegs, const uint8_t *symbols, int64_t nSymbolBytes,
                                  int64_t outTriplesPerList, int nLists, int64_t dbgCells, int64_t dbgDiags,
                                  double *h2dMs) {
-    HIP_TRY(hipSetDevice(d->device));
+    CPK_ON_DEVICE(d->device);
     free_all(d);
+    d->kernelMsAccum = 0.0;
     d->geo = *geo;
     d->kc = KConsts{model->matchContinue, model->matchFromShortX, model->matchFromShortY, model->matchFromLongX,
                     model->matchFromLongY, model->shortOpenX, model->shortOpenY, model->shortExtendX,
@@ -522,7 +597,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                        2.0 * 12.0 * nLists * outTriplesPerList /* the triples and their compact copy */;
         size_t freeB = 0, totalB = 0;
         HIP_TRY(hipMemGetInfo(&freeB, &totalB));
-        double budget = 0.9 * (double)freeB;
+        double budget = 0.9 * ((double)freeB + (double)cache_bytes(d->device));  // idle cached blocks are ours to reuse or drop
         if (const char *mb = getenv("CPECAN_MEM_BUDGET_MB")) budget = 1048576.0 * atof(mb);  // test / diagnostic knob
         double need = fixed, floorNeed = fixed;
         for (const LaunchClass &c : d->classes) {
@@ -593,65 +668,73 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (int rc = dev_alloc(d, &d->dSegStarts, (size_t)nLists * nSegs)) return rc;
     if (int rc = dev_alloc(d, &d->dTriples, (size_t)nLists * outTriplesPerList * 3)) return rc;
     if (int rc = dev_alloc(d, &d->dQueue, (size_t)kMaxClasses)) return rc;
-    HIP_TRY(hipMemset(d->dCounts, 0, sizeof(int32_t) * (size_t)nLists * geo->nRegions));
-    HIP_TRY(hipMemset(d->dSegStarts, 0, sizeof(int32_t) * (size_t)nLists * (nSegs ? nSegs : 1)));
+    hipStream_t io = d->io;
+    HIP_TRY(hipMemsetAsync(d->dCounts, 0, sizeof(int32_t) * (size_t)nLists * geo->nRegions, io));
+    HIP_TRY(hipMemsetAsync(d->dSegStarts, 0, sizeof(int32_t) * (size_t)nLists * (nSegs ? nSegs : 1), io));
     if (geo->debug) {
         if (int rc = dev_alloc(d, &d->dDbgFb, (size_t)dbgCells)) return rc;
         if (int rc = dev_alloc(d, &d->dDbgTotals, (size_t)dbgDiags)) return rc;
-        HIP_TRY(hipMemset(d->dDbgFb, 0xff, sizeof(double) * (size_t)dbgCells));      // NaN pattern
-        HIP_TRY(hipMemset(d->dDbgTotals, 0xff, sizeof(double) * (size_t)dbgDiags));
+        HIP_TRY(hipMemsetAsync(d->dDbgFb, 0xff, sizeof(double) * (size_t)dbgCells, io));      // NaN pattern
+        HIP_TRY(hipMemsetAsync(d->dDbgTotals, 0xff, sizeof(double) * (size_t)dbgDiags, io));
     }
 
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, nullptr));
-    HIP_TRY(hipMemcpy(d->dRegions, regions, sizeof(CpkRegion) * (size_t)geo->nRegions, hipMemcpyHostToDevice));
+    // Everything below is ordered on the batch's own stream and the call returns when that stream is done (the host
+    // buffers are the caller's); a failure in between leaves nothing behind: the anchor block is one of the batch's.
+    HIP_TRY(hipEventRecord(d->evA, io));
+    HIP_TRY(hipMemcpyAsync(d->dRegions, regions, sizeof(CpkRegion) * (size_t)geo->nRegions, hipMemcpyHostToDevice, io));
     {
         // anchors -> per-diagonal table, on the device (the anchors are only needed for this)
         int64_t *dAnchors = nullptr;
-        const size_t anchorBytes = sizeof(int64_t) * 3 * (size_t)(nAnchors > 0 ? nAnchors : 1);
-        HIP_TRY(cache_alloc(d->device, (void **)&dAnchors, anchorBytes));
+        if (int rc = dev_alloc(d, &dAnchors, 3 * (size_t)(nAnchors > 0 ? nAnchors : 1))) return rc;
         if (nAnchors > 0)
-            HIP_TRY(hipMemcpy(dAnchors, anchors, sizeof(int64_t) * 3 * (size_t)nAnchors, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(cpecan_build_diag_table, dim3((unsigned)((geo->nRegions + 63) / 64)), dim3(64), 0, nullptr,
+            HIP_TRY(hipMemcpyAsync(dAnchors, anchors, sizeof(int64_t) * 3 * (size_t)nAnchors, hipMemcpyHostToDevice, io));
+        hipLaunchKernelGGL(cpecan_build_diag_table, dim3((unsigned)((geo->nRegions + 63) / 64)), dim3(64), 0, io,
                            d->dRegions, geo->nRegions, dAnchors, d->dDiags, expansion, dynamic);
-        const hipError_t launched = hipGetLastError();
-        const hipError_t done = hipDeviceSynchronize();
-        cache_free(d->device, dAnchors, anchorBytes);  // after the synchronise above
-        HIP_TRY(launched);
-        HIP_TRY(done);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(d->dSegs, segs, sizeof(CpkSegment) * (size_t)nSegs, hipMemcpyHostToDevice, io));
+        HIP_TRY(hipMemcpyAsync(d->dSymbols, symbols, (size_t)nSymbolBytes, hipMemcpyHostToDevice, io));
+        HIP_TRY(hipMemcpyAsync(d->dModel, model, sizeof(CpkModel), hipMemcpyHostToDevice, io));
+        HIP_TRY(hipEventRecord(d->evB, io));
+        HIP_TRY(hipStreamSynchronize(io));
+        dev_release(d, dAnchors);
     }
-    HIP_TRY(hipMemcpy(d->dSegs, segs, sizeof(CpkSegment) * (size_t)nSegs, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d->dSymbols, symbols, (size_t)nSymbolBytes, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d->dModel, model, sizeof(CpkModel), hipMemcpyHostToDevice));
-    HIP_TRY(hipEventRecord(e1, nullptr));
-    HIP_TRY(hipEventSynchronize(e1));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    HIP_TRY(hipEventElapsedTime(&ms, d->evA, d->evB));
     if (h2dMs) *h2dMs = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return CPECAN_OK;
 }
 
 extern "C" int cpk_device_update_regions(CpkDevice *d, const CpkRegion *regions, int64_t outTriplesPerList) {
-    HIP_TRY(hipSetDevice(d->device));
+    CPK_ON_DEVICE(d->device);
+    batch_quiesce(d);  // the run that overflowed has finished with the triples and the regions
     if (outTriplesPerList != d->outTriplesPerList) {
         if (d->dTriples) {
-            HIP_TRY(hipDeviceSynchronize());  // the run that overflowed has finished with it
             dev_release(d, d->dTriples);
             d->dTriples = nullptr;
         }
         d->outTriplesPerList = outTriplesPerList;
         if (int rc = dev_alloc(d, &d->dTriples, (size_t)d->nLists * outTriplesPerList * 3)) return rc;
     }
-    HIP_TRY(hipMemcpy(d->dRegions, regions, sizeof(CpkRegion) * (size_t)d->geo.nRegions, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpyAsync(d->dRegions, regions, sizeof(CpkRegion) * (size_t)d->geo.nRegions, hipMemcpyHostToDevice, d->io));
+    HIP_TRY(hipStreamSynchronize(d->io));
     return CPECAN_OK;
 }
 
+// Runs the batch once more on the stream of its last run (after an output overflow); the time of the launches so far
+// is kept so that the batch's kernel time covers all of them.
+extern "C" int cpk_device_rerun(CpkDevice *d) {
+    CPK_ON_DEVICE(d->device);
+    if (d->ran) {
+        HIP_TRY(hipEventSynchronize(d->evStop));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, d->evStart, d->evStop));
+        d->kernelMsAccum += ms;
+    }
+    return cpk_device_run(d, (void *)d->lastStream);
+}
+
 extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
-    HIP_TRY(hipSetDevice(d->device));
+    CPK_ON_DEVICE(d->device);
     hipStream_t st = (hipStream_t)stream;
     KArgs a{};
     a.kc = d->kc;
@@ -721,34 +804,34 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
 
 extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segStarts, double *expect, double *kernelMs,
                                    double *d2hMs) {
-    HIP_TRY(hipSetDevice(d->device));
+    CPK_ON_DEVICE(d->device);
     if (!d->ran) {
         cpk_set_error("download before run");
         return CPECAN_ESTATE;
     }
-    HIP_TRY(hipStreamSynchronize(d->lastStream));
+    // the batch's own stop event, not the caller's stream: that stream may already hold the next batch's launches
+    HIP_TRY(hipEventSynchronize(d->evStop));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, d->evStart, d->evStop));
-    if (kernelMs) *kernelMs = ms;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, nullptr));
-    HIP_TRY(hipMemcpy(counts, d->dCounts, sizeof(int32_t) * (size_t)d->nLists * d->geo.nRegions, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(segStarts, d->dSegStarts, sizeof(int32_t) * (size_t)d->nLists * d->nSegs, hipMemcpyDeviceToHost));
-    HIP_TRY(hipEventRecord(e1, nullptr));
-    HIP_TRY(hipEventSynchronize(e1));
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    if (kernelMs) *kernelMs = d->kernelMsAccum + ms;  // every launch of the batch (an overflow re-run included)
+    hipStream_t io = d->io;
+    HIP_TRY(hipEventRecord(d->evA, io));
+    HIP_TRY(hipMemcpyAsync(counts, d->dCounts, sizeof(int32_t) * (size_t)d->nLists * d->geo.nRegions, hipMemcpyDeviceToHost, io));
+    HIP_TRY(hipMemcpyAsync(segStarts, d->dSegStarts, sizeof(int32_t) * (size_t)d->nLists * d->nSegs, hipMemcpyDeviceToHost, io));
+    HIP_TRY(hipEventRecord(d->evB, io));
+    HIP_TRY(hipStreamSynchronize(io));
+    HIP_TRY(hipEventElapsedTime(&ms, d->evA, d->evB));
     if (d2hMs) *d2hMs = ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    if (expect && d->geo.emit == kEmitForward)
-        HIP_TRY(hipMemcpy(expect, d->dForward, sizeof(double) * (size_t)d->geo.nRegions, hipMemcpyDeviceToHost));
+    if (expect && d->geo.emit == kEmitForward) {
+        HIP_TRY(hipMemcpyAsync(expect, d->dForward, sizeof(double) * (size_t)d->geo.nRegions, hipMemcpyDeviceToHost, io));
+        HIP_TRY(hipStreamSynchronize(io));
+    }
     if (expect && d->geo.emit == CPECAN_EMIT_EXPECT) {
         // sum the per-wave partials (every launched wave wrote its 106 values, zeros included)
         const int nWaves = d->totalWaves;
         std::vector<double> part((size_t)nWaves * 128);
-        HIP_TRY(hipMemcpy(part.data(), d->dExpect, sizeof(double) * part.size(), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(part.data(), d->dExpect, sizeof(double) * part.size(), hipMemcpyDeviceToHost, io));
+        HIP_TRY(hipStreamSynchronize(io));
         for (int i = 0; i < 106; i++) expect[i] = 0.0;
         for (int w = 0; w < nWaves; w++)
             for (int i = 0; i < 106; i++) expect[i] += part[(size_t)w * 128 + i];
@@ -757,9 +840,9 @@ extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segSt
 }
 
 extern "C" int cpk_device_gather(CpkDevice *d, const CpkChunk *chunks, int64_t nChunks, int64_t total) {
-    HIP_TRY(hipSetDevice(d->device));
+    CPK_ON_DEVICE(d->device);
     if (nChunks <= 0 || total <= 0) return CPECAN_OK;
-    if (nChunks > d->chunkCap || total > d->compactCap) HIP_TRY(hipDeviceSynchronize());  // before blocks are recycled
+    if (nChunks > d->chunkCap || total > d->compactCap) batch_quiesce(d);  // before blocks are recycled
     if (nChunks > d->chunkCap) {
         cache_free(d->device, d->dChunks, d->chunkBytes);
         d->dChunks = nullptr;
@@ -774,41 +857,47 @@ extern "C" int cpk_device_gather(CpkDevice *d, const CpkChunk *chunks, int64_t n
         HIP_TRY(cache_alloc(d->device, (void **)&d->dCompact, d->compactBytes));
         d->compactCap = total;
     }
-    HIP_TRY(hipMemcpy(d->dChunks, chunks, sizeof(CpkChunk) * (size_t)nChunks, hipMemcpyHostToDevice));
+    // the caller (cpecan_batch_download) has waited for the sweep; the chunk array is the caller's until the copy is done
+    HIP_TRY(hipMemcpyAsync(d->dChunks, chunks, sizeof(CpkChunk) * (size_t)nChunks, hipMemcpyHostToDevice, d->io));
     const int64_t blocks = nChunks < 16384 ? nChunks : 16384;
-    hipLaunchKernelGGL(cpecan_gather_lists, dim3((unsigned)blocks), dim3(256), 0, nullptr, d->dChunks, nChunks, d->dTriples,
+    hipLaunchKernelGGL(cpecan_gather_lists, dim3((unsigned)blocks), dim3(256), 0, d->io, d->dChunks, nChunks, d->dTriples,
                        d->dCompact);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(d->io));
     return CPECAN_OK;
 }
 
 extern "C" int cpk_device_fetch(CpkDevice *d, int32_t *hostOut, int64_t total, double *d2hMs) {
-    HIP_TRY(hipSetDevice(d->device));
+    CPK_ON_DEVICE(d->device);
     if (total <= 0) return CPECAN_OK;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    HIP_TRY(hipEventRecord(e0, nullptr));
-    HIP_TRY(hipMemcpy(hostOut, d->dCompact, sizeof(int32_t) * 3 * (size_t)total, hipMemcpyDeviceToHost));
-    HIP_TRY(hipEventRecord(e1, nullptr));
-    HIP_TRY(hipEventSynchronize(e1));
+    HIP_TRY(hipEventRecord(d->evA, d->io));
+    HIP_TRY(hipMemcpyAsync(hostOut, d->dCompact, sizeof(int32_t) * 3 * (size_t)total, hipMemcpyDeviceToHost, d->io));
+    HIP_TRY(hipEventRecord(d->evB, d->io));
+    HIP_TRY(hipStreamSynchronize(d->io));
     float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+    HIP_TRY(hipEventElapsedTime(&ms, d->evA, d->evB));
     if (d2hMs) *d2hMs += ms;
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     return CPECAN_OK;
 }
 
 // The consumers on a device-resident triple buffer.  Scratch lives for the duration of the call.
 namespace {
-struct PostScratch {  // device blocks of one consumer stage, on the current device
+struct PostScratch {  // device blocks of one consumer stage, on the current device, used on ONE stream
     std::vector<CachedBlock> blocks;
     int device = 0;
-    PostScratch() { (void)hipGetDevice(&device); }
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    explicit PostScratch(hipStream_t st) : stream(st) {
+        (void)hipGetDevice(&device);
+        if (!stream) {  // lists given by the host (no batch): a stream of the call's own, never the null stream
+            ownStream = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess;
+            if (!ownStream) stream = nullptr;
+        }
+    }
     ~PostScratch() {
-        if (!blocks.empty()) (void)hipDeviceSynchronize();  // the stage's kernels are done with them
+        if (!blocks.empty()) (void)hipStreamSynchronize(stream);  // the stage's kernels are done with them
         for (const CachedBlock &b : blocks) cache_free(device, b.ptr, b.bytes);
+        if (ownStream) (void)hipStreamDestroy(stream);
     }
     template <typename T>
     int alloc(T **out, size_t count) {
@@ -825,24 +914,24 @@ struct PostScratch {  // device blocks of one consumer stage, on the current dev
 };
 }  // namespace
 
-static int post_core(int32_t *dTriples, const CpkPostJob *job) {
+static int post_core(PostScratch &sc, int32_t *dTriples, const CpkPostJob *job) {
     const int64_t nP = job->nProblems;
     if (nP <= 0) return CPECAN_OK;
-    PostScratch sc;
+    hipStream_t st = sc.stream;
     CpkPostProblem *dProblems = nullptr;
     double *dScores = nullptr;
     int32_t *dCounts = nullptr;
     if (int rc = sc.alloc(&dProblems, (size_t)nP)) return rc;
     if (int rc = sc.alloc(&dScores, (size_t)nP * kPostScores)) return rc;
     if (int rc = sc.alloc(&dCounts, (size_t)nP * 2)) return rc;
-    HIP_TRY(hipMemcpy(dProblems, job->problems, sizeof(CpkPostProblem) * (size_t)nP, hipMemcpyHostToDevice));
-    HIP_TRY(hipMemset(dScores, 0, sizeof(double) * (size_t)nP * kPostScores));
-    HIP_TRY(hipMemset(dCounts, 0, sizeof(int32_t) * (size_t)nP * 2));
+    HIP_TRY(hipMemcpyAsync(dProblems, job->problems, sizeof(CpkPostProblem) * (size_t)nP, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(dScores, 0, sizeof(double) * (size_t)nP * kPostScores, st));
+    HIP_TRY(hipMemsetAsync(dCounts, 0, sizeof(int32_t) * (size_t)nP * 2, st));
     {
         int32_t *dMass = nullptr;
         const bool rw = (job->flags & kPostReweight) != 0;
         if (int rc = sc.alloc(&dMass, rw ? (size_t)job->seqSlots : 1)) return rc;
-        hipLaunchKernelGGL(cpecan_post_reweight, dim3((unsigned)nP), dim3(256), 0, nullptr, dProblems, dTriples, dMass,
+        hipLaunchKernelGGL(cpecan_post_reweight, dim3((unsigned)nP), dim3(256), 0, st, dProblems, dTriples, dMass,
                            job->gapGamma, rw ? 1 : 0, dScores);
         HIP_TRY(hipGetLastError());
     }
@@ -853,7 +942,7 @@ static int post_core(int32_t *dTriples, const CpkPostJob *job) {
         if (int rc = sc.alloc(&dMea, (size_t)job->meaCap * 3)) return rc;
     if (job->chars) {
         if (int rc = sc.alloc(&dChars, (size_t)(job->nChars > 0 ? job->nChars : 1))) return rc;
-        if (job->nChars > 0) HIP_TRY(hipMemcpy(dChars, job->chars, (size_t)job->nChars, hipMemcpyHostToDevice));
+        if (job->nChars > 0) HIP_TRY(hipMemcpyAsync(dChars, job->chars, (size_t)job->nChars, hipMemcpyHostToDevice, st));
     }
     if (job->flags & kPostOrdered) {
         int32_t *dSeq = nullptr, *dPrev = nullptr, *dNext = nullptr;
@@ -864,13 +953,13 @@ static int post_core(int32_t *dTriples, const CpkPostJob *job) {
         if (int rc = sc.alloc(&dPrev, (size_t)job->chainSlots)) return rc;
         if (int rc = sc.alloc(&dNext, (size_t)job->chainSlots)) return rc;
         if (int rc = sc.alloc(&dChosen, (size_t)job->chainSlots)) return rc;
-        hipLaunchKernelGGL(cpecan_post_ordered, dim3(laneBlocks), dim3(64), 0, nullptr, dProblems, nP, dTriples, dSeq,
+        hipLaunchKernelGGL(cpecan_post_ordered, dim3(laneBlocks), dim3(64), 0, st, dProblems, nP, dTriples, dSeq,
                            dBest, dPrev, dNext, dChosen, job->matchGamma, dMea, dCounts);
         HIP_TRY(hipGetLastError());
     }
     if ((job->flags & kPostOrdered) || dChars) {
         const int fromOut = (job->flags & kPostOrdered) ? 1 : 0;
-        hipLaunchKernelGGL(cpecan_post_list_scores, dim3((unsigned)nP), dim3(256), 0, nullptr, dProblems, dTriples, dMea,
+        hipLaunchKernelGGL(cpecan_post_list_scores, dim3((unsigned)nP), dim3(256), 0, st, dProblems, dTriples, dMea,
                            dCounts, fromOut, fromOut, dChars, dScores);
         HIP_TRY(hipGetLastError());
     }
@@ -883,11 +972,11 @@ static int post_core(int32_t *dTriples, const CpkPostJob *job) {
         if (int rc = sc.alloc(&dBest, (size_t)job->chainSlots)) return rc;
         if (int rc = sc.alloc(&dPrev, (size_t)job->chainSlots)) return rc;
         if (int rc = sc.alloc(&dRecord, (size_t)job->chainSlots)) return rc;
-        hipLaunchKernelGGL(cpecan_post_mea, dim3(laneBlocks), dim3(64), 0, nullptr, dProblems, nP, dTriples, dCum, dBest,
+        hipLaunchKernelGGL(cpecan_post_mea, dim3(laneBlocks), dim3(64), 0, st, dProblems, nP, dTriples, dCum, dBest,
                            dPrev, dRecord, (float)job->gapGamma, dMea, dCounts, dScores);
         HIP_TRY(hipGetLastError());
     } else if (job->flags & kPostLeftShift) {
-        hipLaunchKernelGGL(cpecan_post_copy_chain, dim3((unsigned)nP), dim3(256), 0, nullptr, dProblems, dTriples, dMea,
+        hipLaunchKernelGGL(cpecan_post_copy_chain, dim3((unsigned)nP), dim3(256), 0, st, dProblems, dTriples, dMea,
                            dCounts);
         HIP_TRY(hipGetLastError());
     }
@@ -897,29 +986,31 @@ static int post_core(int32_t *dTriples, const CpkPostJob *job) {
             return CPECAN_EINVAL;
         }
         if (int rc = sc.alloc(&dShift, (size_t)job->shiftCap * 3)) return rc;
-        hipLaunchKernelGGL(cpecan_post_left_shift, dim3(laneBlocks), dim3(64), 0, nullptr, dProblems, nP, dMea, dChars,
+        hipLaunchKernelGGL(cpecan_post_left_shift, dim3(laneBlocks), dim3(64), 0, st, dProblems, nP, dMea, dChars,
                            dShift, dCounts);
         HIP_TRY(hipGetLastError());
     }
-    HIP_TRY(hipDeviceSynchronize());
     if (job->scores)
-        HIP_TRY(hipMemcpy(job->scores, dScores, sizeof(double) * (size_t)nP * kPostScores, hipMemcpyDeviceToHost));
-    if (job->counts) HIP_TRY(hipMemcpy(job->counts, dCounts, sizeof(int32_t) * (size_t)nP * 2, hipMemcpyDeviceToHost));
-    if (job->mea && dMea) HIP_TRY(hipMemcpy(job->mea, dMea, sizeof(int32_t) * 3 * (size_t)job->meaCap, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(job->scores, dScores, sizeof(double) * (size_t)nP * kPostScores, hipMemcpyDeviceToHost, st));
+    if (job->counts) HIP_TRY(hipMemcpyAsync(job->counts, dCounts, sizeof(int32_t) * (size_t)nP * 2, hipMemcpyDeviceToHost, st));
+    if (job->mea && dMea)
+        HIP_TRY(hipMemcpyAsync(job->mea, dMea, sizeof(int32_t) * 3 * (size_t)job->meaCap, hipMemcpyDeviceToHost, st));
     if (job->shift && dShift)
-        HIP_TRY(hipMemcpy(job->shift, dShift, sizeof(int32_t) * 3 * (size_t)job->shiftCap, hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpyAsync(job->shift, dShift, sizeof(int32_t) * 3 * (size_t)job->shiftCap, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
     return CPECAN_OK;
 }
 
 extern "C" int cpk_device_post(CpkDevice *d, const CpkPostJob *job) {
-    HIP_TRY(hipSetDevice(d->device));
+    CPK_ON_DEVICE(d->device);
     if (!d->dCompact && job->nProblems > 0) {
         // every list is empty: the consumers still need a valid base pointer
         d->compactBytes = sizeof(int32_t) * 3;
         HIP_TRY(cache_alloc(d->device, (void **)&d->dCompact, d->compactBytes));
         d->compactCap = 1;
     }
-    return post_core(d->dCompact, job);
+    PostScratch sc(d->io);
+    return post_core(sc, d->dCompact, job);
 }
 
 extern "C" int cpk_post_lists(int device, int32_t *triples, int64_t total, const CpkPostJob *job) {
@@ -928,18 +1019,27 @@ extern "C" int cpk_post_lists(int device, int32_t *triples, int64_t total, const
         cpk_set_error("no usable HIP device (count=%d, requested=%d): the HIP path has no CPU fallback", nDev, device);
         return CPECAN_ENODEVICE;
     }
-    HIP_TRY(hipSetDevice(device));
-    PostScratch sc;
+    CPK_ON_DEVICE(device);
+    PostScratch sc(nullptr);
+    if (!sc.stream) {
+        cpk_set_error("hipStreamCreate failed in the list consumers");
+        return CPECAN_EHIP;
+    }
     int32_t *dTriples = nullptr;
     if (int rc = sc.alloc(&dTriples, (size_t)(total > 0 ? total : 1) * 3)) return rc;
-    if (total > 0) HIP_TRY(hipMemcpy(dTriples, triples, sizeof(int32_t) * 3 * (size_t)total, hipMemcpyHostToDevice));
-    if (int rc = post_core(dTriples, job)) return rc;
-    if (total > 0) HIP_TRY(hipMemcpy(triples, dTriples, sizeof(int32_t) * 3 * (size_t)total, hipMemcpyDeviceToHost));
+    if (total > 0)
+        HIP_TRY(hipMemcpyAsync(dTriples, triples, sizeof(int32_t) * 3 * (size_t)total, hipMemcpyHostToDevice, sc.stream));
+    if (int rc = post_core(sc, dTriples, job)) return rc;
+    if (total > 0) {
+        HIP_TRY(hipMemcpyAsync(triples, dTriples, sizeof(int32_t) * 3 * (size_t)total, hipMemcpyDeviceToHost, sc.stream));
+        HIP_TRY(hipStreamSynchronize(sc.stream));
+    }
     return CPECAN_OK;
 }
 
 extern "C" int cpk_device_debug_fetch(CpkDevice *d, double *fb, int64_t cells, double *totals, int64_t diags) {
-    HIP_TRY(hipSetDevice(d->device));
+    CPK_ON_DEVICE(d->device);
+    batch_quiesce(d);
     if (!d->geo.debug || !d->dDbgFb) {
         cpk_set_error("debug buffers were not enabled before upload");
         return CPECAN_ESTATE;

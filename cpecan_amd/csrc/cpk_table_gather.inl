@@ -5,6 +5,8 @@
 // own iterator (cpecan_band.inl; the host has already validated the anchors with it) and writes
 // {x-y of the first cell, width, position in the region's forward ring, cells on earlier diagonals}.  The ring
 // position follows the rule the kernels rely on: diagonals are laid end to end and never straddle the ring's end.
+// (In a pipeline of batches this kernel of batch k+1 runs on that batch's own stream; its 56 allocated VGPRs do not fit
+// in the 48 a resident sweep of batch k leaves free per lane, so it starts when that sweep drains: ~3 ms per config-B batch.)
 __global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *regions, int nRegions, const int64_t *anchors,
                                                               CpkDiag *diags, int64_t expansion, int dynamic) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

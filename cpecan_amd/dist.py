@@ -34,22 +34,45 @@ def vector_to_hmm(vec, hmm):
     return hmm
 
 
+def local_device_index():
+    """The GPU this rank works on: torch's current device when a GPU is visible (launchers set it from LOCAL_RANK),
+    else LOCAL_RANK, else 0."""
+    import os
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.cuda.current_device()
+    except Exception:  # noqa: BLE001 -- no torch / no GPU: fall through
+        pass
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def reduce_device_for_backend():
+    """Where the count vector must live for the collective: RCCL ("nccl") reduces GPU tensors only; gloo takes CPU ones."""
+    import torch
+    import torch.distributed as dist
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", local_device_index())
+    return torch.device("cpu")
+
+
 def allreduce_hmm(hmm, device=None):
-    """In-place sum of expectation counts over all ranks (one collective of S*S + S*16 + 1 doubles)."""
+    """In-place sum of expectation counts over all ranks (one collective of S*S + S*16 + 1 doubles).  `device` defaults
+    to what the process group's backend needs (a GPU tensor under RCCL)."""
     import torch
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return hmm
-    t = torch.from_numpy(hmm_to_vector(hmm))
-    if device is not None:
-        t = t.to(device)
+    t = torch.from_numpy(hmm_to_vector(hmm)).to(device if device is not None else reduce_device_for_backend())
     dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return vector_to_hmm(t.cpu().numpy(), hmm)
 
 
-def expectation_step(sM, problems, p, pseudo=1e-12, device_index=0, reduce_device=None):
-    """One E-step over this rank's problems on its GPU, then the all-reduce; returns the summed (un-normalised) Hmm.
-    problems: iterable of (sX, sY, anchors, raggedLeft, raggedRight)."""
+def expectation_step(sM, problems, p, pseudo=1e-12, device_index=None, reduce_device=None):
+    """One E-step over this rank's problems on its GPU (default: this rank's own, see local_device_index), then the
+    all-reduce; returns the summed (un-normalised) Hmm.  problems: iterable of (sX, sY, anchors, raggedLeft, raggedRight)."""
+    if device_index is None:
+        device_index = local_device_index()
     acc = api.hmm_constructEmpty(0.0, sM.type)
     with api.Batch(sM, p, emit=api.EMIT_EXPECT, device=device_index) as b:
         n = 0
@@ -84,6 +107,22 @@ def cost_balanced_bounds(costs, rank, world_size):
     for k in range(1, world_size + 1):
         cuts[k] = max(cuts[k], cuts[k - 1])
     return cuts[rank], cuts[rank + 1]
+
+
+def lpt_assign(costs, world_size):
+    """Longest-processing-time-first assignment of items to ranks: items by decreasing cost, each to the
+    least loaded rank so far; ties by index, so every rank computes the same answer without talking to the others.
+    Returns one sorted index array per rank.  Equal costs give a round-robin deal."""
+    import heapq
+    c = np.asarray(costs, dtype=np.float64)
+    order = np.lexsort((np.arange(len(c)), -c))
+    heap = [(0.0, r) for r in range(world_size)]
+    out = [[] for _ in range(world_size)]
+    for i in order:
+        load, r = heapq.heappop(heap)
+        out[r].append(int(i))
+        heapq.heappush(heap, (load + float(c[i]), r))
+    return [np.array(sorted(v), dtype=np.int64) for v in out]
 
 
 def cigar_cost(c, expansion=4):

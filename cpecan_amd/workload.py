@@ -69,15 +69,43 @@ def make_batch(seed, n_pairs, length, expansion, first=0, **kw):
     return [make_pair(seed, first + i, length, expansion, **kw) for i in range(n_pairs)]
 
 
-def make_realign_batch(seed, n_pairs, min_len=100, max_len=5000, expansion=4, first=0):
+def realign_lengths(seed, indices, min_len=100, max_len=5000):
+    """Sequence length of pair i of a realign-mode batch: log-uniform in [min_len, max_len], a function of (seed, i)."""
+    u = _unit(splitmix64(seed ^ 0xC0FFEE, np.asarray(indices, dtype=np.uint64)))
+    return np.rint(np.exp(np.log(min_len) + u * (np.log(max_len) - np.log(min_len)))).astype(np.int64)
+
+
+def make_realign_batch(seed, n_pairs, min_len=100, max_len=5000, expansion=4, first=0, indices=None):
     """BASELINE config 4 (cPecanRealign mode): lengths log-uniform in [min_len, max_len]; anchors = every
     aligned column of the true alignment whose bases are equal (cPecanRealign.c:525-529 keeps exact matches only)."""
-    out = []
-    for i in range(n_pairs):
-        u = _unit(splitmix64(seed ^ 0xC0FFEE, [first + i]))[0]
-        length = int(round(np.exp(np.log(min_len) + u * (np.log(max_len) - np.log(min_len)))))
-        out.append(make_pair(seed, first + i, length, expansion, anchor_every=1))
-    return out
+    idx = np.arange(first, first + n_pairs) if indices is None else np.asarray(indices)
+    lengths = realign_lengths(seed, idx, min_len, max_len)
+    return [make_pair(seed, int(i), int(L), expansion, anchor_every=1) for i, L in zip(idx, lengths)]
+
+
+def config_problems(name, indices):
+    """The pairs `indices` of a BASELINE config as (sX, sY, anchors, raggedLeft, raggedRight) -- any rank can make any
+    subset (strong scaling deals pairs out by cost, see pair_costs)."""
+    cfg = CONFIGS[name]
+    idx = [int(i) for i in indices]
+    if cfg.get("realign"):
+        probs = make_realign_batch(cfg["seed"], 0, cfg["min_len"], cfg["max_len"], cfg["expansion"], indices=idx)
+    else:
+        probs = [make_pair(cfg["seed"], i, cfg["length"], cfg["expansion"]) for i in idx]
+    rg = bool(cfg.get("ragged"))
+    return [(sx, sy, (a if cfg["anchors"] else ()), rg, rg) for sx, sy, a in probs]
+
+
+def pair_costs(name, n_pairs):
+    """Band cells a pair costs, near enough to balance ranks: diagonals (2 L) times band width; a function of the
+    pair's length alone, so no sequence has to be generated to partition a batch."""
+    cfg = CONFIGS[name]
+    if cfg.get("realign"):
+        L = realign_lengths(cfg["seed"], np.arange(n_pairs), cfg["min_len"], cfg["max_len"])
+    else:
+        L = np.full(n_pairs, cfg["length"], dtype=np.int64)
+    width = (cfg["expansion"] + 1) if cfg["anchors"] else L
+    return 2.0 * L * width
 
 
 # The BASELINE.json configs this repo measures (SURVEY.md section 8d).
@@ -85,7 +113,9 @@ CONFIGS = {
     "plumbing": dict(seed=1, n_pairs=1, length=200, expansion=0, model="fiveState", anchors=False),
     "A": dict(seed=2, n_pairs=1000, length=1000, expansion=50, model="threeState", anchors=True),
     "B": dict(seed=3, n_pairs=10000, length=2000, expansion=100, model="fiveState", anchors=True),
-    # configs 4 and 5 of BASELINE.json are parity / multi-GPU cases, not bench lines (see tests/test_gpu_parity.py):
-    #  4: make_realign_batch(seed=4, 50000 pairs, 100-5000 bp, expansion 4), ragged ends, splitMatrixBiggerThanThis=10
-    #  5: make_batch(seed=5, 100000 pairs, 1000 bp, expansion 10), expectation emitter + all-reduce of the counts
+    # cPecanRealign mode (cPecanRealign.c:355-357, :525-537): expansion 4, split at gaps of 10, ragged ends (1, 1)
+    "4": dict(seed=4, n_pairs=50000, realign=True, min_len=100, max_len=5000, length=0, expansion=4, model="fiveState",
+              anchors=True, ragged=True, split=10),
+    # cPecanEm expectation step (pairwiseAligner.c:735-746; cPecanRealign.c:493,530-534): expectation emitter
+    "5": dict(seed=5, n_pairs=100000, length=1000, expansion=10, model="fiveState", anchors=True, emit="expect"),
 }

@@ -900,6 +900,43 @@ int64_t orc_batch_aligned_pairs(const OrcModel *m, const char *seqBlob, const in
     return totalPairs;
 }
 
+/* The expectation step over a batch (cPecanRealign.c:509-534 with --outputExpectations, one problem after the other;
+ * here: OpenMP over problems, every thread summing into an Hmm of its own, the thread sums added at the end -- linear-space
+ * sums, order-insensitive at the 1e-5 gate).  Returns the band cells processed. */
+int64_t orc_batch_expectations(const OrcModel *m, OrcHmm *acc, const char *seqBlob, const int64_t *seqOff,
+                               const int64_t *anchors, const int64_t *anchorOff, int64_t nPairs, const OrcParams *p,
+                               int raggedLeft, int raggedRight, int nThreads) {
+    int64_t totalCells = 0;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nThreads > 0 ? nThreads : 1) reduction(+ : totalCells)
+#endif
+    {
+        OrcHmm mine = *acc;
+        for (int i = 0; i < ORC_MAX_STATES * ORC_MAX_STATES; i++) mine.T[i] = 0.0;
+        for (int i = 0; i < ORC_MAX_STATES * 16; i++) mine.E[i] = 0.0;
+        mine.likelihood = 0.0;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic)
+#endif
+        for (int64_t i = 0; i < nPairs; i++) {
+            const char *sX = seqBlob + seqOff[2 * i], *sY = seqBlob + seqOff[2 * i + 1];
+            Triples out[3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+            totalCells += run_regions(m, sX, sY, anchors + 3 * anchorOff[i], anchorOff[i + 1] - anchorOff[i], p, raggedLeft,
+                                      raggedRight, 2, out, &mine, NULL);
+        }
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+        {
+            for (int i = 0; i < ORC_MAX_STATES * ORC_MAX_STATES; i++) acc->T[i] += mine.T[i];
+            for (int i = 0; i < ORC_MAX_STATES * 16; i++) acc->E[i] += mine.E[i];
+            acc->likelihood += mine.likelihood;
+        }
+    }
+    (void)nThreads;
+    return totalCells;
+}
+
 /* ------------------------------------------------------------------------------------------------
  * Consumers of the posterior lists
  * ---------------------------------------------------------------------------------------------- */

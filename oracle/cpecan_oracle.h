@@ -154,6 +154,12 @@ int64_t orc_batch_aligned_pairs(const OrcModel *m, const char *seqBlob, const in
                                 const OrcParams *p, int raggedLeft, int raggedRight, int nThreads,
                                 int64_t *cells);
 
+/* orc_expectations over a batch (same blob layout as orc_batch_aligned_pairs), OpenMP over problems; the counts are
+ * ADDED to *acc.  Returns the band cells processed. */
+int64_t orc_batch_expectations(const OrcModel *m, OrcHmm *acc, const char *seqBlob, const int64_t *seqOff,
+                               const int64_t *anchors, const int64_t *anchorOff, int64_t nPairs, const OrcParams *p,
+                               int raggedLeft, int raggedRight, int nThreads);
+
 /* ---- consumers of the posterior lists.  Triples are (score, x, y) int64. ----
  * Pinning: orc_left_shift_alignment is pinned by the reference's test vector (tests/pairwiseAlignerTest.c:944-995).
  * The reference has no test of reweightAlignedPairs2 or of the MEA chain: those two restatements are checked by

@@ -112,6 +112,9 @@ def lib():
         L.orc_batch_aligned_pairs.restype = C.c_int64
         L.orc_batch_aligned_pairs.argtypes = [C.POINTER(Model), C.c_char_p, i64p, i64p, i64p, C.c_int64,
                                               C.POINTER(Params), C.c_int, C.c_int, C.c_int, i64p]
+        L.orc_batch_expectations.restype = C.c_int64
+        L.orc_batch_expectations.argtypes = [C.POINTER(Model), C.POINTER(Hmm), C.c_char_p, i64p, i64p, i64p, C.c_int64,
+                                             C.POINTER(Params), C.c_int, C.c_int, C.c_int]
         L.orc_reweight_aligned_pairs.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int64, C.c_double]
         L.orc_score_by_posterior.restype = C.c_double
         L.orc_score_by_posterior.argtypes = [C.c_int64, C.c_int64, i64p, C.c_int64]
@@ -282,29 +285,40 @@ def band_cells(sx, sy, anchors=(), p=None, ragged_left=False, ragged_right=False
     return lib().orc_band_cells(_b(sx), _b(sy), ptr, n, C.byref(p), int(ragged_left), int(ragged_right))
 
 
-def batch_aligned_pairs(m, problems, p=None, ragged_left=False, ragged_right=False, threads=1):
-    """problems: list of (sx, sy, anchors[n,3]). Returns (pairs emitted, band cells)."""
-    p = p or params()
+def _pack_problems(problems):
+    """(sx, sy, anchors[, ...]) tuples as one NUL-separated sequence blob + offsets, and one anchor array + offsets."""
     blob = bytearray()
     seq_off = []
     anchor_rows = []
     anchor_off = [0]
-    for sx, sy, anchors in problems:
+    for pr in problems:
+        sx, sy, anchors = pr[0], pr[1], pr[2]
         seq_off.append(len(blob)); blob += _b(sx) + b"\0"
         seq_off.append(len(blob)); blob += _b(sy) + b"\0"
         a = np.asarray(anchors, dtype=np.int64).reshape(-1, 3)
         anchor_rows.append(a)
         anchor_off.append(anchor_off[-1] + len(a))
-    so, sop = _i64(seq_off)
     aa = np.concatenate(anchor_rows) if anchor_rows else np.zeros((0, 3), dtype=np.int64)
     if aa.size == 0:
         aa = np.zeros((1, 3), dtype=np.int64)
-    aa, aap = _i64(aa)
-    ao, aop = _i64(anchor_off)
+    return bytes(blob), _i64(seq_off), _i64(aa), _i64(anchor_off)
+
+
+def batch_aligned_pairs(m, problems, p=None, ragged_left=False, ragged_right=False, threads=1):
+    """problems: list of (sx, sy, anchors[n,3][, ...]). Returns (pairs emitted, band cells)."""
+    p = p or params()
+    blob, (so, sop), (aa, aap), (ao, aop) = _pack_problems(problems)
     cells = C.c_int64()
-    n = lib().orc_batch_aligned_pairs(C.byref(m), bytes(blob), sop, aap, aop, len(problems), C.byref(p),
+    n = lib().orc_batch_aligned_pairs(C.byref(m), blob, sop, aap, aop, len(problems), C.byref(p),
                                       int(ragged_left), int(ragged_right), int(threads), C.byref(cells))
     return n, cells.value
+
+
+def batch_expectations(m, problems, p, acc, ragged_left=False, ragged_right=False, threads=1):
+    """orc_expectations over a batch with OpenMP over problems; counts are added to acc. Returns the band cells."""
+    blob, (so, sop), (aa, aap), (ao, aop) = _pack_problems(problems)
+    return lib().orc_batch_expectations(C.byref(m), C.byref(acc), blob, sop, aap, aop, len(problems), C.byref(p),
+                                        int(ragged_left), int(ragged_right), int(threads))
 
 
 # ---- consumers of the posterior lists (SURVEY 8f ranks 3-4) ----

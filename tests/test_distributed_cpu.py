@@ -131,3 +131,56 @@ def test_two_rank_realign_sharding_keeps_input_order(tmp_path):
     cost = [10 * (i + 1) for i in range(23)]
     assert abs(sum(cost[:cut]) - sum(cost[cut:])) <= max(cost) * 2  # balanced by cost, not by count
     assert cut > 23 // 2
+
+
+def test_lpt_assign_deals_every_item_once_and_balances():
+    """longest-first bin packing of pairs by band cells.  Every rank computes the same deal on its own."""
+    from cpecan_amd import workload
+    costs = workload.pair_costs("4", 3000)  # mixed lengths, 100-5000 bp
+    for world in (1, 2, 3, 8):
+        parts = cdist.lpt_assign(costs, world)
+        allidx = np.concatenate(parts)
+        assert sorted(allidx.tolist()) == list(range(3000))
+        loads = np.array([costs[p].sum() for p in parts])
+        assert loads.max() - loads.min() <= costs.max()          # the LPT bound: within one item of each other
+        assert [p.tolist() for p in cdist.lpt_assign(costs, world)] == [p.tolist() for p in parts]  # deterministic
+    # equal costs: a round-robin deal
+    assert [p.tolist() for p in cdist.lpt_assign(np.ones(7), 3)] == [[0, 3, 6], [1, 4], [2, 5]]
+
+
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` with no launcher around it starts the two ranks itself (before anything touches a GPU),
+    deals the batch out (strong scaling is the default for N > 1), runs the rendezvous and the reductions.  Here on the
+    CPU with gloo and --dry-run (no GPU work); the N = 1 form of the same command is what the driver runs."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--dry-run", "--backend", "gloo",
+                          "--pairs", "301", "--config", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["config"]["world_size"] == 2
+    assert line["config"]["pairs_total"] == 301                   # every pair on exactly one rank
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--dry-run", "--pairs", "301",
+                          "--config", "4"], env=env, capture_output=True, text=True, timeout=300)
+    assert one.returncode == 0, one.stderr[-2000:]
+    line1 = json.loads([ln for ln in one.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line1["config"]["estimated_cells_total"] == line["config"]["estimated_cells_total"]  # the SAME batch
+
+
+def test_reduce_device_follows_the_backend():
+    """under RCCL the count vector must be a GPU tensor; under gloo a CPU one.  (The gloo half runs here.)"""
+    port = _free_port()
+
+    def _body():
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=0, world_size=1)
+        try:
+            assert cdist.reduce_device_for_backend() == torch.device("cpu")
+        finally:
+            dist.destroy_process_group()
+    _body()
+    assert cdist.local_device_index() == int(os.environ.get("LOCAL_RANK", "0"))  # no GPU here: LOCAL_RANK, else 0

@@ -804,3 +804,67 @@ def test_cell_values_and_totals_match_oracle(case):
     mt = ~np.isnan(otot)
     assert mt.any()
     assert np.all(np.abs(tot[mt] - otot[mt]) <= LOG_TOL * np.maximum(1.0, np.abs(otot[mt]))), float(np.max(np.abs(tot[mt] - otot[mt])))
+
+
+# ---- batches as a pipeline: every batch on streams and events of its own (SURVEY 8d's host-to-host clock) ----
+def test_pipelined_batches_equal_unpipelined_ones():
+    """Two batches in flight from one host thread -- batch k+1 is packed, planned and uploaded and batch k-1 is gathered and
+    downloaded while the sweep kernel of batch k runs -- give, list for list, what the same batches give one after the
+    other; and so do batches driven from two host threads at once.  (bench.py's `value_e2e` is measured this way.)"""
+    import threading
+    rng = random.Random(907)
+    pkw = dict(diagonalExpansion=20, splitMatrixBiggerThanThis=900)
+    jobs = [_fuzz_problems(rng, 60, 20) for _ in range(5)]
+    jobs.append(([make_pair(3, i, 2000, 100) for i in range(3)], [(False, False)] * 3))  # multi-segment regions too
+    serial = [_run_batch(0, probs, raggeds, **pkw)[0] for probs, raggeds in jobs]
+    p = api.pairwiseAlignmentBandingParameters_construct(**pkw)
+
+    def start(k):
+        probs, raggeds = jobs[k]
+        b = api.Batch(_sm(0), p)
+        b.add_many([(sx, sy, a, rl, rr) for (sx, sy, a), (rl, rr) in zip(probs, raggeds)])
+        b.upload()
+        b.run()
+        return b
+
+    def finish(k, b, into):
+        b.download()
+        into[k] = [b.result(i) for i in range(len(jobs[k][0]))]
+        b.close()
+
+    piped = [None] * len(jobs)
+    prev = start(0)
+    for k in range(1, len(jobs)):
+        cur = start(k)          # while batch k-1 is still running or waiting to be read
+        finish(k - 1, prev, piped)
+        prev = cur
+    finish(len(jobs) - 1, prev, piped)
+    threaded = [None] * len(jobs)
+
+    def worker(t):
+        for k in range(t, len(jobs), 2):
+            finish(k, start(k), threaded)
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for got in (piped, threaded):
+        for g, w in zip(got, serial):
+            assert g is not None and len(g) == len(w)
+            for a, b in zip(g, w):
+                assert np.array_equal(a, b)
+
+
+def test_entry_points_leave_the_callers_current_device_alone():
+    """a batch works on ITS device and restores the calling thread's current device (torch follows
+    hipGetDevice); single-problem calls run on the caller's current device.  One GPU here: the guard must at least
+    be a no-op that keeps device 0 current through every stage."""
+    import torch
+    assert torch.cuda.current_device() == 0
+    sx, sy, a = make_pair(1, 0, 300, 20)
+    p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=20)
+    got = api.getAlignedPairsUsingAnchors(api.stateMachine5_construct(), sx, sy, a, p)
+    assert len(got) > 0 and torch.cuda.current_device() == 0
+    x = torch.ones(4, device="cuda")  # still allocates on the device the caller chose
+    assert x.device.index == 0
