@@ -877,21 +877,25 @@ struct Sweep {
             double total = NEG_INF, straddle = NEG_INF;
             const int WcMax = wave_max_i32(Wc), WmMax = wave_max_i32(Wm);
             // loads are issued eight at a time, then folded in order; padding with -inf leaves the fold unchanged
-            // because logAdd(x, -inf) returns x exactly
-            for (int k = 0; k < WcMax; k += 8) {
-                double x[8];
+            // because logAdd(x, -inf) returns x exactly.  The two series are independent chains of sequential logAdds:
+            // they advance side by side (one lane cannot hide a logAdd's latency behind anything else here).
+            const int WMax = WcMax > WmMax ? WcMax : WmMax;
+            double ts[2] = {total, straddle};
+            for (int k = 0; k < WMax; k += 8) {
+                double x[8], y[8];
 #pragma unroll
-                for (int i = 0; i < 8; i++) x[i] = k + i < Wc ? ld_self(cbuf + (size_t)(k + i) * J + j) : NEG_INF;
+                for (int i = 0; i < 8; i++) {
+                    x[i] = k + i < Wc ? ld_self(cbuf + (size_t)(k + i) * J + j) : NEG_INF;
+                    y[i] = k + i < Wm ? ld_self(mbuf + (size_t)(k + i) * J + j) : NEG_INF;
+                }
 #pragma unroll
-                for (int i = 0; i < 8; i++) total = logadd(lg, total, x[i]);
+                for (int i = 0; i < 8; i++) {
+                    const double xy[2] = {x[i], y[i]};
+                    logadd_n<2>(lg, ts, xy);
+                }
             }
-            for (int k = 0; k < WmMax; k += 8) {
-                double x[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) x[i] = k + i < Wm ? ld_self(mbuf + (size_t)(k + i) * J + j) : NEG_INF;
-#pragma unroll
-                for (int i = 0; i < 8; i++) straddle = logadd(lg, straddle, x[i]);
-            }
+            total = ts[0];
+            straddle = ts[1];
             if (on) {
                 if (r + 1 <= sg.dTop) total = logadd(lg, total, straddle);
                 totals[j] = total;
