@@ -318,3 +318,35 @@ def test_filter_to_remove_overlap():
     assert api.filterToRemoveOverlap([]).shape == (0, 3)
     with pytest.raises(api.CpecanError):
         api.filterToRemoveOverlap([(5, 5, 0), (4, 9, 0)])  # not sorted (asserted in the reference, :1124)
+
+
+def test_hmm_loadFromFile_reads_the_reference_trained_hmm_text():
+    """The on-disk layout is the reference's (stateMachine.c:133-202), not merely what this build's writer emits: the
+    trained five-state-asymmetric HMM that cPecanEmTest.py:112-113 holds as text (space separated, 12 significant digits)
+    loads to exactly the numbers in the text, and hmm_getStateMachine follows stateMachine5_loadAsymmetric (:529-575)."""
+    import math
+    import reference_cases as rc
+    mtype, T, lik, E = rc.trained_hmm_numbers()
+    h = api.hmm_loadFromFile(rc.TRAINED_HMM)
+    assert h.type == api.fiveStateAsymmetric == mtype and h.stateNumber == 5
+    assert list(h.transitions) == T and list(h.emissions) == E and h.likelihood == lik
+    m = api.hmm_getStateMachine(h)
+    assert m.matchContinue == math.log(T[0])
+    assert m.gapShortOpenX == math.log(T[1]) and m.gapShortOpenY == math.log(T[2])
+    assert m.gapLongOpenX == math.log(T[3]) and m.gapLongOpenY == math.log(T[4])
+    assert m.matchFromShortGapX == math.log(T[5]) and m.gapShortExtendX == math.log(T[6])
+    assert m.matchFromShortGapY == math.log(T[10]) and m.gapShortExtendY == math.log(T[12])
+    assert m.matchFromLongGapX == math.log(T[15]) and m.gapLongExtendX == math.log(T[18])
+    assert m.matchFromLongGapY == math.log(T[20]) and m.gapLongExtendY == math.log(T[24])
+    for x in range(4):
+        for y in range(4):
+            assert m.emissionMatch[x * 4 + y] == math.log(E[x * 4 + y])
+    # the oracle builds the same model from the same numbers
+    oh = ob.hmm(ob.FIVE_STATE_ASYM, 0.0)
+    for i, v in enumerate(T):
+        oh.T[i] = v
+    for i, v in enumerate(E):
+        oh.E[i] = v
+    om = ob.model_from_hmm(oh)
+    for x in range(4):
+        assert abs(m.emissionGapX[x] - om.gapXEm[x]) < 1e-15 and abs(m.emissionGapY[x] - om.gapYEm[x]) < 1e-15

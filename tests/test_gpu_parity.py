@@ -868,3 +868,80 @@ def test_entry_points_leave_the_callers_current_device_alone():
     assert len(got) > 0 and torch.cuda.current_device() == 0
     x = torch.ones(4, device="cuda")  # still allocates on the device the caller chose
     assert x.device.index == 0
+
+
+# ---- the cases the reference's tests hold beyond geometry, through the HIP path ----
+def test_getAlignedPairsWithRaggedEnds_exact_outcome_gpu():
+    """tests/pairwiseAlignerTest.c:676-715 through getAlignedPairs + filterPairwiseAlignmentToMakePairsOrdered on the GPU:
+    exactly the 100 pairs (x, x + 100), 120 seeded trials in one batch (ragged priors + ordered filter, exact outcome),
+    and list for list what the oracle gives."""
+    import reference_cases as rc
+    p = api.pairwiseAlignmentBandingParameters_construct()
+    trials = [rc.ragged_ends_trial(t) for t in range(120)]
+    with api.Batch(api.stateMachine5_construct(), p) as b:
+        b.add_many([(sx, sy, (), True, True) for sx, sy in trials])
+        b.set_post(api.POST_ORDERED, matchGamma=0.2)
+        b.upload()
+        b.run()
+        b.download()
+        om, op = ob.model(ob.FIVE_STATE), ob.params()
+        for i, (sx, sy) in enumerate(trials):
+            out = b.result(i, 3)
+            assert len(out) == 100 and all(int(y) == int(x) + 100 for _, x, y in out), i
+            if i < 12:
+                want = ob.aligned_pairs(om, sx, sy, (), op, True, True)
+                assert_pairs_match(b.result(i), want, threshold=p.threshold)
+    # the single-call entry points give the same
+    sx, sy = trials[0]
+    pairs = api.getAlignedPairsUsingAnchors(api.stateMachine5_construct(), sx, sy, (), p, True, True)
+    out = api.filterPairwiseAlignmentToMakePairsOrdered(pairs, sx, sy, 0.2)
+    assert len(out) == 100 and all(int(y) == int(x) + 100 for _, x, y in out)
+
+
+def test_trained_hmm_of_the_reference_through_the_gpu():
+    """cPecanEmTest.py:112-113's trained five-state-asymmetric HMM: hmm_loadFromFile -> hmm_getStateMachine -> alignments
+    and expectations on the GPU against the oracle with the model built from the same numbers."""
+    import reference_cases as rc
+    mtype, T, lik, E = rc.trained_hmm_numbers()
+    sm = api.hmm_getStateMachine(api.hmm_loadFromFile(rc.TRAINED_HMM))
+    oh = ob.hmm(ob.FIVE_STATE_ASYM, 0.0)
+    for i, v in enumerate(T):
+        oh.T[i] = v
+    for i, v in enumerate(E):
+        oh.E[i] = v
+    om = ob.model_from_hmm(oh)
+    kw = dict(diagonalExpansion=20)
+    p, op = api.pairwiseAlignmentBandingParameters_construct(**kw), ob.params(**kw)
+    probs = [make_pair(31, i, 700, 20) for i in range(6)]
+    for sx, sy, a in probs:
+        got = api.getAlignedPairsUsingAnchors(sm, sx, sy, a, p, True, False)
+        assert len(got) > 0
+        assert_pairs_match(got, ob.aligned_pairs(om, sx, sy, a, op, True, False), threshold=p.threshold)
+    acc, oacc = api.hmm_constructEmpty(0.0, api.fiveStateAsymmetric), ob.hmm(ob.FIVE_STATE_ASYM, 0.0)
+    for sx, sy, a in probs[:3]:
+        api.getExpectationsUsingAnchors(sm, acc, sx, sy, a, p)
+        ob.expectations(om, oacc, sx, sy, a, op)
+    _assert_hmm_close(acc, oacc, 5)
+
+
+def test_encode_human_chimp_full_length_gpu():
+    """tests/pairwiseAlignerLongTest.c's ~57 kb human / chimp ENCODE pair at full length through the HIP path: 115 k
+    anti-diagonals, ~115 traceback segments in one region; every pair against the oracle, and sensitivity / specificity
+    against the embedded reference alignment as the reference's test logs them (:100-108; the 0.99 bars are ours)."""
+    import reference_cases as rc
+    sx, sy, anchors, true_pairs = rc.encode_human_chimp()
+    kw = dict(diagonalExpansion=20)
+    p = api.pairwiseAlignmentBandingParameters_construct(**kw)
+    got = api.getAlignedPairsUsingAnchors(api.stateMachine5_construct(), sx, sy, anchors, p)
+    want = ob.aligned_pairs(ob.model(ob.FIVE_STATE), sx, sy, anchors, ob.params(**kw))
+    assert len(want) > 56000
+    assert_pairs_match(got, want, threshold=p.threshold)
+    out = api.filterPairwiseAlignmentToMakePairsOrdered(got, sx, sy, 0.5)
+    sens, spec = rc.sensitivity_specificity(out, true_pairs)
+    print("ENCODE human/chimp through the HIP path: %d pairs, sensitivity %.5f, specificity %.5f" % (len(out), sens, spec))
+    assert sens > 0.99 and spec > 0.99
+    # split into regions at large anchor gaps (getSplitPoints): same lists
+    p2 = api.pairwiseAlignmentBandingParameters_construct(splitMatrixBiggerThanThis=100, **kw)
+    got2 = api.getAlignedPairsUsingAnchors(api.stateMachine5_construct(), sx, sy, anchors, p2)
+    want2 = ob.aligned_pairs(ob.model(ob.FIVE_STATE), sx, sy, anchors, ob.params(splitMatrixBiggerThanThis=100, **kw))
+    assert_pairs_match(got2, want2, threshold=p.threshold)

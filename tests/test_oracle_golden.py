@@ -404,3 +404,60 @@ def test_identity_scores_by_hand():
     assert ob.score_by_identity(sx, sy, pairs) == 100.0 * 2 * 3 / 10
     assert ob.score_by_identity_ignoring_gaps(sx, sy, pairs) == 100.0 * 3 / 5
     assert ob.score_by_identity("", "", []) == 0.0
+
+
+# ---- what the reference's tests hold beyond geometry ----
+import reference_cases as rc  # noqa: E402
+
+
+def test_getAlignedPairsWithRaggedEnds_exact_outcome_oracle():
+    """tests/pairwiseAlignerTest.c:676-715: a 100-base core inside 300 bases, ragged on both sides, ordered filter at 0.2
+    => exactly the 100 pairs (x, x + 100).  150 seeded trials; pins the ragged start / end priors of the five-state model
+    (stateMachine.c:407-447) and the jitter-free ordered filter with an exact outcome."""
+    om, op = ob.model(ob.FIVE_STATE), ob.params()
+    for trial in range(150):
+        sx, sy = rc.ragged_ends_trial(trial)
+        pairs = ob.aligned_pairs(om, sx, sy, (), op, True, True)
+        out = ob.filter_pairs_ordered(pairs, len(sx), len(sy), 0.2)
+        assert len(out) == 100, (trial, len(out))
+        assert all(int(y) == int(x) + 100 for _, x, y in out), trial
+        assert all(0 < int(s) <= 10000000 for s, _, _ in out)
+
+
+def test_trained_hmm_text_of_the_reference_loads_into_the_documented_model():
+    """cPecanEmTest.py:112-113 writes this trained five-state-asymmetric HMM as text and loads it back: the file layout is
+    `type, S*S transitions, likelihood` / `S*16 emissions` (stateMachine.c:133-202).  The model built from it follows
+    stateMachine5_loadAsymmetric (stateMachine.c:529-575) term for term; here: no long/short swap is triggered."""
+    mtype, T, lik, E = rc.trained_hmm_numbers()
+    assert mtype == ob.FIVE_STATE_ASYM and len(T) == 25 and len(E) == 80 and lik == -83964693614.2
+    h = ob.hmm(ob.FIVE_STATE_ASYM, 0.0)
+    for i, v in enumerate(T):
+        h.T[i] = v
+    for i, v in enumerate(E):
+        h.E[i] = v
+    m = ob.model_from_hmm(h)
+    tr = {(m.tr[i].frm, m.tr[i].to): m.tr[i].tP for i in range(m.nTransitions)}
+    M, SX, SY, LX, LY = 0, 1, 2, 3, 4
+    for (f, t) in [(M, M), (SX, M), (SY, M), (LX, M), (LY, M), (M, SX), (SX, SX), (M, LX), (LX, LX), (M, SY), (SY, SY), (M, LY), (LY, LY)]:
+        assert tr[(f, t)] == math.log(T[f * 5 + t]), (f, t)
+    for x in range(4):
+        for y in range(4):
+            assert m.matchEm[x * 5 + y] == math.log(E[x * 4 + y])
+    gx = [sum(E[s * 16 + x * 4 + y] for s in (SX, LX) for y in range(4)) for x in range(4)]
+    for x in range(4):
+        assert abs(m.gapXEm[x] - math.log(gx[x] / sum(gx))) < 1e-15
+
+
+def test_encode_human_chimp_full_length_oracle():
+    """tests/pairwiseAlignerLongTest.c: the ~57 kb human / chimp ENCODE fragments, the only real sequences in the
+    reference tree, aligned at full length (115 k anti-diagonals, ~115 traceback segments) and scored against the embedded
+    reference alignment the way the test logs it (:100-108).  The reference asserts nothing but uniqueness; the 0.99
+    bars below are this repo's."""
+    sx, sy, anchors, true_pairs = rc.encode_human_chimp()
+    assert len(sx) == 57553 and len(sy) == 57344 and len(true_pairs) == 56835
+    p = ob.params(diagonalExpansion=20)
+    pairs = ob.aligned_pairs(ob.model(ob.FIVE_STATE), sx, sy, anchors, p)
+    assert len({(int(x), int(y)) for _, x, y in pairs}) == len(pairs)          # the reference's own assertion (:75)
+    out = ob.filter_pairs_ordered(pairs, len(sx), len(sy), 0.5)
+    sens, spec = rc.sensitivity_specificity(out, true_pairs)
+    assert sens > 0.99 and spec > 0.99, (sens, spec)
