@@ -82,7 +82,7 @@ class Stats(C.Structure):
 # Every symbol include/cpecan_hip.h declares (checked by tests/test_abi.py).
 EXPORTS = [
     "cpecan_model_default", "cpecan_model_from_hmm", "cpecan_hmm_init", "cpecan_hmm_normalise", "cpecan_hmm_write",
-    "cpecan_hmm_load", "cpecan_params_default", "cpecan_band", "cpecan_split_points", "cpecan_device_count",
+    "cpecan_hmm_load", "cpecan_params_default", "cpecan_band", "cpecan_split_points", "cpecan_device_count", "cpecan_current_device",
     "cpecan_last_error", "cpecan_batch_create", "cpecan_batch_destroy", "cpecan_batch_add", "cpecan_batch_upload",
     "cpecan_batch_run", "cpecan_batch_download", "cpecan_batch_result", "cpecan_batch_expectations",
     "cpecan_batch_stats", "cpecan_batch_set_debug", "cpecan_batch_debug_fetch", "cpecan_batch_forward_prob",

@@ -411,7 +411,7 @@ void getExpectationsUsingAnchors(StateMachine *sM, Hmm *hmmExpectations, const c
     int64_t n;
     int64_t *anchors = flatten_anchors(anchorPairs, &n);
     cpecan_batch *b = NULL;
-    check(cpecan_batch_create(&b, flat_or_die(sM), &q, CPECAN_EMIT_EXPECT, 0), "cpecan_batch_create");
+    check(cpecan_batch_create(&b, flat_or_die(sM), &q, CPECAN_EMIT_EXPECT, cpecan_current_device()), "cpecan_batch_create");
     if (cpecan_batch_add(b, sX, (int64_t)strlen(sX), sY, (int64_t)strlen(sY), anchors, n, raggedLeft, raggedRight) < 0)
         die("cpecan_hip: invalid anchors");
     check(cpecan_batch_upload(b), "cpecan_batch_upload");
@@ -657,4 +657,257 @@ stList *getSplitPoints(stList *anchorPairs, int64_t lX, int64_t lY, int64_t maxM
     free(out);
     free(anchors);
     return l;
+}
+
+
+/* ---------------- the rest of the reference header's hot-path surface ---------------- */
+
+/* inc/pairwiseAligner.h:23, impl/pairwiseAligner.c:29 */
+const char *PAIRWISE_ALIGNMENT_EXCEPTION_ID = "PAIRWISE_ALIGNMENT_EXCEPTION";
+
+/* The reference raises sonLib exceptions (stThrowNew, setjmp-based) where a diagonal is malformed; sonLib is not
+ * vendored.  The raise goes through this WEAK hook: a program that links sonLib overrides it with one line
+ * (`void cpecan_dropin_throw(const char *id, const char *msg) { stThrowNew(id, "%s", msg); }`); the default does what
+ * an uncaught stExcept does -- prints and aborts. */
+__attribute__((weak)) void cpecan_dropin_throw(const char *exceptionId, const char *message) {
+    die("cpecan_hip: uncaught %s: %s", exceptionId, message);
+}
+
+/* diagonal_construct, impl/pairwiseAligner.c:30-42 (inc/pairwiseAligner.h:122) */
+Diagonal diagonal_construct(int64_t xay, int64_t xmyL, int64_t xmyR) {
+    if ((xay + xmyL) % 2 != 0 || (xay + xmyR) % 2 != 0 || xmyL > xmyR) {
+        char msg[192];
+        snprintf(msg, sizeof msg, "Attempt to create diagonal with invalid coordinates: xay %lld xmyL %lld xmyR %lld",
+                 (long long)xay, (long long)xmyL, (long long)xmyR);
+        cpecan_dropin_throw(PAIRWISE_ALIGNMENT_EXCEPTION_ID, msg);
+    }
+    Diagonal d = {xay, xmyL, xmyR};
+    return d;
+}
+
+/* logAdd, impl/pairwiseAligner.c:290-307 (inc/pairwiseAligner.h:167), operation for operation: this is the host-side
+ * function a caller links, not the device code (cpk_device_common.inl). */
+static inline double logadd_lookup(double x) {
+    if (x <= 1.00f) return ((-0.009350833524763f * x + 0.130659527668286f) * x + 0.498799810682272f) * x + 0.693203116424741f;
+    if (x <= 2.50f) return ((-0.014532321752540f * x + 0.139942324101744f) * x + 0.495635523139337f) * x + 0.692140569840976f;
+    if (x <= 4.50f) return ((-0.004605031767994f * x + 0.063427417320019f) * x + 0.695956496475118f) * x + 0.514272634594009f;
+    return ((-0.000458661602210f * x + 0.009695946122598f) * x + 0.930734667215156f) * x + 0.168037164329057f;
+}
+double logAdd(double x, double y) {
+    if (x < y) return (x == LOG_ZERO || y - x >= 7.5) ? y : logadd_lookup(y - x) + x;
+    return (y == LOG_ZERO || x - y >= 7.5) ? x : logadd_lookup(x - y) + y;
+}
+
+/* band_constructDynamic, impl/pairwiseAligner.c:128-181: every anchor tuple carries its own expansion (third element) */
+Band *band_constructDynamic(stList *anchorPairs, int64_t lX, int64_t lY) {
+    int64_t n;
+    int64_t *anchors = flatten_anchors(anchorPairs, &n);
+    int64_t *flat = malloc(sizeof(int64_t) * 3 * (size_t)(lX + lY + 1));
+    if (!flat) die("cpecan_hip: out of memory");
+    check(cpecan_band(anchors, n, lX, lY, 0, 1, flat), "band_constructDynamic");
+    Band *b = malloc(sizeof *b);
+    b->lXalY = lX + lY;
+    b->diagonals = malloc(sizeof(Diagonal) * (size_t)(lX + lY + 1));
+    for (int64_t d = 0; d <= lX + lY; d++) {
+        b->diagonals[d].xay = flat[3 * d];
+        b->diagonals[d].xmyL = flat[3 * d + 1];
+        b->diagonals[d].xmyR = flat[3 * d + 2];
+    }
+    free(flat);
+    free(anchors);
+    return b;
+}
+
+/* symbols: impl/pairwiseAligner.c:336-366 */
+Symbol *symbol_convertStringToSymbols(const char *s, int64_t sL) {
+    Symbol *cS = malloc(sizeof(Symbol) * (size_t)(sL > 0 ? sL : 1));
+    if (!cS) die("cpecan_hip: out of memory");
+    for (int64_t i = 0; i < sL; i++) cS[i] = symbol_convertCharToSymbol(s[i]);
+    return cS;
+}
+SymbolString symbolString_construct(const char *sequence, int64_t length) {
+    SymbolString sS;
+    sS.sequence = symbol_convertStringToSymbols(sequence, length);
+    sS.length = length;
+    return sS;
+}
+
+/* sonLib's st_random (a uniform double in [0, 1)); weak, so that a linked sonLib's takes precedence */
+__attribute__((weak)) double st_random(void) {
+    static uint64_t state = 0x9E3779B97F4A7C15ull;
+    uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* hmm_randomise, impl/stateMachine.c:114-131 */
+void hmm_randomise(Hmm *hmm) {
+    for (int64_t from = 0; from < hmm->stateNumber; from++)
+        for (int64_t to = 0; to < hmm->stateNumber; to++) hmm_setTransition(hmm, from, to, st_random());
+    for (int64_t state = 0; state < hmm->stateNumber; state++)
+        for (int64_t x = 0; x < SYMBOL_NUMBER_NO_N; x++)
+            for (int64_t y = 0; y < SYMBOL_NUMBER_NO_N; y++) hmm_setEmissionsExpectation(hmm, state, (Symbol)x, (Symbol)y, st_random());
+    hmm_normalise(hmm);
+}
+
+/* hmm_jsonParse, impl/stateMachine.c:204-253: {"type": t, "transitions": [S*S], "emissions": [S*16], "likelihood": l};
+ * "type" must come first (:214-218), transitions and emissions are mandatory (:240-245), any other key aborts. */
+static const char *json_number_array(const char *s, const char *end, double *out, int64_t n, const char *what) {
+    s = json_skip(s, end);
+    if (s >= end || *s != '[') die("cpecan_hip: hmm json: expected an array for %s", what);
+    s++;
+    for (int64_t i = 0; i < n; i++) {
+        s = json_skip(s, end);
+        char *stop = NULL;
+        out[i] = strtod(s, &stop);
+        if (stop == s || stop > end) die("cpecan_hip: hmm json: %s holds fewer than %lld numbers", what, (long long)n);
+        s = stop;
+    }
+    s = json_skip(s, end);
+    if (s >= end || *s != ']') die("cpecan_hip: hmm json: %s holds more than %lld numbers", what, (long long)n);
+    return s + 1;
+}
+Hmm *hmm_jsonParse(char *buf, size_t r) {
+    const char *s = buf, *end = buf + r;
+    s = json_skip(s, end);
+    if (s >= end || *s != '{') die("cpecan_hip: hmm json: expected an object");
+    s++;
+    Hmm *hmm = NULL;
+    int gotEmissions = 0, gotTransitions = 0;
+    for (;;) {
+        s = json_skip(s, end);
+        if (s >= end) die("cpecan_hip: hmm json: unterminated object");
+        if (*s == '}') break;
+        if (*s != '"') die("cpecan_hip: hmm json: expected a key");
+        const char *key = ++s;
+        while (s < end && *s != '"') s++;
+        if (s >= end) die("cpecan_hip: hmm json: unterminated key");
+        const size_t keyLen = (size_t)(s - key);
+        s = json_skip(s + 1, end);
+#define KEY(name) (keyLen == strlen(name) && strncmp(key, name, keyLen) == 0)
+        if (!hmm) {
+            if (!KEY("type")) die("cpecan_hip: ERROR: Unrecognised key in polish params json: %.*s", (int)keyLen, key);
+            char *stop = NULL;
+            const long long type = strtoll(s, &stop, 10);
+            if (stop == s) die("cpecan_hip: hmm json: type without a value");
+            s = stop;
+            hmm = hmm_constructEmpty(0, (StateMachineType)type);
+        } else if (KEY("transitions")) {
+            s = json_number_array(s, end, hmm->transitions, hmm->stateNumber * hmm->stateNumber, "transitions");
+            gotTransitions = 1;
+        } else if (KEY("emissions")) {
+            s = json_number_array(s, end, hmm->emissions, hmm->stateNumber * SYMBOL_NUMBER_NO_N * SYMBOL_NUMBER_NO_N, "emissions");
+            gotEmissions = 1;
+        } else if (KEY("likelihood")) {
+            char *stop = NULL;
+            hmm->likelihood = strtod(s, &stop);
+            if (stop == s) die("cpecan_hip: hmm json: likelihood without a value");
+            s = stop;
+        } else {
+            die("cpecan_hip: ERROR: Unrecognised key in hmm json: %.*s", (int)keyLen, key);
+        }
+#undef KEY
+    }
+    if (!hmm) die("cpecan_hip: ERROR: too few tokens to parse in hmm json");
+    if (!gotEmissions) die("cpecan_hip: ERROR: Did not find emissions specified in json HMM");
+    if (!gotTransitions) die("cpecan_hip: ERROR: Did not find transitions specified in json HMM");
+    return hmm;
+}
+
+/* The reference's per-diagonal emitters (impl/pairwiseAligner.c:666-689, :691-733, :735-746).  They read DpMatrix rows,
+ * which this library never materialises on the host (the diagonals live in LDS): here they are the TOKENS by which a
+ * caller of getPosteriorProbsWithBanding names the emitter -- recognised by address and routed to the device emitters.
+ * Calling one directly aborts. */
+void diagonalCalculationPosteriorMatchProbs(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix, DpMatrix *backwardDpMatrix,
+                                            const SymbolString sX, const SymbolString sY, double totalProbability,
+                                            PairwiseAlignmentParameters *p, void *extraArgs) {
+    (void)sM; (void)xay; (void)forwardDpMatrix; (void)backwardDpMatrix; (void)sX; (void)sY; (void)totalProbability; (void)p; (void)extraArgs;
+    die("cpecan_hip: diagonalCalculationPosteriorMatchProbs is an emitter token for getPosteriorProbsWithBanding; the DP diagonals exist on the GPU only");
+}
+void diagonalCalculationPosteriorProbs(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix, DpMatrix *backwardDpMatrix,
+                                       const SymbolString sX, const SymbolString sY, double totalProbability,
+                                       PairwiseAlignmentParameters *p, void *extraArgs) {
+    (void)sM; (void)xay; (void)forwardDpMatrix; (void)backwardDpMatrix; (void)sX; (void)sY; (void)totalProbability; (void)p; (void)extraArgs;
+    die("cpecan_hip: diagonalCalculationPosteriorProbs is an emitter token for getPosteriorProbsWithBanding; the DP diagonals exist on the GPU only");
+}
+void diagonalCalculationExpectations(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix, DpMatrix *backwardDpMatrix,
+                                     const SymbolString sX, const SymbolString sY, double totalProbability,
+                                     PairwiseAlignmentParameters *p, void *extraArgs) {
+    (void)sM; (void)xay; (void)forwardDpMatrix; (void)backwardDpMatrix; (void)sX; (void)sY; (void)totalProbability; (void)p; (void)extraArgs;
+    die("cpecan_hip: diagonalCalculationExpectations is an emitter token for getPosteriorProbsWithBanding; the DP diagonals exist on the GPU only");
+}
+
+static char *chars_of(const SymbolString s) {
+    char *out = malloc((size_t)s.length + 1);
+    if (!out) die("cpecan_hip: out of memory");
+    for (int64_t i = 0; i < s.length; i++) out[i] = symbol_convertSymbolToChar(s.sequence[i]);
+    out[s.length] = 0;
+    return out;
+}
+/* appends the triples in the order in which the reference's emitter appends them: traceback after traceback as the
+ * forward sweep advances, within a traceback the diagonals DEScending, within a diagonal x-y AScending
+ * (impl/pairwiseAligner.c:813-841, :673-688) -- the exact reverse of the list order of getAlignedPairsUsingAnchors,
+ * whose wrapper pops each traceback's pairs from the end (:1411-1418) */
+static void append_reversed(stList *to, const int32_t *tr, int64_t n) {
+    for (int64_t i = n - 1; i >= 0; i--) stList_append(to, stIntTuple_construct3(tr[3 * i], tr[3 * i + 1], tr[3 * i + 2]));
+}
+
+/* getPosteriorProbsWithBanding, impl/pairwiseAligner.c:756-877 (inc/pairwiseAligner.h:245-248): one region, no splitting. */
+void getPosteriorProbsWithBanding(StateMachine *sM, stList *anchorPairs, const SymbolString sX, const SymbolString sY,
+                                  PairwiseAlignmentParameters *p, bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd,
+                                  void (*diagonalPosteriorProbFn)(StateMachine *, int64_t, DpMatrix *, DpMatrix *, const SymbolString,
+                                                                  const SymbolString, double, PairwiseAlignmentParameters *, void *),
+                                  void *extraArgs) {
+    cpecan_params q;
+    flatten_params(p, &q);
+    q.splitMatrixBiggerThanThis = INT64_MAX / 4; /* this function is what the splitting wrapper calls per region */
+    int64_t n;
+    int64_t *anchors = flatten_anchors(anchorPairs, &n);
+    char *cX = chars_of(sX), *cY = chars_of(sY);
+    if (diagonalPosteriorProbFn == diagonalCalculationPosteriorMatchProbs) {
+        int32_t *tr = NULL;
+        int64_t cnt = 0;
+        check(cpecan_get_aligned_pairs_using_anchors(flat_or_die(sM), cX, cY, anchors, n, &q, alignmentHasRaggedLeftEnd,
+                                                     alignmentHasRaggedRightEnd, &tr, &cnt), "getPosteriorProbsWithBanding");
+        append_reversed((stList *)((void **)extraArgs)[0], tr, cnt);
+        cpecan_free(tr);
+    } else if (diagonalPosteriorProbFn == diagonalCalculationPosteriorProbs) {
+        int32_t *t0 = NULL, *t1 = NULL, *t2 = NULL;
+        int64_t c0 = 0, c1 = 0, c2 = 0;
+        check(cpecan_get_aligned_pairs_with_indels_using_anchors(flat_or_die(sM), cX, cY, anchors, n, &q, alignmentHasRaggedLeftEnd,
+                                                                 alignmentHasRaggedRightEnd, &t0, &c0, &t1, &c1, &t2, &c2),
+              "getPosteriorProbsWithBanding");
+        /* the indel emitter's lists sit at extraArgs[0], [2] and [4] (:697-699) */
+        append_reversed((stList *)((void **)extraArgs)[0], t0, c0);
+        append_reversed((stList *)((void **)extraArgs)[2], t1, c1);
+        append_reversed((stList *)((void **)extraArgs)[4], t2, c2);
+        cpecan_free(t0);
+        cpecan_free(t1);
+        cpecan_free(t2);
+    } else if (diagonalPosteriorProbFn == diagonalCalculationExpectations) {
+        stList *one = NULL; /* the anchors are already flat: go through the batch directly */
+        (void)one;
+        cpecan_batch *b = NULL;
+        check(cpecan_batch_create(&b, flat_or_die(sM), &q, CPECAN_EMIT_EXPECT, cpecan_current_device()), "cpecan_batch_create");
+        if (cpecan_batch_add(b, cX, sX.length, cY, sY.length, anchors, n, alignmentHasRaggedLeftEnd, alignmentHasRaggedRightEnd) < 0)
+            die("cpecan_hip: invalid anchors");
+        check(cpecan_batch_upload(b), "cpecan_batch_upload");
+        check(cpecan_batch_run(b, NULL), "cpecan_batch_run");
+        check(cpecan_batch_download(b), "cpecan_batch_download");
+        cpecan_hmm acc;
+        to_flat((Hmm *)extraArgs, &acc);
+        check(cpecan_batch_expectations(b, &acc), "cpecan_batch_expectations");
+        from_flat(&acc, (Hmm *)extraArgs);
+        cpecan_batch_destroy(b);
+    } else {
+        /* a foreign per-diagonal callback would have to be fed DpMatrix rows diagonal by diagonal from the host: that is
+         * the CPU algorithm, which this library does not contain */
+        die("cpecan_hip: getPosteriorProbsWithBanding: the emitter must be one of diagonalCalculationPosteriorMatchProbs, "
+            "diagonalCalculationPosteriorProbs, diagonalCalculationExpectations (routed to the device emitters)");
+    }
+    free(cX);
+    free(cY);
+    free(anchors);
 }

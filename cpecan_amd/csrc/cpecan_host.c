@@ -494,6 +494,7 @@ int64_t cpecan_filter_to_remove_overlap(const int64_t *pairs, int64_t n, int64_t
 }
 
 int cpecan_device_count(void) { return cpk_device_count(); }
+int cpecan_current_device(void) { return cpk_current_device(); }
 const char *cpecan_last_error(void) { return cpk_last_error(); }
 
 static void init_byte_tables(void);

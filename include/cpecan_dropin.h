@@ -14,13 +14,15 @@
  * minimal implementation of exactly the container calls the API needs, exported as WEAK symbols so that a real
  * sonLib linked into the same program takes precedence.
  *
- * Not provided (out of the hot path): getAlignedPairs / getExpectations without anchors (they
- * shell out to lastz, impl/pairwiseAligner.c:1032-1042), MEA / reweighting helpers, DpMatrix/DpDiagonal primitives.
- * sM->cellCalculate is a stub that aborts: per-cell recurrences are evaluated on the GPU only.
+ * Not provided: the lastz path of getAlignedPairs / getExpectations (beyond anchorMatrixBiggerThanThis the reference shells
+ * out to lastz, impl/pairwiseAligner.c:1032-1042) and the host-side DpMatrix / DpDiagonal / cell_* primitives: the DP
+ * diagonals never exist on the host.  sM->cellCalculate is a stub that aborts; getPosteriorProbsWithBanding accepts the
+ * reference's three emitters (recognised by address, see below) and refuses foreign callbacks.
  */
 #ifndef CPECAN_DROPIN_H_
 #define CPECAN_DROPIN_H_
 
+#include <math.h>
 #include <stdbool.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -86,6 +88,9 @@ void hmm_addToEmissionsExpectation(Hmm *hmm, int64_t state, Symbol x, Symbol y, 
 double hmm_getEmissionsExpectation(Hmm *hmm, int64_t state, Symbol x, Symbol y);
 void hmm_setEmissionsExpectation(Hmm *hmm, int64_t state, Symbol x, Symbol y, double p);
 Hmm *hmm_loadFromFile(const char *fileName);
+void hmm_randomise(Hmm *hmm);              /* inc/stateMachine.h:71 (impl/stateMachine.c:114); st_random is a weak symbol */
+Hmm *hmm_jsonParse(char *buf, size_t r);   /* inc/stateMachine.h:91 (impl/stateMachine.c:204) */
+double st_random(void);                     /* sonLib's; weak here */
 void hmm_normalise(Hmm *hmm);
 StateMachine *hmm_getStateMachine(Hmm *hmm);
 StateMachine *stateMachine5_construct(StateMachineType type);
@@ -198,6 +203,12 @@ typedef struct _diagonal {
     int64_t xmyL;
     int64_t xmyR;
 } Diagonal;
+/* inc/pairwiseAligner.h:23: the id of the exception diagonal_construct raises (impl/pairwiseAligner.c:29-35).  sonLib's
+ * stExcept is not vendored: the raise goes through the WEAK hook cpecan_dropin_throw, which a sonLib program overrides
+ * with stThrowNew(id, "%s", message); the default prints the message and aborts (an uncaught exception). */
+extern const char *PAIRWISE_ALIGNMENT_EXCEPTION_ID;
+void cpecan_dropin_throw(const char *exceptionId, const char *message);
+Diagonal diagonal_construct(int64_t xay, int64_t xmyL, int64_t xmyR); /* inc/pairwiseAligner.h:122 */
 int64_t diagonal_getXay(Diagonal diagonal);
 int64_t diagonal_getMinXmy(Diagonal diagonal);
 int64_t diagonal_getMaxXmy(Diagonal diagonal);
@@ -208,6 +219,7 @@ int64_t diagonal_equals(Diagonal diagonal1, Diagonal diagonal2);
 
 typedef struct _band Band;
 Band *band_construct(stList *anchorPairs, int64_t lX, int64_t lY, int64_t expansion);
+Band *band_constructDynamic(stList *anchorPairs, int64_t lX, int64_t lY); /* impl/pairwiseAligner.c:128 (anchors carry their expansion) */
 void band_destruct(Band *band);
 typedef struct _bandIterator BandIterator;
 BandIterator *bandIterator_construct(Band *band);
@@ -218,6 +230,37 @@ Diagonal bandIterator_getPrevious(BandIterator *bandIterator);
 
 Symbol symbol_convertCharToSymbol(char i);
 char symbol_convertSymbolToChar(Symbol i);
+Symbol *symbol_convertStringToSymbols(const char *s, int64_t sL); /* inc/pairwiseAligner.h:175 */
+typedef struct _symbolString {
+    Symbol *sequence;
+    int64_t length;
+} SymbolString;
+SymbolString symbolString_construct(const char *sequence, int64_t length); /* inc/pairwiseAligner.h:182 */
+
+/* inc/pairwiseAligner.h:165-167 */
+#define LOG_ZERO (-INFINITY)
+double logAdd(double x, double y);
+
+/* inc/pairwiseAligner.h:245-248: the banded engine itself, one region, with the reference's emitter-callback signature.
+ * The per-diagonal emitters of the reference read DpMatrix rows; this library keeps the DP diagonals on the GPU, so the
+ * three emitters below are TOKENS: getPosteriorProbsWithBanding recognises them by address and runs the device emitter
+ * (extraArgs as in the reference: {alignedPairs} / {alignedPairs, _, gapXPairs, _, gapYPairs} / Hmm*); any other callback
+ * is refused (abort with a message).  Lists are appended in the reference emitter's own order. */
+typedef struct _dpMatrix DpMatrix;
+void diagonalCalculationPosteriorMatchProbs(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix, DpMatrix *backwardDpMatrix,
+                                            const SymbolString sX, const SymbolString sY, double totalProbability,
+                                            PairwiseAlignmentParameters *p, void *extraArgs);
+void diagonalCalculationPosteriorProbs(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix, DpMatrix *backwardDpMatrix,
+                                       const SymbolString sX, const SymbolString sY, double totalProbability,
+                                       PairwiseAlignmentParameters *p, void *extraArgs);
+void diagonalCalculationExpectations(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix, DpMatrix *backwardDpMatrix,
+                                     const SymbolString sX, const SymbolString sY, double totalProbability,
+                                     PairwiseAlignmentParameters *p, void *extraArgs);
+void getPosteriorProbsWithBanding(StateMachine *sM, stList *anchorPairs, const SymbolString sX, const SymbolString sY,
+                                  PairwiseAlignmentParameters *p, bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd,
+                                  void (*diagonalPosteriorProbFn)(StateMachine *, int64_t, DpMatrix *, DpMatrix *, const SymbolString,
+                                                                  const SymbolString, double, PairwiseAlignmentParameters *, void *),
+                                  void *extraArgs);
 stList *getSplitPoints(stList *anchorPairs, int64_t lX, int64_t lY, int64_t maxMatrixSize, bool alignmentHasRaggedLeftEnd,
                        bool alignmentHasRaggedRightEnd);
 

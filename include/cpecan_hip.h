@@ -134,6 +134,11 @@ int64_t cpecan_filter_to_remove_overlap(const int64_t *pairs, int64_t n, int64_t
 
 /* ---- device ---- */
 int cpecan_device_count(void);
+/* The calling thread's current HIP device (hipGetDevice).  Device rule of this library: a batch works on the device it
+ * was created for and every entry point leaves the caller's current device as it found it; the single-problem entry
+ * points (cpecan_get_aligned_pairs_using_anchors ... and the reference-named layer in cpecan_dropin.h) run on the
+ * caller's CURRENT device, so in a one-process-per-GPU job they follow hipSetDevice / torch.cuda.set_device. */
+int cpecan_current_device(void);
 const char *cpecan_last_error(void);
 
 /* ---- batch API ---- */

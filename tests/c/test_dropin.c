@@ -257,6 +257,157 @@ static void test_consumers_gpu(void) {
     pairwiseAlignmentBandingParameters_destruct(p);
 }
 
+/* ---- the rest of the reference header's hot-path surface (inc/pairwiseAligner.h:23,122,128,167,245-248;
+ * inc/stateMachine.h:71,91) ---- */
+static int thrown = 0;
+static char thrownId[64];
+void cpecan_dropin_throw(const char *exceptionId, const char *message) { /* overrides the library's weak default */
+    (void)message;
+    thrown++;
+    strncpy(thrownId, exceptionId, sizeof thrownId - 1);
+}
+
+static void test_diagonal_logadd_dynamic_band_hmm_json(void) {
+    /* test_diagonal, tests/pairwiseAlignerTest.c:17-59 */
+    Diagonal d = diagonal_construct(30, -10, 30);
+    CHECK(diagonal_getXay(d) == 30 && diagonal_getMinXmy(d) == -10 && diagonal_getMaxXmy(d) == 30 && diagonal_getWidth(d) == 21);
+    CHECK(diagonal_getXCoordinate(30, -10) == 10 && diagonal_getYCoordinate(30, -10) == 20);
+    CHECK(diagonal_equals(d, diagonal_construct(30, -10, 30)) && !diagonal_equals(d, diagonal_construct(0, 0, 0)));
+    CHECK(thrown == 0);
+    (void)diagonal_construct(10, 5, 5); /* parity violation: the reference throws PAIRWISE_ALIGNMENT_EXCEPTION (:31-35) */
+    CHECK(thrown == 1 && strcmp(thrownId, PAIRWISE_ALIGNMENT_EXCEPTION_ID) == 0 && strcmp(thrownId, "PAIRWISE_ALIGNMENT_EXCEPTION") == 0);
+    (void)diagonal_construct(10, 6, 4); /* xmyL > xmyR */
+    CHECK(thrown == 2);
+
+    /* test_logAdd, :134-144: within 0.001 of the exact value in linear space; and the documented special cases */
+    unsigned long long st = 12345;
+    for (int i = 0; i < 100000; i++) {
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        const double x = (double)(st >> 11) / 9007199254740992.0;
+        st = st * 6364136223846793005ull + 1442695040888963407ull;
+        const double y = (double)(st >> 11) / 9007199254740992.0;
+        const double z = x + y;
+        CHECK(fabs(exp(logAdd(log(x), log(y))) - z) < 0.001);
+    }
+    CHECK(logAdd(LOG_ZERO, -3.5) == -3.5 && logAdd(-3.5, LOG_ZERO) == -3.5 && logAdd(LOG_ZERO, LOG_ZERO) == LOG_ZERO);
+    CHECK(logAdd(-10.0, -2.5) == -2.5 && logAdd(-2.5, -10.0) == -2.5);            /* difference 7.5: the larger one */
+    CHECK(logAdd(-1.0, -1.0) == (double)0.693203116424741f + -1.0);              /* x == y: second branch, lookup(0) + y */
+    CHECK(logAdd(-1.0, -2.0) == logAdd(-2.0, -1.0));
+
+    /* band_constructDynamic (:128-181): anchors carry their own expansion; with one common expansion it is band_construct */
+    stList *fixed = stList_construct3(0, (void (*)(void *))stIntTuple_destruct), *dyn = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    const int64_t pts[3][2] = {{1, 0}, {2, 1}, {3, 3}};
+    for (int i = 0; i < 3; i++) {
+        stList_append(fixed, stIntTuple_construct2(pts[i][0], pts[i][1]));
+        stList_append(dyn, stIntTuple_construct3(pts[i][0], pts[i][1], 2));
+    }
+    Band *bf = band_construct(fixed, 6, 5, 2), *bd = band_constructDynamic(dyn, 6, 5);
+    BandIterator *itf = bandIterator_construct(bf), *itd = bandIterator_construct(bd);
+    for (int i = 0; i < 12; i++) CHECK(diagonal_equals(bandIterator_getNext(itf), bandIterator_getNext(itd)));
+    bandIterator_destruct(itf);
+    bandIterator_destruct(itd);
+    band_destruct(bf);
+    band_destruct(bd);
+    stList_destruct(fixed);
+    stList_destruct(dyn);
+
+    /* hmm_randomise (stateMachine.c:114-131): a normalised HMM of values in (0, 1) */
+    Hmm *h = hmm_constructEmpty(0.0, fiveState);
+    hmm_randomise(h);
+    for (int64_t from = 0; from < 5; from++) {
+        double row = 0.0;
+        for (int64_t to = 0; to < 5; to++) {
+            CHECK(hmm_getTransition(h, from, to) > 0.0 && hmm_getTransition(h, from, to) < 1.0);
+            row += hmm_getTransition(h, from, to);
+        }
+        CHECK(fabs(row - 1.0) < 1e-9);
+        double e = 0.0;
+        for (int x = 0; x < 4; x++)
+            for (int y = 0; y < 4; y++) e += hmm_getEmissionsExpectation(h, from, (Symbol)x, (Symbol)y);
+        CHECK(fabs(e - 1.0) < 1e-9);
+    }
+    hmm_destruct(h);
+
+    /* hmm_jsonParse (stateMachine.c:204-253) */
+    char js[4096];
+    int at = snprintf(js, sizeof js, "{\"type\": 2, \"transitions\": [0.9, 0.05, 0.05, 0.4, 0.6, 0, 0.4, 0, 0.6], \"emissions\": [");
+    for (int i = 0; i < 48; i++) at += snprintf(js + at, sizeof js - (size_t)at, "%s%g", i ? ", " : "", 0.0625 + 0.001 * i);
+    at += snprintf(js + at, sizeof js - (size_t)at, "], \"likelihood\": -12.5}");
+    Hmm *hj = hmm_jsonParse(js, (size_t)at);
+    CHECK(hj->type == threeState && hj->stateNumber == 3 && hj->likelihood == -12.5);
+    CHECK(hmm_getTransition(hj, 0, 0) == 0.9 && hmm_getTransition(hj, 1, 1) == 0.6 && hmm_getTransition(hj, 2, 0) == 0.4);
+    CHECK(hmm_getEmissionsExpectation(hj, 0, a, a) == 0.0625 && hmm_getEmissionsExpectation(hj, 2, t, t) == 0.0625 + 0.001 * 47);
+    hmm_destruct(hj);
+
+    SymbolString ss = symbolString_construct("AcGTntNCG", 9);
+    const Symbol gold[9] = {a, c, g, t, n, t, n, c, g};
+    for (int i = 0; i < 9; i++) CHECK(ss.sequence[i] == gold[i]);
+    CHECK(ss.length == 9);
+    free(ss.sequence);
+}
+
+/* getPosteriorProbsWithBanding with the reference's own emitters, as tests/pairwiseAlignerTest.c:403-438 calls it */
+static void test_getPosteriorProbsWithBanding_gpu(void) {
+    const char *sx = "AGCG", *sy = "AGTTCG";
+    SymbolString sX = symbolString_construct(sx, 4), sY = symbolString_construct(sy, 6);
+    PairwiseAlignmentParameters *p = pairwiseAlignmentBandingParameters_construct();
+    p->threshold = 0.2;
+    StateMachine *sM = stateMachine5_construct(fiveState);
+    stList *anchors = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    stList *alignedPairs = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    void *extraArgs[1] = {alignedPairs};
+    getPosteriorProbsWithBanding(sM, anchors, sX, sY, p, 0, 0, diagonalCalculationPosteriorMatchProbs, extraArgs);
+    /* the four pairs of test_diagonalDPCalculations (:311-322) with the SURVEY 8c scores, in the EMITTER's order: one
+     * traceback from the last diagonal, diagonals descending */
+    const int64_t gold[4][3] = {{9893294, 3, 5}, {8665179, 2, 4}, {9259684, 1, 1}, {9944673, 0, 0}};
+    CHECK(stList_length(alignedPairs) == 4);
+    for (int i = 0; i < 4 && i < stList_length(alignedPairs); i++) {
+        stIntTuple *tp = stList_get(alignedPairs, i);
+        CHECK(llabs(stIntTuple_get(tp, 0) - gold[i][0]) <= 1 && stIntTuple_get(tp, 1) == gold[i][1] && stIntTuple_get(tp, 2) == gold[i][2]);
+    }
+    /* ... which is getAlignedPairsUsingAnchors' list reversed (its wrapper pops the pairs of each traceback, :1411-1418) */
+    stList *viaApi = getAlignedPairsUsingAnchors(sM, sx, sy, anchors, p, 0, 0);
+    CHECK(stList_length(viaApi) == stList_length(alignedPairs));
+    for (int64_t i = 0; i < stList_length(viaApi) && i < stList_length(alignedPairs); i++) {
+        stIntTuple *u = stList_get(viaApi, i), *v = stList_get(alignedPairs, stList_length(alignedPairs) - 1 - i);
+        CHECK(stIntTuple_get(u, 0) == stIntTuple_get(v, 0) && stIntTuple_get(u, 1) == stIntTuple_get(v, 1) && stIntTuple_get(u, 2) == stIntTuple_get(v, 2));
+    }
+    stList_destruct(viaApi);
+    stList_destruct(alignedPairs);
+
+    /* the indel emitter: lists at extraArgs[0], [2], [4] (:697-699) */
+    stList *m0 = stList_construct3(0, (void (*)(void *))stIntTuple_destruct), *gx = stList_construct3(0, (void (*)(void *))stIntTuple_destruct),
+           *gy = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    void *extra5[5] = {m0, NULL, gx, NULL, gy};
+    getPosteriorProbsWithBanding(sM, anchors, sX, sY, p, 0, 0, diagonalCalculationPosteriorProbs, extra5);
+    CHECK(stList_length(m0) == 4 && stList_length(gy) >= 1);
+    stList_destruct(m0);
+    stList_destruct(gx);
+    stList_destruct(gy);
+
+    /* the expectation emitter: extraArgs is the Hmm (SURVEY 8c known answers) */
+    Hmm *h = hmm_constructEmpty(0.0, fiveState);
+    getPosteriorProbsWithBanding(sM, anchors, sX, sY, p, 0, 0, diagonalCalculationExpectations, h);
+    CHECK(fabs(h->likelihood + 175.193211612) < 1e-8 && fabs(hmm_getTransition(h, 0, 0) - 3.010391804) < 1e-8);
+    hmm_destruct(h);
+
+    /* dynamic anchor expansion through the engine: every anchor with its own band */
+    stList *dyn = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    stList_append(dyn, stIntTuple_construct3(1, 1, 2));
+    p->dynamicAnchorExpansion = 1;
+    stList *out = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    void *extra1[1] = {out};
+    getPosteriorProbsWithBanding(sM, dyn, sX, sY, p, 0, 0, diagonalCalculationPosteriorMatchProbs, extra1);
+    CHECK(stList_length(out) >= 3);
+    stList_destruct(out);
+    stList_destruct(dyn);
+    stList_destruct(anchors);
+    stateMachine_destruct(sM);
+    pairwiseAlignmentBandingParameters_destruct(p);
+    free(sX.sequence);
+    free(sY.sequence);
+}
+
 int main(int argc, char **argv) {
     const int gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
     test_bands();
@@ -268,7 +419,9 @@ int main(int argc, char **argv) {
     test_hmm(threeStateAsymmetric);
     test_symbols();
     test_models();
+    test_diagonal_logadd_dynamic_band_hmm_json();
     if (gpu) test_known_answers_gpu();
+    if (gpu) test_getPosteriorProbsWithBanding_gpu();
     if (gpu) test_consumers_gpu();
     printf("%s: %d failure(s)\n", gpu ? "gpu" : "cpu", failures);
     return failures != 0;
