@@ -253,30 +253,42 @@ static void rebase(int64_t *start, int64_t *end, int32_t *strand, int64_t shift,
     }
 }
 
-/* convertAlignedPairsToPairwiseAlignment, cPecanRealign.c:49-96: xy holds n (x, y) in increasing order */
+/* One more op of the cigar being built; a match directly after a match extends it (two diagonal runs that touch). */
+static int cigar_emit(cpecan_cigar *c, int64_t *cap, int64_t type, int64_t length) {
+    if (length <= 0) return CPECAN_OK;
+    if (type == CPECAN_OP_MATCH && c->nOps > 0 && c->ops[2 * (c->nOps - 1)] == CPECAN_OP_MATCH) {
+        c->ops[2 * (c->nOps - 1) + 1] += length;
+        return CPECAN_OK;
+    }
+    return cigar_push(c, cap, type, length);
+}
+
+/* The cigar of a chain of aligned pairs (what convertAlignedPairsToPairwiseAlignment, cPecanRealign.c:49-96, produces):
+ * xy holds n (x, y) pairs.  The chain is read as maximal DIAGONAL RUNS -- pairs (x0 + k, y0 + k), k = 0 .. run-1 --
+ * each one match op; the bases of X that no op has covered when a run starts become one X-indel, then those of Y one
+ * Y-indel, and the same once more for what is left behind the last run.  A pair that does not lie beyond everything
+ * covered so far in BOTH sequences is passed over (the reference's input is an ordered chain, where there is none). */
 static int cigar_from_pairs(cpecan_cigar *c, const char *contig1, const char *contig2, double score, int64_t length1,
                             int64_t length2, const int64_t *xy, int64_t n) {
     int rc = cigar_set(c, contig1, 0, length1, 1, contig2, 0, length2, 1, score);
-    int64_t cap = 0, pX = -1, pY = -1, mL = 0;
-    for (int64_t i = 0; rc == CPECAN_OK && i <= n; i++) {
-        const int64_t x = i < n ? xy[2 * i] : length1, y = i < n ? xy[2 * i + 1] : length2; /* the end matched pair (:56) */
-        if (x - pX > 0 && y - pY > 0) { /* "a hack for filtering" (:63) */
-            if (x - pX > 1) {
-                if (mL > 0) rc = cigar_push(c, &cap, CPECAN_OP_MATCH, mL);
-                mL = 0;
-                if (rc == CPECAN_OK) rc = cigar_push(c, &cap, CPECAN_OP_INDEL_X, x - pX - 1);
-            }
-            if (rc == CPECAN_OK && y - pY > 1) {
-                if (mL > 0) rc = cigar_push(c, &cap, CPECAN_OP_MATCH, mL);
-                mL = 0;
-                if (rc == CPECAN_OK) rc = cigar_push(c, &cap, CPECAN_OP_INDEL_Y, y - pY - 1);
-            }
-            mL++;
-            pX = x;
-            pY = y;
+    int64_t cap = 0, covered1 = 0, covered2 = 0; /* bases of each sequence that the ops so far account for */
+    for (int64_t i = 0; rc == CPECAN_OK && i < n;) {
+        const int64_t x0 = xy[2 * i], y0 = xy[2 * i + 1];
+        if (x0 < covered1 || y0 < covered2 || x0 >= length1 || y0 >= length2) {
+            i++;
+            continue;
         }
+        int64_t run = 1;
+        while (i + run < n && xy[2 * (i + run)] == x0 + run && xy[2 * (i + run) + 1] == y0 + run) run++;
+        rc = cigar_emit(c, &cap, CPECAN_OP_INDEL_X, x0 - covered1);
+        if (rc == CPECAN_OK) rc = cigar_emit(c, &cap, CPECAN_OP_INDEL_Y, y0 - covered2);
+        if (rc == CPECAN_OK) rc = cigar_emit(c, &cap, CPECAN_OP_MATCH, run);
+        covered1 = x0 + run;
+        covered2 = y0 + run;
+        i += run;
     }
-    if (rc == CPECAN_OK && mL > 1) rc = cigar_push(c, &cap, CPECAN_OP_MATCH, mL - 1); /* without the end pair (:86) */
+    if (rc == CPECAN_OK) rc = cigar_emit(c, &cap, CPECAN_OP_INDEL_X, length1 - covered1);
+    if (rc == CPECAN_OK) rc = cigar_emit(c, &cap, CPECAN_OP_INDEL_Y, length2 - covered2);
     return rc;
 }
 

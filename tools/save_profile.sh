@@ -5,6 +5,7 @@ tag=$1
 src=gpurun_out/$tag
 cp $src/bench.json profiles/${tag}_bench.json
 cp $src/traffic.json profiles/${tag}_traffic.json
+cp $src/compute.json profiles/${tag}_compute.json
 cp $src/stats/*/*_kernel_stats.csv profiles/${tag}_kernel_stats.csv
 python3 - $src profiles/$tag <<'PY'
 import csv, glob, sys
@@ -13,7 +14,7 @@ kt = glob.glob(src + '/stats/*/*_kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(kt)))
 keep = [r for r in rows if 'pairhmm' in r['Kernel_Name']]
 w = csv.DictWriter(open(dst + '_kernel_trace.csv', 'w', newline=''), fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
-for name in ('fetch', 'write'):
+for name in ('fetch', 'write', 'valu', 'lds'):
     f = glob.glob(src + '/' + name + '/*/*_counter_collection.csv')[0]
     rows = list(csv.DictReader(open(f)))
     keep = [r for r in rows if 'pairhmm' in r['Kernel_Name']]
