@@ -999,7 +999,23 @@ int cpecan_batch_upload(cpecan_batch *b) {
             dbgDiags += r->lX + r->lY + 1;
         }
         totalCells += r->cells;
+        g->cells = r->cells;
         g->outCap = (int32_t)default_out_cap(b, r);
+        /* every traceback segment gets a part of the region's output slice of its own (used when the segments run as
+         * separate queue items, see CpkItem): in proportion to its emitted diagonals, the parts add up to outCap */
+        {
+            CpkSegment *sg = segs + segStart[hiRegion];
+            const int64_t N = r->lX + r->lY;
+            int64_t at = 0;
+            for (int64_t si = 0; si < pl->nSeg; si++) {
+                int64_t cap = N > 0 ? (int64_t)g->outCap * (sg[si].tbFrom - sg[si].tbPrev) / N + 16 : 1;
+                if (b->params.threshold <= 0.0) cap = r->cells; /* every cell may be emitted */
+                sg[si].outOff = (int32_t)at;
+                sg[si].outCap = (int32_t)cap;
+                at += cap;
+            }
+            if (at > g->outCap) g->outCap = (int32_t)imin(at, ((int64_t)1 << 31) - 1);
+        }
         g->outOff = outAt;
         outAt += g->outCap;
         if (keys[di].cls < 3) { /* narrow: scratch of the packed kernel's sub-slots */
@@ -1101,8 +1117,8 @@ int cpecan_batch_run(cpecan_batch *b, void *stream) {
 /* The copy plan of cpk_device_gather for the whole batch: per list, problems in order, regions in order, traceback
  * segments in DEScending order (each traceback's pairs are prepended, pairwiseAligner.c:1415-1417), every triple shifted
  * by its region's offset (:1411-1418).  Sets the per-problem result pointers into b->results. */
-static int plan_results(cpecan_batch *b, const int32_t *counts, const int32_t *segStarts, CpkChunk **chunksOut,
-                        int64_t *nChunksOut, int64_t *totalOut) {
+static int plan_results(cpecan_batch *b, const int32_t *counts, const int32_t *segStarts, const int32_t *segCounts,
+                        CpkChunk **chunksOut, int64_t *nChunksOut, int64_t *totalOut) {
     int64_t total = 0;
     for (int l = 0; l < b->nLists; l++)
         for (int64_t di = 0; di < b->nRegions; di++) total += counts[(size_t)l * b->nRegions + di];
@@ -1116,6 +1132,7 @@ static int plan_results(cpecan_batch *b, const int32_t *counts, const int32_t *s
     for (int l = 0; l < b->nLists; l++) {
         const int32_t *cnt = counts + (size_t)l * b->nRegions;
         const int32_t *ss = segStarts + (size_t)l * b->nSegs;
+        const int32_t *sc = segCounts + (size_t)l * b->nSegs;
         for (int64_t pi = 0; pi < b->nProblems; pi++) {
             HostProblem *pr = &b->problems[pi];
             pr->triples[l] = b->results + 3 * at;
@@ -1126,7 +1143,8 @@ static int plan_results(cpecan_batch *b, const int32_t *counts, const int32_t *s
                 const int32_t n = cnt[r->devIndex];
                 for (int sgi = g->nSeg - 1; sgi >= 0; sgi--) {
                     const int32_t from = ss[g->segOff + sgi];
-                    const int32_t to = sgi + 1 < g->nSeg ? ss[g->segOff + sgi + 1] : n;
+                    /* a split region's segments were written apart, each with its own count */
+                    const int32_t to = g->split ? from + sc[g->segOff + sgi] : (sgi + 1 < g->nSeg ? ss[g->segOff + sgi + 1] : n);
                     if (to <= from) continue;
                     CpkChunk *c = &chunks[nChunks++];
                     c->src = (int64_t)l * b->outTriples + g->outOff + from;
@@ -1280,13 +1298,15 @@ int cpecan_batch_download(cpecan_batch *b) {
         return CPECAN_OK;
     }
     int rc = CPECAN_OK;
-    int32_t *counts = NULL, *segStarts = NULL;
+    int32_t *counts = NULL, *segStarts = NULL, *segCounts = NULL;
     for (int attempt = 0; attempt < 3; attempt++) {
         free(counts);
         free(segStarts);
+        free(segCounts);
         counts = malloc(sizeof(int32_t) * (size_t)b->nLists * b->nRegions);
         segStarts = malloc(sizeof(int32_t) * (size_t)b->nLists * (b->nSegs ? b->nSegs : 1));
-        if (!counts || !segStarts) {
+        segCounts = malloc(sizeof(int32_t) * (size_t)b->nLists * (b->nSegs ? b->nSegs : 1));
+        if (!counts || !segStarts || !segCounts) {
             rc = CPECAN_ENOMEM;
             break;
         }
@@ -1297,29 +1317,51 @@ int cpecan_batch_download(cpecan_batch *b) {
                 break;
             }
         }
-        rc = cpk_device_download(b->dev, counts, segStarts, b->forward, &b->stats.kernelMs, &b->stats.d2hMs);
+        rc = cpk_device_download(b->dev, counts, segStarts, segCounts, b->forward, &b->stats.kernelMs, &b->stats.d2hMs);
         if (rc != CPECAN_OK) break;
         if (b->emit == CPECAN_EMIT_FORWARD || b->emit == CPECAN_EMIT_EXPECT) break; /* these emitters produce no lists */
         /* did any region overflow its output slice?  If so enlarge exactly and run once more. */
         int overflow = 0;
         int64_t outAt = 0;
         for (int64_t di = 0; di < b->nRegions; di++) {
-            int32_t need = 0;
-            for (int l = 0; l < b->nLists; l++) {
-                const int32_t c = counts[(size_t)l * b->nRegions + di];
-                need = c > need ? c : need;
-            }
             CpkRegion *g = &b->devRegions[di];
-            if (need > g->outCap) {
-                overflow = 1;
-                g->outCap = need;
+            if (g->split) {
+                /* the segments were written apart: a region's count is the sum, and each segment has its own capacity */
+                int64_t at = 0;
+                for (int l = 0; l < b->nLists; l++) counts[(size_t)l * b->nRegions + di] = 0;
+                for (int32_t si = 0; si < g->nSeg; si++) {
+                    CpkSegment *sg = &b->segs[g->segOff + si];
+                    int32_t need = 0;
+                    for (int l = 0; l < b->nLists; l++) {
+                        const int32_t c = segCounts[(size_t)l * b->nSegs + g->segOff + si];
+                        need = c > need ? c : need;
+                        counts[(size_t)l * b->nRegions + di] += c < sg->outCap ? c : sg->outCap;
+                    }
+                    if (need > sg->outCap) {
+                        overflow = 1;
+                        sg->outCap = need;
+                    }
+                    sg->outOff = (int32_t)at;
+                    at += sg->outCap;
+                }
+                if (at > g->outCap) g->outCap = (int32_t)at;
+            } else {
+                int32_t need = 0;
+                for (int l = 0; l < b->nLists; l++) {
+                    const int32_t c = counts[(size_t)l * b->nRegions + di];
+                    need = c > need ? c : need;
+                }
+                if (need > g->outCap) {
+                    overflow = 1;
+                    g->outCap = need;
+                }
             }
             g->outOff = outAt;
             outAt += g->outCap;
         }
         if (!overflow) break;
         b->outTriples = outAt;
-        rc = cpk_device_update_regions(b->dev, b->devRegions, b->outTriples);
+        rc = cpk_device_update_regions(b->dev, b->devRegions, b->segs, b->outTriples);
         if (rc != CPECAN_OK) break;
         rc = cpk_device_rerun(b->dev); /* same stream as the run that overflowed */
         if (rc != CPECAN_OK) break;
@@ -1333,7 +1375,7 @@ int cpecan_batch_download(cpecan_batch *b) {
         /* the lists are put in order on the device; only the emitted triples cross PCIe */
         CpkChunk *chunks = NULL;
         int64_t nChunks = 0, total = 0;
-        rc = plan_results(b, counts, segStarts, &chunks, &nChunks, &total);
+        rc = plan_results(b, counts, segStarts, segCounts, &chunks, &nChunks, &total);
         if (rc == CPECAN_OK) rc = cpk_device_gather(b->dev, chunks, nChunks, total);
         free(chunks);
         if (rc == CPECAN_OK) rc = run_post(b); /* consumers of the lists, on the device, before they leave it */
@@ -1343,6 +1385,7 @@ int cpecan_batch_download(cpecan_batch *b) {
     if (rc == CPECAN_OK) b->downloaded = 1;
     free(counts);
     free(segStarts);
+    free(segCounts);
     return rc;
 }
 

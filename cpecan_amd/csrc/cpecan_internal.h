@@ -35,8 +35,15 @@ typedef struct {
     int32_t tbFrom;   /* tracedBackFrom: highest emitted diagonal */
     int32_t atEnd;    /* dTop == lX+lY */
     int32_t nRefresh; /* number of total-probability refresh points in the segment */
-    int32_t pad[3];
+    int32_t outOff;   /* the segment's own part of the region's output slice (per list), used when the tracebacks of a */
+    int32_t outCap;   /* region run as separate queue items (split classes): first triple and capacity */
+    int32_t pad;
 } CpkSegment;
+
+/* One traceback work item of a split class: segment `seg` (index within its region) of device region `region`. */
+typedef struct {
+    int32_t region, seg;
+} CpkItem;
 
 /* One DP region (a whole problem, or one rectangle of getSplitPoints). */
 typedef struct {
@@ -47,6 +54,8 @@ typedef struct {
     int64_t dbgCellOff;       /* debug: first cell in the debug fb array */
     int64_t dbgDiagOff;       /* debug: first diagonal in the debug total array */
     int64_t anchorOff;        /* first anchor triple of the region (coordinates relative to the region) */
+    int64_t ringBase;         /* split classes: first cell of the region's own forward ring (it holds every segment) */
+    int64_t cells;            /* band cells of the region */
     int32_t lX, lY;
     int32_t nSeg;
     int32_t outCap;           /* capacity in triples (per output list) */
@@ -54,7 +63,7 @@ typedef struct {
     int32_t maxWidth;
     int32_t ringCap;          /* cells of forward ring the region needs: its longest live span + its widest diagonal */
     int32_t nAnchors;
-    int32_t pad;
+    int32_t split;            /* set by the device layer: the region's tracebacks run as separate queue items */
 } CpkRegion;
 
 /* Model constants as the kernels use them: per-state priors, named transitions and padded emissions. */
@@ -126,19 +135,20 @@ int cpk_device_create(CpkDevice **out, int device);
 void cpk_device_destroy(CpkDevice *dev);
 /* Copies the packed inputs to the GPU and sizes every scratch buffer. */
 /* The per-diagonal table (nDiags entries) is built on the device from the anchors (cpecan_band.inl). */
-int cpk_device_upload(CpkDevice *dev, const CpkGeometry *geo, const CpkModel *model, const CpkRegion *regions,
+/* Regions of a class that is split (see CpkItem) get ringCap / ringBase / split set here, in the caller's array. */
+int cpk_device_upload(CpkDevice *dev, const CpkGeometry *geo, const CpkModel *model, CpkRegion *regions,
                       const int64_t *anchors, int64_t nAnchors, int64_t nDiags, int64_t expansion, int dynamic,
                       const CpkSegment *segs, int64_t nSegs, const uint8_t *symbols, int64_t nSymbolBytes,
                       int64_t outTriplesPerList, int nLists, int64_t dbgCells, int64_t dbgDiags, double *h2dMs);
-int cpk_device_update_regions(CpkDevice *dev, const CpkRegion *regions, int64_t outTriplesPerList);
+int cpk_device_update_regions(CpkDevice *dev, const CpkRegion *regions, const CpkSegment *segs, int64_t outTriplesPerList);
 int cpk_device_run(CpkDevice *dev, void *stream);
 /* Once more on the stream of the last run (after an output overflow); kernel times of a batch's launches add up. */
 int cpk_device_rerun(CpkDevice *dev);
 /* Blocks until the run is complete and copies back the per-region counts and per-segment start offsets (and the
  * expectation sums / forward probabilities). The triples stay on the device: see cpk_device_gather. */
 int cpk_device_download(CpkDevice *dev, int32_t *counts /* [nLists][nRegions] */,
-                        int32_t *segStarts /* [nLists][nSegsTotal] */, double *expect /* [106] */, double *kernelMs,
-                        double *d2hMs);
+                        int32_t *segStarts /* [nLists][nSegsTotal] */, int32_t *segCounts /* [nLists][nSegsTotal]: split regions */,
+                        double *expect /* [106] */, double *kernelMs, double *d2hMs);
 /* Moves the chunks into one compact buffer on the device (reference list order, region offsets applied). */
 int cpk_device_gather(CpkDevice *dev, const CpkChunk *chunks, int64_t nChunks, int64_t total);
 /* Copies the compact buffer -- `total` triples, nothing else -- to hostOut. */

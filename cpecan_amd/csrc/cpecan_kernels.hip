@@ -35,6 +35,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <algorithm>
+#include <utility>
 #include <vector>
 
 #include "cpecan_internal.h"
@@ -89,6 +91,13 @@ struct LaunchClass {
     int64_t subSlots = 0;  // scratch slots: one per wave (sweep) or one per region group of a wave (packed)
     size_t ldsBytes = 0;
     int regionBase = 0, regionCount = 0;
+    // A SPLIT class (fewer regions than wave slots): launch 1 = forward sweeps of whole regions into per-REGION rings,
+    // launch 2 = one queue item per (region, traceback segment); see kModeForward / kModeTrace in cpk_sweep.inl.
+    bool split = false;
+    KernelFn fnTrace = nullptr;
+    int wavesTrace = 0;
+    int64_t itemBase = 0, itemCount = 0;  // its items in dItems
+    int64_t ringTotal = 0;                // cells of all its regions' rings (ringEl is 0 then: nothing per slot)
     int64_t ringEl = 0, candEl = 0, refEl = 0, totEl = 0, bringEl = 0, grollEl = 0;  // elements per scratch slot
     int64_t oRing = 0, oCand = 0, oRef = 0, oTot = 0, oBring = 0, oGroll = 0, oExpect = 0;  // element offsets of the class
     double slotBytes() const {
@@ -229,7 +238,8 @@ struct CpkDevice {
     uint8_t *dSymbols = nullptr;
     CpkModel *dModel = nullptr;
     double *dRing = nullptr; Candidate *dCand = nullptr; double *dForward = nullptr, *dExpect = nullptr; double *dC = nullptr, *dM = nullptr, *dTotals = nullptr, *dGroll = nullptr, *dBring = nullptr;
-    int32_t *dCounts = nullptr, *dSegStarts = nullptr, *dTriples = nullptr;
+    int32_t *dCounts = nullptr, *dSegStarts = nullptr, *dSegCounts = nullptr, *dTriples = nullptr;
+    CpkItem *dItems = nullptr;
     int32_t *dCompact = nullptr; CpkChunk *dChunks = nullptr; int64_t compactCap = 0, chunkCap = 0;
     unsigned int *dQueue = nullptr;
     double *dDbgFb = nullptr, *dDbgTotals = nullptr;
@@ -337,7 +347,8 @@ static void free_all(CpkDevice *d) {
     d->dCand = nullptr;
     d->dForward = nullptr;
     d->dExpect = nullptr;
-    d->dCounts = d->dSegStarts = d->dTriples = nullptr;
+    d->dCounts = d->dSegStarts = d->dSegCounts = d->dTriples = nullptr;
+    d->dItems = nullptr;
     d->dCompact = nullptr; d->dChunks = nullptr; d->compactCap = d->chunkCap = 0;
     d->dQueue = nullptr;
     d->dDbgFb = d->dDbgTotals = nullptr;
@@ -396,6 +407,18 @@ static KernelFn pick_packed_kernel(const CpkGeometry &g, int cls) {  // class k:
     return nullptr;
 }
 
+// the two kernels of a split class (match emitter)
+static void pick_split_kernels(const CpkGeometry &g, KernelFn *fwd, KernelFn *trace) {
+    const bool fast = !g.useGlobalRoll;
+    if (g.nStates == 5) {
+        *fwd = fast ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeForward> : cpecan_pairhmm_sweep<5, false, CPECAN_EMIT_MATCH, kModeForward>;
+        *trace = fast ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeTrace> : cpecan_pairhmm_sweep<5, false, CPECAN_EMIT_MATCH, kModeTrace>;
+    } else {
+        *fwd = fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeForward> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeForward>;
+        *trace = fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeTrace> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeTrace>;
+    }
+}
+
 static KernelFn pick_kernel(const CpkGeometry &g) {
     const bool fast = !g.useGlobalRoll;  // second template argument = FAST (LDS rolling buffers + LDS symbol strings)
 #define CPK_PICK(E)                                                                                          \
@@ -411,7 +434,7 @@ static KernelFn pick_kernel(const CpkGeometry &g) {
     return nullptr;
 }
 
-extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const CpkModel *model, const CpkRegion *regions,
+extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const CpkModel *model, CpkRegion *regions,
                                  const int64_t *anchors, int64_t nAnchors, int64_t nDiags, int64_t expansion, int dynamic,
                                  const CpkSegment *segs, int64_t nSegs, const uint8_t *symbols, int64_t nSymbolBytes,
                                  int64_t outTriplesPerList, int nLists, int64_t dbgCells, int64_t dbgDiags,
@@ -575,6 +598,24 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         c.regionBase = regionAt;
         c.regionCount = geo->nWide[k];
         regionAt += geo->nWide[k];
+        {
+            // Split the class when its regions do not fill the chip and have tracebacks to hand out: the segments of a
+            // region are independent once its forward values exist.  CPECAN_SPLIT=1 / 0 (tests, diagnostics): always / never.
+            int64_t nSegClass = 0;
+            for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++) nSegClass += regions[di].nSeg;
+            const char *env = getenv("CPECAN_SPLIT");
+            const int64_t slots = (int64_t)perCU * d->numCUs;
+            const bool eligible = c.threads == CPK_WAVE && geo->emit == CPECAN_EMIT_MATCH && !geo->debug && nSegClass > 0;
+            const bool wanted = env ? atoi(env) != 0 : (n * 20 < slots * 17 && nSegClass * 4 >= n * 5);
+            if (eligible && wanted) {
+                c.split = true;
+                pick_split_kernels(c.geo, &c.fn, &c.fnTrace);
+                int64_t wt = slots < nSegClass ? slots : nSegClass;
+                c.wavesTrace = (int)wt;
+                if (wt > c.subSlots) c.subSlots = wt;
+                c.itemCount = nSegClass;
+            }
+        }
         c.ringEl = c.geo.ringCells * S;
         c.candEl = c.geo.fbCells * nCandLists;
         c.refEl = c.geo.refreshCells;
@@ -599,10 +640,41 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         HIP_TRY(hipMemGetInfo(&freeB, &totalB));
         double budget = 0.9 * ((double)freeB + (double)cache_bytes(d->device));  // idle cached blocks are ours to reuse or drop
         if (const char *mb = getenv("CPECAN_MEM_BUDGET_MB")) budget = 1048576.0 * atof(mb);  // test / diagnostic knob
-        double need = fixed, floorNeed = fixed;
-        for (const LaunchClass &c : d->classes) {
-            need += c.slotBytes() * (double)c.subSlots;
-            floorNeed += c.slotBytes() * (double)(c.subSlots / (c.waves > 0 ? c.waves : 1));  // one wave each
+        // split classes keep one ring per REGION (it holds every segment of the region), nothing per slot
+        auto planSplit = [&]() {
+            for (LaunchClass &c : d->classes) {
+                if (!c.split) continue;
+                c.ringTotal = 0;
+                for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++)
+                    c.ringTotal += regions[di].cells + regions[di].maxWidth;
+                c.ringEl = 0;
+            }
+        };
+        auto unsplit = [&]() {  // back to one wave per region with a per-wave ring
+            for (LaunchClass &c : d->classes) {
+                if (!c.split) continue;
+                c.split = false;
+                c.fn = pick_kernel(c.geo);
+                c.fnTrace = nullptr;
+                c.subSlots = c.waves;
+                c.itemCount = 0;
+                c.ringTotal = 0;
+                c.ringEl = c.geo.ringCells * S;
+            }
+        };
+        planSplit();
+        double need = 0, floorNeed = 0;
+        auto tally = [&]() {
+            need = floorNeed = fixed;
+            for (const LaunchClass &c : d->classes) {
+                need += c.slotBytes() * (double)c.subSlots + 8.0 * S * (double)c.ringTotal;
+                floorNeed += c.slotBytes() * (double)(c.subSlots / (c.waves > 0 ? c.waves : 1)) + 8.0 * S * (double)c.ringTotal;
+            }
+        };
+        tally();
+        if (need > budget) {  // whole-region rings are a luxury: give them up before giving up resident waves
+            unsplit();
+            tally();
         }
         if (floorNeed > budget) {
             cpk_set_error("out of device memory: the batch needs %.0f MB with one resident wave per size class, %.0f MB are free",
@@ -635,16 +707,19 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             c.oBring = oBring;
             c.oGroll = oGroll;
             c.oExpect = oExpect;
-            oRing += c.subSlots * c.ringEl;
+            oRing += c.split ? c.ringTotal * S : c.subSlots * c.ringEl;
             oCand += c.subSlots * c.candEl;
             oRef += c.subSlots * c.refEl;
             oTot += c.subSlots * c.totEl;
             oBring += c.subSlots * c.bringEl;
             oGroll += c.subSlots * c.grollEl;
             oExpect += (int64_t)c.waves * 128;
-            d->totalWaves += c.waves * (c.threads / CPK_WAVE);
-            if (c.ldsBytes > 64 * 1024)
+            d->totalWaves += (c.split && c.wavesTrace > c.waves ? c.wavesTrace : c.waves) * (c.threads / CPK_WAVE);
+            if (c.ldsBytes > 64 * 1024) {
                 HIP_TRY(hipFuncSetAttribute((const void *)c.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.ldsBytes));
+                if (c.fnTrace)
+                    HIP_TRY(hipFuncSetAttribute((const void *)c.fnTrace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.ldsBytes));
+            }
         }
         if (int rc = dev_alloc(d, &d->dRing, (size_t)oRing)) return rc;
         if (int rc = dev_alloc(d, &d->dCand, (size_t)oCand)) return rc;
@@ -666,11 +741,41 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (int rc = dev_alloc(d, &d->dForward, (size_t)geo->nRegions)) return rc;
     if (int rc = dev_alloc(d, &d->dCounts, (size_t)nLists * geo->nRegions)) return rc;
     if (int rc = dev_alloc(d, &d->dSegStarts, (size_t)nLists * nSegs)) return rc;
+    if (int rc = dev_alloc(d, &d->dSegCounts, (size_t)nLists * nSegs)) return rc;
+    // split classes: the regions get rings of their own (no wrap: every segment stays readable) and their tracebacks
+    // become queue items, longest first
+    std::vector<CpkItem> items;
+    {
+        for (LaunchClass &c : d->classes) {
+            if (!c.split) continue;
+            int64_t ringAt = 0;  // in cells, from the class's ring pointer (dRing + oRing)
+            c.itemBase = (int64_t)items.size();
+            std::vector<std::pair<int64_t, CpkItem>> byCost;
+            for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++) {
+                CpkRegion &rg = regions[di];
+                rg.ringCap = (int32_t)(rg.cells + rg.maxWidth);
+                rg.ringBase = ringAt;
+                rg.split = 1;
+                ringAt += rg.ringCap;
+                for (int32_t si = 0; si < rg.nSeg; si++) {
+                    const CpkSegment &sg = segs[rg.segOff + si];
+                    byCost.push_back({(int64_t)(sg.dTop - sg.tbPrev) * rg.maxWidth, CpkItem{(int32_t)di, si}});
+                }
+            }
+            std::stable_sort(byCost.begin(), byCost.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
+            for (const auto &e : byCost) items.push_back(e.second);
+            c.itemCount = (int64_t)items.size() - c.itemBase;
+        }
+    }
+    if (int rc = dev_alloc(d, &d->dItems, items.empty() ? 1 : items.size())) return rc;
     if (int rc = dev_alloc(d, &d->dTriples, (size_t)nLists * outTriplesPerList * 3)) return rc;
-    if (int rc = dev_alloc(d, &d->dQueue, (size_t)kMaxClasses)) return rc;
+    if (int rc = dev_alloc(d, &d->dQueue, (size_t)2 * kMaxClasses)) return rc;
     hipStream_t io = d->io;
     HIP_TRY(hipMemsetAsync(d->dCounts, 0, sizeof(int32_t) * (size_t)nLists * geo->nRegions, io));
     HIP_TRY(hipMemsetAsync(d->dSegStarts, 0, sizeof(int32_t) * (size_t)nLists * (nSegs ? nSegs : 1), io));
+    HIP_TRY(hipMemsetAsync(d->dSegCounts, 0, sizeof(int32_t) * (size_t)nLists * (nSegs ? nSegs : 1), io));
+    if (!items.empty())
+        HIP_TRY(hipMemcpyAsync(d->dItems, items.data(), sizeof(CpkItem) * items.size(), hipMemcpyHostToDevice, io));
     if (geo->debug) {
         if (int rc = dev_alloc(d, &d->dDbgFb, (size_t)dbgCells)) return rc;
         if (int rc = dev_alloc(d, &d->dDbgTotals, (size_t)dbgDiags)) return rc;
@@ -704,7 +809,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     return CPECAN_OK;
 }
 
-extern "C" int cpk_device_update_regions(CpkDevice *d, const CpkRegion *regions, int64_t outTriplesPerList) {
+extern "C" int cpk_device_update_regions(CpkDevice *d, const CpkRegion *regions, const CpkSegment *segs, int64_t outTriplesPerList) {
     CPK_ON_DEVICE(d->device);
     batch_quiesce(d);  // the run that overflowed has finished with the triples and the regions
     if (outTriplesPerList != d->outTriplesPerList) {
@@ -716,6 +821,8 @@ extern "C" int cpk_device_update_regions(CpkDevice *d, const CpkRegion *regions,
         if (int rc = dev_alloc(d, &d->dTriples, (size_t)d->nLists * outTriplesPerList * 3)) return rc;
     }
     HIP_TRY(hipMemcpyAsync(d->dRegions, regions, sizeof(CpkRegion) * (size_t)d->geo.nRegions, hipMemcpyHostToDevice, d->io));
+    if (segs && d->nSegs > 0)
+        HIP_TRY(hipMemcpyAsync(d->dSegs, segs, sizeof(CpkSegment) * (size_t)d->nSegs, hipMemcpyHostToDevice, d->io));
     HIP_TRY(hipStreamSynchronize(d->io));
     return CPECAN_OK;
 }
@@ -756,6 +863,8 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.bring = d->dBring;
     a.outCounts = d->dCounts;
     a.segStarts = d->dSegStarts;
+    a.segCounts = d->dSegCounts;
+    a.items = d->dItems;
     a.triples = d->dTriples;
     a.outTriplesPerList = d->outTriplesPerList;
     a.nSegsTotal = d->nSegs;
@@ -764,7 +873,7 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.expectOut = d->dExpect;
     a.dbgFb = d->dDbgFb;
     a.dbgTotals = d->dDbgTotals;
-    HIP_TRY(hipMemsetAsync(d->dQueue, 0, kMaxClasses * sizeof(unsigned int), st));
+    HIP_TRY(hipMemsetAsync(d->dQueue, 0, 2 * kMaxClasses * sizeof(unsigned int), st));
     if (d->geo.emit == CPECAN_EMIT_EXPECT)
         HIP_TRY(hipMemsetAsync(d->dExpect, 0, sizeof(double) * 128 * (size_t)(d->totalWaves > 0 ? d->totalWaves : 1), st));
     HIP_TRY(hipEventRecord(d->evStart, st));
@@ -792,6 +901,14 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
         if (!onCaller) HIP_TRY(hipStreamWaitEvent(cs, d->evStart, 0));
         hipLaunchKernelGGL(c.fn, dim3((unsigned)c.waves), dim3((unsigned)c.threads), c.ldsBytes, cs, p);
         HIP_TRY(hipGetLastError());
+        if (c.split) {  // the tracebacks of the class's regions, one queue item each, behind the forward launch
+            KArgs t = p;
+            t.items = d->dItems + c.itemBase;
+            t.regionCount = (int32_t)c.itemCount;
+            t.queue = d->dQueue + kMaxClasses + i;
+            hipLaunchKernelGGL(c.fnTrace, dim3((unsigned)c.wavesTrace), dim3((unsigned)c.threads), c.ldsBytes, cs, t);
+            HIP_TRY(hipGetLastError());
+        }
         if (!onCaller) HIP_TRY(hipEventRecord(d->sideDone[i], cs));
     }
     for (int i = 0; i + 1 < nClasses; i++)  // join: the caller's stream continues when every class is done
@@ -802,8 +919,8 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     return CPECAN_OK;
 }
 
-extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segStarts, double *expect, double *kernelMs,
-                                   double *d2hMs) {
+extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segStarts, int32_t *segCounts, double *expect,
+                                   double *kernelMs, double *d2hMs) {
     CPK_ON_DEVICE(d->device);
     if (!d->ran) {
         cpk_set_error("download before run");
@@ -818,6 +935,7 @@ extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segSt
     HIP_TRY(hipEventRecord(d->evA, io));
     HIP_TRY(hipMemcpyAsync(counts, d->dCounts, sizeof(int32_t) * (size_t)d->nLists * d->geo.nRegions, hipMemcpyDeviceToHost, io));
     HIP_TRY(hipMemcpyAsync(segStarts, d->dSegStarts, sizeof(int32_t) * (size_t)d->nLists * d->nSegs, hipMemcpyDeviceToHost, io));
+    HIP_TRY(hipMemcpyAsync(segCounts, d->dSegCounts, sizeof(int32_t) * (size_t)d->nLists * d->nSegs, hipMemcpyDeviceToHost, io));
     HIP_TRY(hipEventRecord(d->evB, io));
     HIP_TRY(hipStreamSynchronize(io));
     HIP_TRY(hipEventElapsedTime(&ms, d->evA, d->evB));

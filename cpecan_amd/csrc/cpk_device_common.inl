@@ -36,6 +36,8 @@ struct KArgs {
     double *bring;     // [slots][fbCells*S]     expectation emitter: backward values of the emitted cells of the segment
     int32_t *outCounts;  // [nLists][nRegions]
     int32_t *segStarts;  // [nLists][nSegsTotal]
+    int32_t *segCounts;  // [nLists][nSegsTotal]  triples of a segment (split classes: their segments are written apart)
+    const CpkItem *items;  // (region, segment) queue of a split class's traceback launch
     int32_t *triples;    // [nLists][outTriplesPerList*3]
     int64_t outTriplesPerList;
     int64_t nSegsTotal;

@@ -970,7 +970,18 @@ __device__ __forceinline__ void fill_weights(double *wt, const CpkModel &m, cons
 // EMIT: CPECAN_EMIT_MATCH (0), CPECAN_EMIT_INDEL (1) or kEmitForward (3: forward sweep only, total probability out)
 constexpr int kEmitForward = 3;
 
-template <int S, bool FAST, int EMIT>
+// MODE: how a launch uses the kernel.
+//   kModeWhole    a queue of REGIONS; a wave takes a region through forward sweeps and tracebacks, segment by segment, with
+//                 the forward values of ONE segment in its per-wave ring (the default)
+//   kModeForward  a queue of regions; forward sweep of the whole region into the REGION's own ring, no traceback
+//   kModeTrace    a queue of (region, segment) ITEMS; traceback, totals and emission of one segment from the region's ring
+// The last two are the two launches of a SPLIT class (cpecan_kernels.hip): when a class has fewer regions than the
+// chip has wave slots (BASELINE config A: 1000 regions on 2048 slots; a strong-scaled batch on 8 GPUs), the tracebacks
+// of a region -- independent of each other once its forward values exist (the backward sweep of a segment starts from
+// a constant end-state vector, pairwiseAligner.c:798) -- become queue items of their own and fill the idle slots.
+constexpr int kModeWhole = 0, kModeForward = 1, kModeTrace = 2;
+
+template <int S, bool FAST, int EMIT, int MODE = kModeWhole>
 __global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(CPK_SWEEP_WAVES, CPK_SWEEP_WAVES)))
 cpecan_pairhmm_sweep(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -1015,7 +1026,9 @@ cpecan_pairhmm_sweep(const KArgs a) {
         const unsigned int ticket = atomicAdd(a.queue, lane == 0 ? 1u : 0u);
         const int tk = __builtin_amdgcn_readfirstlane((int)ticket);
         if (tk >= a.regionCount) break;
-        const int r = a.regionBase + tk;
+        // kModeTrace: the queue holds (region, segment) items, longest first; otherwise regions
+        const int r = MODE == kModeTrace ? a.items[tk].region : a.regionBase + tk;
+        const int itemSeg = MODE == kModeTrace ? a.items[tk].seg : 0;
 
         const CpkRegion &rg = a.regions[r];
         const int lX = rg.lX, lY = rg.lY, N = lX + lY;
@@ -1043,7 +1056,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                           em,
                           wt,
                           lg,
-                          a.ring + slot * (size_t)a.geo.ringCells * S,
+                          MODE == kModeWhole ? a.ring + slot * (size_t)a.geo.ringCells * S : a.ring + (size_t)rg.ringBase * S,
                           a.cand + slot * (size_t)a.geo.fbCells * (EMIT == CPECAN_EMIT_INDEL ? 3 : 1),
                           stageLds,
                           a.cbuf + slot * (size_t)a.geo.refreshCells,
@@ -1100,7 +1113,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
             sw.dc.load(0);
             // diagonal 0: the single cell (0,0) holds the start prior (pairwiseAligner.c:776-777)
             const double *startPrior = rg.raggedLeft ? m.raggedStart : m.start;
-            {
+            if (MODE != kModeTrace) {
                 const CpkDiag g0 = sw.dc.get(0, false);
                 double *cur = sw.fbuf1(0);
                 double *o0 = sw.ringAt(g0);
@@ -1114,14 +1127,15 @@ cpecan_pairhmm_sweep(const KArgs a) {
             }
             int d = 1;
             int emitSeg = 0, emitFrom = a.segs[rg.segOff].tbFrom;  // the segment whose traceback emits diagonal d: the first with tbFrom >= d
-            for (int si = 0; si < rg.nSeg; si++) {
+            const int siFirst = MODE == kModeTrace ? itemSeg : 0, siEnd = MODE == kModeTrace ? itemSeg + 1 : rg.nSeg;
+            for (int si = siFirst; si < siEnd; si++) {
                 const CpkSegment sg = a.segs[rg.segOff + si];
                 // Which states of F[d] the traceback will read back: the match row always (posteriors), every state on the
                 // refresh points of the segment that emits d (cell dot products, pairwiseAligner.c:636-653; the schedule is
                 // known up front) and on the two diagonals the forward sweep is resumed from; the indel and expectation
                 // emitters read every state of every diagonal.  For the match emitter this cuts the ring stores from 8*S to
                 // ~8 + 0.8*(S-1) bytes per cell.
-                while (d <= sg.dTop) {
+                while (MODE != kModeTrace && d <= sg.dTop) {
                     sw.dc.load(d);  // table entries of diagonals d .. d+63
                     const int dEnd = d + CPK_WAVE - 1 < sg.dTop ? d + CPK_WAVE - 1 : sg.dTop;
                     for (; d <= dEnd; d++) {
@@ -1131,7 +1145,8 @@ cpecan_pairhmm_sweep(const KArgs a) {
                         else sw.forward(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
                     }
                 }
-                if (FAST) sw.flushTail();  // the traceback needs every cell of dTop
+                if (FAST && MODE != kModeTrace) sw.flushTail();  // the traceback needs every cell of dTop
+                if (MODE == kModeForward) continue;  // the tracebacks of this region are items of the next launch
 #ifdef CPK_DIAGNOSTICS
                 if (a.geo.debug & 2) continue;  // diagnostic build only: time the forward sweep alone (no traceback, no output)
 #endif
@@ -1147,12 +1162,23 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 if (EMIT == CPECAN_EMIT_EXPECT) sw.expectations(sg, tAcc, eLds, likelihood);
 #pragma unroll
                 for (int l = 0; l < (EMIT == CPECAN_EMIT_EXPECT ? 0 : NL); l++) {
-                    if (lane == 0) a.segStarts[(size_t)l * a.nSegsTotal + rg.segOff + si] = count[l];
-                    count[l] = sw.emitMatches(sg, sw.cand + (size_t)l * a.geo.fbCells, nCand[l],
-                                              a.triples + 3 * ((size_t)l * a.outTriplesPerList + rg.outOff), rg.outCap,
-                                              count[l]);
+                    if (MODE == kModeTrace) {
+                        // the segment's own part of the region's output slice (the other segments are written by other waves)
+                        const int n = sw.emitMatches(sg, sw.cand + (size_t)l * a.geo.fbCells, nCand[l],
+                                                     a.triples + 3 * ((size_t)l * a.outTriplesPerList + rg.outOff + sg.outOff),
+                                                     sg.outCap, 0);
+                        if (lane == 0) {
+                            a.segStarts[(size_t)l * a.nSegsTotal + rg.segOff + si] = sg.outOff;
+                            a.segCounts[(size_t)l * a.nSegsTotal + rg.segOff + si] = n;
+                        }
+                    } else {
+                        if (lane == 0) a.segStarts[(size_t)l * a.nSegsTotal + rg.segOff + si] = count[l];
+                        count[l] = sw.emitMatches(sg, sw.cand + (size_t)l * a.geo.fbCells, nCand[l],
+                                                  a.triples + 3 * ((size_t)l * a.outTriplesPerList + rg.outOff), rg.outCap,
+                                                  count[l]);
+                    }
                 }
-                if (!sg.atEnd) {
+                if (MODE == kModeWhole && !sg.atEnd) {
                     // the traceback reused the rolling buffers: restore F[dTop-1], F[dTop] for the forward sweep
                     const CpkDiag gTopM1 = sw.dc.get(sg.dTop - 1, false);
                     const CpkDiag gTop = sw.dc.get(sg.dTop, false);
@@ -1165,7 +1191,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
         }
 #pragma unroll
         for (int l = 0; l < NL; l++)
-            if (lane == 0) a.outCounts[(size_t)l * a.geo.nRegions + r] = count[l];
+            if (MODE == kModeWhole && lane == 0) a.outCounts[(size_t)l * a.geo.nRegions + r] = count[l];
     }
     if (EMIT == CPECAN_EMIT_EXPECT) {
         // one partial result per resident wave: [0,25) transitions [from*S+to], [25,105) emissions, [105] likelihood

@@ -945,3 +945,34 @@ def test_encode_human_chimp_full_length_gpu():
     got2 = api.getAlignedPairsUsingAnchors(api.stateMachine5_construct(), sx, sy, anchors, p2)
     want2 = ob.aligned_pairs(ob.model(ob.FIVE_STATE), sx, sy, anchors, ob.params(splitMatrixBiggerThanThis=100, **kw))
     assert_pairs_match(got2, want2, threshold=p.threshold)
+
+
+# ---- split classes: the tracebacks of a region as queue items of their own (fills the chip when regions < wave slots) ----
+def test_split_classes_equal_whole_region_waves(monkeypatch):
+    """A class with fewer regions than the chip has wave slots runs as two launches: forward sweeps of whole regions into
+    per-region rings, then one queue item per (region, traceback segment).  Forced on (CPECAN_SPLIT=1) over a mixed batch
+    -- multi-segment 2 kb pairs, short-schedule pairs, single-segment and empty regions, split rectangles, thresholds down
+    to 0 (every cell emitted: the per-segment output slices overflow and the batch re-runs) -- it must give, list for
+    list, what one wave per region gives (CPECAN_SPLIT=0), and the oracle's lists."""
+    rng = random.Random(1207)
+    cases = []
+    probs = [make_pair(3, i, 2000, 100) for i in range(6)] + [make_pair(2, i, 1000, 50) for i in range(6)]
+    cases.append((0, probs, dict(diagonalExpansion=100)))
+    cases.append((2, [make_pair(2, i, 1000, 50) for i in range(12)], dict(diagonalExpansion=50)))
+    fz, rg = _fuzz_problems(rng, 50, 20)
+    cases.append((0, fz, dict(diagonalExpansion=20, minDiagsBetweenTraceBack=60, traceBackDiagonals=7, splitMatrixBiggerThanThis=900)))
+    cases.append((0, [make_pair(7, i, 700, 20) for i in range(4)] + [("", "", ()), ("ACGT", "", ())],
+                  dict(diagonalExpansion=20, minDiagsBetweenTraceBack=90, traceBackDiagonals=10, threshold=0.0)))
+    for mtype, problems, pkw in cases:
+        monkeypatch.setenv("CPECAN_SPLIT", "0")
+        whole, st0 = _run_batch(mtype, problems, **pkw)
+        monkeypatch.setenv("CPECAN_SPLIT", "1")
+        split, st1 = _run_batch(mtype, problems, **pkw)
+        assert st1.cells == st0.cells
+        for a, b in zip(split, whole):
+            assert np.array_equal(a, b)
+        om, op = ob.model(mtype), ob.params(**pkw)
+        for i in range(0, len(problems), 5):
+            sx, sy, an = problems[i]
+            assert_pairs_match(split[i], ob.aligned_pairs(om, sx, sy, an, op), threshold=op.threshold)
+    monkeypatch.delenv("CPECAN_SPLIT")

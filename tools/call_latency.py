@@ -4,8 +4,11 @@ from cpecan_amd import api
 from cpecan_amd.workload import make_pair
 p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=20)
 sm = api.stateMachine5_construct()
-for L in (100, 1000):
-    sx, sy, a = make_pair(3, 0, L, 20)
+# usage: python tools/call_latency.py   (CPECAN_SPLIT=0: one wave per region; unset: tracebacks as queue items when the
+# launch leaves wave slots idle, as a lone pair does)
+for L, E in ((100, 20), (1000, 20), (2000, 100), (10000, 100)):
+    p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=E)
+    sx, sy, a = make_pair(3, 0, L, E)
     api.getAlignedPairsUsingAnchors(sm, sx, sy, a, p)
     t = time.time()
     n = 50
