@@ -232,7 +232,10 @@ def main():
     upload_s = time.perf_counter() - t0
     st = batch.stats()
     cells = st.cells
-    stream = torch.cuda.current_stream()
+    # An explicit (non-blocking) stream, not the legacy null stream: work on the null stream synchronises implicitly with
+    # other streams, which would serialise a batch's sweep with the copies of the batches before and after it.
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
 
     def barrier():
         torch.cuda.synchronize()
@@ -310,14 +313,23 @@ def main():
         prev = make_batch()
         prev.run(stream.cuda_stream)
         pairs_out, t_first = 0, None
+        trace = os.environ.get("CPECAN_BENCH_TRACE") == "1"
         for _ in range(1, nb):
+            ta = time.perf_counter()
             cur = make_batch()
+            tb = time.perf_counter()
             cur.run(stream.cuda_stream)
             prev.download()
+            tc = time.perf_counter()
             if t_first is None:
                 t_first = time.perf_counter()  # the first batch's lists are on the host: the pipeline is full from here
-            pairs_out += int(prev.stats().pairs)
+            pst = prev.stats()
+            pairs_out += int(pst.pairs)
+            kms, dms = pst.kernelMs, pst.d2hMs
             prev.close()
+            if trace and rank == 0:
+                print("pipeline: pack+plan+upload %.1f ms, run+download(prev) %.1f ms (its kernel %.1f ms, d2h %.1f ms), close(prev) %.1f ms"
+                      % (1e3 * (tb - ta), 1e3 * (tc - tb), kms, dms, 1e3 * (time.perf_counter() - tc)), file=sys.stderr, flush=True)
             prev = cur
         prev.download()
         t_last = time.perf_counter()
@@ -417,6 +429,25 @@ def main():
                     want = ob.aligned_pairs(om, sx, sy, a, op, rl, rr)
                     assert_pairs_match(batch.result(i), want, threshold=params.threshold)
                 out["parity_spot_check"] = "4 pairs match the oracle"
+            else:
+                # the expectation emitter: a batch of the first 32 problems against the oracle's counts (1e-5 relative)
+                nchk = min(32, len(problems))
+                acc = api.hmm_constructEmpty(0.0, mtype)
+                with api.Batch(sm, params, emit=api.EMIT_EXPECT, device=local_rank) as cb:
+                    cb.add_many(problems[:nchk])
+                    cb.upload()
+                    cb.run()
+                    cb.download()
+                    cb.expectations(acc)
+                oacc = ob.hmm(ob.FIVE_STATE if cfg["model"] == "fiveState" else ob.THREE_STATE, 0.0)
+                rgd = bool(cfg.get("ragged"))
+                ob.batch_expectations(om, problems[:nchk], op, oacc, rgd, rgd, threads=threads)
+                for i in range(S * S):
+                    assert abs(acc.transitions[i] - oacc.T[i]) <= 1e-5 * abs(oacc.T[i]) + 1e-9, ("T", i)
+                for i in range(S * 16):
+                    assert abs(acc.emissions[i] - oacc.E[i]) <= 1e-5 * abs(oacc.E[i]) + 1e-9, ("E", i)
+                assert abs(acc.likelihood - oacc.likelihood) <= 1e-9 * abs(oacc.likelihood)
+                out["parity_spot_check"] = "expectation counts of %d problems match the oracle to 1e-5" % nchk
         print(json.dumps(out), flush=True)
     batch.close()
     if world > 1:

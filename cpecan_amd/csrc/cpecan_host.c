@@ -497,8 +497,6 @@ int cpecan_device_count(void) { return cpk_device_count(); }
 int cpecan_current_device(void) { return cpk_current_device(); }
 const char *cpecan_last_error(void) { return cpk_last_error(); }
 
-static void init_byte_tables(void);
-
 int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpecan_params *params, int emit,
                         int device) {
     if (!out || !model || !params) return CPECAN_EINVAL;
@@ -515,7 +513,6 @@ int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpe
         return CPECAN_EINVAL;
     }
     /* The GPU is bound at upload time: adding problems and planning (bands, schedules) are host-only integer work. */
-    init_byte_tables();
     cpecan_batch *b = calloc(1, sizeof *b);
     if (!b) return CPECAN_ENOMEM;
     b->model = *model;
@@ -565,7 +562,10 @@ int cpecan_batch_set_debug(cpecan_batch *b, int on) {
 
 /* symbol_convertCharToSymbol (pairwiseAligner.c:317-334) and toupper as byte tables: both run over every base added */
 static uint8_t g_symbolOf[256], g_upperOf[256];
-static void init_byte_tables(void) { /* idempotent: every caller writes the same values */
+/* Filled ONCE, when the library is loaded.  (Round 1 refilled them in every cpecan_batch_create, resetting every entry to
+ * N first: a batch created on one host thread while another thread converted bases saw A/C/G/T as N for an instant --
+ * the intermittent mismatch of the two-host-thread test, found in round 2.) */
+__attribute__((constructor)) static void init_byte_tables(void) {
     for (int c = 0; c < 256; c++) {
         g_symbolOf[c] = CPK_SYM_N;
         g_upperOf[c] = (uint8_t)((c >= 'a' && c <= 'z') ? c - 'a' + 'A' : c);

@@ -255,6 +255,12 @@ struct CpkDevice {
     // kernel of batch k runs (a pipeline of batches from one host thread, or batches on several host threads).
     hipStream_t io = nullptr;
     double kernelMsAccum = 0.0;  // launches before the last one (an overflow re-run)
+    // Host-to-device copies go through this pinned buffer of the shell's own.  A copy from the caller's pageable memory
+    // makes the runtime pin and unpin those pages around the transfer -- GPU page-table updates that stall whatever
+    // kernel is running: a batch uploaded beside another batch's sweep cost that sweep 25-30 ms
+    // (profiles/r02_interference.txt).
+    void *hStage = nullptr;
+    size_t hStageBytes = 0;
     // every class but the first runs beside it on a stream of its own (fork / join around cpk_device_run)
     hipStream_t sideStream[kMaxClasses] = {};
     hipEvent_t sideDone[kMaxClasses] = {};
@@ -274,6 +280,7 @@ extern "C" int cpk_current_device(void) {
 }
 
 static void shell_delete(CpkDevice *d) {  // the shell's device is current
+    if (d->hStage) (void)hipHostFree(d->hStage);
     if (d->evStart) (void)hipEventDestroy(d->evStart);
     if (d->evStop) (void)hipEventDestroy(d->evStop);
     if (d->evA) (void)hipEventDestroy(d->evA);
@@ -296,10 +303,10 @@ static int shell_init(CpkDevice *d, int device) {
     HIP_TRY(hipEventCreate(&d->evA));
     HIP_TRY(hipEventCreate(&d->evB));
     HIP_TRY(hipStreamCreateWithFlags(&d->io, hipStreamNonBlocking));
-    for (int k = 0; k < kMaxClasses; k++) {
-        HIP_TRY(hipStreamCreateWithFlags(&d->sideStream[k], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&d->sideDone[k], hipEventDisableTiming));
-    }
+    // The side streams of a multi-class batch are created when a batch first needs them (cpk_device_run): the runtime
+    // maps streams onto a handful of hardware queues (4 by default), and ten idle streams per shell put a batch's sweep
+    // into the same hardware queue as another batch's copies -- a pipeline of batches then ran its sweeps ~100 ms late
+    // (profiles/r02_pipeline_trace.txt).
     return CPECAN_OK;
 }
 
@@ -432,6 +439,31 @@ static KernelFn pick_kernel(const CpkGeometry &g) {
     CPK_PICK(kEmitForward)
 #undef CPK_PICK
     return nullptr;
+}
+
+// Queues dst <- src (host) on the batch's stream through the shell's pinned buffer; `at` is the running offset in it.
+static int staged_h2d(CpkDevice *d, void *dst, const void *src, size_t bytes, size_t *at) {
+    if (bytes == 0) return CPECAN_OK;
+    const size_t off = (*at + 255) / 256 * 256;
+    if (off + bytes > d->hStageBytes) {
+        cpk_set_error("internal: staging buffer too small");
+        return CPECAN_ESTATE;
+    }
+    memcpy((char *)d->hStage + off, src, bytes);
+    HIP_TRY(hipMemcpyAsync(dst, (char *)d->hStage + off, bytes, hipMemcpyHostToDevice, d->io));
+    *at = off + bytes;
+    return CPECAN_OK;
+}
+static int stage_reserve(CpkDevice *d, size_t bytes) {
+    if (bytes <= d->hStageBytes) return CPECAN_OK;
+    HIP_TRY(hipStreamSynchronize(d->io));
+    if (d->hStage) (void)hipHostFree(d->hStage);
+    d->hStage = nullptr;
+    d->hStageBytes = 0;
+    const size_t want = (bytes + (bytes >> 2) + (1u << 20)) / 4096 * 4096;
+    HIP_TRY(hipHostMalloc(&d->hStage, want, hipHostMallocDefault));
+    d->hStageBytes = want;
+    return CPECAN_OK;
 }
 
 extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const CpkModel *model, CpkRegion *regions,
@@ -774,8 +806,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     HIP_TRY(hipMemsetAsync(d->dCounts, 0, sizeof(int32_t) * (size_t)nLists * geo->nRegions, io));
     HIP_TRY(hipMemsetAsync(d->dSegStarts, 0, sizeof(int32_t) * (size_t)nLists * (nSegs ? nSegs : 1), io));
     HIP_TRY(hipMemsetAsync(d->dSegCounts, 0, sizeof(int32_t) * (size_t)nLists * (nSegs ? nSegs : 1), io));
-    if (!items.empty())
-        HIP_TRY(hipMemcpyAsync(d->dItems, items.data(), sizeof(CpkItem) * items.size(), hipMemcpyHostToDevice, io));
+
     if (geo->debug) {
         if (int rc = dev_alloc(d, &d->dDbgFb, (size_t)dbgCells)) return rc;
         if (int rc = dev_alloc(d, &d->dDbgTotals, (size_t)dbgDiags)) return rc;
@@ -785,20 +816,27 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
 
     // Everything below is ordered on the batch's own stream and the call returns when that stream is done (the host
     // buffers are the caller's); a failure in between leaves nothing behind: the anchor block is one of the batch's.
+    size_t stageAt = 0;
+    if (int rc = stage_reserve(d, sizeof(CpkRegion) * (size_t)geo->nRegions + sizeof(int64_t) * 3 * (size_t)(nAnchors > 0 ? nAnchors : 1) +
+                                  sizeof(CpkSegment) * (size_t)nSegs + (size_t)nSymbolBytes + sizeof(CpkModel) +
+                                  sizeof(CpkItem) * items.size() + 8 * 256))
+        return rc;
+    if (!items.empty())
+        if (int rc = staged_h2d(d, d->dItems, items.data(), sizeof(CpkItem) * items.size(), &stageAt)) return rc;
     HIP_TRY(hipEventRecord(d->evA, io));
-    HIP_TRY(hipMemcpyAsync(d->dRegions, regions, sizeof(CpkRegion) * (size_t)geo->nRegions, hipMemcpyHostToDevice, io));
+    if (int rc = staged_h2d(d, d->dRegions, regions, sizeof(CpkRegion) * (size_t)geo->nRegions, &stageAt)) return rc;
     {
         // anchors -> per-diagonal table, on the device (the anchors are only needed for this)
         int64_t *dAnchors = nullptr;
         if (int rc = dev_alloc(d, &dAnchors, 3 * (size_t)(nAnchors > 0 ? nAnchors : 1))) return rc;
         if (nAnchors > 0)
-            HIP_TRY(hipMemcpyAsync(dAnchors, anchors, sizeof(int64_t) * 3 * (size_t)nAnchors, hipMemcpyHostToDevice, io));
+            if (int rc = staged_h2d(d, dAnchors, anchors, sizeof(int64_t) * 3 * (size_t)nAnchors, &stageAt)) return rc;
         hipLaunchKernelGGL(cpecan_build_diag_table, dim3((unsigned)((geo->nRegions + 63) / 64)), dim3(64), 0, io,
                            d->dRegions, geo->nRegions, dAnchors, d->dDiags, expansion, dynamic);
         HIP_TRY(hipGetLastError());
-        HIP_TRY(hipMemcpyAsync(d->dSegs, segs, sizeof(CpkSegment) * (size_t)nSegs, hipMemcpyHostToDevice, io));
-        HIP_TRY(hipMemcpyAsync(d->dSymbols, symbols, (size_t)nSymbolBytes, hipMemcpyHostToDevice, io));
-        HIP_TRY(hipMemcpyAsync(d->dModel, model, sizeof(CpkModel), hipMemcpyHostToDevice, io));
+        if (int rc = staged_h2d(d, d->dSegs, segs, sizeof(CpkSegment) * (size_t)nSegs, &stageAt)) return rc;
+        if (int rc = staged_h2d(d, d->dSymbols, symbols, (size_t)nSymbolBytes, &stageAt)) return rc;
+        if (int rc = staged_h2d(d, d->dModel, model, sizeof(CpkModel), &stageAt)) return rc;
         HIP_TRY(hipEventRecord(d->evB, io));
         HIP_TRY(hipStreamSynchronize(io));
         dev_release(d, dAnchors);
@@ -897,6 +935,10 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
         p.expectOut = d->dExpect + c.oExpect;
         p.queue = d->dQueue + i;
         const bool onCaller = i == nClasses - 1;
+        if (!onCaller && !d->sideStream[i]) {
+            HIP_TRY(hipStreamCreateWithFlags(&d->sideStream[i], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&d->sideDone[i], hipEventDisableTiming));
+        }
         hipStream_t cs = onCaller ? st : d->sideStream[i];
         if (!onCaller) HIP_TRY(hipStreamWaitEvent(cs, d->evStart, 0));
         hipLaunchKernelGGL(c.fn, dim3((unsigned)c.waves), dim3((unsigned)c.threads), c.ldsBytes, cs, p);

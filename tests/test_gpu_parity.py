@@ -849,11 +849,11 @@ def test_pipelined_batches_equal_unpipelined_ones():
         t.start()
     for t in ts:
         t.join()
-    for got in (piped, threaded):
-        for g, w in zip(got, serial):
-            assert g is not None and len(g) == len(w)
-            for a, b in zip(g, w):
-                assert np.array_equal(a, b)
+    for name, got in (("pipelined", piped), ("two host threads", threaded)):
+        for k, (g, w) in enumerate(zip(got, serial)):
+            assert g is not None and len(g) == len(w), (name, k)
+            for i, (a, b) in enumerate(zip(g, w)):
+                assert np.array_equal(a, b), (name, "job", k, "problem", i, len(a), len(b))
 
 
 def test_entry_points_leave_the_callers_current_device_alone():
