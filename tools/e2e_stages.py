@@ -1,16 +1,17 @@
-"""diagnostic: wall time of every stage of a config-B batch, batch after batch (serial), then two in flight.
-usage: python tools/e2e_stages.py [pairs]"""
+"""diagnostic: wall time of every stage of a batch of one bench config, batch after batch (serial), then two in flight.
+usage: python tools/e2e_stages.py [pairs] [config]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from cpecan_amd import api, workload
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+import bench
+name = sys.argv[2] if len(sys.argv) > 2 else "B"
+cfg = workload.CONFIGS[name]
+n = int(sys.argv[1]) if len(sys.argv) > 1 else cfg["n_pairs"]
 torch.zeros(1, device="cuda"); torch.cuda.synchronize()
-cfg = workload.CONFIGS["B"]
-sm = api.stateMachine5_construct(api.fiveState)
-p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=cfg["expansion"], splitMatrixBiggerThanThis=10 ** 15)
-probs = workload.config_problems("B", range(n))
+sm, p, _ = bench.model_and_params(api, cfg)
+probs = workload.config_problems(name, range(n))
 arr, cnt, keep = api.Batch.prepare_problems(probs)
 T = time.perf_counter
 
