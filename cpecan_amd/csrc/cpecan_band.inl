@@ -17,8 +17,14 @@
 #define CPK_HD static inline
 #endif
 
+/* The batch's own copy of the anchors: 32-bit values (coordinates are below 2^30), `stride` of them per anchor -- (x, y)
+ * for a fixed expansion, (x, y, expansion) for per-anchor expansions.  At 8 bytes an anchor instead of the API's 24 the
+ * anchors of a realignment batch (one per aligned column) stop being the largest upload. */
+typedef int32_t cpk_anchor_t;
+
 typedef struct {
-    const int64_t *anchors; /* triples (x, y, expansion), coordinates relative to the region */
+    const cpk_anchor_t *anchors; /* (x, y[, expansion]), coordinates relative to the region */
+    int stride;
     int64_t n, lX, lY;
     int64_t used;
     int64_t pX, pY;         /* previous anchor (matrix coordinates) */
@@ -31,11 +37,12 @@ typedef struct {
 CPK_HD int64_t cpk_clamp(int64_t v, int64_t hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
 
 /* Returns 0, or -1 for parameters the reference asserts on (pairwiseAligner.c:131, :186). */
-CPK_HD int cpk_band_init(CpkBandIter *it, const int64_t *anchors, int64_t n, int64_t lX, int64_t lY, int64_t expansion,
-                         int dynamic) {
+CPK_HD int cpk_band_init(CpkBandIter *it, const cpk_anchor_t *anchors, int stride, int64_t n, int64_t lX, int64_t lY,
+                         int64_t expansion, int dynamic) {
     if (lX < 0 || lY < 0) return -1;
     if (!dynamic && (expansion < 0 || expansion % 2 != 0)) return -1;
     it->anchors = anchors;
+    it->stride = stride;
     it->n = n;
     it->lX = lX;
     it->lY = lY;
@@ -63,9 +70,10 @@ CPK_HD int cpk_band_next(CpkBandIter *it, int64_t d, int64_t *xmyL, int64_t *xmy
     it->qX = it->lX;
     it->qY = it->lY;
     if (it->used < it->n) {
-        it->qX = it->anchors[3 * it->used] + 1;
-        it->qY = it->anchors[3 * it->used + 1] + 1;
-        if (it->dynamic) it->e = it->anchors[3 * it->used + 2];
+        const cpk_anchor_t *q = it->anchors + (int64_t)it->stride * it->used;
+        it->qX = (int64_t)q[0] + 1;
+        it->qY = (int64_t)q[1] + 1;
+        if (it->dynamic) it->e = q[2]; /* stride 3 whenever dynamic */
         it->used++;
         if (it->qX <= it->pX || it->qY <= it->pY || it->qX > it->lX || it->qY > it->lY || it->e < 0 || it->e % 2 != 0)
             return -1;

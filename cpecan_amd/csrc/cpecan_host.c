@@ -288,6 +288,16 @@ static void kernel_model(const cpecan_model *m, double threshold, CpkModel *k) {
 /* ------------------------------------------------------------------------------------------------
  * band and split geometry (integers only)
  * ---------------------------------------------------------------------------------------------- */
+/* CPECAN_TRACE_HOST=1: wall time of the host stages of upload and download on stderr (diagnostic) */
+static double now_ms(void) { return 1e3 * omp_get_wtime(); }
+static int trace_host(void) {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("CPECAN_TRACE_HOST");
+        v = e && atoi(e) != 0;
+    }
+    return v;
+}
 static int64_t imax(int64_t a, int64_t b) { return a > b ? a : b; }
 static int64_t imin(int64_t a, int64_t b) { return a < b ? a : b; }
 
@@ -296,16 +306,28 @@ int cpecan_band(const int64_t *anchors, int64_t nAnchors, int64_t lX, int64_t lY
                 int64_t *out) {
     const int64_t n = lX + lY + 1;
     if (n <= 0 || !out || nAnchors < 0) return CPECAN_EINVAL;
+    if (nAnchors > 0 && !anchors) return CPECAN_EINVAL;
+    int32_t *a32 = malloc(sizeof(int32_t) * 3 * (size_t)(nAnchors ? nAnchors : 1)); /* the iterator reads 32-bit values */
+    if (!a32) return CPECAN_ENOMEM;
+    int rc = CPECAN_OK;
+    for (int64_t i = 0; i < 3 * nAnchors; i++) {
+        if (anchors[i] < INT32_MIN || anchors[i] > INT32_MAX) rc = CPECAN_EINVAL;
+        a32[i] = (int32_t)anchors[i];
+    }
     CpkBandIter it;
-    if (cpk_band_init(&it, anchors, nAnchors, lX, lY, expansion, dynamic)) return CPECAN_EINVAL;
-    for (int64_t d = 0; d < n; d++) {
+    if (rc == CPECAN_OK && cpk_band_init(&it, a32, 3, nAnchors, lX, lY, expansion, dynamic)) rc = CPECAN_EINVAL;
+    for (int64_t d = 0; rc == CPECAN_OK && d < n; d++) {
         int64_t lo, hi;
-        if (cpk_band_next(&it, d, &lo, &hi)) return CPECAN_EINVAL;
+        if (cpk_band_next(&it, d, &lo, &hi)) {
+            rc = CPECAN_EINVAL;
+            break;
+        }
         out[3 * d] = d;
         out[3 * d + 1] = lo;
         out[3 * d + 2] = hi;
     }
-    return CPECAN_OK;
+    free(a32);
+    return rc;
 }
 
 /* getSplitPoints, pairwiseAligner.c:1206-1257.  A gap between consecutive anchors whose matrix exceeds
@@ -392,7 +414,8 @@ struct cpecan_batch {
     int64_t nRegions, capRegions;
     uint8_t *symbols;
     int64_t nSymbols, capSymbols;
-    int64_t *anchors;
+    int32_t *anchors; /* cpk_anchor_t: anchorStride values per anchor, coordinates relative to the region */
+    int anchorStride; /* 2: (x, y); 3: (x, y, expansion) for per-anchor expansions */
     int64_t nAnchorVals, capAnchorVals;
     /* frozen state */
     CpkRegion *devRegions; /* cost-sorted */
@@ -416,15 +439,23 @@ struct cpecan_batch {
     cpecan_stats stats;
 };
 
+/* The batch's arrays live in blocks of the host pool (cpk_host_alloc: pinned and recycled when there is a GPU). */
 static int grow(void **p, int64_t *cap, int64_t need, size_t elem) {
     if (need <= *cap) return 0;
     int64_t c = *cap ? *cap : 16;
-    while (c < need) c *= 2;
-    void *q = realloc(*p, (size_t)c * elem);
+    while (c < need) c += c < ((int64_t)1 << 20) ? c : c / 4; /* doubling while small, +25 % steps beyond */
+    void *q = cpk_host_alloc((size_t)c * elem);
     if (!q) return -1;
+    if (*p) memcpy(q, *p, (size_t)*cap * elem);
+    cpk_host_free(*p);
     *p = q;
     *cap = c;
     return 0;
+}
+static void *host_zalloc(size_t count, size_t elem) {
+    void *q = cpk_host_alloc((count ? count : 1) * elem);
+    if (q) memset(q, 0, (count ? count : 1) * elem);
+    return q;
 }
 
 int64_t cpecan_anchors_from_alignment(const int64_t *ops, int64_t nOps, int64_t start1, int64_t start2, int64_t trim,
@@ -521,6 +552,7 @@ int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpe
     b->device = device;
     b->dev = NULL;
     b->nLists = emit == CPECAN_EMIT_INDEL ? 3 : 1;
+    b->anchorStride = params->dynamicAnchorExpansion ? 3 : 2;
     b->postMatchGamma = 0.85f; /* cPecanRealign.c:355 */
     *out = b;
     return CPECAN_OK;
@@ -532,9 +564,9 @@ static void free_results(cpecan_batch *b) {
             b->problems[i].triples[l] = NULL;
             b->problems[i].nTriples[l] = 0;
         }
-    free(b->results);
-    free(b->postMea);
-    free(b->postShift);
+    cpk_host_free(b->results);
+    cpk_host_free(b->postMea);
+    cpk_host_free(b->postShift);
     b->results = b->postMea = b->postShift = NULL;
 }
 
@@ -542,15 +574,15 @@ void cpecan_batch_destroy(cpecan_batch *b) {
     if (!b) return;
     free_results(b);
     cpk_device_destroy(b->dev);
-    free(b->problems);
-    free(b->regions);
-    free(b->symbols);
-    free(b->anchors);
-    free(b->devRegions);
-    free(b->devToHost);
-    free(b->segs);
+    cpk_host_free(b->problems);
+    cpk_host_free(b->regions);
+    cpk_host_free(b->symbols);
+    cpk_host_free(b->anchors);
+    cpk_host_free(b->devRegions);
+    cpk_host_free(b->devToHost);
+    cpk_host_free(b->segs);
     free(b->forward);
-    free(b->chars);
+    cpk_host_free(b->chars);
     free(b);
 }
 
@@ -593,7 +625,13 @@ typedef struct {
 /* The split rectangles of one problem (getSplitPoints semantics, pairwiseAligner.c:1230-1271) into *rects, grown as
  * needed.  Returns their number or < 0. */
 static int64_t problem_rects(const cpecan_batch *b, const cpecan_problem *it, int64_t **rects, int64_t *cap) {
-    if (grow((void **)rects, cap, 4 * (it->nAnchors + 2), sizeof(int64_t))) return CPECAN_ENOMEM;
+    if (4 * (it->nAnchors + 2) > *cap) { /* the caller's scratch: plain heap memory, freed with free() */
+        const int64_t c = 8 * (it->nAnchors + 2);
+        int64_t *q = realloc(*rects, sizeof(int64_t) * (size_t)c);
+        if (!q) return CPECAN_ENOMEM;
+        *rects = q;
+        *cap = c;
+    }
     if (b->emit == CPECAN_EMIT_FORWARD) { /* computeForwardProbability never splits (pairwiseAligner.c:936-949) */
         (*rects)[0] = 0;
         (*rects)[1] = 0;
@@ -614,6 +652,7 @@ static int problem_valid(const cpecan_problem *it) {
     for (int64_t i = 0; i < it->nAnchors; i++) {
         const int64_t x = it->anchors[3 * i], y = it->anchors[3 * i + 1];
         if (x < 0 || y < 0 || x >= it->lX || y >= it->lY) return 0;
+        if (it->anchors[3 * i + 2] < INT32_MIN || it->anchors[3 * i + 2] > INT32_MAX) return 0; /* kept as 32-bit values */
         if (i > 0 && (x <= it->anchors[3 * (i - 1)] || y <= it->anchors[3 * (i - 1) + 1])) return 0;
     }
     return 1;
@@ -674,12 +713,12 @@ int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *items, int6
         offs[4 * i + 3] = nChars;
         nRegions += cnt[i].nRects;
         nSymbols += cnt[i].symbolBytes;
-        nAnchorVals += 3 * cnt[i].nAnchorsKept;
+        nAnchorVals += b->anchorStride * cnt[i].nAnchorsKept;
         nChars += items[i].lX + items[i].lY;
     }
     if (grow((void **)&b->problems, &b->capProblems, b->nProblems + n, sizeof(HostProblem)) ||
         grow((void **)&b->regions, &b->capRegions, nRegions, sizeof(HostRegion)) ||
-        grow((void **)&b->anchors, &b->capAnchorVals, nAnchorVals, sizeof(int64_t)) ||
+        grow((void **)&b->anchors, &b->capAnchorVals, nAnchorVals, sizeof(int32_t)) ||
         grow((void **)&b->symbols, &b->capSymbols, nSymbols, 1) || grow((void **)&b->chars, &b->capChars, nChars + 1, 1)) {
         free(cnt);
         free(offs);
@@ -727,13 +766,13 @@ int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *items, int6
                 symAt = put_symbols(b->symbols, symAt, it->sX + x1, r->lX);
                 r->seqYOff = symAt;
                 symAt = put_symbols(b->symbols, symAt, it->sY + y1, r->lY);
-                r->anchorOff = anchorAt / 3;
+                r->anchorOff = anchorAt / b->anchorStride;
                 while (next < it->nAnchors && it->anchors[3 * next] + it->anchors[3 * next + 1] < x2 + y2) {
-                    int64_t *a = b->anchors + anchorAt;
-                    a[0] = it->anchors[3 * next] - x1;
-                    a[1] = it->anchors[3 * next + 1] - y1;
-                    a[2] = it->anchors[3 * next + 2];
-                    anchorAt += 3;
+                    int32_t *a = b->anchors + anchorAt;
+                    a[0] = (int32_t)(it->anchors[3 * next] - x1);
+                    a[1] = (int32_t)(it->anchors[3 * next + 1] - y1);
+                    if (b->anchorStride == 3) a[2] = (int32_t)it->anchors[3 * next + 2];
+                    anchorAt += b->anchorStride;
                     r->nAnchors++;
                     next++;
                 }
@@ -812,6 +851,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
      * cell count, widest diagonal, the traceback schedule (pairwiseAligner.c:791-810) and the scratch sizes it implies.
      * The per-diagonal table the kernels read (16 bytes per diagonal, 640 MB at 10 000 pairs x 2 kb) is built on the
      * device from the anchors by the same iterator (cpk_device_upload).  Regions are independent: OpenMP. */
+    const double tU0 = now_ms();
     int64_t totalDiags = 0;
     int64_t *diagStart = malloc(sizeof(int64_t) * (size_t)b->nRegions);
     int64_t *segStart = malloc(sizeof(int64_t) * (size_t)b->nRegions);
@@ -831,7 +871,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
         /* consecutive traceback points are at least minDiagsBetweenTraceBack - (traceBackDiagonals + 1) >= 1 apart */
         nSegs += N / (p->minDiagsBetweenTraceBack - p->traceBackDiagonals - 1) + 2;
     }
-    segs = calloc((size_t)(nSegs ? nSegs : 1), sizeof(CpkSegment));
+    segs = host_zalloc((size_t)nSegs, sizeof(CpkSegment));
     if (!segs) {
         rc = CPECAN_ENOMEM;
         goto fail1;
@@ -856,12 +896,16 @@ int cpecan_batch_upload(cpecan_batch *b) {
             keys[i].index = i;
             if (!histOff) continue;
             CpkBandIter it;
-            int bad = cpk_band_init(&it, b->anchors + 3 * r->anchorOff, r->nAnchors, r->lX, r->lY, p->diagonalExpansion, dynamic);
+            int bad = cpk_band_init(&it, b->anchors + (int64_t)b->anchorStride * r->anchorOff, b->anchorStride, r->nAnchors, r->lX, r->lY,
+                                    p->diagonalExpansion, dynamic);
             CpkSegment *sg = segs + segStart[i];
             int64_t cells = 0, tracedBackTo = 0;
             int64_t offTracedBackTo = 0; /* cells before diagonal tracedBackTo */
             int64_t offAfter = 0;        /* cells before diagonal tracedBackTo + 1 */
-            for (int64_t d = 0; d <= N && !bad; d++) {
+            int64_t slot = 0; /* d % K without the division: this loop runs once per diagonal of the batch */
+            int64_t maxW = 0;
+            const int64_t minBetween = p->minDiagsBetweenTraceBack, narrow = p->diagonalExpansion * 2 + 1;
+            for (int64_t d = 0; d <= N && !bad; d++, slot = slot + 1 == K ? 0 : slot + 1) {
                 int64_t lo, hi;
                 if (cpk_band_next(&it, d, &lo, &hi)) {
                     bad = 1;
@@ -872,15 +916,14 @@ int cpecan_batch_upload(cpecan_batch *b) {
                     bad = 1;
                     break;
                 }
-                histOff[d % K] = cells;
-                histW[d % K] = w;
+                histOff[slot] = cells;
+                histW[slot] = w;
                 if (d == 1) offAfter = cells; /* tracedBackTo == 0 for the first segment */
-                pl->maxW = w > pl->maxW ? w : pl->maxW;
+                maxW = w > maxW ? w : maxW;
                 cells += w;
                 if (d == 0) continue;
                 const int atEnd = d == N;
-                const int tracebackPoint =
-                    d >= tracedBackTo + p->minDiagsBetweenTraceBack && w <= p->diagonalExpansion * 2 + 1;
+                const int tracebackPoint = d >= tracedBackTo + minBetween && w <= narrow;
                 if (!atEnd && !tracebackPoint) continue;
                 memset(sg, 0, sizeof *sg);
                 sg->tbPrev = (int32_t)tracedBackTo;
@@ -892,15 +935,17 @@ int cpecan_batch_upload(cpecan_batch *b) {
                 /* forward diagonals tbPrev..dTop are live during this traceback */
                 pl->liveMax = imax(pl->liveMax, cells - offTracedBackTo);
                 const int64_t tf = sg->tbFrom;
-                const int64_t fbCells = histOff[tf % K] + histW[tf % K] - offAfter;
+                const int64_t tfSlot = tf % K; /* once per segment */
+                const int64_t fbCells = histOff[tfSlot] + histW[tfSlot] - offAfter;
                 pl->fbMax = imax(pl->fbMax, fbCells);
                 pl->nSeg++;
                 sg++;
                 /* the next segment starts from tbFrom: remember the cell offsets of tbFrom and tbFrom + 1 */
                 tracedBackTo = tf;
-                offTracedBackTo = histOff[tf % K];
-                offAfter = histOff[tf % K] + histW[tf % K];
+                offTracedBackTo = histOff[tfSlot];
+                offAfter = histOff[tfSlot] + histW[tfSlot];
             }
+            pl->maxW = maxW;
             if (bad) {
 #pragma omp critical(cpk_plan)
                 {
@@ -914,6 +959,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
         }
         free(histOff);
     }
+    const double tU1 = now_ms();
     if (rc != CPECAN_OK) {
         if (badRegion >= 0)
             cpk_set_error("region %lld of problem %lld: anchors do not define a valid band (or the band exceeds 2^31 cells)",
@@ -956,10 +1002,12 @@ int cpecan_batch_upload(cpecan_batch *b) {
             keys[i].cls = 3 + (lds > 64 * 1024 ? CPK_WIDE_CLASSES - 1 : k);
         }
     }
+    const double tU2 = now_ms();
     qsort(keys, (size_t)b->nRegions, sizeof(CostKey), by_cost_desc);
+    const double tU3 = now_ms();
 
-    b->devRegions = calloc((size_t)b->nRegions, sizeof(CpkRegion));
-    b->devToHost = malloc(sizeof(int64_t) * (size_t)b->nRegions);
+    b->devRegions = host_zalloc((size_t)b->nRegions, sizeof(CpkRegion));
+    b->devToHost = cpk_host_alloc(sizeof(int64_t) * (size_t)b->nRegions);
     if (!b->devRegions || !b->devToHost) {
         rc = CPECAN_ENOMEM;
         goto fail2;
@@ -1066,11 +1114,15 @@ int cpecan_batch_upload(cpecan_batch *b) {
     b->stats.diagonals = totalDiags;
     CpkModel km;
     kernel_model(&b->model, p->threshold, &km);
+    const double tU4 = now_ms();
+    if (trace_host())
+        fprintf(stderr, "cpecan upload: %lld regions, %lld segment slots: band walk %.1f ms, classes %.1f, sort %.1f, device order %.1f\n",
+                (long long)b->nRegions, (long long)nSegs, tU1 - tU0, tU2 - tU1, tU3 - tU2, tU4 - tU3);
     if (!b->dev) {
         rc = cpk_device_create(&b->dev, b->device); /* fails with CPECAN_ENODEVICE when there is no GPU */
         if (rc != CPECAN_OK) goto fail2;
     }
-    rc = cpk_device_upload(b->dev, &geo, &km, b->devRegions, b->anchors, b->nAnchorVals / 3, totalDiags,
+    rc = cpk_device_upload(b->dev, &geo, &km, b->devRegions, b->anchors, b->anchorStride, b->nAnchorVals / b->anchorStride, totalDiags,
                            p->diagonalExpansion, dynamic, segs, nSegs, b->symbols, b->nSymbols, b->outTriples, b->nLists,
                            b->dbgCells, b->dbgDiags, &b->stats.h2dMs);
     if (rc != CPECAN_OK) goto fail2;
@@ -1084,14 +1136,14 @@ int cpecan_batch_upload(cpecan_batch *b) {
     return CPECAN_OK;
 
 fail2:
-    free(b->devRegions);
-    free(b->devToHost);
+    cpk_host_free(b->devRegions);
+    cpk_host_free(b->devToHost);
     b->devRegions = NULL;
     b->devToHost = NULL;
     b->segs = NULL;
     b->nSegs = 0;
 fail1:
-    if (!b->segs) free(segs);
+    if (!b->segs) cpk_host_free(segs);
     free(diagStart);
     free(segStart);
     free(keys);
@@ -1122,10 +1174,10 @@ static int plan_results(cpecan_batch *b, const int32_t *counts, const int32_t *s
     int64_t total = 0;
     for (int l = 0; l < b->nLists; l++)
         for (int64_t di = 0; di < b->nRegions; di++) total += counts[(size_t)l * b->nRegions + di];
-    CpkChunk *chunks = malloc(sizeof(CpkChunk) * (size_t)(b->nLists * (b->nSegs ? b->nSegs : 1)));
-    b->results = malloc(sizeof(int32_t) * 3 * (size_t)(total ? total : 1));
+    CpkChunk *chunks = cpk_host_alloc(sizeof(CpkChunk) * (size_t)(b->nLists * (b->nSegs ? b->nSegs : 1)));
+    b->results = cpk_host_alloc(sizeof(int32_t) * 3 * (size_t)(total ? total : 1));
     if (!chunks || !b->results) {
-        free(chunks);
+        cpk_host_free(chunks);
         return CPECAN_ENOMEM;
     }
     int64_t nChunks = 0, at = 0;
@@ -1215,12 +1267,12 @@ static int run_post(cpecan_batch *b) {
         job.chars = b->chars; /* identity scores, left shift */
         job.nChars = b->nChars;
         if (job.flags & (CPECAN_POST_MEA | CPECAN_POST_ORDERED)) {
-            b->postMea = malloc(sizeof(int32_t) * 3 * (size_t)(job.meaCap ? job.meaCap : 1));
+            b->postMea = cpk_host_alloc(sizeof(int32_t) * 3 * (size_t)(job.meaCap ? job.meaCap : 1));
             job.mea = b->postMea;
             if (!b->postMea) rc = CPECAN_ENOMEM;
         }
         if (rc == CPECAN_OK && (job.flags & CPECAN_POST_LEFT_SHIFT)) {
-            b->postShift = malloc(sizeof(int32_t) * 3 * (size_t)(job.shiftCap ? job.shiftCap : 1));
+            b->postShift = cpk_host_alloc(sizeof(int32_t) * 3 * (size_t)(job.shiftCap ? job.shiftCap : 1));
             job.shift = b->postShift;
             if (!b->postShift) rc = CPECAN_ENOMEM;
         }
@@ -1299,13 +1351,15 @@ int cpecan_batch_download(cpecan_batch *b) {
     }
     int rc = CPECAN_OK;
     int32_t *counts = NULL, *segStarts = NULL, *segCounts = NULL;
+    const double tD0 = now_ms();
+    double tD1 = tD0;
     for (int attempt = 0; attempt < 3; attempt++) {
-        free(counts);
-        free(segStarts);
-        free(segCounts);
-        counts = malloc(sizeof(int32_t) * (size_t)b->nLists * b->nRegions);
-        segStarts = malloc(sizeof(int32_t) * (size_t)b->nLists * (b->nSegs ? b->nSegs : 1));
-        segCounts = malloc(sizeof(int32_t) * (size_t)b->nLists * (b->nSegs ? b->nSegs : 1));
+        cpk_host_free(counts);
+        cpk_host_free(segStarts);
+        cpk_host_free(segCounts);
+        counts = cpk_host_alloc(sizeof(int32_t) * (size_t)b->nLists * b->nRegions);
+        segStarts = cpk_host_alloc(sizeof(int32_t) * (size_t)b->nLists * (b->nSegs ? b->nSegs : 1));
+        segCounts = cpk_host_alloc(sizeof(int32_t) * (size_t)b->nLists * (b->nSegs ? b->nSegs : 1));
         if (!counts || !segStarts || !segCounts) {
             rc = CPECAN_ENOMEM;
             break;
@@ -1319,6 +1373,8 @@ int cpecan_batch_download(cpecan_batch *b) {
         }
         rc = cpk_device_download(b->dev, counts, segStarts, segCounts, b->forward, &b->stats.kernelMs, &b->stats.d2hMs);
         if (rc != CPECAN_OK) break;
+        b->stats.h2dMs = cpk_device_h2d_ms(b->dev);
+        tD1 = now_ms();
         if (b->emit == CPECAN_EMIT_FORWARD || b->emit == CPECAN_EMIT_EXPECT) break; /* these emitters produce no lists */
         /* did any region overflow its output slice?  If so enlarge exactly and run once more. */
         int overflow = 0;
@@ -1375,17 +1431,24 @@ int cpecan_batch_download(cpecan_batch *b) {
         /* the lists are put in order on the device; only the emitted triples cross PCIe */
         CpkChunk *chunks = NULL;
         int64_t nChunks = 0, total = 0;
+        const double tD2 = now_ms();
         rc = plan_results(b, counts, segStarts, segCounts, &chunks, &nChunks, &total);
+        const double tD3 = now_ms();
         if (rc == CPECAN_OK) rc = cpk_device_gather(b->dev, chunks, nChunks, total);
-        free(chunks);
+        cpk_host_free(chunks);
+        const double tD4 = now_ms();
         if (rc == CPECAN_OK) rc = run_post(b); /* consumers of the lists, on the device, before they leave it */
+        const double tD5 = now_ms();
         if (rc == CPECAN_OK) rc = cpk_device_fetch(b->dev, b->results, total, &b->stats.d2hMs);
         b->stats.pairs = total;
+        if (trace_host())
+            fprintf(stderr, "cpecan download: wait + counts %.1f ms, overflow scan %.1f, list plan %.1f (%lld chunks), gather %.1f, consumers %.1f, fetch %.1f (%lld triples)\n",
+                    tD1 - tD0, tD2 - tD1, tD3 - tD2, (long long)nChunks, tD4 - tD3, tD5 - tD4, now_ms() - tD5, (long long)total);
     }
     if (rc == CPECAN_OK) b->downloaded = 1;
-    free(counts);
-    free(segStarts);
-    free(segCounts);
+    cpk_host_free(counts);
+    cpk_host_free(segStarts);
+    cpk_host_free(segCounts);
     return rc;
 }
 

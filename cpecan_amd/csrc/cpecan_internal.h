@@ -128,6 +128,9 @@ typedef struct {
 typedef struct CpkDevice CpkDevice;
 
 /* ---- implemented in cpecan_kernels.hip ---- */
+/* Host blocks of a batch: pinned and recycled when a HIP device is present, plain malloc below 256 KB or without a GPU. */
+void *cpk_host_alloc(size_t bytes);
+void cpk_host_free(void *p);
 int cpk_device_count(void);
 int cpk_current_device(void); /* the calling thread's current HIP device (0 when there is none) */
 const char *cpk_last_error(void);
@@ -137,9 +140,11 @@ void cpk_device_destroy(CpkDevice *dev);
 /* The per-diagonal table (nDiags entries) is built on the device from the anchors (cpecan_band.inl). */
 /* Regions of a class that is split (see CpkItem) get ringCap / ringBase / split set here, in the caller's array. */
 int cpk_device_upload(CpkDevice *dev, const CpkGeometry *geo, const CpkModel *model, CpkRegion *regions,
-                      const int64_t *anchors, int64_t nAnchors, int64_t nDiags, int64_t expansion, int dynamic,
+                      const int32_t *anchors /* cpk_anchor_t, cpecan_band.inl */, int anchorStride, int64_t nAnchors, int64_t nDiags,
+                      int64_t expansion, int dynamic,
                       const CpkSegment *segs, int64_t nSegs, const uint8_t *symbols, int64_t nSymbolBytes,
                       int64_t outTriplesPerList, int nLists, int64_t dbgCells, int64_t dbgDiags, double *h2dMs);
+double cpk_device_h2d_ms(CpkDevice *dev); /* the upload's copy time; waits for the copies */
 int cpk_device_update_regions(CpkDevice *dev, const CpkRegion *regions, const CpkSegment *segs, int64_t outTriplesPerList);
 int cpk_device_run(CpkDevice *dev, void *stream);
 /* Once more on the stream of the last run (after an output overflow); kernel times of a batch's launches add up. */

@@ -30,6 +30,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -198,6 +199,116 @@ void cache_free(int device, void *ptr, size_t bytes) {
 }
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------
+// Host blocks.  The large host arrays of a batch (symbols, anchors, region and segment tables, the result triples)
+// come from here: pinned memory when a HIP device is present, recycled like the device blocks.  A realignment batch
+// (BASELINE config 4: 50 000 alignments, 60 M anchors, 74 M result triples) holds ~2 GB of them; from malloc every batch
+// paid ~90 ms of first-touch page faults while filling them, ~200 ms of munmap in cpecan_batch_destroy, a staging copy
+// on the way up and a pageable (pin-as-you-go) copy on the way down (profiles/r02_e2e_stages_config4_before.txt).
+// Blocks below 256 KB are plain malloc.  CPECAN_HOST_CACHE_MB bounds what idle blocks may hold (default 16 GiB);
+// CPECAN_PINNED=0 keeps everything pageable.
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct HostBlock {
+    void *ptr;
+    size_t bytes;
+    bool pinned;
+};
+constexpr size_t kHostPoolMin = (size_t)256 << 10;
+std::mutex g_hostMutex;
+std::vector<HostBlock> g_hostLive, g_hostIdle;
+size_t g_hostIdleBytes = 0;
+size_t host_cache_max_bytes() {
+    static const size_t v = [] {
+        const char *mb = getenv("CPECAN_HOST_CACHE_MB");
+        return mb ? (size_t)(atof(mb) * 1048576.0) : ((size_t)16 << 30);
+    }();
+    return v;
+}
+bool host_pinning_enabled() {
+    static const bool v = [] {
+        const char *e = getenv("CPECAN_PINNED");
+        if (e && atoi(e) == 0) return false;
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        return n > 0;
+    }();
+    return v;
+}
+void host_release(const HostBlock &b) {
+    if (b.pinned) (void)hipHostFree(b.ptr);
+    else free(b.ptr);
+}
+}  // namespace
+
+// mustPin: the block will be written by kernels (it has to be device-visible whatever CPECAN_PINNED says)
+static void *host_alloc_impl(size_t bytes, bool mustPin) {
+    if (bytes < kHostPoolMin && !mustPin) return malloc(bytes ? bytes : 1);
+    bytes = (bytes + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
+    {
+        std::lock_guard<std::mutex> lock(g_hostMutex);
+        int best = -1;
+        for (int i = 0; i < (int)g_hostIdle.size(); i++)
+            if (g_hostIdle[i].bytes >= bytes && g_hostIdle[i].bytes <= 2 * bytes + ((size_t)8 << 20) &&
+                (g_hostIdle[i].pinned || !mustPin) && (best < 0 || g_hostIdle[i].bytes < g_hostIdle[best].bytes))
+                best = i;
+        if (best >= 0) {
+            const HostBlock b = g_hostIdle[best];
+            g_hostIdle[best] = g_hostIdle.back();
+            g_hostIdle.pop_back();
+            g_hostIdleBytes -= b.bytes;
+            g_hostLive.push_back(b);
+            return b.ptr;
+        }
+    }
+    HostBlock b{nullptr, bytes, false};
+    if (host_pinning_enabled() || mustPin) {
+        if (hipHostMalloc(&b.ptr, bytes, hipHostMallocPortable) == hipSuccess) b.pinned = true;
+        else {
+            (void)hipGetLastError();
+            b.ptr = nullptr;
+        }
+    }
+    if (!b.ptr && (mustPin || posix_memalign(&b.ptr, 4096, bytes) != 0)) return nullptr;
+    std::lock_guard<std::mutex> lock(g_hostMutex);
+    g_hostLive.push_back(b);
+    return b.ptr;
+}
+extern "C" void *cpk_host_alloc(size_t bytes) { return host_alloc_impl(bytes, false); }
+
+extern "C" void cpk_host_free(void *p) {
+    if (!p) return;
+    HostBlock b{nullptr, 0, false};
+    {
+        std::lock_guard<std::mutex> lock(g_hostMutex);
+        for (size_t i = 0; i < g_hostLive.size(); i++)
+            if (g_hostLive[i].ptr == p) {
+                b = g_hostLive[i];
+                g_hostLive[i] = g_hostLive.back();
+                g_hostLive.pop_back();
+                break;
+            }
+        if (b.ptr && g_hostIdleBytes + b.bytes <= host_cache_max_bytes() && g_hostIdle.size() < 256) {
+            g_hostIdle.push_back(b);
+            g_hostIdleBytes += b.bytes;
+            return;
+        }
+    }
+    if (b.ptr) host_release(b);
+    else free(p);  // a small block
+}
+
+// is [p, p + bytes) inside a pinned block of the pool?  (then a copy needs no staging)
+static bool host_is_pinned(const void *p, size_t bytes) {
+    std::lock_guard<std::mutex> lock(g_hostMutex);
+    for (const HostBlock &b : g_hostLive)
+        if (b.pinned && (const char *)p >= (const char *)b.ptr && (const char *)p + bytes <= (const char *)b.ptr + b.bytes) return true;
+    return false;
+}
+
 // Every entry point works on its batch's device and leaves the calling thread's current device as it found it: in a
 // one-process-per-GPU job (torch.distributed, RCCL) the caller's allocations and collectives follow hipGetDevice().
 namespace {
@@ -238,7 +349,12 @@ struct CpkDevice {
     uint8_t *dSymbols = nullptr;
     CpkModel *dModel = nullptr;
     double *dRing = nullptr; Candidate *dCand = nullptr; double *dForward = nullptr, *dExpect = nullptr; double *dC = nullptr, *dM = nullptr, *dTotals = nullptr, *dGroll = nullptr, *dBring = nullptr;
+    // The per-region counts and per-segment offsets the sweeps write (a few integers per region, never read back on the
+    // device) live in PINNED HOST memory that the kernels store to directly: the host reads them as soon as the sweep's
+    // stop event has completed.  As device buffers they needed three small copies on the batch's stream, and those
+    // queued behind the NEXT batch's upload in a pipeline: 18 ms per config-4 batch (profiles/r02_e2e_stages_config4.txt).
     int32_t *dCounts = nullptr, *dSegStarts = nullptr, *dSegCounts = nullptr, *dTriples = nullptr;
+    void *hostCounts = nullptr;  // the block of the host pool that holds the three
     CpkItem *dItems = nullptr;
     int32_t *dCompact = nullptr; CpkChunk *dChunks = nullptr; int64_t compactCap = 0, chunkCap = 0;
     unsigned int *dQueue = nullptr;
@@ -248,6 +364,9 @@ struct CpkDevice {
     size_t compactBytes = 0, chunkBytes = 0;
     hipEvent_t evStart = nullptr, evStop = nullptr;
     hipEvent_t evA = nullptr, evB = nullptr;  // copy timing (owned by the shell: nothing to leak on an error path)
+    hipEvent_t evUp0 = nullptr, evUp1 = nullptr;  // around the upload's copies; the sweep waits for evUp1 (cpk_device_run)
+    bool uploadTimed = true;
+    double h2dMs = 0.0;
     hipStream_t lastStream = nullptr;
     // Copies, memsets and the small kernels around the sweep (table build, list gather, consumers) run on this
     // non-blocking stream of the batch's own, never on the null stream, and the batch waits on ITS events and streams,
@@ -285,6 +404,8 @@ static void shell_delete(CpkDevice *d) {  // the shell's device is current
     if (d->evStop) (void)hipEventDestroy(d->evStop);
     if (d->evA) (void)hipEventDestroy(d->evA);
     if (d->evB) (void)hipEventDestroy(d->evB);
+    if (d->evUp0) (void)hipEventDestroy(d->evUp0);
+    if (d->evUp1) (void)hipEventDestroy(d->evUp1);
     if (d->io) (void)hipStreamDestroy(d->io);
     for (int k = 0; k < kMaxClasses; k++) {
         if (d->sideStream[k]) (void)hipStreamDestroy(d->sideStream[k]);
@@ -302,6 +423,8 @@ static int shell_init(CpkDevice *d, int device) {
     HIP_TRY(hipEventCreate(&d->evStop));
     HIP_TRY(hipEventCreate(&d->evA));
     HIP_TRY(hipEventCreate(&d->evB));
+    HIP_TRY(hipEventCreate(&d->evUp0));
+    HIP_TRY(hipEventCreate(&d->evUp1));
     HIP_TRY(hipStreamCreateWithFlags(&d->io, hipStreamNonBlocking));
     // The side streams of a multi-class batch are created when a batch first needs them (cpk_device_run): the runtime
     // maps streams onto a handful of hardware queues (4 by default), and ten idle streams per shell put a batch's sweep
@@ -355,6 +478,8 @@ static void free_all(CpkDevice *d) {
     d->dForward = nullptr;
     d->dExpect = nullptr;
     d->dCounts = d->dSegStarts = d->dSegCounts = d->dTriples = nullptr;
+    cpk_host_free(d->hostCounts);
+    d->hostCounts = nullptr;
     d->dItems = nullptr;
     d->dCompact = nullptr; d->dChunks = nullptr; d->compactCap = d->chunkCap = 0;
     d->dQueue = nullptr;
@@ -444,6 +569,10 @@ static KernelFn pick_kernel(const CpkGeometry &g) {
 // Queues dst <- src (host) on the batch's stream through the shell's pinned buffer; `at` is the running offset in it.
 static int staged_h2d(CpkDevice *d, void *dst, const void *src, size_t bytes, size_t *at) {
     if (bytes == 0) return CPECAN_OK;
+    if (host_is_pinned(src, bytes)) {  // a block of the host pool: the copy engine reads it where it lies
+        HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->io));
+        return CPECAN_OK;
+    }
     const size_t off = (*at + 255) / 256 * 256;
     if (off + bytes > d->hStageBytes) {
         cpk_set_error("internal: staging buffer too small");
@@ -467,7 +596,7 @@ static int stage_reserve(CpkDevice *d, size_t bytes) {
 }
 
 extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const CpkModel *model, CpkRegion *regions,
-                                 const int64_t *anchors, int64_t nAnchors, int64_t nDiags, int64_t expansion, int dynamic,
+                                 const cpk_anchor_t *anchors, int anchorStride, int64_t nAnchors, int64_t nDiags, int64_t expansion, int dynamic,
                                  const CpkSegment *segs, int64_t nSegs, const uint8_t *symbols, int64_t nSymbolBytes,
                                  int64_t outTriplesPerList, int nLists, int64_t dbgCells, int64_t dbgDiags,
                                  double *h2dMs) {
@@ -771,9 +900,20 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (int rc = dev_alloc(d, &d->dSymbols, (size_t)nSymbolBytes)) return rc;
     if (int rc = dev_alloc(d, &d->dModel, 1)) return rc;
     if (int rc = dev_alloc(d, &d->dForward, (size_t)geo->nRegions)) return rc;
-    if (int rc = dev_alloc(d, &d->dCounts, (size_t)nLists * geo->nRegions)) return rc;
-    if (int rc = dev_alloc(d, &d->dSegStarts, (size_t)nLists * nSegs)) return rc;
-    if (int rc = dev_alloc(d, &d->dSegCounts, (size_t)nLists * nSegs)) return rc;
+    {
+        const size_t nC = (size_t)nLists * geo->nRegions, nS = (size_t)nLists * (nSegs ? nSegs : 1);
+        const size_t words = (nC + 63) / 64 * 64 + 2 * ((nS + 63) / 64 * 64);
+        const size_t bytes = sizeof(int32_t) * words;
+        d->hostCounts = host_alloc_impl(bytes, true);
+        if (!d->hostCounts) {
+            cpk_set_error("no pinned host memory for the result counts (%zu bytes)", bytes);
+            return CPECAN_ENOMEM;
+        }
+        memset(d->hostCounts, 0, sizeof(int32_t) * words);  // the block is idle: nothing is in flight for this batch yet
+        d->dCounts = static_cast<int32_t *>(d->hostCounts);
+        d->dSegStarts = d->dCounts + (nC + 63) / 64 * 64;
+        d->dSegCounts = d->dSegStarts + (nS + 63) / 64 * 64;
+    }
     // split classes: the regions get rings of their own (no wrap: every segment stays readable) and their tracebacks
     // become queue items, longest first
     std::vector<CpkItem> items;
@@ -803,9 +943,6 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     if (int rc = dev_alloc(d, &d->dTriples, (size_t)nLists * outTriplesPerList * 3)) return rc;
     if (int rc = dev_alloc(d, &d->dQueue, (size_t)2 * kMaxClasses)) return rc;
     hipStream_t io = d->io;
-    HIP_TRY(hipMemsetAsync(d->dCounts, 0, sizeof(int32_t) * (size_t)nLists * geo->nRegions, io));
-    HIP_TRY(hipMemsetAsync(d->dSegStarts, 0, sizeof(int32_t) * (size_t)nLists * (nSegs ? nSegs : 1), io));
-    HIP_TRY(hipMemsetAsync(d->dSegCounts, 0, sizeof(int32_t) * (size_t)nLists * (nSegs ? nSegs : 1), io));
 
     if (geo->debug) {
         if (int rc = dev_alloc(d, &d->dDbgFb, (size_t)dbgCells)) return rc;
@@ -814,37 +951,51 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         HIP_TRY(hipMemsetAsync(d->dDbgTotals, 0xff, sizeof(double) * (size_t)dbgDiags, io));
     }
 
-    // Everything below is ordered on the batch's own stream and the call returns when that stream is done (the host
-    // buffers are the caller's); a failure in between leaves nothing behind: the anchor block is one of the batch's.
+    // Everything below is ordered on the batch's own stream and the call returns WITHOUT waiting for it: the sources are
+    // either blocks of the host pool that the batch owns until it is destroyed, or already copied into the shell's
+    // staging buffer; cpk_device_run makes the sweep wait for evUp1.  (The host goes on planning the next batch while
+    // the copy engine works: 19 ms per config-4 batch.)  The anchor block stays with the batch until it is destroyed.
     size_t stageAt = 0;
-    if (int rc = stage_reserve(d, sizeof(CpkRegion) * (size_t)geo->nRegions + sizeof(int64_t) * 3 * (size_t)(nAnchors > 0 ? nAnchors : 1) +
-                                  sizeof(CpkSegment) * (size_t)nSegs + (size_t)nSymbolBytes + sizeof(CpkModel) +
-                                  sizeof(CpkItem) * items.size() + 8 * 256))
-        return rc;
+    const size_t anchorBytes = sizeof(cpk_anchor_t) * (size_t)anchorStride * (size_t)(nAnchors > 0 ? nAnchors : 1);
+    {
+        auto staged = [](const void *p, size_t bytes) { return host_is_pinned(p, bytes) ? (size_t)0 : bytes + 256; };
+        if (int rc = stage_reserve(d, staged(regions, sizeof(CpkRegion) * (size_t)geo->nRegions) + staged(anchors, anchorBytes) +
+                                      staged(segs, sizeof(CpkSegment) * (size_t)nSegs) + staged(symbols, (size_t)nSymbolBytes) +
+                                      sizeof(CpkModel) + sizeof(CpkItem) * items.size() + 8 * 256))
+            return rc;
+    }
     if (!items.empty())
         if (int rc = staged_h2d(d, d->dItems, items.data(), sizeof(CpkItem) * items.size(), &stageAt)) return rc;
-    HIP_TRY(hipEventRecord(d->evA, io));
+    HIP_TRY(hipEventRecord(d->evUp0, io));
     if (int rc = staged_h2d(d, d->dRegions, regions, sizeof(CpkRegion) * (size_t)geo->nRegions, &stageAt)) return rc;
     {
         // anchors -> per-diagonal table, on the device (the anchors are only needed for this)
-        int64_t *dAnchors = nullptr;
-        if (int rc = dev_alloc(d, &dAnchors, 3 * (size_t)(nAnchors > 0 ? nAnchors : 1))) return rc;
+        cpk_anchor_t *dAnchors = nullptr;
+        if (int rc = dev_alloc(d, &dAnchors, (size_t)anchorStride * (size_t)(nAnchors > 0 ? nAnchors : 1))) return rc;
         if (nAnchors > 0)
-            if (int rc = staged_h2d(d, dAnchors, anchors, sizeof(int64_t) * 3 * (size_t)nAnchors, &stageAt)) return rc;
+            if (int rc = staged_h2d(d, dAnchors, anchors, sizeof(cpk_anchor_t) * (size_t)anchorStride * (size_t)nAnchors, &stageAt)) return rc;
         hipLaunchKernelGGL(cpecan_build_diag_table, dim3((unsigned)((geo->nRegions + 63) / 64)), dim3(64), 0, io,
-                           d->dRegions, geo->nRegions, dAnchors, d->dDiags, expansion, dynamic);
+                           d->dRegions, geo->nRegions, dAnchors, anchorStride, d->dDiags, expansion, dynamic);
         HIP_TRY(hipGetLastError());
         if (int rc = staged_h2d(d, d->dSegs, segs, sizeof(CpkSegment) * (size_t)nSegs, &stageAt)) return rc;
         if (int rc = staged_h2d(d, d->dSymbols, symbols, (size_t)nSymbolBytes, &stageAt)) return rc;
         if (int rc = staged_h2d(d, d->dModel, model, sizeof(CpkModel), &stageAt)) return rc;
-        HIP_TRY(hipEventRecord(d->evB, io));
-        HIP_TRY(hipStreamSynchronize(io));
-        dev_release(d, dAnchors);
+        HIP_TRY(hipEventRecord(d->evUp1, io));
     }
-    float ms = 0.f;
-    HIP_TRY(hipEventElapsedTime(&ms, d->evA, d->evB));
-    if (h2dMs) *h2dMs = ms;
+    d->uploadTimed = false;
+    d->h2dMs = 0.0;
+    if (h2dMs) *h2dMs = 0.0;  // known once the copies are done: cpk_device_download reports it
     return CPECAN_OK;
+}
+
+// duration of the upload's copies (valid once the batch has run: the sweep waited for them)
+extern "C" double cpk_device_h2d_ms(CpkDevice *d) {
+    if (!d->uploadTimed && d->evUp1 && hipEventSynchronize(d->evUp1) == hipSuccess) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, d->evUp0, d->evUp1) == hipSuccess) d->h2dMs = ms;
+        d->uploadTimed = true;
+    }
+    return d->h2dMs;
 }
 
 extern "C" int cpk_device_update_regions(CpkDevice *d, const CpkRegion *regions, const CpkSegment *segs, int64_t outTriplesPerList) {
@@ -911,6 +1062,7 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.expectOut = d->dExpect;
     a.dbgFb = d->dDbgFb;
     a.dbgTotals = d->dDbgTotals;
+    HIP_TRY(hipStreamWaitEvent(st, d->evUp1, 0));  // the upload's copies and the table build (the batch's own stream)
     HIP_TRY(hipMemsetAsync(d->dQueue, 0, 2 * kMaxClasses * sizeof(unsigned int), st));
     if (d->geo.emit == CPECAN_EMIT_EXPECT)
         HIP_TRY(hipMemsetAsync(d->dExpect, 0, sizeof(double) * 128 * (size_t)(d->totalWaves > 0 ? d->totalWaves : 1), st));
@@ -969,15 +1121,19 @@ extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segSt
         return CPECAN_ESTATE;
     }
     // the batch's own stop event, not the caller's stream: that stream may already hold the next batch's launches
+    const bool trace = getenv("CPECAN_TRACE_HOST") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(hipEventSynchronize(d->evStop));
+    if (trace) fprintf(stderr, "cpecan download: waited %.1f ms for the sweep\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, d->evStart, d->evStop));
     if (kernelMs) *kernelMs = d->kernelMsAccum + ms;  // every launch of the batch (an overflow re-run included)
     hipStream_t io = d->io;
     HIP_TRY(hipEventRecord(d->evA, io));
-    HIP_TRY(hipMemcpyAsync(counts, d->dCounts, sizeof(int32_t) * (size_t)d->nLists * d->geo.nRegions, hipMemcpyDeviceToHost, io));
-    HIP_TRY(hipMemcpyAsync(segStarts, d->dSegStarts, sizeof(int32_t) * (size_t)d->nLists * d->nSegs, hipMemcpyDeviceToHost, io));
-    HIP_TRY(hipMemcpyAsync(segCounts, d->dSegCounts, sizeof(int32_t) * (size_t)d->nLists * d->nSegs, hipMemcpyDeviceToHost, io));
+    // written by the sweeps straight into pinned host memory; complete with the stop event
+    memcpy(counts, d->dCounts, sizeof(int32_t) * (size_t)d->nLists * d->geo.nRegions);
+    memcpy(segStarts, d->dSegStarts, sizeof(int32_t) * (size_t)d->nLists * d->nSegs);
+    memcpy(segCounts, d->dSegCounts, sizeof(int32_t) * (size_t)d->nLists * d->nSegs);
     HIP_TRY(hipEventRecord(d->evB, io));
     HIP_TRY(hipStreamSynchronize(io));
     HIP_TRY(hipEventElapsedTime(&ms, d->evA, d->evB));

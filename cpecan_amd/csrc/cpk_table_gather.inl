@@ -7,7 +7,7 @@
 // position follows the rule the kernels rely on: diagonals are laid end to end and never straddle the ring's end.
 // (In a pipeline of batches this kernel of batch k+1 runs on that batch's own stream; its 56 allocated VGPRs do not fit
 // in the 48 a resident sweep of batch k leaves free per lane, so it starts when that sweep drains: ~3 ms per config-B batch.)
-__global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *regions, int nRegions, const int64_t *anchors,
+__global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *regions, int nRegions, const cpk_anchor_t *anchors, int anchorStride,
                                                               CpkDiag *diags, int64_t expansion, int dynamic) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nRegions) return;
@@ -15,7 +15,7 @@ __global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *r
     CpkDiag *table = diags + rg.diagOff;
     const int64_t N = (int64_t)rg.lX + rg.lY;
     CpkBandIter it;
-    cpk_band_init(&it, anchors + 3 * rg.anchorOff, rg.nAnchors, rg.lX, rg.lY, expansion, dynamic);
+    cpk_band_init(&it, anchors + (size_t)anchorStride * rg.anchorOff, anchorStride, rg.nAnchors, rg.lX, rg.lY, expansion, dynamic);
     int32_t cells = 0, pos = 0;
     for (int64_t d = 0; d <= N; d++) {
         int64_t lo = 0, hi = 0;
