@@ -106,11 +106,21 @@ cpecan_pairhmm_packed(const KArgs a) {
         // Stages the table entries of `cnt` (<= 64) diagonals first, first + step, ... into ebuf and the X / Y symbols
         // their cells use (shifted by `shift`: the backward step reads the symbols of (x+1, y+1)) into the two windows.
         // One global round trip per 64 diagonals instead of three per diagonal.
+        // Every load of a stage is issued before the first one is waited for (unrolled loops over registers, addresses
+        // clamped instead of predicated): as loops of load-then-store the compiler waited for each in turn, ~30 global
+        // round trips in a row per chunk.
         auto stage_chunk = [&](bool on, int first, int step, int cnt, int shift, int &x0, int &y0) {
-            for (int i = c; i < kPackChunk; i += GW) {
-                int dd = first + step * (i < cnt ? i : (cnt > 0 ? cnt - 1 : 0));
-                dd = dd < 0 ? 0 : (dd > N ? N : dd);
-                ebuf[i] = on ? *reinterpret_cast<const int4 *>(table + dd) : int4{0, 1, 0, 0};
+            {
+                int4 t[kPackChunk / GW];
+#pragma unroll
+                for (int j = 0; j < kPackChunk / GW; j++) {
+                    const int i = c + j * GW;
+                    int dd = first + step * (i < cnt ? i : (cnt > 0 ? cnt - 1 : 0));
+                    dd = dd < 0 ? 0 : (dd > N ? N : dd);
+                    t[j] = *reinterpret_cast<const int4 *>(table + dd);  // N = 0 for a group without a region: entry 0 of a valid table
+                }
+#pragma unroll
+                for (int j = 0; j < kPackChunk / GW; j++) ebuf[c + j * GW] = on ? t[j] : int4{0, 1, 0, 0};
             }
             // both ends of the chunk bound the coordinates in between (x and y never decrease with the diagonal)
             int dA = step > 0 ? first : first - (cnt - 1), dB = step > 0 ? first + (cnt - 1) : first;
@@ -122,10 +132,22 @@ cpecan_pairhmm_packed(const KArgs a) {
             x0 = xloA + shift;
             y0 = dA - (xloA + eA.width - 1) + shift;
             const int x1 = xloB + eB.width - 1 + shift, y1 = dB - xloB + shift;
-            for (int i = c; i < kWin; i += GW) {
+            constexpr int kWinIter = (kWin + GW - 1) / GW;
+            uint8_t bx[kWinIter], by[kWinIter];
+#pragma unroll
+            for (int j = 0; j < kWinIter; j++) {
+                const int px = x0 + c + j * GW, py = y0 + c + j * GW;
+                bx[j] = gx[px < 0 ? 0 : (px > rg.lX + 1 ? rg.lX + 1 : px)];  // the padded strings hold indices 0 .. l+1
+                by[j] = gy[py < 0 ? 0 : (py > rg.lY + 1 ? rg.lY + 1 : py)];
+            }
+#pragma unroll
+            for (int j = 0; j < kWinIter; j++) {
+                const int i = c + j * GW;
                 const int px = x0 + i, py = y0 + i;
-                xwin[i] = (on && cnt > 0 && px >= 0 && px <= x1 && px <= rg.lX + 1) ? gx[px] : (uint8_t)CPK_SYM_N;
-                ywin[i] = (on && cnt > 0 && py >= 0 && py <= y1 && py <= rg.lY + 1) ? gy[py] : (uint8_t)CPK_SYM_N;
+                if (i < kWin) {
+                    xwin[i] = (on && cnt > 0 && px >= 0 && px <= x1 && px <= rg.lX + 1) ? bx[j] : (uint8_t)CPK_SYM_N;
+                    ywin[i] = (on && cnt > 0 && py >= 0 && py <= y1 && py <= rg.lY + 1) ? by[j] : (uint8_t)CPK_SYM_N;
+                }
             }
         };
 
@@ -208,34 +230,72 @@ cpecan_pairhmm_packed(const KArgs a) {
                 const int cnt = more ? (d2 - sg.tbPrev < kPackChunk ? d2 - sg.tbPrev : kPackChunk) : 0;
                 int x0, y0;
                 stage_chunk(more, d2, -1, cnt, 1, x0, y0);
-                // F.match of the chunk's first diagonal; inside the loop the next diagonal's is requested one step ahead
-                double fNext = 0.0;
-                {
-                    const CpkDiag e = unpack(ebuf[0]);
-                    if (cnt > 0 && c < e.width) fNext = ld_self(ringAt(e) + SW::ringIdx(e.width, 0, c));
-                }
-                for (int i = 0; i < kPackChunk; i++) {
-                    if (!__ballot(i < cnt)) break;
+                // F.match of this lane's cell (and, for a refresh diagonal, the other states of that cell) come from the ring
+                // in HBM.  They are requested a BLOCK of kAhead diagonals ahead: at the top of a block the values of the
+                // block are taken over -- the one place the wave waits for memory -- and the requests of the next block go
+                // out; the kAhead steps in between issue no load.  hipcc cannot do better than `s_waitcnt vmcnt(0)` for a
+                // load once stores may be in flight as well (gfx9 counts both in vmcnt and lets them complete out of
+                // order), and these steps store candidates, cbuf and mbuf values all the time: with a request per step,
+                // every step waited for the request of the step before (waves waiting 55 % of their cycles, round 2).
+                // The loads are unconditional: clamped to a valid cell of a valid diagonal.
+                constexpr int kAhead = 4;
+                static_assert(kPackChunk % kAhead == 0, "the chunk loop is unrolled by the block size");
+                double fqN[kAhead], rfN[S];
+                // block [i0, i0 + kAhead): F.match of every step, and the rows of the (at most one: period 10) refresh step
+                auto request = [&](int i0, int dAt) {
+                    int iRef = i0;  // without a refresh step in the block: any valid entry
+#pragma unroll
+                    for (int j = 0; j < kAhead; j++) {
+                        const int i = i0 + j;
+                        const CpkDiag en = unpack(ebuf[i < kPackChunk ? i : kPackChunk - 1]);  // past the chunk: its last diagonal again
+                        fqN[j] = ld_self(ringAt(en) + SW::ringIdx(en.width, 0, c < en.width ? c : en.width - 1));
+                        const int dd = dAt - j;
+                        if (i < cnt && dd <= sg.tbFrom && (sg.tbFrom - dd) % CPK_REFRESH_PERIOD == 0) iRef = i;
+                    }
+                    const CpkDiag er = unpack(ebuf[iRef < kPackChunk ? iRef : kPackChunk - 1]);
+#pragma unroll
+                    for (int s2 = 1; s2 < S; s2++)
+                        rfN[s2] = ld_self(ringAt(er) + SW::ringIdx(er.width, s2, c < er.width ? c : er.width - 1));
+                };
+                rfN[0] = 0.0;
+                request(0, d2);
+                bool chunkDone = false;
+                for (int i0 = 0; i0 < kPackChunk && !chunkDone; i0 += kAhead) {
+                  if (!__ballot(i0 < cnt)) break;
+                  double fq[kAhead], rf[S];
+#pragma unroll
+                  for (int j = 0; j < kAhead; j++) {
+                      asm volatile("" : "+v"(fqN[j]));
+                      fq[j] = fqN[j];
+                  }
+                  rf[0] = 0.0;
+#pragma unroll
+                  for (int s2 = 1; s2 < S; s2++) {
+                      asm volatile("" : "+v"(rfN[s2]));
+                      rf[s2] = rfN[s2];
+                  }
+                  if (i0 + kAhead < kPackChunk) request(i0 + kAhead, d2 - kAhead);  // a group's d2 falls by one per active step
+#pragma unroll
+                  for (int j = 0; j < kAhead; j++) {
+                    const int i = i0 + j;
+                    if (!__ballot(i < cnt)) {
+                        chunkDone = true;
+                        break;
+                    }
                     const bool act = i < cnt;
                     const CpkDiag e = act ? unpack(ebuf[i]) : CpkDiag{0, 1, 0, 0};
                     const int W = e.width;
                     const bool on = act && c < W;
-                    asm volatile("" : "+v"(fNext));  // the wait for the prefetched value sits here, a whole step after its load
-                    const double f0 = fNext;
-                    if (i + 1 < kPackChunk) {
-                        const CpkDiag en = unpack(ebuf[i + 1]);
-                        fNext = (i + 1 < cnt && c < en.width) ? ld_self(ringAt(en) + SW::ringIdx(en.width, 0, c)) : 0.0;
-                    }
-                    const bool seeded = d2 == sg.dTop;
                     const bool emit = act && d2 <= sg.tbFrom;
                     const int sinceFrom = sg.tbFrom - d2;
                     const bool refresh = emit && sinceFrom % CPK_REFRESH_PERIOD == 0;
+                    const double f0 = fq[j];
+                    const bool seeded = d2 == sg.dTop;
                     const int jr = sinceFrom / CPK_REFRESH_PERIOD;
                     // the fb values of the diagonal above a refresh point are its straddle series (see Sweep::traceback)
                     const bool feeds = act && d2 - 1 > sg.tbPrev && d2 - 1 <= sg.tbFrom &&
                                        (sg.tbFrom - (d2 - 1)) % CPK_REFRESH_PERIOD == 0;
                     const int jrNext = (sg.tbFrom - (d2 - 1)) / CPK_REFRESH_PERIOD;
-                    const double *fsrc = ringAt(e);
                     typename SW::BwdCtx bc;
                     bc.d2 = d2;
                     bc.xlo = (d2 + e.xmyL) >> 1;
@@ -291,7 +351,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                         if (refresh && on) {
 #pragma unroll
                             for (int s2 = 1; s2 < S; s2++)
-                                t = logadd(lg, t, ld_self(fsrc + SW::ringIdx(W, s2, c)) + v[0][s2]);
+                                t = logadd(lg, t, rf[s2] + v[0][s2]);
                             cbuf[(size_t)c * J + jr] = t;
                             if (!kExpect && x > 0 && y > 0) fbf = (float)fbv;
                         }
@@ -303,6 +363,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                         eb = e;
                         d2--;
                     }
+                  }
                 }
             }
             if (!kExpect && __ballot(pend > 0)) flush(pend);
@@ -314,10 +375,25 @@ cpecan_pairhmm_packed(const KArgs a) {
                     const int rr = sg.tbFrom - CPK_REFRESH_PERIOD * j;
                     const int Wc = table[rr].width;
                     const int Wm = rr + 1 <= sg.dTop ? table[rr + 1].width : 0;
-                    double total = NEG_INF, straddle = NEG_INF;
-                    for (int k = 0; k < Wc; k++) total = logadd(lg, total, ld_self(cbuf + (size_t)k * J + j));
-                    for (int k = 0; k < Wm; k++) straddle = logadd(lg, straddle, ld_self(mbuf + (size_t)k * J + j));
-                    if (rr + 1 <= sg.dTop) total = logadd(lg, total, straddle);
+                    // eight values of each series are requested together, then folded in order (the two series side by side);
+                    // padding with -inf leaves a fold unchanged because logAdd(x, -inf) returns x exactly
+                    double ts[2] = {NEG_INF, NEG_INF};
+                    for (int k0 = 0; k0 < Wc || k0 < Wm; k0 += 8) {
+                        double xs[8], ys[8];
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const int k = k0 + q < GW ? k0 + q : GW - 1;  // inside the group's slice whatever Wc, Wm
+                            xs[q] = ld_self(cbuf + (size_t)k * J + j);
+                            ys[q] = ld_self(mbuf + (size_t)k * J + j);
+                        }
+#pragma unroll
+                        for (int q = 0; q < 8; q++) {
+                            const double xy[2] = {k0 + q < Wc ? xs[q] : NEG_INF, k0 + q < Wm ? ys[q] : NEG_INF};
+                            logadd_n<2>(lg, ts, xy);
+                        }
+                    }
+                    double total = ts[0];
+                    if (rr + 1 <= sg.dTop) total = logadd(lg, total, ts[1]);
                     totals[j] = total;
                 }
             }
@@ -412,32 +488,46 @@ cpecan_pairhmm_packed(const KArgs a) {
             } else {
             // ---------------- thresholded posteriors from the candidates, walked backwards (:655-689) ----------------
                 if (segOn && c == 0) a.segStarts[rg.segOff + si] = count;
-                for (int top = nCand; __ballot(segOn && top > 0); top -= GW) {
-                    const int i = top - 1 - c;
-                    const bool valid = segOn && top > 0 && i >= 0;
-                    double p = 0.0;
-                    int x = 0, y = 0;
-                    if (valid) {
-                        const double fbv = ld_self(&cand[i].fb);
-                        const long long xy = __hip_atomic_load(reinterpret_cast<const long long *>(&cand[i].x), __ATOMIC_RELAXED,
-                                                               __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        x = (int)(xy & 0xffffffffll);
-                        y = (int)(xy >> 32);
-                        const double total = ld_self(totals + (sg.tbFrom - (x + y)) / CPK_REFRESH_PERIOD);
-                        p = exp(fbv - total);
+                // kEmitU candidates per lane and pass: their loads (candidate, then the total of its diagonal) are in flight
+                // together -- one candidate per lane was two dependent global round trips for every GW pairs
+                constexpr int kEmitU = 4;
+                for (int top = nCand; __ballot(segOn && top > 0); top -= kEmitU * GW) {
+                    double fbv[kEmitU], tot[kEmitU];
+                    long long xyv[kEmitU];
+                    bool valid[kEmitU];
+#pragma unroll
+                    for (int u = 0; u < kEmitU; u++) {
+                        const int i = top - 1 - (u * GW + c);
+                        valid[u] = segOn && i >= 0;
+                        const Candidate *cp = cand + (valid[u] ? i : 0);  // slot 0 exists in every group's list
+                        fbv[u] = ld_self(&cp->fb);
+                        xyv[u] = __hip_atomic_load(reinterpret_cast<const long long *>(&cp->x), __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_WAVEFRONT);
                     }
-                    const bool keep = valid && p >= thr;
-                    const unsigned long long mask = __ballot(keep);
-                    if (keep) {
-                        if (p > 1.0) p = 1.0;
-                        const int pos = count + __popcll(mask & belowMe);
-                        if (pos < rg.outCap) {
-                            out[3 * (size_t)pos + 0] = (int32_t)floor(p * (double)CPECAN_PROB_1);
-                            out[3 * (size_t)pos + 1] = x - 1;
-                            out[3 * (size_t)pos + 2] = y - 1;
+#pragma unroll
+                    for (int u = 0; u < kEmitU; u++) {
+                        const int x = (int)(xyv[u] & 0xffffffffll), y = (int)(xyv[u] >> 32);
+                        int jt = valid[u] ? (sg.tbFrom - (x + y)) / CPK_REFRESH_PERIOD : 0;
+                        jt = jt < 0 ? 0 : jt;
+                        tot[u] = ld_self(totals + jt);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kEmitU; u++) {
+                        const int x = (int)(xyv[u] & 0xffffffffll), y = (int)(xyv[u] >> 32);
+                        double p = valid[u] ? exp(fbv[u] - tot[u]) : 0.0;
+                        const bool keep = valid[u] && p >= thr;
+                        const unsigned long long mask = __ballot(keep);
+                        if (keep) {
+                            if (p > 1.0) p = 1.0;
+                            const int pos = count + __popcll(mask & belowMe);
+                            if (pos < rg.outCap) {
+                                out[3 * (size_t)pos + 0] = (int32_t)floor(p * (double)CPECAN_PROB_1);
+                                out[3 * (size_t)pos + 1] = x - 1;
+                                out[3 * (size_t)pos + 2] = y - 1;
+                            }
                         }
+                        count += __popcll(mask & groupBits);
                     }
-                    count += __popcll(mask & groupBits);
                 }
             }
             // ---------------- the traceback used the rolling buffers: restore F[dTop-1], F[dTop] ----------------
