@@ -443,11 +443,9 @@ struct cpecan_batch {
 static int grow(void **p, int64_t *cap, int64_t need, size_t elem) {
     if (need <= *cap) return 0;
     int64_t c = *cap ? *cap : 16;
-    while (c < need) c += c < ((int64_t)1 << 20) ? c : c / 4; /* doubling while small, +25 % steps beyond */
-    void *q = cpk_host_alloc((size_t)c * elem);
+    while (c < need) c *= 2;
+    void *q = cpk_host_grow(*p, (size_t)*cap * elem, (size_t)c * elem);
     if (!q) return -1;
-    if (*p) memcpy(q, *p, (size_t)*cap * elem);
-    cpk_host_free(*p);
     *p = q;
     *cap = c;
     return 0;
@@ -1264,8 +1262,9 @@ static int run_post(cpecan_batch *b) {
         job.problems = pp;
         job.scores = scores;
         job.counts = counts;
-        job.chars = b->chars; /* identity scores, left shift */
-        job.nChars = b->nChars;
+        /* identity scores and the left shift compare letters; neither exists without a consumer (cpecan_batch_identity_scores) */
+        job.chars = job.flags ? b->chars : NULL;
+        job.nChars = job.flags ? b->nChars : 0;
         if (job.flags & (CPECAN_POST_MEA | CPECAN_POST_ORDERED)) {
             b->postMea = cpk_host_alloc(sizeof(int32_t) * 3 * (size_t)(job.meaCap ? job.meaCap : 1));
             job.mea = b->postMea;

@@ -131,6 +131,7 @@ typedef struct CpkDevice CpkDevice;
 /* Host blocks of a batch: pinned and recycled when a HIP device is present, plain malloc below 256 KB or without a GPU. */
 void *cpk_host_alloc(size_t bytes);
 void cpk_host_free(void *p);
+void *cpk_host_grow(void *p, size_t usedBytes, size_t newBytes); /* NULL on failure: p is still valid then */
 int cpk_device_count(void);
 int cpk_current_device(void); /* the calling thread's current HIP device (0 when there is none) */
 const char *cpk_last_error(void);

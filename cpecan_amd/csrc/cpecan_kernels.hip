@@ -205,6 +205,10 @@ void cache_free(int device, void *ptr, size_t bytes) {
 // (BASELINE config 4: 50 000 alignments, 60 M anchors, 74 M result triples) holds ~2 GB of them; from malloc every batch
 // paid ~90 ms of first-touch page faults while filling them, ~200 ms of munmap in cpecan_batch_destroy, a staging copy
 // on the way up and a pageable (pin-as-you-go) copy on the way down (profiles/r02_e2e_stages_config4_before.txt).
+// A block is pinned (hipHostRegister) when it is REUSED, not when it is first allocated: pinning costs ~0.2 ms per MB,
+// twice the first-touch faults it replaces, and a process that runs one batch and exits (the cpecan_realign command
+// line on one file) would only pay for it -- its copies go the pageable way, as before.  From its second life on a
+// block is read and written by the copy engines in place.
 // Blocks below 256 KB are plain malloc.  CPECAN_HOST_CACHE_MB bounds what idle blocks may hold (default 16 GiB);
 // CPECAN_PINNED=0 keeps everything pageable.
 // ------------------------------------------------------------------------------------------------
@@ -213,6 +217,7 @@ struct HostBlock {
     void *ptr;
     size_t bytes;
     bool pinned;
+    bool registered;  // pinned by hipHostRegister (memory of posix_memalign) rather than allocated by hipHostMalloc
 };
 constexpr size_t kHostPoolMin = (size_t)256 << 10;
 std::mutex g_hostMutex;
@@ -239,8 +244,12 @@ bool host_pinning_enabled() {
     return v;
 }
 void host_release(const HostBlock &b) {
-    if (b.pinned) (void)hipHostFree(b.ptr);
-    else free(b.ptr);
+    if (b.pinned && !b.registered) {
+        (void)hipHostFree(b.ptr);
+        return;
+    }
+    if (b.registered) (void)hipHostUnregister(b.ptr);
+    free(b.ptr);
 }
 }  // namespace
 
@@ -256,16 +265,20 @@ static void *host_alloc_impl(size_t bytes, bool mustPin) {
                 (g_hostIdle[i].pinned || !mustPin) && (best < 0 || g_hostIdle[i].bytes < g_hostIdle[best].bytes))
                 best = i;
         if (best >= 0) {
-            const HostBlock b = g_hostIdle[best];
+            HostBlock b = g_hostIdle[best];
             g_hostIdle[best] = g_hostIdle.back();
             g_hostIdle.pop_back();
             g_hostIdleBytes -= b.bytes;
+            if (!b.pinned && host_pinning_enabled()) {  // a second life: worth pinning now (its pages are resident)
+                if (hipHostRegister(b.ptr, b.bytes, hipHostRegisterPortable) == hipSuccess) b.pinned = b.registered = true;
+                else (void)hipGetLastError();
+            }
             g_hostLive.push_back(b);
             return b.ptr;
         }
     }
-    HostBlock b{nullptr, bytes, false};
-    if (host_pinning_enabled() || mustPin) {
+    HostBlock b{nullptr, bytes, false, false};
+    if (mustPin) {
         if (hipHostMalloc(&b.ptr, bytes, hipHostMallocPortable) == hipSuccess) b.pinned = true;
         else {
             (void)hipGetLastError();
@@ -281,7 +294,7 @@ extern "C" void *cpk_host_alloc(size_t bytes) { return host_alloc_impl(bytes, fa
 
 extern "C" void cpk_host_free(void *p) {
     if (!p) return;
-    HostBlock b{nullptr, 0, false};
+    HostBlock b{nullptr, 0, false, false};
     {
         std::lock_guard<std::mutex> lock(g_hostMutex);
         for (size_t i = 0; i < g_hostLive.size(); i++)
@@ -299,6 +312,40 @@ extern "C" void cpk_host_free(void *p) {
     }
     if (b.ptr) host_release(b);
     else free(p);  // a small block
+}
+
+// Grows a block to newBytes keeping its first usedBytes.  A block that is not pinned grows in place where the C library
+// can do that (realloc: mremap for large blocks, no copy and no new page faults for the part that exists) -- a batch that
+// is filled a slice at a time grows its arrays a dozen times.
+extern "C" void *cpk_host_grow(void *p, size_t usedBytes, size_t newBytes) {
+    if (!p) return cpk_host_alloc(newBytes);
+    bool pooled = false, pinned = false;
+    {
+        std::lock_guard<std::mutex> lock(g_hostMutex);
+        for (size_t i = 0; i < g_hostLive.size(); i++)
+            if (g_hostLive[i].ptr == p) {
+                pooled = true;
+                pinned = g_hostLive[i].pinned;
+                if (!pinned) {  // out of the books while it may move
+                    g_hostLive[i] = g_hostLive.back();
+                    g_hostLive.pop_back();
+                }
+                break;
+            }
+    }
+    if (pooled && !pinned) {
+        const size_t rounded = (newBytes + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
+        void *q = realloc(p, rounded);
+        std::lock_guard<std::mutex> lock(g_hostMutex);
+        g_hostLive.push_back(HostBlock{q ? q : p, q ? rounded : usedBytes, false, false});
+        return q;  // on failure the old block is still the caller's (and back in the books)
+    }
+    if (!pooled && newBytes < kHostPoolMin) return realloc(p, newBytes);
+    void *q = cpk_host_alloc(newBytes);
+    if (!q) return nullptr;
+    memcpy(q, p, usedBytes);
+    cpk_host_free(p);
+    return q;
 }
 
 // is [p, p + bytes) inside a pinned block of the pool?  (then a copy needs no staging)
@@ -567,9 +614,13 @@ static KernelFn pick_kernel(const CpkGeometry &g) {
 }
 
 // Queues dst <- src (host) on the batch's stream through the shell's pinned buffer; `at` is the running offset in it.
+constexpr size_t kStageMaxCopy = (size_t)64 << 20;  // larger sources are never copied through the shell's staging buffer
 static int staged_h2d(CpkDevice *d, void *dst, const void *src, size_t bytes, size_t *at) {
     if (bytes == 0) return CPECAN_OK;
-    if (host_is_pinned(src, bytes)) {  // a block of the host pool: the copy engine reads it where it lies
+    // a pinned block of the host pool: the copy engine reads it where it lies.  A large block in its first life is not
+    // pinned yet: the runtime copies it the pageable way (through its own staging), which only hurts beside a running
+    // sweep -- and in a pipeline the blocks are in their second life.
+    if (bytes > kStageMaxCopy || host_is_pinned(src, bytes)) {
         HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, d->io));
         return CPECAN_OK;
     }
@@ -958,7 +1009,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     size_t stageAt = 0;
     const size_t anchorBytes = sizeof(cpk_anchor_t) * (size_t)anchorStride * (size_t)(nAnchors > 0 ? nAnchors : 1);
     {
-        auto staged = [](const void *p, size_t bytes) { return host_is_pinned(p, bytes) ? (size_t)0 : bytes + 256; };
+        auto staged = [](const void *p, size_t bytes) { return (bytes > kStageMaxCopy || host_is_pinned(p, bytes)) ? (size_t)0 : bytes + 256; };
         if (int rc = stage_reserve(d, staged(regions, sizeof(CpkRegion) * (size_t)geo->nRegions) + staged(anchors, anchorBytes) +
                                       staged(segs, sizeof(CpkSegment) * (size_t)nSegs) + staged(symbols, (size_t)nSymbolBytes) +
                                       sizeof(CpkModel) + sizeof(CpkItem) * items.size() + 8 * 256))
