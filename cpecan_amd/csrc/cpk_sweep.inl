@@ -1023,7 +1023,13 @@ cpecan_pairhmm_sweep(const KArgs a) {
         // Every lane takes part in the ticket fetch (lane 0 adds 1, the others add 0; hipcc folds this into one
         // atomic per wave).  Do NOT write this as `if (lane == 0) ticket = atomicAdd(..)`: hipcc 7.2 jump-threads
         // the lane test across the loop back-edge and re-runs the readfirstlane with 63 lanes -> endless loop.
+#if defined(CPK_DIAGNOSTICS) && defined(CPK_TICKET_LANE0)
+        // the form that hangs, kept for the ISA comparison only (profiles/r02_ticket_fetch_isa.txt)
+        unsigned int ticket = 0;
+        if (lane == 0) ticket = atomicAdd(a.queue, 1u);
+#else
         const unsigned int ticket = atomicAdd(a.queue, lane == 0 ? 1u : 0u);
+#endif
         const int tk = __builtin_amdgcn_readfirstlane((int)ticket);
         if (tk >= a.regionCount) break;
         // kModeTrace: the queue holds (region, segment) items, longest first; otherwise regions

@@ -150,6 +150,59 @@ def test_realign_keeps_coordinates_and_matches_the_stepwise_flow():
                 assert 0.0 <= a.score <= 100.0
 
 
+def _oracle_flow(seqs, c, o):
+    """One cigar through cPecanRealign.c:511-581 WITHOUT the library: anchors and cigar operations restated here in
+    Python, posteriors / reweighting / ordered chain from the CPU oracle (tests/oracle_binding.py)."""
+    import oracle_binding as orc
+    sx, sy = _sub(seqs, c)
+    trim, expansion = o.constraintDiagonalTrim, o.params.diagonalExpansion
+    anchors, x, y = [], 0, 0
+    for t, n in c.ops:  # aligned columns of the input, `trim` columns cut from both ends of a block, mismatches dropped (:277-281)
+        if t == M:
+            for l in range(trim, n - trim):
+                a, b = sx[x + l].upper(), sy[y + l].upper()
+                if a == b and a != "N":
+                    anchors.append((x + l, y + l, expansion))
+        x += n if t != IY else 0
+        y += n if t != DX else 0
+    m = orc.model(orc.FIVE_STATE)
+    p = orc.params(diagonalExpansion=expansion, splitMatrixBiggerThanThis=o.params.splitMatrixBiggerThanThis)
+    pairs = orc.aligned_pairs(m, sx, sy, anchors, p, True, True)
+    pairs = orc.reweight_aligned_pairs(pairs, len(sx), len(sy), float(np.float32(o.gapGamma)))
+    final = orc.filter_pairs_ordered(pairs, len(sx), len(sy), o.matchGamma)
+    xy = sorted((int(px), int(py)) for _, px, py in np.asarray(final).reshape(-1, 3).tolist())
+    ops, cx, cy, i = [], 0, 0, 0  # maximal diagonal runs; what lies between them is an X-indel, then a Y-indel (:49-96)
+    while i < len(xy):
+        x0, y0 = xy[i]
+        run = 1
+        while i + run < len(xy) and xy[i + run] == (x0 + run, y0 + run):
+            run += 1
+        if x0 > cx:
+            ops.append((DX, x0 - cx))
+        if y0 > cy:
+            ops.append((IY, y0 - cy))
+        ops.append((M, run))
+        cx, cy, i = x0 + run, y0 + run, i + run
+    if len(sx) > cx:
+        ops.append((DX, len(sx) - cx))
+    if len(sy) > cy:
+        ops.append((IY, len(sy) - cy))
+    return ops
+
+
+def test_realign_matches_the_oracle_flow():
+    """The batched realignment against a flow that shares no code with the library: Python for the cigar <-> columns
+    conversions, the CPU oracle for posteriors, reweighting and the ordered chain.  Coordinates are the input's."""
+    rng = random.Random(47 + SHIFT)
+    seqs, cigars = _world(rng, n_cigars=50)
+    o = realign_options()
+    with _realigner(seqs) as r:
+        got = r.realign(cigars)
+    for a, c in zip(got, cigars):
+        assert a.same_coordinates(c)
+        assert [tuple(op) for op in a.ops] == _oracle_flow(seqs, c, o), c.format()
+
+
 def test_realign_options_change_the_flow_consistently():
     rng = random.Random(47 + SHIFT)
     seqs, cigars = _world(rng, n_cigars=25)
