@@ -1231,7 +1231,7 @@ static void post_layout(CpkPostJob *job, CpkPostProblem *pp, int64_t i, const in
     pp->charY = charY;
     pp->meaOut = job->meaCap;
     pp->shiftOut = job->shiftCap;
-    job->seqSlots += lX + lY;
+    job->seqSlots += lX + 2 * lY; /* ORDERED: column heads + the staircase's two arrays; the other consumers use lX + lY */
     job->chainSlots += n[0] + 1;
     job->meaCap += n[0];
     job->shiftCap += n[0] + imin(lX, lY) + 1;

@@ -191,61 +191,80 @@ __global__ void __launch_bounds__(64) cpecan_post_left_shift(const CpkPostProble
 // filterPairwiseAlignmentToMakePairsOrdered (impl/multipleAligner.c:945-972), one lane per problem: the heaviest chain
 // of the pairs whose weight reaches matchGamma, as a filter of list 0.  With two sequences the reference's
 // pairwiseAlignColumns (:358-492) keeps a frontier of chain ends sorted by y with strictly increasing scores; the
-// predecessor it gives a pair (the frontier entry with the largest y below it, :397) is the processed pair that is
-// maximal under (score, then smaller y, then later column), because every other processed pair is dominated by a
-// frontier entry in exactly that order (:418-427).  That maximum is what the Fenwick tree over y holds here, so no
-// entry ever has to be deleted.  Pairs of one X column are all scored before any of them is inserted (:389-409).
+// predecessor it gives a pair is the frontier entry with the largest y below it (:397), and an entry is dropped for
+// one that is maximal under (score, then smaller y, then later column) (:418-427).
+// That frontier is kept here as what it is: a STAIRCASE, the chain ends that no other end dominates, sorted by y with
+// strictly growing scores (stairY / stairI).  An alignment is close to monotone, so nearly every pair finds its
+// predecessor in the last entry and is appended behind it -- two or three memory operations of this lane, where the
+// Fenwick tree over y of rounds 1-2 (prefix maxima, nothing ever deleted) walked ~2 log2(lY) nodes and their scores for
+// every pair: 38.6 ms for the 50 000 cigars of the realign benchmark, more than the DP kernels.
+// Pairs of one X column are all scored before any of them is inserted (:389-409).
 // The reference's st_random() * 0.00001 per weight (:145) is left out.
-struct OrderedCtx {
+struct OrderedStairs {
     const int32_t *pairs;
     const double *best;
-    // the better chain end of a (score sa) and b (score sb): higher score, then smaller y, then the later column
-    __device__ __forceinline__ int pick(int a, double sa, int b, double sb) const {
-        if (a < 0) return b;
-        if (b < 0) return a;
-        if (sa != sb) return sa > sb ? a : b;
-        const int ya = pairs[3 * a + 2], yb = pairs[3 * b + 2];
-        if (ya != yb) return ya < yb ? a : b;
-        return pairs[3 * a + 1] > pairs[3 * b + 1] ? a : b;
+    int32_t *stairY, *stairI;  // y and pair index of the entries, ascending y (at most one entry per y: lY words each)
+    int len;
+    int lastY, lastI;  // the last entry, in registers: the usual pair needs nothing else of the staircase
+    double lastS;
+    __device__ __forceinline__ void reloadLast() {
+        lastY = len > 0 ? stairY[len - 1] : -1;
+        lastI = len > 0 ? stairI[len - 1] : -1;
+        lastS = len > 0 ? best[lastI] : 0.0;
     }
-    __device__ __forceinline__ double score(int i) const { return i >= 0 ? best[i] : -__builtin_huge_val(); }
-    // Fenwick prefix maximum over y' < y.  The nodes of a query are known from y alone: four nodes, then their four
-    // scores, are loaded side by side -- two dependent round trips per four nodes instead of eight (one lane per
-    // problem: this walk is pure memory latency).
-    __device__ __forceinline__ int query(const int32_t *tree, int y) const {
-        int from = -1;
-        double sFrom = -__builtin_huge_val();
-        for (int k = y; k > 0;) {
-            const int k0 = k, k1 = k0 - (k0 & -k0), k2 = k1 - (k1 & -k1), k3 = k2 - (k2 & -k2);  // 0 stays 0
-            const int i0 = tree[k0 - 1], i1 = k1 > 0 ? tree[k1 - 1] : -1, i2 = k2 > 0 ? tree[k2 - 1] : -1,
-                      i3 = k3 > 0 ? tree[k3 - 1] : -1;
-            const double s0 = score(i0), s1 = score(i1), s2 = score(i2), s3 = score(i3);
-            int a = pick(i0, s0, i1, s1);
-            const double sa = a == i0 ? s0 : s1;
-            int b = pick(i2, s2, i3, s3);
-            const double sb = b == i2 ? s2 : s3;
-            a = pick(a, sa, b, sb);
-            const double sab = a == b ? sb : sa;
-            const int f = pick(from, sFrom, a, sab);
-            sFrom = f == from ? sFrom : sab;
-            from = f;
-            k = k3 - (k3 & -k3);
+    // number of entries with y' < y
+    __device__ __forceinline__ int below(int y) const {
+        if (len == 0 || lastY < y) return len;  // the usual case: the pair extends the alignment
+        int lo = 0, hi = len - 1;                         // stairY[hi] >= y
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (stairY[mid] < y) lo = mid + 1;
+            else hi = mid;
         }
-        return from;
+        return lo;
     }
-    // pair i (score si) becomes a candidate end for every prefix that contains y
-    __device__ __forceinline__ void update(int32_t *tree, int lY, int y, int i, double si) const {
-        for (int k = y + 1; k <= lY;) {
-            const int k0 = k, k1 = k0 + (k0 & -k0), k2 = k1 + (k1 & -k1), k3 = k2 + (k2 & -k2);
-            const bool v1 = k1 <= lY, v2 = k2 <= lY, v3 = k3 <= lY;
-            const int i0 = tree[k0 - 1], i1 = v1 ? tree[k1 - 1] : -1, i2 = v2 ? tree[k2 - 1] : -1, i3 = v3 ? tree[k3 - 1] : -1;
-            const double s0 = score(i0), s1 = score(i1), s2 = score(i2), s3 = score(i3);
-            if (pick(i0, s0, i, si) == i) tree[k0 - 1] = i;
-            if (v1 && pick(i1, s1, i, si) == i) tree[k1 - 1] = i;
-            if (v2 && pick(i2, s2, i, si) == i) tree[k2 - 1] = i;
-            if (v3 && pick(i3, s3, i, si) == i) tree[k3 - 1] = i;
-            k = v3 ? k3 + (k3 & -k3) : lY + 1;
+    // best chain end with y' < y: the last entry below y (the highest score; of equal scores only the smaller y is kept)
+    __device__ __forceinline__ int query(int y) const {
+        const int pos = below(y);
+        return pos == 0 ? -1 : (pos == len ? lastI : stairI[pos - 1]);
+    }
+    // pair i (end y, chain score si, of the current column -- later than every entry's) becomes a chain end
+    __device__ __forceinline__ void insert(int y, int i, double si) {
+        const int pos = below(y);
+        // an end at a smaller y with at least this score is preferred wherever both are candidates
+        if (pos > 0 && (pos == len ? lastS : best[stairI[pos - 1]]) >= si) return;
+        if (pos == len) {  // appended behind everything: no entry to compare with, nothing to move
+            stairY[len] = y;
+            stairI[len] = i;
+            len++;
+            lastY = y;
+            lastI = i;
+            lastS = si;
+            return;
         }
+        int q = pos;
+        if (q < len && stairY[q] == y) {  // the same y: the higher score, then the later column (this pair)
+            if (best[stairI[q]] > si) return;
+            q++;
+        }
+        while (q < len && best[stairI[q]] <= si) q++;  // ends at a larger y that do not beat this score are dominated
+        // entries [pos, q) go, the pair takes position pos, the tail [q, len) follows it
+        const int shift = pos + 1 - q;
+        if (shift > 0) {
+            for (int k = len - 1; k >= q; k--) {
+                stairY[k + 1] = stairY[k];
+                stairI[k + 1] = stairI[k];
+            }
+        } else if (shift < 0) {
+            for (int k = q; k < len; k++) {
+                stairY[k + shift] = stairY[k];
+                stairI[k + shift] = stairI[k];
+            }
+        }
+        stairY[pos] = y;
+        stairI[pos] = i;
+        len += shift;
+        reloadLast();
     }
 };
 
@@ -258,32 +277,36 @@ __global__ void __launch_bounds__(64) cpecan_post_ordered(const CpkPostProblem *
     const CpkPostProblem pb = problems[p];
     const int32_t *pairs = triples + 3 * pb.off[0];
     const int n = pb.n[0], lX = pb.lX, lY = pb.lY;
-    int32_t *head = seqScratch + pb.seqOff, *tree = head + lX;  // pairs of each X column; Fenwick tree over y
+    // seqScratch: lX + 2 lY words of this problem (post_layout): first pair of each X column, then the staircase
+    int32_t *head = seqScratch + pb.seqOff;
     double *bs = best + pb.chainOff;
     int32_t *pv = prev + pb.chainOff, *nx = next + pb.chainOff;
     uint8_t *ch = chosen + pb.chainOff;
-    for (int i = 0; i < lX + lY; i++) head[i] = -1;
+    for (int i = 0; i < lX; i++) head[i] = -1;
     for (int i = n - 1; i >= 0; i--) {
         const int x = pairs[3 * i + 1];
         nx[i] = head[x];
         head[x] = i;
         ch[i] = 0;
     }
-    const OrderedCtx cx{pairs, bs};
+    OrderedStairs st{pairs, bs, head + lX, head + lX + lY, 0, -1, -1, 0.0};
     for (int x = 0; x < lX; x++) {
+        bool any = false;
         for (int i = head[x]; i >= 0; i = nx[i]) {
             const double w = (double)pairs[3 * i] / (double)CPECAN_PROB_1;
             if (w >= matchGamma && w > 0.0) {  // :393
-                const int from = cx.query(tree, pairs[3 * i + 2]);  // y' < y
+                const int from = st.query(pairs[3 * i + 2]);  // y' < y
                 pv[i] = from;
                 bs[i] = (from < 0 ? 0.0 : bs[from]) + w * 1.0;  // :404
                 ch[i] = 2;
+                any = true;
             }
         }
+        if (!any) continue;
         for (int i = head[x]; i >= 0; i = nx[i])
-            if (ch[i] == 2) cx.update(tree, lY, pairs[3 * i + 2], i, bs[i]);
+            if (ch[i] == 2) st.insert(pairs[3 * i + 2], i, bs[i]);
     }
-    const int last = cx.query(tree, lY);
+    const int last = st.lastI;  // the best chain end over every y (-1: no pair reached matchGamma)
     for (int i = last; i >= 0; i = pv[i]) ch[i] = 1;  // :437-475
     int32_t *o = out + 3 * pb.meaOut;
     int count = 0;
