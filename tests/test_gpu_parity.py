@@ -645,6 +645,101 @@ def test_config5_expectation_sample_band10():
     _assert_hmm_close(acc, oacc, 5)
 
 
+@pytest.mark.parametrize("name", ["A", "B"])
+def test_configs_A_and_B_at_full_size(name):
+    """configs[1] and configs[2] with every pair of the BASELINE batch in ONE launch, as bench.py runs them (config A:
+    a split class, tracebacks as queue items of their own): a sample spread over the batch against the oracle, and a
+    slice run again in a batch of its own -- identical lists."""
+    from cpecan_amd import workload
+    cfg = workload.CONFIGS[name]
+    n, mtype = cfg["n_pairs"], (0 if cfg["model"] == "fiveState" else 2)
+    problems = workload.config_problems(name, range(n))
+    kw = dict(diagonalExpansion=cfg["expansion"])
+    p = api.pairwiseAlignmentBandingParameters_construct(**kw)
+    with api.Batch(_sm(mtype), p) as b:
+        b.add_many(problems)
+        b.upload()
+        b.run()
+        b.download()
+        st = b.stats()
+        assert st.problems == n
+        om, op = ob.model(mtype), ob.params(**kw)
+        for i in sorted(set(range(0, n, n // 12)) | {n - 1}):
+            sx, sy, a, rl, rr = problems[i]
+            assert_pairs_match(b.result(i), ob.aligned_pairs(om, sx, sy, a, op, rl, rr), threshold=op.threshold)
+        keep = [b.result(i).copy() for i in range(n // 2, n // 2 + 40)]
+        assert sum(len(b.result(i)) for i in range(n)) == st.pairs
+    again, _ = _run_batch(mtype, [pr[:3] for pr in problems[n // 2:n // 2 + 40]], **kw)
+    for t1, t2 in zip(keep, again):
+        assert np.array_equal(t1, t2)
+
+
+def test_config4_at_full_size():
+    """configs[3] at BASELINE's size -- all 50 000 pairs in ONE batch, as bench.py runs it: a sample spread over the batch
+    (the longest pair included) against the oracle, every list's size-independent properties, and a slice of the batch
+    run again in a batch of its own (other size classes, other wave slots): identical lists."""
+    from cpecan_amd import workload
+    cfg = workload.CONFIGS["4"]
+    n = cfg["n_pairs"]
+    problems = workload.config_problems("4", range(n))
+    kw = dict(diagonalExpansion=cfg["expansion"], splitMatrixBiggerThanThis=cfg["split"])
+    p = api.pairwiseAlignmentBandingParameters_construct(**kw)
+    with api.Batch(_sm(0), p) as b:
+        b.add_many(problems)
+        b.upload()
+        b.run()
+        b.download()
+        st = b.stats()
+        assert st.problems == n and st.regions >= n
+        longest = max(range(n), key=lambda i: len(problems[i][0]))
+        sample = sorted(set(range(0, n, n // 24)) | {longest, n - 1})
+        om, op = ob.model(0), ob.params(**kw)
+        for i in sample:
+            sx, sy, a, rl, rr = problems[i]
+            assert_pairs_match(b.result(i), ob.aligned_pairs(om, sx, sy, a, op, rl, rr), threshold=op.threshold)
+        total = 0
+        for i in range(n):
+            tri = b.result(i)
+            total += len(tri)
+            if len(tri) == 0:
+                continue
+            sx, sy = problems[i][0], problems[i][1]
+            assert tri[:, 0].min() > 0 and tri[:, 0].max() <= api.PAIR_ALIGNMENT_PROB_1
+            assert tri[:, 1].min() >= 0 and tri[:, 1].max() < len(sx) and tri[:, 2].min() >= 0 and tri[:, 2].max() < len(sy)
+            assert len(np.unique(tri[:, 1].astype(np.int64) * (len(sy) + 1) + tri[:, 2])) == len(tri)
+        assert total == st.pairs
+        keep = [b.result(i).copy() for i in range(3000, 3400)]
+    again, _ = _run_batch(0, [pr[:3] for pr in problems[3000:3400]], [(True, True)] * 400, **kw)
+    for t1, t2 in zip(keep, again):
+        assert np.array_equal(t1, t2)
+
+
+def test_config5_at_full_size_counts_add_up():
+    """configs[4] at BASELINE's size: the expectation counts of all 100 000 pairs in one batch equal the sum of the counts
+    of four quarters run as batches of their own (the counts are sums over cells: additive whatever the batching), and a
+    sample of the pairs agrees with the oracle (test_config5_expectation_sample_band10 does the oracle side)."""
+    from cpecan_amd import workload
+    cfg = workload.CONFIGS["5"]
+    n = cfg["n_pairs"]
+    problems = workload.config_problems("5", range(n))
+    p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=cfg["expansion"])
+
+    def counts(probs):
+        acc = api.hmm_constructEmpty(0.0, api.fiveState)
+        with api.Batch(api.stateMachine5_construct(), p, emit=api.EMIT_EXPECT) as b:
+            b.add_many(probs)
+            b.upload()
+            b.run()
+            b.download()
+            b.expectations(acc)
+        return np.array(list(acc.transitions[:25]) + list(acc.emissions[:80]) + [acc.likelihood])
+
+    whole = counts(problems)
+    parts = sum(counts(problems[k * n // 4:(k + 1) * n // 4]) for k in range(4))
+    assert np.all(np.isfinite(whole)) and whole[:25].sum() > n * 1000  # about one transition per cell of the path
+    np.testing.assert_allclose(whole, parts, rtol=1e-9, atol=1e-6)
+
+
 # ---- narrow bands: the packed kernel (several regions per wave) ----
 @pytest.fixture
 def force_packed(monkeypatch):
