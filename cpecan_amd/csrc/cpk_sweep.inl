@@ -591,9 +591,12 @@ struct Sweep {
                     for (int s = 1; s < S; s++) curG[s + kR0] = v[0][s];
                 }
                 if (!CANDS && bring && emit && on) {  // kept for the expectation step: it needs B again, not its neighbours
-                    double *bo = bring + (size_t)(g.cellOff - bBase + k0) * S;
+                    // per group of gN cells state-major, [s][cell]: every store (and every load of the expectation step)
+                    // is one contiguous run of the group's lanes
+                    const int gN = W - kb < CPK_WAVE ? W - kb : CPK_WAVE;
+                    double *bo = bring + (size_t)(g.cellOff - bBase + kb) * S + lane;
 #pragma unroll
-                    for (int s = 0; s < S; s++) bo[s] = v[0][s];
+                    for (int s = 0; s < S; s++) bo[s * gN] = v[0][s];
                 }
                 if (feeds && on) mbuf[(size_t)k0 * J + jrNext] = f0[0] + v[0][0];  // every cell of the diagonal (:647)
                 if (emit) {
@@ -723,44 +726,50 @@ struct Sweep {
 
     // One group of 64 cells of one emitted diagonal, as the expectation step sees it.
     struct ExpItem {
-        int d2, kb, W, xlo, dl, dm, w1, w2, cellOff;
+        int d2, kb, W, xlo, dl, dm, w1, w2, w2Load, cellOff;
         const double *f1, *f2;
-        double total;
+        int jt;  // refresh point whose total normalises the diagonal
         bool valid;
     };
     // What the step reads for its cell: B of the cell, F[d2-1] at the lower / upper neighbour, F[d2-2] at the middle one.
     struct ExpLoads {
         double v[S], fL[S], fU[S], fM[S];
+        double total;
     };
 
     __device__ void expectations(const CpkSegment &sg, double (&tAcc)[kNT], double *eLds, double &likelihood) {
         const int bBase = dc.table[sg.tbPrev + 1].cellOff;
-        // The step has no dependency between cells: it is a stream of (diagonal, group) items.  The loads of the NEXT
-        // item are issued before the events of the current one are computed, so the HBM round trip of 16 values per
-        // cell runs beside ~250 vector instructions instead of in front of them.
+        // The step has no dependency between cells: it is a stream of (diagonal, group) items.  Three items are in
+        // flight: the loads of an item (16 values per cell) are issued two items before its events are computed, i.e.
+        // ~500 vector instructions ahead -- one item of lead (~250 instructions, round 1) is shorter than a loaded HBM
+        // round trip, and the waves of this emitter waited 47 % of their cycles.  The pass stores nothing to global
+        // memory, and every load is unconditional (an item behind the last one reads valid words it never uses), so
+        // the wait in front of an item's events can count the younger loads and leave them in flight.
         auto first_of = [&](int d2) {
             ExpItem it{};
             it.valid = d2 > sg.tbPrev;
-            if (!it.valid) return it;
-            const CpkDiag g = dc.get(d2, true);
-            const CpkDiag g1 = dc.get(d2 - 1, true);      // F[d2-1]: always alive (d2-1 >= tbPrev)
-            const bool haveM2 = d2 - 2 >= sg.tbPrev;      // F[d2-2] is gone at d2 == tbPrev+1 (:843-845)
-            const CpkDiag g2 = haveM2 ? dc.get(d2 - 2, true) : CpkDiag{};
-            it.d2 = d2;
+            const int dd = it.valid ? d2 : sg.tbPrev + 1;  // behind the last diagonal: the last one again, never used
+            const CpkDiag g = dc.get(dd, true);
+            const CpkDiag g1 = dc.get(dd - 1, true);      // F[d2-1]: always alive (d2-1 >= tbPrev)
+            const bool haveM2 = dd - 2 >= sg.tbPrev;      // F[d2-2] is gone at d2 == tbPrev+1 (:843-845)
+            const CpkDiag g2 = haveM2 ? dc.get(dd - 2, true) : g1;
+            it.d2 = dd;
             it.kb = 0;
             it.W = g.width;
-            it.xlo = (d2 + g.xmyL) >> 1;
+            it.xlo = (dd + g.xmyL) >> 1;
             it.dl = (g.xmyL - 1 - g1.xmyL) >> 1;  // lower neighbour (d2-1, xmy-1) is cell k+dl of F[d2-1]
             it.dm = (g.xmyL - g2.xmyL) >> 1;      // middle neighbour (d2-2, xmy) is cell k+dm of F[d2-2]
             it.w1 = g1.width;
             it.w2 = haveM2 ? g2.width : 0;
+            it.w2Load = g2.width;                 // the row the middle loads read (g1's when F[d2-2] is gone: unused then)
             it.cellOff = g.cellOff;
             it.f1 = ringAt(g1);
             it.f2 = ringAt(g2);
-            it.total = ld_self(totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
+            it.jt = (sg.tbFrom - dd) / CPK_REFRESH_PERIOD;  // its total is loaded with the item's other values (issue)
             return it;
         };
         auto next_of = [&](const ExpItem &it) {
+            if (!it.valid) return it;
             if (it.kb + CPK_WAVE < it.W) {
                 ExpItem n = it;
                 n.kb += CPK_WAVE;
@@ -773,31 +782,22 @@ struct Sweep {
             k = k < it.W ? k : it.W - 1;  // lanes past the end re-read the last cell
             const int kL = k + it.dl, kU = k + it.dl + 1, kM = k + it.dm;
             const int qL = (unsigned)kL < (unsigned)it.w1 ? kL : 0, qU = (unsigned)kU < (unsigned)it.w1 ? kU : 0;
-            const bool okM = (unsigned)kM < (unsigned)it.w2;
-            const int qM = okM ? kM : 0;
-            const double *bo = bring + (size_t)(it.cellOff - bBase + k) * S;
+            const int qM = (unsigned)kM < (unsigned)it.w2Load ? kM : 0;
+            const int gN = it.W - it.kb < CPK_WAVE ? it.W - it.kb : CPK_WAVE;
+            const double *bo = bring + (size_t)(it.cellOff - bBase + it.kb) * S + (k - it.kb);
+            L.total = ld_self(totals + it.jt);
 #pragma unroll
             for (int s = 0; s < S; s++) {
                 // 5 states: the lower block reads M, sX, lX, the upper block M, sY, lY; 3 states: all three
                 const bool needL = S == 3 || s == 0 || s == 1 || s == 3, needU = S == 3 || s == 0 || s == 2 || s == 4;
-                L.v[s] = it.valid ? ld_self(bo + s) : 0.0;
-                L.fL[s] = (it.valid && needL) ? ld_self(it.f1 + ringIdx(it.w1, s, qL)) : 0.0;
-                L.fU[s] = (it.valid && needU) ? ld_self(it.f1 + ringIdx(it.w1, s, qU)) : 0.0;
-                L.fM[s] = (it.valid && it.w2 > 0) ? ld_self(it.f2 + ringIdx(it.w2, s, qM)) : 0.0;
+                L.v[s] = ld_self(bo + s * gN);
+                L.fL[s] = needL ? ld_self(it.f1 + ringIdx(it.w1, s, qL)) : 0.0;
+                L.fU[s] = needU ? ld_self(it.f1 + ringIdx(it.w1, s, qU)) : 0.0;
+                L.fM[s] = ld_self(it.f2 + ringIdx(it.w2Load, s, qM));
             }
         };
-        ExpItem cur = first_of(sg.tbFrom);
-        ExpLoads Lc;
-        issue(cur, Lc);
-        while (cur.valid) {
-            const ExpItem nxt = next_of(cur);
-            ExpLoads Ln;
-            issue(nxt, Ln);
-#pragma unroll
-            for (int s = 0; s < S; s++) {  // the wait for the current item's loads sits here, one item after their issue
-                asm volatile("" : "+v"(Lc.v[s]), "+v"(Lc.fL[s]), "+v"(Lc.fU[s]), "+v"(Lc.fM[s]));
-            }
-            if (cur.kb == 0) likelihood += cur.total;  // once per diagonal (:743)
+        auto events = [&](const ExpItem &cur, const ExpLoads &Lc) {
+            if (cur.kb == 0) likelihood += Lc.total;  // once per diagonal (:743)
             const int k = cur.kb + lane;
             if (k < cur.W) {
                 const int kL = k + cur.dl, kU = k + cur.dl + 1, kM = k + cur.dm;
@@ -816,7 +816,7 @@ struct Sweep {
                 const double *wM = wt + (cX * 5 + cY) * kWM, *wX = wt + 25 * kWM + cX * kWG, *wY = wt + 25 * kWM + 5 * kWG + cY * kWG;
                 const bool acgt = cX < CPK_SYM_N && cY < CPK_SYM_N;
                 const int eIdx = cX * 4 + cY;
-                const double total = cur.total;
+                const double total = Lc.total;
                 double eAcc[S];  // this cell's events summed per target state: one LDS atomic per state, not per event
 #pragma unroll
                 for (int s = 0; s < S; s++) eAcc[s] = 0.0;
@@ -857,8 +857,34 @@ struct Sweep {
                     for (int s = 0; s < S; s++) atomicAdd(&copy[s * 16 + eIdx], eAcc[s]);
                 }
             }
-            cur = nxt;
-            Lc = Ln;
+        };
+#ifndef CPK_EXP_DEPTH
+#define CPK_EXP_DEPTH 4
+#endif
+        constexpr int kDepth = CPK_EXP_DEPTH;
+        ExpItem it[kDepth];
+        ExpLoads L[kDepth];
+        it[0] = first_of(sg.tbFrom);
+#pragma unroll
+        for (int j = 1; j < kDepth; j++) it[j] = next_of(it[j - 1]);
+#pragma unroll
+        for (int j = 0; j < kDepth; j++) issue(it[j], L[j]);
+        for (bool more = it[0].valid; more;) {
+#pragma unroll
+            for (int j = 0; j < kDepth; j++) {
+                if (!it[j].valid) {  // wave-uniform: the items behind it are invalid as well
+                    more = false;
+                    break;
+                }
+#pragma unroll
+                for (int s = 0; s < S; s++) {  // the wait for this item's loads: kDepth - 1 younger items stay in flight
+                    asm volatile("" : "+v"(L[j].v[s]), "+v"(L[j].fL[s]), "+v"(L[j].fU[s]), "+v"(L[j].fM[s]));
+                }
+                asm volatile("" : "+v"(L[j].total));
+                events(it[j], L[j]);
+                it[j] = next_of(it[(j + kDepth - 1) % kDepth]);  // the item behind the youngest one in flight
+                issue(it[j], L[j]);
+            }
         }
     }
 
