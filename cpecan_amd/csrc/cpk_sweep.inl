@@ -1191,11 +1191,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                     for (int d2 = sg.tbPrev + 1 + lane; d2 <= sg.tbFrom; d2 += CPK_WAVE)
                         a.dbgTotals[rg.dbgDiagOff + d2] = ld_self(sw.totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
                 }
-#ifdef CPK_DIAGNOSTICS
-                if (EMIT == CPECAN_EMIT_EXPECT && !(a.geo.debug & 4)) sw.expectations(sg, tAcc, eLds, likelihood);  // 4: time the sweeps alone
-#else
                 if (EMIT == CPECAN_EMIT_EXPECT) sw.expectations(sg, tAcc, eLds, likelihood);
-#endif
 #pragma unroll
                 for (int l = 0; l < (EMIT == CPECAN_EMIT_EXPECT ? 0 : NL); l++) {
                     if (MODE == kModeTrace) {
