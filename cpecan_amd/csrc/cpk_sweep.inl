@@ -330,21 +330,19 @@ struct Sweep {
                 flushTail();
             }
         }
-        // whole groups of this diagonal, in its direction; what is left over waits for the next diagonal
-        while (hi - lo >= CPK_WAVE) {
-            if (asc) {
-                fwdGroupUniform(c, cur, out, W, ringStates, lo, lo, hi);
-                lo += CPK_WAVE;
-            } else {
-                fwdGroupUniform(c, cur, out, W, ringStates, hi - CPK_WAVE, lo, hi);
-                hi -= CPK_WAVE;
-            }
+        // whole groups of this diagonal, in its direction; what is left over waits for the next diagonal -- except that
+        // a diagonal of fewer than 64 cells can never share (its first cell would have to be behind the reads of the
+        // next diagonal) and is done now.  ONE call site for all of these: every inlined copy of the group is ~1.4 KB
+        // of code, and the kernel's hot loops compete for the instruction cache of two CUs.
+        const bool lone = W < CPK_WAVE;
+        while (hi - lo >= CPK_WAVE || (lone && hi > lo)) {
+            const int kb = (asc || lone) ? lo : hi - CPK_WAVE;
+            fwdGroupUniform(c, cur, out, W, ringStates, kb, lo, hi);
+            if (lone) lo = hi;
+            else if (asc) lo += CPK_WAVE;
+            else hi -= CPK_WAVE;
         }
-        if (hi > lo && W < CPK_WAVE) {
-            // a diagonal of fewer than 64 cells can never share (its first cell would have to be behind the reads of
-            // the next diagonal): do it now
-            fwdGroupUniform(c, cur, out, W, ringStates, lo, lo, hi);
-        } else if (hi > lo) {
+        if (hi > lo) {
             tail.has = true;
             tail.asc = asc;
             tail.lo = lo;
