@@ -313,9 +313,16 @@ def main():
         # (a) one batch after the other: create + pack + plan + upload + run + gather + download, nothing overlapped
         t0 = time.perf_counter()
         b = make_batch()
+        t1 = time.perf_counter()
         b.run(stream.cuda_stream)
         b.download()
-        e2e["serial_s_per_batch"] = time.perf_counter() - t0
+        t2 = time.perf_counter()
+        e2e["serial_s_per_batch"] = t2 - t0
+        # the two host stages in the steady state (the figures above are the FIRST batch of the process: cold device
+        # memory, unpinned host blocks)
+        e2e["first_batch_plan_upload_s"] = e2e.pop("plan_upload_s")
+        e2e["plan_upload_s"] = t1 - t0
+        e2e["run_download_assemble_s"] = t2 - t1
         b.close()
         # (b) two batches in flight from ONE host thread: while the sweep of batch k runs, batch k+1 is packed, planned and
         # uploaded and batch k-1 is gathered and downloaded (every batch works on streams and events of its own)
