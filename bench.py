@@ -325,12 +325,14 @@ def main():
         e2e["run_download_assemble_s"] = t2 - t1
         b.close()
         # (b) two batches in flight from ONE host thread: while the sweep of batch k runs, batch k+1 is packed, planned and
-        # uploaded and batch k-1 is gathered and downloaded (every batch works on streams and events of its own)
+        # uploaded and batch k-1 is gathered and downloaded (every batch works on streams and events of its own; its download
+        # runs on the helper thread the library gives every batch)
         nb = max(3, args.e2e_batches)
         barrier()
         t0 = time.perf_counter()
         prev = make_batch()
         prev.run(stream.cuda_stream)
+        prev.download_begin()  # the batch's helper thread waits for the sweep, gathers and fetches (cpecan_batch_download_begin)
         pairs_out, t_first = 0, None
         trace = os.environ.get("CPECAN_BENCH_TRACE") == "1"
         for _ in range(1, nb):
@@ -338,7 +340,8 @@ def main():
             cur = make_batch()
             tb = time.perf_counter()
             cur.run(stream.cuda_stream)
-            prev.download()
+            cur.download_begin()
+            prev.download_end()
             tc = time.perf_counter()
             if t_first is None:
                 t_first = time.perf_counter()  # the first batch's lists are on the host: the pipeline is full from here
@@ -350,7 +353,7 @@ def main():
                 print("pipeline: pack+plan+upload %.1f ms, run+download(prev) %.1f ms (its kernel %.1f ms, d2h %.1f ms), close(prev) %.1f ms"
                       % (1e3 * (tb - ta), 1e3 * (tc - tb), kms, dms, 1e3 * (time.perf_counter() - tc)), file=sys.stderr, flush=True)
             prev = cur
-        prev.download()
+        prev.download_end()
         t_last = time.perf_counter()
         pairs_out += int(prev.stats().pairs)
         prev.close()

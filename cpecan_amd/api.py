@@ -84,7 +84,7 @@ EXPORTS = [
     "cpecan_model_default", "cpecan_model_from_hmm", "cpecan_hmm_init", "cpecan_hmm_normalise", "cpecan_hmm_write",
     "cpecan_hmm_load", "cpecan_params_default", "cpecan_band", "cpecan_split_points", "cpecan_device_count", "cpecan_current_device",
     "cpecan_last_error", "cpecan_batch_create", "cpecan_batch_destroy", "cpecan_batch_add", "cpecan_batch_upload",
-    "cpecan_batch_run", "cpecan_batch_download", "cpecan_batch_result", "cpecan_batch_expectations",
+    "cpecan_batch_run", "cpecan_batch_download", "cpecan_batch_download_begin", "cpecan_batch_download_end", "cpecan_batch_result", "cpecan_batch_expectations",
     "cpecan_batch_stats", "cpecan_batch_set_debug", "cpecan_batch_debug_fetch", "cpecan_batch_forward_prob",
     "cpecan_get_aligned_pairs_using_anchors", "cpecan_get_aligned_pairs_with_indels_using_anchors",
     "cpecan_compute_forward_probability", "cpecan_free",
@@ -132,6 +132,8 @@ def lib():
     L.cpecan_batch_upload.argtypes = [vp]
     L.cpecan_batch_run.argtypes = [vp, vp]
     L.cpecan_batch_download.argtypes = [vp]
+    L.cpecan_batch_download_begin.argtypes = [vp]
+    L.cpecan_batch_download_end.argtypes = [vp]
     L.cpecan_batch_result.argtypes = [vp, C.c_int64, C.c_int, C.POINTER(i32p), i64p]
     L.cpecan_batch_expectations.argtypes = [vp, C.POINTER(Hmm)]
     L.cpecan_batch_stats.argtypes = [vp, C.POINTER(Stats)]
@@ -345,6 +347,13 @@ class Batch:
 
     def download(self):
         _check(lib().cpecan_batch_download(self._h), "cpecan_batch_download")
+
+    def download_begin(self):
+        """download() on a helper thread of the batch's own; download_end() waits for it."""
+        _check(lib().cpecan_batch_download_begin(self._h), "cpecan_batch_download_begin")
+
+    def download_end(self):
+        _check(lib().cpecan_batch_download_end(self._h), "cpecan_batch_download_end")
 
     def result(self, problem, which=0):
         ptr = C.POINTER(C.c_int32)()

@@ -11,6 +11,7 @@
 #include <math.h>
 #include <stdio.h>
 #include <omp.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -437,6 +438,10 @@ struct cpecan_batch {
     float postMatchGamma; /* ORDERED: matchGamma of cPecanRealign.c:355 */
     int32_t *postMea, *postShift;
     cpecan_stats stats;
+    /* cpecan_batch_download_begin / _end */
+    pthread_t dlThread;
+    int dlActive, dlResult;
+    char dlError[256]; /* the helper's error text: cpk_last_error is per thread */
 };
 
 /* The batch's arrays live in blocks of the host pool (cpk_host_alloc: pinned and recycled when there is a GPU). */
@@ -570,6 +575,7 @@ static void free_results(cpecan_batch *b) {
 
 void cpecan_batch_destroy(cpecan_batch *b) {
     if (!b) return;
+    if (b->dlActive) (void)cpecan_batch_download_end(b);
     free_results(b);
     cpk_device_destroy(b->dev);
     cpk_host_free(b->problems);
@@ -1449,6 +1455,36 @@ int cpecan_batch_download(cpecan_batch *b) {
     cpk_host_free(segStarts);
     cpk_host_free(segCounts);
     return rc;
+}
+
+static void *download_helper(void *arg) {
+    cpecan_batch *b = arg;
+    b->dlResult = cpecan_batch_download(b);
+    if (b->dlResult != CPECAN_OK) {
+        strncpy(b->dlError, cpk_last_error(), sizeof b->dlError - 1);
+        b->dlError[sizeof b->dlError - 1] = 0;
+    }
+    return NULL;
+}
+
+int cpecan_batch_download_begin(cpecan_batch *b) {
+    if (!b || !b->ran || b->dlActive) return CPECAN_ESTATE;
+    b->dlResult = CPECAN_OK;
+    b->dlError[0] = 0;
+    if (pthread_create(&b->dlThread, NULL, download_helper, b) != 0) {
+        cpk_set_error("cannot start the download helper thread");
+        return CPECAN_ENOMEM;
+    }
+    b->dlActive = 1;
+    return CPECAN_OK;
+}
+
+int cpecan_batch_download_end(cpecan_batch *b) {
+    if (!b || !b->dlActive) return CPECAN_ESTATE;
+    pthread_join(b->dlThread, NULL);
+    b->dlActive = 0;
+    if (b->dlResult != CPECAN_OK) cpk_set_error("%s", b->dlError);
+    return b->dlResult;
 }
 
 int cpecan_batch_result(const cpecan_batch *b, int64_t problem, int which, const int32_t **triples, int64_t *n) {

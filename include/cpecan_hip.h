@@ -176,6 +176,12 @@ int cpecan_batch_run(cpecan_batch *b, void *stream);
 
 /* Waits for the run, copies results to the host and orders them as the reference's lists. */
 int cpecan_batch_download(cpecan_batch *b);
+/* The same on a helper thread of the batch's own: _begin returns at once, _end waits for the helper and returns what
+ * cpecan_batch_download would have returned.  Between the two the caller may do anything that does not touch THIS batch
+ * -- typically pack, plan and upload the next one (a stream of batches).  One download at a
+ * time per batch; cpecan_batch_destroy waits for a download that was begun and never ended. */
+int cpecan_batch_download_begin(cpecan_batch *b);
+int cpecan_batch_download_end(cpecan_batch *b);
 
 /* Results for problem i after download. Triples are (score, x, y) int32 in the reference's list order
  * (per region: traceback segments descending, diagonals ascending, x-y descending).

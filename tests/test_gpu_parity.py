@@ -944,7 +944,26 @@ def test_pipelined_batches_equal_unpipelined_ones():
         t.start()
     for t in ts:
         t.join()
-    for name, got in (("pipelined", piped), ("two host threads", threaded)):
+    # the download on the batch's own helper thread (cpecan_batch_download_begin / _end): begun right behind the launch,
+    # ended one batch later -- the caller packs and uploads the next batch in between
+    helped = [None] * len(jobs)
+
+    def end(k, b):
+        b.download_end()
+        helped[k] = [b.result(i) for i in range(len(jobs[k][0]))]
+        b.close()
+
+    prev = start(0)
+    prev.download_begin()
+    with pytest.raises(api.CpecanError):
+        prev.download_begin()  # one download at a time per batch
+    for k in range(1, len(jobs)):
+        cur = start(k)
+        cur.download_begin()
+        end(k - 1, prev)
+        prev = cur
+    end(len(jobs) - 1, prev)
+    for name, got in (("pipelined", piped), ("two host threads", threaded), ("helper-thread downloads", helped)):
         for k, (g, w) in enumerate(zip(got, serial)):
             assert g is not None and len(g) == len(w), (name, k)
             for i, (a, b) in enumerate(zip(g, w)):

@@ -6,5 +6,5 @@ tag=$1; shift
 cd "$(dirname "$0")/../cpecan_amd/csrc"
 mkdir -p ../../build_ab
 /opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=off -fPIC -Wno-unused-function -Wno-pass-failed -I../../include -I. "$@" -c -o /tmp/ab_$tag.o cpecan_kernels.hip
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build_ab/$tag.so cpecan_host.o cpecan_dropin.o cpecan_realign.o /tmp/ab_$tag.o -lm -lgomp
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../../build_ab/$tag.so cpecan_host.o cpecan_dropin.o cpecan_realign.o /tmp/ab_$tag.o -lm -lgomp -lpthread
 echo built build_ab/$tag.so
