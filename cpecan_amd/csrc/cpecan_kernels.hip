@@ -29,6 +29,7 @@
  * build changes against the reference's operation sequence, and the EXACT=1 diagnostic build that does not).
  */
 #include <hip/hip_runtime.h>
+#include <sys/mman.h>
 
 #include <chrono>
 #include <cstdarg>
@@ -243,13 +244,19 @@ bool host_pinning_enabled() {
     }();
     return v;
 }
+// Blocks that are not hipHostMalloc'ed are anonymous mappings of whole pages: page-aligned for hipHostRegister, and
+// mremap grows them without a copy.
+void *host_map(size_t bytes) {
+    void *p = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    return p == MAP_FAILED ? nullptr : p;
+}
 void host_release(const HostBlock &b) {
     if (b.pinned && !b.registered) {
         (void)hipHostFree(b.ptr);
         return;
     }
     if (b.registered) (void)hipHostUnregister(b.ptr);
-    free(b.ptr);
+    (void)munmap(b.ptr, b.bytes);
 }
 }  // namespace
 
@@ -285,7 +292,7 @@ static void *host_alloc_impl(size_t bytes, bool mustPin) {
             b.ptr = nullptr;
         }
     }
-    if (!b.ptr && (mustPin || posix_memalign(&b.ptr, 4096, bytes) != 0)) return nullptr;
+    if (!b.ptr && (mustPin || (b.ptr = host_map(bytes)) == nullptr)) return nullptr;
     std::lock_guard<std::mutex> lock(g_hostMutex);
     g_hostLive.push_back(b);
     return b.ptr;
@@ -320,12 +327,14 @@ extern "C" void cpk_host_free(void *p) {
 extern "C" void *cpk_host_grow(void *p, size_t usedBytes, size_t newBytes) {
     if (!p) return cpk_host_alloc(newBytes);
     bool pooled = false, pinned = false;
+    size_t oldBytes = 0;
     {
         std::lock_guard<std::mutex> lock(g_hostMutex);
         for (size_t i = 0; i < g_hostLive.size(); i++)
             if (g_hostLive[i].ptr == p) {
                 pooled = true;
                 pinned = g_hostLive[i].pinned;
+                oldBytes = g_hostLive[i].bytes;
                 if (!pinned) {  // out of the books while it may move
                     g_hostLive[i] = g_hostLive.back();
                     g_hostLive.pop_back();
@@ -335,9 +344,10 @@ extern "C" void *cpk_host_grow(void *p, size_t usedBytes, size_t newBytes) {
     }
     if (pooled && !pinned) {
         const size_t rounded = (newBytes + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
-        void *q = realloc(p, rounded);
+        void *q = rounded <= oldBytes ? p : mremap(p, oldBytes, rounded, MREMAP_MAYMOVE);
+        if (q == MAP_FAILED) q = nullptr;
         std::lock_guard<std::mutex> lock(g_hostMutex);
-        g_hostLive.push_back(HostBlock{q ? q : p, q ? rounded : usedBytes, false, false});
+        g_hostLive.push_back(HostBlock{q ? q : p, q ? (rounded > oldBytes ? rounded : oldBytes) : oldBytes, false, false});
         return q;  // on failure the old block is still the caller's (and back in the books)
     }
     if (!pooled && newBytes < kHostPoolMin) return realloc(p, newBytes);
