@@ -161,6 +161,31 @@ __device__ __forceinline__ double exp_1e7(double x) {
     return __builtin_ldexp((double)__builtin_amdgcn_exp2f(yf), (int)yi);
 }
 
+// Packs the nSym one-byte symbols at src into LDS, two to a byte (low nibble = even index; a missing partner reads as
+// N), with LANES threads.  The loads of a batch go out together and are clamped instead of predicated: as a loop of
+// load-then-store every iteration was a global round trip of its own -- 16 in a row for a 1 kb pair, for every region and
+// (in a split class) every traceback item.
+template <int LANES>
+__device__ __forceinline__ void stage_symbols(uint8_t *dst, const uint8_t *src, int nSym, int tid) {
+    const int nOut = (nSym + 1) >> 1;
+    constexpr int kBatch = 4;
+    for (int i0 = 0; i0 < nOut; i0 += LANES * kBatch) {
+        int lo[kBatch], hi[kBatch];
+#pragma unroll
+        for (int j = 0; j < kBatch; j++) {
+            const int i = i0 + j * LANES + tid;
+            const int e = 2 * i < nSym ? 2 * i : nSym - 1, o = 2 * i + 1 < nSym ? 2 * i + 1 : nSym - 1;
+            lo[j] = src[e];
+            hi[j] = src[o];
+        }
+#pragma unroll
+        for (int j = 0; j < kBatch; j++) {
+            const int i = i0 + j * LANES + tid;
+            if (i < nOut) dst[i] = (uint8_t)(lo[j] | ((2 * i + 1 < nSym ? hi[j] : CPK_SYM_N) << 4));
+        }
+    }
+}
+
 // N independent logAdds advanced in lock-step stages (compare/select -> table fetch -> Horner) so that the N LDS
 // table fetches are in flight together instead of one fetch + wait per logAdd.  acc[i] = logAdd(acc[i], t[i]).
 template <int N>

@@ -1065,15 +1065,8 @@ cpecan_pairhmm_sweep(const KArgs a) {
         const uint8_t *gx = a.symbols + rg.seqXOff, *gy = a.symbols + rg.seqYOff;
         if (FAST) {
             // stage N + bases + N of both strings into LDS, two symbols per byte (per-cell reads come from here)
-            const int bx = (lX + 3) >> 1, by = (lY + 3) >> 1;
-            for (int i = lane; i < bx; i += CPK_WAVE) {
-                const int lo4 = gx[2 * i], hi4 = 2 * i + 1 < lX + 2 ? gx[2 * i + 1] : CPK_SYM_N;
-                seqLds[i] = (uint8_t)(lo4 | (hi4 << 4));
-            }
-            for (int i = lane; i < by; i += CPK_WAVE) {
-                const int lo4 = gy[2 * i], hi4 = 2 * i + 1 < lY + 2 ? gy[2 * i + 1] : CPK_SYM_N;
-                seqLds[bx + i] = (uint8_t)(lo4 | (hi4 << 4));
-            }
+            stage_symbols<CPK_WAVE>(seqLds, gx, lX + 2, lane);
+            stage_symbols<CPK_WAVE>(seqLds + ((lX + 3) >> 1), gy, lY + 2, lane);
             roll_fence<false>();
         }
         const CpkDiag *table = a.diags + rg.diagOff;

@@ -69,15 +69,8 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
         const int lX = rg.lX, lY = rg.lY, N = lX + lY;
         const uint8_t *gx = a.symbols + rg.seqXOff, *gy = a.symbols + rg.seqYOff;
         {
-            const int bx = (lX + 3) >> 1, by = (lY + 3) >> 1;
-            for (int i = tid; i < bx; i += CPK_WAVE * T) {
-                const int lo4 = gx[2 * i], hi4 = 2 * i + 1 < lX + 2 ? gx[2 * i + 1] : CPK_SYM_N;
-                seqLds[i] = (uint8_t)(lo4 | (hi4 << 4));
-            }
-            for (int i = tid; i < by; i += CPK_WAVE * T) {
-                const int lo4 = gy[2 * i], hi4 = 2 * i + 1 < lY + 2 ? gy[2 * i + 1] : CPK_SYM_N;
-                seqLds[bx + i] = (uint8_t)(lo4 | (hi4 << 4));
-            }
+            stage_symbols<CPK_WAVE * T>(seqLds, gx, lX + 2, tid);
+            stage_symbols<CPK_WAVE * T>(seqLds + ((lX + 3) >> 1), gy, lY + 2, tid);
         }
         const CpkDiag *table = a.diags + rg.diagOff;
         SweepT sw{a,
