@@ -96,6 +96,7 @@ struct LaunchClass {
     // A SPLIT class (fewer regions than wave slots): launch 1 = forward sweeps of whole regions into per-REGION rings,
     // launch 2 = one queue item per (region, traceback segment); see kModeForward / kModeTrace in cpk_sweep.inl.
     bool split = false;
+    bool fused = false;  // split, as ONE launch (kModeFused): regions and their traceback items in one queue
     KernelFn fnTrace = nullptr;
     int wavesTrace = 0;
     int64_t itemBase = 0, itemCount = 0;  // its items in dItems
@@ -111,7 +112,7 @@ struct LaunchClass {
 // Device memory and device shells are recycled: a batch of one small problem (the single-call entry points, a caller's
 // loop over alignments) would otherwise spend ~40 ms in hipMalloc / hipFree / stream creation around a 1 ms kernel, and
 // a pipeline of large batches cannot afford hipFree at all: it waits for the whole device, i.e. for the other batch's
-// sweep kernel.  Freed blocks up to a bounded total (CPECAN_CACHE_MB, default 128 GiB of the 288 GB a MI355X has; two
+// sweep kernel.  Freed blocks up to a bounded total (CPECAN_CACHE_MB, default 256 GiB of the 288 GB a MI355X has -- idle blocks are given back when an allocation fails; two
 // config-B batches in flight hold 36 GB) wait in a per-device list and serve later requests of about their size; what
 // the list will not hold goes back to the driver, and all of it does when an allocation fails.  A block is recycled
 // only after its batch's own streams and events have completed.
@@ -126,12 +127,12 @@ struct BlockCache {
     size_t bytes = 0;
 };
 constexpr int kMaxDevices = 64;
-constexpr size_t kCacheMaxBlock = (size_t)64 << 30;
+constexpr size_t kCacheMaxBlock = (size_t)256 << 30;  // the rings of a fused config-B batch are one block of 196 GB
 constexpr int kCacheMaxBlocks = 512;
 size_t cache_max_bytes() {
     static const size_t v = [] {
         const char *mb = getenv("CPECAN_CACHE_MB");
-        return mb ? (size_t)(atof(mb) * 1048576.0) : ((size_t)128 << 30);
+        return mb ? (size_t)(atof(mb) * 1048576.0) : ((size_t)256 << 30);
     }();
     return v;
 }
@@ -413,6 +414,7 @@ struct CpkDevice {
     int32_t *dCounts = nullptr, *dSegStarts = nullptr, *dSegCounts = nullptr, *dTriples = nullptr;
     void *hostCounts = nullptr;  // the block of the host pool that holds the three
     CpkItem *dItems = nullptr;
+    int *dProgress = nullptr;  // fused classes: per region, segments whose forward values are complete (+ an error word)
     int32_t *dCompact = nullptr; CpkChunk *dChunks = nullptr; int64_t compactCap = 0, chunkCap = 0;
     unsigned int *dQueue = nullptr;
     double *dDbgFb = nullptr, *dDbgTotals = nullptr;
@@ -538,6 +540,7 @@ static void free_all(CpkDevice *d) {
     cpk_host_free(d->hostCounts);
     d->hostCounts = nullptr;
     d->dItems = nullptr;
+    d->dProgress = nullptr;
     d->dCompact = nullptr; d->dChunks = nullptr; d->compactCap = d->chunkCap = 0;
     d->dQueue = nullptr;
     d->dDbgFb = d->dDbgTotals = nullptr;
@@ -597,6 +600,12 @@ static KernelFn pick_packed_kernel(const CpkGeometry &g, int cls) {  // class k:
 }
 
 // the two kernels of a split class (match emitter)
+static KernelFn pick_fused_kernel(const CpkGeometry &g) {
+    const bool fast = !g.useGlobalRoll;
+    if (g.nStates == 5)
+        return fast ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeFused> : cpecan_pairhmm_sweep<5, false, CPECAN_EMIT_MATCH, kModeFused>;
+    return fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeFused> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeFused>;
+}
 static void pick_split_kernels(const CpkGeometry &g, KernelFn *fwd, KernelFn *trace) {
     const bool fast = !g.useGlobalRoll;
     if (g.nStates == 5) {
@@ -823,18 +832,43 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         {
             // Split the class when its regions do not fill the chip and have tracebacks to hand out: the segments of a
             // region are independent once its forward values exist.  CPECAN_SPLIT=1 / 0 (tests, diagnostics): always / never.
-            int64_t nSegClass = 0;
-            for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++) nSegClass += regions[di].nSeg;
+            int64_t nSegClass = 0, cellsClass = 0, diagsClass = 0;
+            for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++) {
+                nSegClass += regions[di].nSeg;
+                cellsClass += regions[di].cells;
+                diagsClass += (int64_t)regions[di].lX + regions[di].lY + 1;
+            }
             const char *env = getenv("CPECAN_SPLIT");
             const int64_t slots = (int64_t)perCU * d->numCUs;
             const bool eligible = c.threads == CPK_WAVE && geo->emit == CPECAN_EMIT_MATCH && !geo->debug && nSegClass > 0;
-            const bool wanted = env ? atoi(env) != 0 : (n * 20 < slots * 17 && nSegClass * 4 >= n * 5);
+            // Bands of ~100 cells per diagonal and more (config B: 122) take the ONE-launch form whatever the number of regions: with items the
+            // size of a traceback segment every wave slot is busy to the end (one wave per region leaves 19 % of the
+            // slots idle at 10 000 regions = 4.9 per slot), and a diagonal of two or three groups covers the device-scope
+            // loads of the ring.  Narrower classes (config A: 74 cells) lose with those loads and split only when their
+            // regions leave slots idle, as two launches.  (profiles/r02_ab_fused_split_launch.log)  The rings of whole
+            // regions are given up first when device memory is short (below).
+            const bool wideBand = cellsClass >= 96 * diagsClass;  // cells per diagonal, on average over the class
+            const bool manySegs = nSegClass * 4 >= n * 5;
+            const bool wanted = env ? atoi(env) != 0 : (manySegs && (wideBand || n * 20 < slots * 17));
             if (eligible && wanted) {
                 c.split = true;
-                pick_split_kernels(c.geo, &c.fn, &c.fnTrace);
-                int64_t wt = slots < nSegClass ? slots : nSegClass;
-                c.wavesTrace = (int)wt;
-                if (wt > c.subSlots) c.subSlots = wt;
+                // CPECAN_SPLIT=2 / 1: force the one-launch (kModeFused) / two-launch form
+                c.fused = env ? atoi(env) == 2 : wideBand;
+                if (c.fused) {
+                    c.fn = pick_fused_kernel(c.geo);
+                    // One CU in eight keeps a wave slot (and its 19 KB of LDS) free: a launch that fills every slot to its
+                    // end starves the small kernels of the batch before it -- the list consumers need a few KB of LDS --
+                    // until it drains, and a pipeline two batches deep then idles between sweeps (82 ms measured).
+                    const int64_t room = slots - d->numCUs / 8 > 0 ? slots - d->numCUs / 8 : slots;
+                    int64_t wt = room < n + nSegClass ? room : n + nSegClass;
+                    c.waves = (int)wt;
+                    c.subSlots = wt;
+                } else {
+                    pick_split_kernels(c.geo, &c.fn, &c.fnTrace);
+                    int64_t wt = slots < nSegClass ? slots : nSegClass;
+                    c.wavesTrace = (int)wt;
+                    if (wt > c.subSlots) c.subSlots = wt;
+                }
                 c.itemCount = nSegClass;
             }
         }
@@ -876,6 +910,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             for (LaunchClass &c : d->classes) {
                 if (!c.split) continue;
                 c.split = false;
+                c.fused = false;
                 c.fn = pick_kernel(c.geo);
                 c.fnTrace = nullptr;
                 c.subSlots = c.waves;
@@ -992,7 +1027,10 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                 ringAt += rg.ringCap;
                 for (int32_t si = 0; si < rg.nSeg; si++) {
                     const CpkSegment &sg = segs[rg.segOff + si];
-                    byCost.push_back({(int64_t)(sg.dTop - sg.tbPrev) * rg.maxWidth, CpkItem{(int32_t)di, si}});
+                    // fused: a segment's forward values exist when the forward wave has passed its top diagonal -- items in
+                    // the order in which they become ready (that diagonal), longest first among equals
+                    const int64_t cost = (int64_t)(sg.dTop - sg.tbPrev) * rg.maxWidth;
+                    byCost.push_back({c.fused ? ((int64_t)0x7fffffff - sg.dTop) * ((int64_t)1 << 32) + (cost >> 8) : cost, CpkItem{(int32_t)di, si}});
                 }
             }
             std::stable_sort(byCost.begin(), byCost.end(), [](const auto &x, const auto &y) { return x.first > y.first; });
@@ -1001,6 +1039,12 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         }
     }
     if (int rc = dev_alloc(d, &d->dItems, items.empty() ? 1 : items.size())) return rc;
+    {
+        bool anyFused = false;
+        for (const LaunchClass &c : d->classes) anyFused = anyFused || c.fused;
+        if (anyFused)
+            if (int rc = dev_alloc(d, &d->dProgress, (size_t)geo->nRegions + 1)) return rc;
+    }
     if (int rc = dev_alloc(d, &d->dTriples, (size_t)nLists * outTriplesPerList * 3)) return rc;
     if (int rc = dev_alloc(d, &d->dQueue, (size_t)2 * kMaxClasses)) return rc;
     hipStream_t io = d->io;
@@ -1115,6 +1159,8 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.segStarts = d->dSegStarts;
     a.segCounts = d->dSegCounts;
     a.items = d->dItems;
+    a.progress = d->dProgress;
+    a.itemCount = 0;
     a.triples = d->dTriples;
     a.outTriplesPerList = d->outTriplesPerList;
     a.nSegsTotal = d->nSegs;
@@ -1125,6 +1171,7 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.dbgTotals = d->dDbgTotals;
     HIP_TRY(hipStreamWaitEvent(st, d->evUp1, 0));  // the upload's copies and the table build (the batch's own stream)
     HIP_TRY(hipMemsetAsync(d->dQueue, 0, 2 * kMaxClasses * sizeof(unsigned int), st));
+    if (d->dProgress) HIP_TRY(hipMemsetAsync(d->dProgress, 0, sizeof(int) * ((size_t)d->geo.nRegions + 1), st));
     if (d->geo.emit == CPECAN_EMIT_EXPECT)
         HIP_TRY(hipMemsetAsync(d->dExpect, 0, sizeof(double) * 128 * (size_t)(d->totalWaves > 0 ? d->totalWaves : 1), st));
     HIP_TRY(hipEventRecord(d->evStart, st));
@@ -1147,6 +1194,10 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
         p.bring = d->dBring ? d->dBring + c.oBring : nullptr;
         p.expectOut = d->dExpect + c.oExpect;
         p.queue = d->dQueue + i;
+        if (c.fused) {
+            p.items = d->dItems + c.itemBase;
+            p.itemCount = (int32_t)c.itemCount;
+        }
         const bool onCaller = i == nClasses - 1;
         if (!onCaller && !d->sideStream[i]) {
             HIP_TRY(hipStreamCreateWithFlags(&d->sideStream[i], hipStreamNonBlocking));
@@ -1156,7 +1207,7 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
         if (!onCaller) HIP_TRY(hipStreamWaitEvent(cs, d->evStart, 0));
         hipLaunchKernelGGL(c.fn, dim3((unsigned)c.waves), dim3((unsigned)c.threads), c.ldsBytes, cs, p);
         HIP_TRY(hipGetLastError());
-        if (c.split) {  // the tracebacks of the class's regions, one queue item each, behind the forward launch
+        if (c.split && !c.fused) {  // the tracebacks of the class's regions, one queue item each, behind the forward launch
             KArgs t = p;
             t.items = d->dItems + c.itemBase;
             t.regionCount = (int32_t)c.itemCount;
@@ -1191,6 +1242,15 @@ extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segSt
     if (kernelMs) *kernelMs = d->kernelMsAccum + ms;  // every launch of the batch (an overflow re-run included)
     hipStream_t io = d->io;
     HIP_TRY(hipEventRecord(d->evA, io));
+    if (d->dProgress) {  // a fused launch reports a traceback whose forward values never came (it waits a bounded time)
+        int err = 0;
+        HIP_TRY(hipMemcpyAsync(&err, d->dProgress + d->geo.nRegions, sizeof(int), hipMemcpyDeviceToHost, io));
+        HIP_TRY(hipStreamSynchronize(io));
+        if (err) {
+            cpk_set_error("fused launch: a traceback item waited in vain for its region's forward sweep");
+            return CPECAN_EHIP;
+        }
+    }
     // written by the sweeps straight into pinned host memory; complete with the stop event
     memcpy(counts, d->dCounts, sizeof(int32_t) * (size_t)d->nLists * d->geo.nRegions);
     memcpy(segStarts, d->dSegStarts, sizeof(int32_t) * (size_t)d->nLists * d->nSegs);

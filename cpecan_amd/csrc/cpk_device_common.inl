@@ -37,6 +37,8 @@ struct KArgs {
     int32_t *outCounts;  // [nLists][nRegions]
     int32_t *segStarts;  // [nLists][nSegsTotal]
     int32_t *segCounts;  // [nLists][nSegsTotal]  triples of a segment (split classes: their segments are written apart)
+    int *progress;       // [nRegions + 1] kModeFused: segments of a region whose forward values are complete; last word: error flag
+    int32_t itemCount;   // kModeFused: items behind the regionCount regions of the queue
     const CpkItem *items;  // (region, segment) queue of a split class's traceback launch
     int32_t *triples;    // [nLists][outTriplesPerList*3]
     int64_t outTriplesPerList;

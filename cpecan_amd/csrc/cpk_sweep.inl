@@ -3,7 +3,9 @@
 
 // ROWS: rows of the rolling buffers per position (2S+1 for one wave per region; the team kernel keeps three forward
 // diagonals, 3S rows)
-template <int S, bool FAST, int ROWS = 2 * S + 1>
+// COH: the forward ring is handed from wave to wave inside ONE launch (kModeFused): its stores and loads are device-scope
+// (sc1, write-through / read-through) so that no L2 write-back or invalidate is needed around the hand-off
+template <int S, bool FAST, int ROWS = 2 * S + 1, bool COH = false>
 struct Sweep {
     const KArgs &a;
     const KConsts &m;  // kernarg-resident constants
@@ -69,6 +71,13 @@ struct Sweep {
         return s == 0 ? (size_t)k : (size_t)W + (size_t)k * (S - 1) + (size_t)(s - 1);
     }
     __device__ __forceinline__ double *ringAt(const CpkDiag &g) const { return ring + (size_t)g.ringOff * S; }
+    __device__ __forceinline__ static void ringSt(double *p, double v) {
+        if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = v;
+    }
+    __device__ __forceinline__ static double ringLd(const double *p) {
+        return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ld_self(p);
+    }
 
     // ---- forward: impl/pairwiseAligner.c:609-629 with stateMachine{5,3}_cellCalculate as the per-cell body ----
     struct FwdCtx {
@@ -201,10 +210,10 @@ struct Sweep {
 #pragma unroll
                 for (int s = 0; s < S; s++) cur[s + kkR[0]] = v[0][s];
                 if (ringStates > 0) {
-                    out[ringIdx(W, 0, k0)] = v[0][0];
+                    ringSt(out + ringIdx(W, 0, k0), v[0][0]);
                     if (ringStates > 1) {
 #pragma unroll
-                        for (int s = 1; s < S; s++) out[ringIdx(W, s, k0)] = v[0][s];
+                        for (int s = 1; s < S; s++) ringSt(out + ringIdx(W, s, k0), v[0][s]);
                     }
                 }
             }
@@ -250,10 +259,10 @@ struct Sweep {
 #pragma unroll
             for (int s = 0; s < S; s++) cur[s + kkR[0]] = v[0][s];
             if (ringStates > 0) {
-                out[ringIdx(W, 0, k0)] = v[0][0];
+                ringSt(out + ringIdx(W, 0, k0), v[0][0]);
                 if (ringStates > 1) {
 #pragma unroll
-                    for (int s = 1; s < S; s++) out[ringIdx(W, s, k0)] = v[0][s];
+                    for (int s = 1; s < S; s++) ringSt(out + ringIdx(W, s, k0), v[0][s]);
                 }
             }
         }
@@ -316,10 +325,10 @@ struct Sweep {
 #pragma unroll
                     for (int s = 0; s < S; s++) curL[s + kR] = v[0][s];
                     if (rsL > 0) {
-                        outL[ringIdx(WL, 0, k)] = v[0][0];
+                        ringSt(outL + ringIdx(WL, 0, k), v[0][0]);
                         if (rsL > 1) {
 #pragma unroll
-                            for (int s = 1; s < S; s++) outL[ringIdx(WL, s, k)] = v[0][s];
+                            for (int s = 1; s < S; s++) ringSt(outL + ringIdx(WL, s, k), v[0][s]);
                         }
                     }
                 }
@@ -513,7 +522,7 @@ struct Sweep {
 #pragma unroll
                 for (int q = 0; q < kPrefetch; q++) {
                     const int k = q * CPK_WAVE + lane;
-                    dst[l][q] = ld_self(src + ringIdx(gd.width, l, k < gd.width ? k : gd.width - 1));
+                    dst[l][q] = ringLd(src + ringIdx(gd.width, l, k < gd.width ? k : gd.width - 1));
                 }
         };
         loadRows(g, fmCur);
@@ -564,7 +573,7 @@ struct Sweep {
                 for (int q = 0; q < kPrefetch; q++) {
                     const int k = q * CPK_WAVE + lane;
 #pragma unroll
-                    for (int s2 = NL; s2 < S; s2++) rfC[s2][q] = k < W ? ld_self(fsrc + ringIdx(W, s2, k)) : 0.0;
+                    for (int s2 = NL; s2 < S; s2++) rfC[s2][q] = k < W ? ringLd(fsrc + ringIdx(W, s2, k)) : 0.0;
                 }
             }
             // One group of 64 cells.  Wave-uniform (the candidate counts must stay identical in every lane): lanes past
@@ -640,7 +649,7 @@ struct Sweep {
                 double f0[NL];
 #pragma unroll
                 for (int l = 0; l < NL; l++)
-                    f0[l] = ((emit || feeds) && kb + lane < W) ? ld_self(fsrc + ringIdx(W, l, kb + lane)) : 0.0;
+                    f0[l] = ((emit || feeds) && kb + lane < W) ? ringLd(fsrc + ringIdx(W, l, kb + lane)) : 0.0;
                 group(kb, f0);
             }
             roll_fence<!FAST>();
@@ -679,7 +688,7 @@ struct Sweep {
                     if (k < W) {
                         double fRow[S];
 #pragma unroll
-                        for (int s2 = 0; s2 < S; s2++) fRow[s2] = ld_self(fsrc + ringIdx(W, s2, k));
+                        for (int s2 = 0; s2 < S; s2++) fRow[s2] = ringLd(fsrc + ringIdx(W, s2, k));
                         fbf = dotCell(k, kb * R + laneR, fRow);
                     }
                     if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
@@ -1003,7 +1012,14 @@ constexpr int kEmitForward = 3;
 // chip has wave slots (BASELINE config A: 1000 regions on 2048 slots; a strong-scaled batch on 8 GPUs), the tracebacks
 // of a region -- independent of each other once its forward values exist (the backward sweep of a segment starts from
 // a constant end-state vector, pairwiseAligner.c:798) -- become queue items of their own and fill the idle slots.
-constexpr int kModeWhole = 0, kModeForward = 1, kModeTrace = 2;
+//   kModeFused    ONE launch for a split class: the queue holds the class's regions (forward sweep into the region's ring,
+//                 as kModeForward) and, behind them, its (region, segment) items (as kModeTrace), segments in ascending
+//                 order.  The forward wave of a region publishes how many of its segments have their forward values
+//                 complete (release at agent scope); a wave that draws an item waits for that count (acquire).  A region's
+//                 ticket is always drawn before any item's, so whatever an item waits for is in progress on a running wave
+//                 or done: no deadlock whatever the number of resident waves.  The tracebacks of a region's first
+//                 segments then run beside the forward sweeps of the class instead of behind the slowest of them.
+constexpr int kModeWhole = 0, kModeForward = 1, kModeTrace = 2, kModeFused = 3;
 
 template <int S, bool FAST, int EMIT, int MODE = kModeWhole>
 __global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(CPK_SWEEP_WAVES, CPK_SWEEP_WAVES)))
@@ -1055,10 +1071,13 @@ cpecan_pairhmm_sweep(const KArgs a) {
         const unsigned int ticket = atomicAdd(a.queue, lane == 0 ? 1u : 0u);
 #endif
         const int tk = __builtin_amdgcn_readfirstlane((int)ticket);
-        if (tk >= a.regionCount) break;
-        // kModeTrace: the queue holds (region, segment) items, longest first; otherwise regions
-        const int r = MODE == kModeTrace ? a.items[tk].region : a.regionBase + tk;
-        const int itemSeg = MODE == kModeTrace ? a.items[tk].seg : 0;
+        if (tk >= a.regionCount + (MODE == kModeFused ? a.itemCount : 0)) break;
+        // kModeTrace: the queue holds (region, segment) items, longest first; kModeFused: regions, then items; else regions
+        const bool traceRole = MODE == kModeTrace || (MODE == kModeFused && tk >= a.regionCount);  // wave-uniform
+        const bool forwardRole = MODE == kModeForward || (MODE == kModeFused && !traceRole);
+        const int ti = MODE == kModeFused ? tk - a.regionCount : tk;
+        const int r = traceRole ? a.items[ti].region : a.regionBase + tk;
+        const int itemSeg = traceRole ? a.items[ti].seg : 0;
 
         const CpkRegion &rg = a.regions[r];
         const int lX = rg.lX, lY = rg.lY, N = lX + lY;
@@ -1070,7 +1089,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
             roll_fence<false>();
         }
         const CpkDiag *table = a.diags + rg.diagOff;
-        Sweep<S, FAST> sw{a,
+        Sweep<S, FAST, 2 * S + 1, MODE == kModeFused> sw{a,
                           a.kc,
                           DiagCache{table, N, 0, lane, 0, 0, 0, 0},
                           FAST ? seqLds : gx,
@@ -1136,13 +1155,13 @@ cpecan_pairhmm_sweep(const KArgs a) {
             sw.dc.load(0);
             // diagonal 0: the single cell (0,0) holds the start prior (pairwiseAligner.c:776-777)
             const double *startPrior = rg.raggedLeft ? m.raggedStart : m.start;
-            if (MODE != kModeTrace) {
+            if (!traceRole) {
                 const CpkDiag g0 = sw.dc.get(0, false);
                 double *cur = sw.fbuf1(0);
                 double *o0 = sw.ringAt(g0);
                 if (lane < S) {
                     cur[lane] = startPrior[lane];
-                    o0[lane] = startPrior[lane];
+                    sw.ringSt(o0 + lane, startPrior[lane]);
                 }
                 roll_fence<!FAST>();
                 sw.f1 = g0;
@@ -1150,7 +1169,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
             }
             int d = 1;
             int emitSeg = 0, emitFrom = a.segs[rg.segOff].tbFrom;  // the segment whose traceback emits diagonal d: the first with tbFrom >= d
-            const int siFirst = MODE == kModeTrace ? itemSeg : 0, siEnd = MODE == kModeTrace ? itemSeg + 1 : rg.nSeg;
+            const int siFirst = traceRole ? itemSeg : 0, siEnd = traceRole ? itemSeg + 1 : rg.nSeg;
             for (int si = siFirst; si < siEnd; si++) {
                 const CpkSegment sg = a.segs[rg.segOff + si];
                 // Which states of F[d] the traceback will read back: the match row always (posteriors), every state on the
@@ -1158,7 +1177,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 // known up front) and on the two diagonals the forward sweep is resumed from; the indel and expectation
                 // emitters read every state of every diagonal.  For the match emitter this cuts the ring stores from 8*S to
                 // ~8 + 0.8*(S-1) bytes per cell.
-                while (MODE != kModeTrace && d <= sg.dTop) {
+                while (!traceRole && d <= sg.dTop) {
                     sw.dc.load(d);  // table entries of diagonals d .. d+63
                     const int dEnd = d + CPK_WAVE - 1 < sg.dTop ? d + CPK_WAVE - 1 : sg.dTop;
                     for (; d <= dEnd; d++) {
@@ -1168,8 +1187,32 @@ cpecan_pairhmm_sweep(const KArgs a) {
                         else sw.forward(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
                     }
                 }
-                if (FAST && MODE != kModeTrace) sw.flushTail();  // the traceback needs every cell of dTop
-                if (MODE == kModeForward) continue;  // the tracebacks of this region are items of the next launch
+                if (FAST && !traceRole) sw.flushTail();  // the traceback needs every cell of dTop
+                if (forwardRole) {  // the tracebacks of this region are items of their own (of the next launch, or of this one)
+                    if (MODE == kModeFused) {
+                        // the ring stores are device-scope write-through (Sweep::ringSt): once they are acknowledged -- this
+                        // fence is the wait, nothing else at workgroup scope -- they are where every XCD reads them, and the
+                        // count goes out.  (An agent-scope release here writes back the XCD's whole L2: measured, 10 % slower.)
+                        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        if (lane == 0) __hip_atomic_store(a.progress + r, si + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    continue;
+                }
+                if (MODE == kModeFused) {
+                    // wait until the region's forward wave has passed this segment's top diagonal (bounded: a count that
+                    // never comes is reported, not waited for)
+                    int seen = 0;
+                    for (int spin = 0; spin < (1 << 24); spin++) {
+                        seen = __hip_atomic_load(a.progress + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (seen > si) break;
+                        __builtin_amdgcn_s_sleep(16);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");  // ordering only: the ring loads are device-scope (ringLd)
+                    if (__builtin_amdgcn_readfirstlane(seen) <= si) {
+                        if (lane == 0) a.progress[a.geo.nRegions] = 1;  // the error word behind the counts
+                        continue;
+                    }
+                }
 #ifdef CPK_DIAGNOSTICS
                 if (a.geo.debug & 2) continue;  // diagnostic build only: time the forward sweep alone (no traceback, no output)
 #endif
@@ -1185,7 +1228,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 if (EMIT == CPECAN_EMIT_EXPECT) sw.expectations(sg, tAcc, eLds, likelihood);
 #pragma unroll
                 for (int l = 0; l < (EMIT == CPECAN_EMIT_EXPECT ? 0 : NL); l++) {
-                    if (MODE == kModeTrace) {
+                    if (traceRole) {
                         // the segment's own part of the region's output slice (the other segments are written by other waves)
                         const int n = sw.emitMatches(sg, sw.cand + (size_t)l * a.geo.fbCells, nCand[l],
                                                      a.triples + 3 * ((size_t)l * a.outTriplesPerList + rg.outOff + sg.outOff),

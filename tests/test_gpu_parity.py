@@ -1085,6 +1085,13 @@ def test_split_classes_equal_whole_region_waves(monkeypatch):
         assert st1.cells == st0.cells
         for a, b in zip(split, whole):
             assert np.array_equal(a, b)
+        # ... and as ONE launch (CPECAN_SPLIT=2: regions and their traceback items in one queue, an item waits for its
+        # region's forward wave to pass its segment)
+        monkeypatch.setenv("CPECAN_SPLIT", "2")
+        fused, st2 = _run_batch(mtype, problems, **pkw)
+        assert st2.cells == st0.cells
+        for a, b in zip(fused, whole):
+            assert np.array_equal(a, b)
         om, op = ob.model(mtype), ob.params(**pkw)
         for i in range(0, len(problems), 5):
             sx, sy, an = problems[i]
