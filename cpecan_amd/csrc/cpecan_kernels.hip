@@ -841,10 +841,10 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             const char *env = getenv("CPECAN_SPLIT");
             const int64_t slots = (int64_t)perCU * d->numCUs;
             const bool eligible = c.threads == CPK_WAVE && geo->emit == CPECAN_EMIT_MATCH && !geo->debug && nSegClass > 0;
-            // Bands of ~100 cells per diagonal and more (config B: 122) take the ONE-launch form whatever the number of regions: with items the
-            // size of a traceback segment every wave slot is busy to the end (one wave per region leaves 19 % of the
-            // slots idle at 10 000 regions = 4.9 per slot), and a diagonal of two or three groups covers the device-scope
-            // loads of the ring.  Narrower classes (config A: 74 cells) lose with those loads and split only when their
+            // Bands of ~100 cells per diagonal and more (config B: 122) take the ONE-launch form whatever the number of regions: measured faster
+            // than one wave per region from 300 to 10 000 config-B pairs (-3 % at 10 000, -35 % at 2500, where regions
+            // per slot do not come out even), and a diagonal of two or three groups covers the device-scope loads of
+            // the ring.  Narrower classes (config A: 74 cells) lose with those loads and split only when their
             // regions leave slots idle, as two launches.  (profiles/r02_ab_fused_split_launch.log)  The rings of whole
             // regions are given up first when device memory is short (below).
             const bool wideBand = cellsClass >= 96 * diagsClass;  // cells per diagonal, on average over the class
