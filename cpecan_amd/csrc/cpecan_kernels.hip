@@ -100,7 +100,7 @@ struct LaunchClass {
     KernelFn fnTrace = nullptr;
     int wavesTrace = 0;
     int64_t itemBase = 0, itemCount = 0;  // its items in dItems
-    int64_t ringTotal = 0;                // cells of all its regions' rings (ringEl is 0 then: nothing per slot)
+    int64_t ringTotal = 0;                // doubles of all its regions' rings (ringEl is 0 then: nothing per slot)
     int64_t ringEl = 0, candEl = 0, refEl = 0, totEl = 0, bringEl = 0, grollEl = 0;  // elements per scratch slot
     int64_t oRing = 0, oCand = 0, oRef = 0, oTot = 0, oBring = 0, oGroll = 0, oExpect = 0;  // element offsets of the class
     double slotBytes() const {
@@ -600,6 +600,16 @@ static KernelFn pick_packed_kernel(const CpkGeometry &g, int cls) {  // class k:
 }
 
 // the two kernels of a split class (match emitter)
+// Doubles of the ring a split region keeps its forward values in.  The match emitter stores the match row of every
+// diagonal and every state only where the traceback reads it back: diagonal 0, the refresh diagonals of the emitting
+// segment (one in CPK_REFRESH_PERIOD) and the two diagonals a forward sweep would resume from -- the table builder lays
+// the diagonals end to end with exactly that many doubles each (cpk_table_gather.inl); this is the upper bound it stays
+// below.  (Every state of every cell, as the per-wave rings are sized, is 204 GB for BASELINE config B; this is 62.)
+static int64_t split_ring_doubles(const CpkRegion &rg, int S) {
+    const int64_t N = (int64_t)rg.lX + rg.lY;
+    const int64_t fullDiags = N / CPK_REFRESH_PERIOD + 3 * (int64_t)rg.nSeg + 4;  // refresh points + two resume diagonals per segment
+    return (int64_t)rg.cells + (int64_t)(S - 1) * rg.maxWidth * fullDiags + S;
+}
 static KernelFn pick_fused_kernel(const CpkGeometry &g) {
     const bool fast = !g.useGlobalRoll;
     if (g.nStates == 5)
@@ -901,8 +911,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             for (LaunchClass &c : d->classes) {
                 if (!c.split) continue;
                 c.ringTotal = 0;
-                for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++)
-                    c.ringTotal += regions[di].cells + regions[di].maxWidth;
+                for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++) c.ringTotal += split_ring_doubles(regions[di], S);
                 c.ringEl = 0;
             }
         };
@@ -924,8 +933,8 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         auto tally = [&]() {
             need = floorNeed = fixed;
             for (const LaunchClass &c : d->classes) {
-                need += c.slotBytes() * (double)c.subSlots + 8.0 * S * (double)c.ringTotal;
-                floorNeed += c.slotBytes() * (double)(c.subSlots / (c.waves > 0 ? c.waves : 1)) + 8.0 * S * (double)c.ringTotal;
+                need += c.slotBytes() * (double)c.subSlots + 8.0 * (double)c.ringTotal;
+                floorNeed += c.slotBytes() * (double)(c.subSlots / (c.waves > 0 ? c.waves : 1)) + 8.0 * (double)c.ringTotal;
             }
         };
         tally();
@@ -964,7 +973,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             c.oBring = oBring;
             c.oGroll = oGroll;
             c.oExpect = oExpect;
-            oRing += c.split ? c.ringTotal * S : c.subSlots * c.ringEl;
+            oRing += c.split ? c.ringTotal : c.subSlots * c.ringEl;
             oCand += c.subSlots * c.candEl;
             oRef += c.subSlots * c.refEl;
             oTot += c.subSlots * c.totEl;
@@ -1016,15 +1025,15 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     {
         for (LaunchClass &c : d->classes) {
             if (!c.split) continue;
-            int64_t ringAt = 0;  // in cells, from the class's ring pointer (dRing + oRing)
+            int64_t ringAt = 0;  // in doubles, from the class's ring pointer (dRing + oRing)
             c.itemBase = (int64_t)items.size();
             std::vector<std::pair<int64_t, CpkItem>> byCost;
             for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++) {
                 CpkRegion &rg = regions[di];
-                rg.ringCap = (int32_t)(rg.cells + rg.maxWidth);
+                rg.ringCap = 0x7fffffff;  // never wraps: the ring holds every diagonal of the region
                 rg.ringBase = ringAt;
                 rg.split = 1;
-                ringAt += rg.ringCap;
+                ringAt += split_ring_doubles(rg, S);
                 for (int32_t si = 0; si < rg.nSeg; si++) {
                     const CpkSegment &sg = segs[rg.segOff + si];
                     // fused: a segment's forward values exist when the forward wave has passed its top diagonal -- items in
@@ -1079,10 +1088,10 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         if (int rc = dev_alloc(d, &dAnchors, (size_t)anchorStride * (size_t)(nAnchors > 0 ? nAnchors : 1))) return rc;
         if (nAnchors > 0)
             if (int rc = staged_h2d(d, dAnchors, anchors, sizeof(cpk_anchor_t) * (size_t)anchorStride * (size_t)nAnchors, &stageAt)) return rc;
+        if (int rc = staged_h2d(d, d->dSegs, segs, sizeof(CpkSegment) * (size_t)nSegs, &stageAt)) return rc;  // the builder reads the schedule
         hipLaunchKernelGGL(cpecan_build_diag_table, dim3((unsigned)((geo->nRegions + 63) / 64)), dim3(64), 0, io,
-                           d->dRegions, geo->nRegions, dAnchors, anchorStride, d->dDiags, expansion, dynamic);
+                           d->dRegions, geo->nRegions, dAnchors, anchorStride, d->dSegs, geo->nStates, d->dDiags, expansion, dynamic);
         HIP_TRY(hipGetLastError());
-        if (int rc = staged_h2d(d, d->dSegs, segs, sizeof(CpkSegment) * (size_t)nSegs, &stageAt)) return rc;
         if (int rc = staged_h2d(d, d->dSymbols, symbols, (size_t)nSymbolBytes, &stageAt)) return rc;
         if (int rc = staged_h2d(d, d->dModel, model, sizeof(CpkModel), &stageAt)) return rc;
         HIP_TRY(hipEventRecord(d->evUp1, io));

@@ -5,7 +5,9 @@
 // diagonals, 3S rows)
 // COH: the forward ring is handed from wave to wave inside ONE launch (kModeFused): its stores and loads are device-scope
 // (sc1, write-through / read-through) so that no L2 write-back or invalidate is needed around the hand-off
-template <int S, bool FAST, int ROWS = 2 * S + 1, bool COH = false>
+// RDBL: a table entry's ringOff counts doubles (the ring of a split region keeps only the states that are read back,
+// cpk_table_gather.inl) instead of cells of S doubles
+template <int S, bool FAST, int ROWS = 2 * S + 1, bool COH = false, bool RDBL = false>
 struct Sweep {
     const KArgs &a;
     const KConsts &m;  // kernarg-resident constants
@@ -70,7 +72,7 @@ struct Sweep {
     __device__ __forceinline__ static size_t ringIdx(int W, int s, int k) {
         return s == 0 ? (size_t)k : (size_t)W + (size_t)k * (S - 1) + (size_t)(s - 1);
     }
-    __device__ __forceinline__ double *ringAt(const CpkDiag &g) const { return ring + (size_t)g.ringOff * S; }
+    __device__ __forceinline__ double *ringAt(const CpkDiag &g) const { return ring + (size_t)g.ringOff * (RDBL ? 1 : S); }
     __device__ __forceinline__ static void ringSt(double *p, double v) {
         if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *p = v;
@@ -1089,7 +1091,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
             roll_fence<false>();
         }
         const CpkDiag *table = a.diags + rg.diagOff;
-        Sweep<S, FAST, 2 * S + 1, MODE == kModeFused> sw{a,
+        Sweep<S, FAST, 2 * S + 1, MODE == kModeFused, MODE != kModeWhole> sw{a,
                           a.kc,
                           DiagCache{table, N, 0, lane, 0, 0, 0, 0},
                           FAST ? seqLds : gx,
@@ -1098,7 +1100,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                           em,
                           wt,
                           lg,
-                          MODE == kModeWhole ? a.ring + slot * (size_t)a.geo.ringCells * S : a.ring + (size_t)rg.ringBase * S,
+                          MODE == kModeWhole ? a.ring + slot * (size_t)a.geo.ringCells * S : a.ring + (size_t)rg.ringBase,
                           a.cand + slot * (size_t)a.geo.fbCells * (EMIT == CPECAN_EMIT_INDEL ? 3 : 1),
                           stageLds,
                           a.cbuf + slot * (size_t)a.geo.refreshCells,

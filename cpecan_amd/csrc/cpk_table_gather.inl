@@ -8,7 +8,7 @@
 // (In a pipeline of batches this kernel of batch k+1 runs on that batch's own stream; its 56 allocated VGPRs do not fit
 // in the 48 a resident sweep of batch k leaves free per lane, so it starts when that sweep drains: ~3 ms per config-B batch.)
 __global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *regions, int nRegions, const cpk_anchor_t *anchors, int anchorStride,
-                                                              CpkDiag *diags, int64_t expansion, int dynamic) {
+                                                              const CpkSegment *segs, int S, CpkDiag *diags, int64_t expansion, int dynamic) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nRegions) return;
     const CpkRegion rg = regions[i];
@@ -17,18 +17,33 @@ __global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *r
     CpkBandIter it;
     cpk_band_init(&it, anchors + (size_t)anchorStride * rg.anchorOff, anchorStride, rg.nAnchors, rg.lX, rg.lY, expansion, dynamic);
     int32_t cells = 0, pos = 0;
+    // A split region's ring (rg.split: match emitter, a ring of the region's own that never wraps) counts DOUBLES and
+    // gives a diagonal S doubles per cell only where the sweep stores every state -- the predicate of the forward loop in
+    // cpecan_pairhmm_sweep: diagonal 0, the refresh diagonals of the segment that emits it, the two diagonals below a
+    // segment's top -- and one double per cell (the match row) elsewhere.  The other rings count cells of S doubles.
+    const CpkSegment *sg = segs + rg.segOff;
+    int emitSeg = 0, covSeg = 0;
+    int emitFrom = rg.nSeg > 0 ? sg[0].tbFrom : 0, covTop = rg.nSeg > 0 ? sg[0].dTop : 0;
     for (int64_t d = 0; d <= N; d++) {
         int64_t lo = 0, hi = 0;
         cpk_band_next(&it, d, &lo, &hi);
         const int32_t w = (int32_t)((hi - lo) / 2 + 1);
-        if (pos + w > rg.ringCap) pos = 0;
         CpkDiag e;
         e.xmyL = (int32_t)lo;
         e.width = w;
-        e.ringOff = pos;
         e.cellOff = cells;
+        if (rg.split) {
+            while (d > emitFrom && emitSeg + 1 < rg.nSeg) emitFrom = sg[++emitSeg].tbFrom;
+            while (d > covTop && covSeg + 1 < rg.nSeg) covTop = sg[++covSeg].dTop;
+            const bool all = d == 0 || (emitFrom - (int)d) % CPK_REFRESH_PERIOD == 0 || d >= covTop - 1;
+            e.ringOff = pos;
+            pos += all ? w * S : w;
+        } else {
+            if (pos + w > rg.ringCap) pos = 0;
+            e.ringOff = pos;
+            pos += w;
+        }
         table[d] = e;
-        pos += w;
         cells += w;
     }
 }
