@@ -298,7 +298,7 @@ def main():
     value_e2e = None
     if not args.no_e2e:
         # the timed batch goes first: a config-B batch in its one-launch form holds the forward values of every region
-        # (196 GB); the pipeline below gets that memory for its own batches
+        # (68 GB at config B); the pipeline below gets that memory for its own batches
         spot = [] if expect else [batch.result(i) for i in range(min(4, len(problems)))]  # for the parity spot check below
         batch.close()
         batch = None

@@ -127,7 +127,7 @@ struct BlockCache {
     size_t bytes = 0;
 };
 constexpr int kMaxDevices = 64;
-constexpr size_t kCacheMaxBlock = (size_t)256 << 30;  // the rings of a fused config-B batch are one block of 196 GB
+constexpr size_t kCacheMaxBlock = (size_t)256 << 30;  // the rings of a batch's split regions are ONE block (60 GB at config B)
 constexpr int kCacheMaxBlocks = 512;
 size_t cache_max_bytes() {
     static const size_t v = [] {
