@@ -167,6 +167,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.backend == "gloo" and not args.dry_run and torch.cuda.device_count() > 0:
+        # a rehearsal of the multi-rank path on a box with fewer GPUs than ranks (gloo only: RCCL wants a GPU per rank)
+        local_rank %= torch.cuda.device_count()
     if world != args.gpus:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     scaling = args.scaling or ("strong" if world > 1 else "weak")
