@@ -842,28 +842,25 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         {
             // Split the class when its regions do not fill the chip and have tracebacks to hand out: the segments of a
             // region are independent once its forward values exist.  CPECAN_SPLIT=1 / 0 (tests, diagnostics): always / never.
-            int64_t nSegClass = 0, cellsClass = 0, diagsClass = 0;
-            for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++) {
-                nSegClass += regions[di].nSeg;
-                cellsClass += regions[di].cells;
-                diagsClass += (int64_t)regions[di].lX + regions[di].lY + 1;
-            }
+            int64_t nSegClass = 0;
+            for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++) nSegClass += regions[di].nSeg;
             const char *env = getenv("CPECAN_SPLIT");
             const int64_t slots = (int64_t)perCU * d->numCUs;
             const bool eligible = c.threads == CPK_WAVE && geo->emit == CPECAN_EMIT_MATCH && !geo->debug && nSegClass > 0;
-            // Bands of ~100 cells per diagonal and more (config B: 122) take the ONE-launch form whatever the number of regions: measured faster
-            // than one wave per region from 300 to 10 000 config-B pairs (-3 % at 10 000, -35 % at 2500, where regions
-            // per slot do not come out even), and a diagonal of two or three groups covers the device-scope loads of
-            // the ring.  Narrower classes (config A: 74 cells) lose with those loads and split only when their
-            // regions leave slots idle, as two launches.  (profiles/r02_ab_fused_split_launch.log)  The rings of whole
-            // regions are given up first when device memory is short (below).
-            const bool wideBand = cellsClass >= 96 * diagsClass;  // cells per diagonal, on average over the class
+            // Regions with tracebacks to hand out (1.25 segments on average and more) run split whenever their rings fit:
+            // measured against one wave per region on 600 to 10 000 pairs of 1-4 kb and bands of 55-124 cells per diagonal,
+            // one of the two split forms won every time (tools/split_forms.py, profiles/r02_split_forms.txt).  Which one:
+            // the ONE-launch form fills the partly empty last round of forward sweeps with traceback items and wins where a
+            // region has many segments (2 kb and longer: -20 to -40 %); with two or three segments per region (1 kb
+            // pairs, config A) its device-scope ring accesses and waiting waves cost more than that gains (+7 to +19 %) and the
+            // two launches win.  The rings of whole regions are given up first when device memory is short (below).
             const bool manySegs = nSegClass * 4 >= n * 5;
-            const bool wanted = env ? atoi(env) != 0 : (manySegs && (wideBand || n * 20 < slots * 17));
+            const bool wanted = env ? atoi(env) != 0 : manySegs;
+            const bool oneLaunch = nSegClass * 2 >= n * 7;  // 3.5 segments per region and more
             if (eligible && wanted) {
                 c.split = true;
                 // CPECAN_SPLIT=2 / 1: force the one-launch (kModeFused) / two-launch form
-                c.fused = env ? atoi(env) == 2 : wideBand;
+                c.fused = env ? atoi(env) == 2 : oneLaunch;
                 if (c.fused) {
                     c.fn = pick_fused_kernel(c.geo);
                     // One CU in eight keeps a wave slot (and its 19 KB of LDS) free: a launch that fills every slot to its
