@@ -148,7 +148,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="override the config's number of pairs (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host to host) measurements")
-    ap.add_argument("--e2e-batches", type=int, default=9, help="batches pushed through the two-deep pipeline (odd: the steady state is read over an even number of batch intervals)")
+    ap.add_argument("--e2e-batches", type=int, default=9, help="batches pushed through the pipeline (odd: the steady state is read over an even number of batch intervals)")
+    ap.add_argument("--e2e-depth", type=int, default=0, help="batches in flight in the end-to-end pipeline; 0: two, or three where the host's packing and planning takes at least half as long as sweep + download and three batches fit in half the device memory")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend: nccl is RCCL; gloo only for the CPU dry run of the launcher (tests)")
     ap.add_argument("--dry-run", action="store_true",
@@ -332,39 +333,46 @@ def main():
         e2e["plan_upload_s"] = t1 - t0
         e2e["run_download_assemble_s"] = t2 - t1
         b.close()
-        # (b) two batches in flight from ONE host thread: while the sweep of batch k runs, batch k+1 is packed, planned and
-        # uploaded and batch k-1 is gathered and downloaded (every batch works on streams and events of its own; its download
-        # runs on the helper thread the library gives every batch)
+        # (b) several batches in flight from ONE host thread: while the sweep of batch k runs, batch k+1 is packed, planned
+        # and uploaded and batch k-1 is gathered and downloaded (every batch works on streams and events of its own; its
+        # download runs on the helper thread the library gives every batch).  Two in flight are enough where the sweep is
+        # the longest stage (config B); where the host's packing and planning is (config 4), the latency of one batch --
+        # upload tail + sweep + gather + fetch -- exceeds the host's interval and a third batch in flight hides it.
         nb = max(3, args.e2e_batches)
+        depth = args.e2e_depth
+        if depth < 2:
+            total_mem = torch.cuda.get_device_properties(local_rank).total_memory
+            host_bound = 2 * e2e["plan_upload_s"] >= e2e["run_download_assemble_s"]
+            depth = 3 if host_bound and 3 * e2e["device_bytes"] < total_mem // 2 else 2
+        e2e["pipeline_depth"] = depth
+        trace = os.environ.get("CPECAN_BENCH_TRACE") == "1"
         barrier()
         t0 = time.perf_counter()
-        prev = make_batch()
-        prev.run(stream.cuda_stream)
-        prev.download_begin()  # the batch's helper thread waits for the sweep, gathers and fetches (cpecan_batch_download_begin)
-        pairs_out, t_first = 0, None
-        trace = os.environ.get("CPECAN_BENCH_TRACE") == "1"
-        for _ in range(1, nb):
-            ta = time.perf_counter()
-            cur = make_batch()
-            tb = time.perf_counter()
-            cur.run(stream.cuda_stream)
-            cur.download_begin()
-            prev.download_end()
-            tc = time.perf_counter()
+        inflight, pairs_out, t_first, done = [], 0, None, 0
+        def retire():
+            nonlocal pairs_out, t_first, done
+            old = inflight.pop(0)
+            old.download_end()
+            t = time.perf_counter()
             if t_first is None:
-                t_first = time.perf_counter()  # the first batch's lists are on the host: the pipeline is full from here
-            pst = prev.stats()
+                t_first = t  # the first batch's lists are on the host: the pipeline is full from here
+            pst = old.stats()
             pairs_out += int(pst.pairs)
-            kms, dms = pst.kernelMs, pst.d2hMs
-            prev.close()
+            old.close()
+            done += 1
             if trace and rank == 0:
-                print("pipeline: pack+plan+upload %.1f ms, run+download(prev) %.1f ms (its kernel %.1f ms, d2h %.1f ms), close(prev) %.1f ms"
-                      % (1e3 * (tb - ta), 1e3 * (tc - tb), kms, dms, 1e3 * (time.perf_counter() - tc)), file=sys.stderr, flush=True)
-            prev = cur
-        prev.download_end()
-        t_last = time.perf_counter()
-        pairs_out += int(prev.stats().pairs)
-        prev.close()
+                print("pipeline: batch %d on the host at %.1f ms (its kernel %.1f ms, d2h %.1f ms)"
+                      % (done, 1e3 * (t - t0), pst.kernelMs, pst.d2hMs), file=sys.stderr, flush=True)
+            return t
+        for _ in range(nb):
+            cur = make_batch()
+            cur.run(stream.cuda_stream)
+            cur.download_begin()  # the batch's helper thread waits for the sweep, gathers and fetches (cpecan_batch_download_begin)
+            inflight.append(cur)
+            if len(inflight) >= depth:
+                retire()
+        while inflight:
+            t_last = retire()
         pipe_s, steady_s = t_last - t0, (t_last - t_first) / (nb - 1)
         if world > 1:
             t = torch.tensor([pipe_s, steady_s], dtype=torch.float64, device=red_dev)

@@ -9,6 +9,10 @@ tests hold as inputs / expected values -- no source text is copied.
   encode_human_chimp.json.gz     tests/pairwiseAlignerLongTest.c:14-38: the ~57 kb human and chimp ENCODE fragments and the
                                  two rows of the reference multiple alignment the test scores against (humanSeq, chimpSeq,
                                  humanAlign, chimpAlign string constants).
+  encode_mouse_dog.json.gz       the same file's mouse (~33 kb) and dog (~54 kb) fragments and their rows of the same
+                                 multiple alignment (mouseSeq, mouseAlign, dogSeq, dogAlign; test_pairwiseAligner_LongHumanMouse
+                                 / _LongHumanDog, :128-134): 67 % / 75 % identity over the aligned columns, unaligned
+                                 stretches of up to 8 kb -- the human row is the one in encode_human_chimp.json.gz.
 """
 import gzip
 import json
@@ -41,6 +45,14 @@ def main():
     assert d["chimpAlign"].replace("-", "").upper() == d["chimpSeq"].upper()
     with gzip.GzipFile(os.path.join(OUT, "encode_human_chimp.json.gz"), "wb", mtime=0) as f:
         f.write(json.dumps(d).encode())
+    e = {"source": "tests/pairwiseAlignerLongTest.c (string constants), scored as in :40-122 by :128-134"}
+    for name in ("mouseSeq", "mouseAlign", "dogSeq", "dogAlign"):
+        e[name] = c_string_constant(c, name)
+    for sp in ("mouse", "dog"):
+        assert len(e[sp + "Align"]) == len(d["humanAlign"])
+        assert e[sp + "Align"].replace("-", "").upper() == e[sp + "Seq"].upper()
+    with gzip.GzipFile(os.path.join(OUT, "encode_mouse_dog.json.gz"), "wb", mtime=0) as f:
+        f.write(json.dumps(e).encode())
     print("wrote", os.listdir(OUT))
 
 

@@ -34,13 +34,9 @@ def trained_hmm_numbers():
     return int(a[0]), [float(v) for v in a[1:26]], float(a[26]), [float(v) for v in l2.split()]
 
 
-def encode_human_chimp(anchor_every=10, flank=14):
-    """tests/pairwiseAlignerLongTest.c: the ~57 kb human / chimp ENCODE fragments with the reference alignment the test
-    scores against.  Returns (sX, sY, anchors[n,3], true_pairs set).  The reference finds its anchors with lastz (absent
-    here); these come from the embedded alignment the way lastz + constraintDiagonalTrim would leave them: columns of
-    equal bases at least `flank` columns inside a gapless run of equal bases, one every `anchor_every` columns."""
-    d = json.load(gzip.open(os.path.join(GOLDEN, "encode_human_chimp.json.gz")))
-    a, b = d["humanAlign"].upper(), d["chimpAlign"].upper()
+def _anchors_from_rows(a, b, anchor_every, flank, equal_bases):
+    """(anchors[n,3], true_pairs) from two rows of an alignment: one column every `anchor_every` among the columns that
+    lie more than `flank` columns inside a gapless run of aligned columns (equal_bases: of equal, non-N bases)."""
     av = np.frombuffer(a.encode(), dtype=np.uint8)
     bv = np.frombuffer(b.encode(), dtype=np.uint8)
     gap = ord("-")
@@ -52,9 +48,9 @@ def encode_human_chimp(anchor_every=10, flank=14):
     # consider only columns where at least one of the two rows has a base (the other rows of the multiple alignment
     # contribute all-gap columns for this pair)
     keep = ina | inb
-    eq = (both & (av == bv) & (av != ord("N")))[keep]
+    eq = ((both & (av == bv) & (av != ord("N"))) if equal_bases else both)[keep]
     xs, ys = x[keep], y[keep]
-    run = np.zeros(len(eq), dtype=np.int64)   # length of the run of equal columns ending here
+    run = np.zeros(len(eq), dtype=np.int64)   # length of the run of such columns ending here
     c = 0
     for i, e in enumerate(eq):
         c = c + 1 if e else 0
@@ -71,7 +67,30 @@ def encode_human_chimp(anchor_every=10, flank=14):
             chosen.append(i)
             last = i
     anchors = np.array([(xs[i], ys[i], 0) for i in chosen], dtype=np.int64).reshape(-1, 3)
+    return anchors, true_pairs
+
+
+def encode_human_chimp(anchor_every=10, flank=14):
+    """tests/pairwiseAlignerLongTest.c: the ~57 kb human / chimp ENCODE fragments with the reference alignment the test
+    scores against.  Returns (sX, sY, anchors[n,3], true_pairs set).  The reference finds its anchors with lastz (absent
+    here); these come from the embedded alignment the way lastz + constraintDiagonalTrim would leave them: columns of
+    equal bases at least `flank` columns inside a gapless run of equal bases, one every `anchor_every` columns."""
+    d = json.load(gzip.open(os.path.join(GOLDEN, "encode_human_chimp.json.gz")))
+    anchors, true_pairs = _anchors_from_rows(d["humanAlign"].upper(), d["chimpAlign"].upper(), anchor_every, flank, True)
     return d["humanSeq"], d["chimpSeq"], anchors, true_pairs
+
+
+def encode_human_other(species, anchor_every=10, flank=14):
+    """The same test file's human / mouse and human / dog pairs (test_pairwiseAligner_LongHumanMouse / _LongHumanDog,
+    :128-134): 67 % / 75 % identical over the aligned columns, so runs of equal bases are too short to anchor on; a lastz
+    block is gapless with mismatches inside, trimmed by constraintDiagonalTrim at both ends -- here: columns more than
+    `flank` inside a gapless run of ALIGNED columns of the embedded alignment, one every `anchor_every`.  The stretches
+    without anchors are up to 1947 x 1329 (mouse) and 1189 x 1145 (dog) bases: full DP rectangles between banded ones."""
+    assert species in ("mouse", "dog")
+    d = json.load(gzip.open(os.path.join(GOLDEN, "encode_human_chimp.json.gz")))
+    e = json.load(gzip.open(os.path.join(GOLDEN, "encode_mouse_dog.json.gz")))
+    anchors, true_pairs = _anchors_from_rows(d["humanAlign"].upper(), e[species + "Align"].upper(), anchor_every, flank, False)
+    return d["humanSeq"], e[species + "Seq"], anchors, true_pairs
 
 
 def sensitivity_specificity(pairs, true_pairs):

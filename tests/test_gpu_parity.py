@@ -1061,6 +1061,27 @@ def test_encode_human_chimp_full_length_gpu():
     assert_pairs_match(got2, want2, threshold=p.threshold)
 
 
+@pytest.mark.parametrize("species", ["mouse", "dog"])
+def test_encode_human_mouse_and_dog_full_length_gpu(species):
+    """tests/pairwiseAlignerLongTest.c:128-134: the divergent human / mouse and human / dog ENCODE pairs at full length
+    through the HIP path.  One region of ~90-110 k anti-diagonals whose band alternates between 40-cell parallelograms
+    and full rectangles of up to 1947 x 1329 cells (diagonals of > 1300 cells: the wide classes), then the same problem
+    split at the large gaps (getSplitPoints, many small regions): every pair against the oracle."""
+    import reference_cases as rc
+    sx, sy, anchors, true_pairs = rc.encode_human_other(species)
+    sm, om = api.stateMachine5_construct(), ob.model(ob.FIVE_STATE)
+    for kw in (dict(diagonalExpansion=20), dict(diagonalExpansion=20, splitMatrixBiggerThanThis=500)):
+        p = api.pairwiseAlignmentBandingParameters_construct(**kw)
+        got = api.getAlignedPairsUsingAnchors(sm, sx, sy, anchors, p)
+        want = ob.aligned_pairs(om, sx, sy, anchors, ob.params(**kw))
+        assert len(want) > 25000
+        assert_pairs_match(got, want, threshold=p.threshold)
+        if len(kw) == 1:
+            out = api.filterPairwiseAlignmentToMakePairsOrdered(got, sx, sy, 0.5)
+            sens, spec = rc.sensitivity_specificity(out, true_pairs)
+            print("ENCODE human/%s through the HIP path: %d pairs, sensitivity %.5f, specificity %.5f" % (species, len(out), sens, spec))
+
+
 # ---- split classes: the tracebacks of a region as queue items of their own (fills the chip when regions < wave slots) ----
 def test_split_classes_equal_whole_region_waves(monkeypatch):
     """A class with fewer regions than the chip has wave slots runs as two launches: forward sweeps of whole regions into

@@ -461,3 +461,20 @@ def test_encode_human_chimp_full_length_oracle():
     out = ob.filter_pairs_ordered(pairs, len(sx), len(sy), 0.5)
     sens, spec = rc.sensitivity_specificity(out, true_pairs)
     assert sens > 0.99 and spec > 0.99, (sens, spec)
+
+
+@pytest.mark.parametrize("species,n_x,n_y,n_true,sens_bar,spec_bar",
+                         [("mouse", 57553, 32750, 20406, 0.75, 0.85), ("dog", 57553, 54187, 39241, 0.90, 0.94)])
+def test_encode_human_mouse_and_dog_oracle(species, n_x, n_y, n_true, sens_bar, spec_bar):
+    """tests/pairwiseAlignerLongTest.c:128-134: the human / mouse and human / dog ENCODE pairs at full length.  Divergent
+    sequences (67 % / 75 % identity), anchors with stretches of up to 8 kb of one sequence between them: banded
+    parallelograms alternate with full rectangles of up to 1947 x 1329 cells.  The reference asserts uniqueness of the
+    pairs (:75) and logs sensitivity / specificity against the embedded alignment; the bars are this repo's."""
+    sx, sy, anchors, true_pairs = rc.encode_human_other(species)
+    assert (len(sx), len(sy), len(true_pairs)) == (n_x, n_y, n_true)
+    pairs = ob.aligned_pairs(ob.model(ob.FIVE_STATE), sx, sy, anchors, ob.params(diagonalExpansion=20))
+    assert len({(int(x), int(y)) for _, x, y in pairs}) == len(pairs)
+    out = ob.filter_pairs_ordered(pairs, len(sx), len(sy), 0.5)
+    sens, spec = rc.sensitivity_specificity(out, true_pairs)
+    assert sens > sens_bar and spec > spec_bar, (sens, spec)
+
