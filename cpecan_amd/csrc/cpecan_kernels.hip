@@ -96,6 +96,7 @@ struct LaunchClass {
     // A SPLIT class (fewer regions than wave slots): launch 1 = forward sweeps of whole regions into per-REGION rings,
     // launch 2 = one queue item per (region, traceback segment); see kModeForward / kModeTrace in cpk_sweep.inl.
     bool split = false;
+    bool dense = false;  // three-state match kernels allocated for three waves per SIMD (WPS = 3)
     bool fused = false;  // split, as ONE launch (kModeFused): regions and their traceback items in one queue
     KernelFn fnTrace = nullptr;
     int wavesTrace = 0;
@@ -610,21 +611,31 @@ static int64_t split_ring_doubles(const CpkRegion &rg, int S) {
     const int64_t fullDiags = N / CPK_REFRESH_PERIOD + 3 * (int64_t)rg.nSeg + 4;  // refresh points + two resume diagonals per segment
     return (int64_t)rg.cells + (int64_t)(S - 1) * rg.maxWidth * fullDiags + S;
 }
-static KernelFn pick_fused_kernel(const CpkGeometry &g) {
+// dense: the three-state match kernels allocated for three waves per SIMD (cpk_sweep.inl, WPS)
+static KernelFn pick_fused_kernel(const CpkGeometry &g, bool dense) {
     const bool fast = !g.useGlobalRoll;
     if (g.nStates == 5)
         return fast ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeFused> : cpecan_pairhmm_sweep<5, false, CPECAN_EMIT_MATCH, kModeFused>;
+    if (dense)
+        return fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeFused, 3> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeFused, 3>;
     return fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeFused> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeFused>;
 }
-static void pick_split_kernels(const CpkGeometry &g, KernelFn *fwd, KernelFn *trace) {
+static void pick_split_kernels(const CpkGeometry &g, bool dense, KernelFn *fwd, KernelFn *trace) {
     const bool fast = !g.useGlobalRoll;
     if (g.nStates == 5) {
         *fwd = fast ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeForward> : cpecan_pairhmm_sweep<5, false, CPECAN_EMIT_MATCH, kModeForward>;
         *trace = fast ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeTrace> : cpecan_pairhmm_sweep<5, false, CPECAN_EMIT_MATCH, kModeTrace>;
     } else {
+        // the forward-only kernel needs 70 VGPRs: one variant
         *fwd = fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeForward> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeForward>;
-        *trace = fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeTrace> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeTrace>;
+        if (dense)
+            *trace = fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeTrace, 3> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeTrace, 3>;
+        else
+            *trace = fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeTrace> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeTrace>;
     }
+}
+static KernelFn pick_dense_kernel(const CpkGeometry &g) {  // one wave per region, three-state match emitter
+    return !g.useGlobalRoll ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeWhole, 3> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeWhole, 3>;
 }
 
 static KernelFn pick_kernel(const CpkGeometry &g) {
@@ -818,6 +829,22 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             if (perCU < 1) perCU = 1;
         } else {
             perCU = soloPerCU;
+            // Three-state match classes with more regions than two waves per SIMD hold take the kernels allocated for
+            // three (168 VGPRs, a handful of spills): 4000 pairs of 1 kb -9 to -19 %, 2500 of 2 kb -17 %, with one wave
+            // per region -34 %; a class that leaves slots empty anyway loses 3-10 % to the spills and the fuller SIMDs
+            // (config A, 1000 pairs: 3.68 -> 4.07 ms) and keeps the 2-wave kernels.  CPECAN_DENSE=1 / 0: always / never.
+            const char *denseEnv = getenv("CPECAN_DENSE");
+            if (S == 3 && geo->emit == CPECAN_EMIT_MATCH && !geo->debug &&
+                (denseEnv ? atoi(denseEnv) != 0 : geo->nWide[k] >= (int64_t)soloPerCU * d->numCUs)) {
+                KernelFn f3 = pick_dense_kernel(c.geo);
+                int p3 = 0;
+                if (int rc = wavesPerCU(f3, c.ldsBytes, &p3)) return rc;
+                if (p3 > perCU) {
+                    c.fn = f3;
+                    c.dense = true;
+                    perCU = p3;
+                }
+            }
         }
         if (perCU < 1) {
             cpk_set_error("kernel does not fit on a CU (LDS %zu bytes)", c.ldsBytes);
@@ -862,7 +889,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                 // CPECAN_SPLIT=2 / 1: force the one-launch (kModeFused) / two-launch form
                 c.fused = env ? atoi(env) == 2 : oneLaunch;
                 if (c.fused) {
-                    c.fn = pick_fused_kernel(c.geo);
+                    c.fn = pick_fused_kernel(c.geo, c.dense);
                     // One CU in eight keeps a wave slot (and its 19 KB of LDS) free: a launch that fills every slot to its
                     // end starves the small kernels of the batch before it -- the list consumers need a few KB of LDS --
                     // until it drains, and a pipeline two batches deep then idles between sweeps (82 ms measured).
@@ -871,7 +898,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                     c.waves = (int)wt;
                     c.subSlots = wt;
                 } else {
-                    pick_split_kernels(c.geo, &c.fn, &c.fnTrace);
+                    pick_split_kernels(c.geo, c.dense, &c.fn, &c.fnTrace);
                     int64_t wt = slots < nSegClass ? slots : nSegClass;
                     c.wavesTrace = (int)wt;
                     if (wt > c.subSlots) c.subSlots = wt;
@@ -917,7 +944,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                 if (!c.split) continue;
                 c.split = false;
                 c.fused = false;
-                c.fn = pick_kernel(c.geo);
+                c.fn = c.dense ? pick_dense_kernel(c.geo) : pick_kernel(c.geo);
                 c.fnTrace = nullptr;
                 c.subSlots = c.waves;
                 c.itemCount = 0;

@@ -1023,8 +1023,11 @@ constexpr int kEmitForward = 3;
 //                 segments then run beside the forward sweeps of the class instead of behind the slowest of them.
 constexpr int kModeWhole = 0, kModeForward = 1, kModeTrace = 2, kModeFused = 3;
 
-template <int S, bool FAST, int EMIT, int MODE = kModeWhole>
-__global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(CPK_SWEEP_WAVES, CPK_SWEEP_WAVES)))
+// WPS: waves per SIMD the registers are allocated for.  Two everywhere (the five-state match kernel needs ~230 VGPRs)
+// except the three-state match kernels of classes with more regions than two waves per SIMD hold: at 168 VGPRs (a
+// handful of spills) three fit, and a queue that long runs 9-34 % faster with them (cpk_device_upload).
+template <int S, bool FAST, int EMIT, int MODE = kModeWhole, int WPS = CPK_SWEEP_WAVES>
+__global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 cpecan_pairhmm_sweep(const KArgs a) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
