@@ -609,7 +609,8 @@ static KernelFn pick_packed_kernel(const CpkGeometry &g, int cls) {  // class k:
 static int64_t split_ring_doubles(const CpkRegion &rg, int S) {
     const int64_t N = (int64_t)rg.lX + rg.lY;
     const int64_t fullDiags = N / CPK_REFRESH_PERIOD + 3 * (int64_t)rg.nSeg + 4;  // refresh points + two resume diagonals per segment
-    return (int64_t)rg.cells + (int64_t)(S - 1) * rg.maxWidth * fullDiags + S;
+    // + one double of padding per diagonal (match rows start and end on even doubles); an even total keeps the next region's ring aligned
+    return ((int64_t)rg.cells + (N + 1) + (int64_t)(S - 1) * rg.maxWidth * fullDiags + S + 1) & ~(int64_t)1;
 }
 // dense: the three-state match kernels allocated for three waves per SIMD (cpk_sweep.inl, WPS)
 static KernelFn pick_fused_kernel(const CpkGeometry &g, bool dense) {
@@ -869,8 +870,12 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         {
             // Split the class when its regions do not fill the chip and have tracebacks to hand out: the segments of a
             // region are independent once its forward values exist.  CPECAN_SPLIT=1 / 0 (tests, diagnostics): always / never.
-            int64_t nSegClass = 0;
-            for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++) nSegClass += regions[di].nSeg;
+            int64_t nSegClass = 0, maxRing = 0;
+            for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++) {
+                nSegClass += regions[di].nSeg;
+                const int64_t rd = split_ring_doubles(regions[di], S);
+                if (rd > maxRing) maxRing = rd;
+            }
             const char *env = getenv("CPECAN_SPLIT");
             const int64_t slots = (int64_t)perCU * d->numCUs;
             const bool eligible = c.threads == CPK_WAVE && geo->emit == CPECAN_EMIT_MATCH && !geo->debug && nSegClass > 0;
@@ -887,7 +892,8 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             if (eligible && wanted) {
                 c.split = true;
                 // CPECAN_SPLIT=2 / 1: force the one-launch (kModeFused) / two-launch form
-                c.fused = env ? atoi(env) == 2 : oneLaunch;
+                // (the one-launch form addresses a region's ring with 32-bit byte offsets: Sweep::ringPut)
+                c.fused = (env ? atoi(env) == 2 : oneLaunch) && maxRing < ((int64_t)1 << 28);
                 if (c.fused) {
                     c.fn = pick_fused_kernel(c.geo, c.dense);
                     // One CU in eight keeps a wave slot (and its 19 KB of LDS) free: a launch that fills every slot to its
@@ -998,6 +1004,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             c.oGroll = oGroll;
             c.oExpect = oExpect;
             oRing += c.split ? c.ringTotal : c.subSlots * c.ringEl;
+            oRing = (oRing + 1) & ~(int64_t)1;  // the rings of a split class start on 16 bytes (Sweep::ringPut)
             oCand += c.subSlots * c.candEl;
             oRef += c.subSlots * c.refEl;
             oTot += c.subSlots * c.totEl;

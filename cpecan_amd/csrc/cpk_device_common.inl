@@ -322,6 +322,15 @@ struct DiagCache {
     }
 };
 
+#ifndef CPK_COH_ST
+#define CPK_COH_ST 1
+#endif
+#ifndef CPK_COH_PAIRS
+#define CPK_COH_PAIRS 1  // 0: the one-launch form stores every ring double on its own (A/B builds; Sweep::ringPut)
+#endif
+#ifndef CPK_COH_LD
+#define CPK_COH_LD 1
+#endif
 #ifndef CPK_SWEEP_WAVES
 #define CPK_SWEEP_WAVES 2  // waves per SIMD the sweep kernel's registers are allocated for
 #endif

@@ -69,16 +69,62 @@ struct Sweep {
     __device__ __forceinline__ double *bG1(int d) const { return roll + R + 2 + (d & 1) * (S - 1); }
     // Forward ring in HBM, per diagonal of W cells: the match row [W], then the other states cell-major [W][S-1]
     // (the traceback reads the match row on its own; a cell's remaining states go out as one 32-byte run).
+    // (Rings of a split region, RDBL: the match row is padded to an even number of doubles and every diagonal starts on
+    // one -- cpecan_build_diag_table -- so that pairs of match cells and a cell's other states are 16-byte aligned.)
     __device__ __forceinline__ static size_t ringIdx(int W, int s, int k) {
-        return s == 0 ? (size_t)k : (size_t)W + (size_t)k * (S - 1) + (size_t)(s - 1);
+        const int We = RDBL ? ((W + 1) & ~1) : W;
+        return s == 0 ? (size_t)k : (size_t)We + (size_t)k * (S - 1) + (size_t)(s - 1);
     }
     __device__ __forceinline__ double *ringAt(const CpkDiag &g) const { return ring + (size_t)g.ringOff * (RDBL ? 1 : S); }
+    // CPK_COH_ST / CPK_COH_LD = 0: timing-only builds (tools/ab_build.sh) that drop one side's device scope -- results
+    // of the one-launch form are then undefined
     __device__ __forceinline__ static void ringSt(double *p, double v) {
-        if (COH) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (COH && CPK_COH_ST) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else *p = v;
     }
+    // One cell's forward values -> the ring (rs states: 1 = the match row only, S = all).  next / prev: the lane above /
+    // below this one holds cell k + 1 / k - 1 of the same diagonal and stores it in this call.
+    // One-launch form (COH): a device-scope store is one fabric write per LANE whatever its size -- 8-byte ones cost 2.7x
+    // the time per byte of 16-byte ones (MI355X_MICROARCH.md; measured here: config B 92.8 ms, 87.6 with plain stores,
+    // profiles/r02_ab_coherent_stores.log).  So the lane of an even cell takes its right neighbour's match value over
+    // DPP and writes both as one aligned 16 bytes, the neighbour writes nothing, and a cell's other states leave as
+    // 16-byte writes too (S - 1 is even, their run starts on an even double).
+    __device__ __forceinline__ void ringPut(double *out, int W, int k, bool next, bool prev, const double (&v)[S], int rs) const {
+        if (!(COH && CPK_COH_ST && CPK_COH_PAIRS)) {
+            if (rs > 0) {
+                ringSt(out + ringIdx(W, 0, k), v[0]);
+                if (rs > 1) {
+#pragma unroll
+                    for (int s = 1; s < S; s++) ringSt(out + ringIdx(W, s, k), v[s]);
+                }
+            }
+            return;
+        }
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        const unsigned lo = (unsigned)__double_as_longlong(v[0]), hi = (unsigned)((unsigned long long)__double_as_longlong(v[0]) >> 32);
+        const unsigned loN = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x130, 0xf, 0xf, false);  // wave_shl:1: lane i <- lane i + 1
+        const unsigned hiN = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x130, 0xf, 0xf, false);
+        if (rs <= 0) return;
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ring, 0, 0x7fffffff, 0x00020000);  // the region's ring: < 2 GiB (cpk_device_upload)
+        const bool even = (k & 1) == 0;
+        const unsigned at = (unsigned)((out - ring) + k) * 8u;
+        if (even && next) {
+            __builtin_amdgcn_raw_buffer_store_b128(u4{lo, hi, loN, hiN}, rsrc, (int)at, 0, 16);  // aux 16 = sc1
+        } else if (even || !prev) {
+            ringSt(out + k, v[0]);
+        }
+        if (rs > 1) {
+            const unsigned at2 = (unsigned)((out - ring) + ringIdx(W, 1, k)) * 8u;
+#pragma unroll
+            for (int s = 1; s + 1 < S; s += 2) {
+                const unsigned long long x = (unsigned long long)__double_as_longlong(v[s]), y = (unsigned long long)__double_as_longlong(v[s + 1]);
+                __builtin_amdgcn_raw_buffer_store_b128(u4{(unsigned)x, (unsigned)(x >> 32), (unsigned)y, (unsigned)(y >> 32)}, rsrc,
+                                                       (int)(at2 + 8u * (unsigned)(s - 1)), 0, 16);
+            }
+        }
+    }
     __device__ __forceinline__ static double ringLd(const double *p) {
-        return COH ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ld_self(p);
+        return (COH && CPK_COH_LD) ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : ld_self(p);
     }
 
     // ---- forward: impl/pairwiseAligner.c:609-629 with stateMachine{5,3}_cellCalculate as the per-cell body ----
@@ -211,13 +257,7 @@ struct Sweep {
                 fwdCells<1>(c, kk, kkR, v);
 #pragma unroll
                 for (int s = 0; s < S; s++) cur[s + kkR[0]] = v[0][s];
-                if (ringStates > 0) {
-                    ringSt(out + ringIdx(W, 0, k0), v[0][0]);
-                    if (ringStates > 1) {
-#pragma unroll
-                        for (int s = 1; s < S; s++) ringSt(out + ringIdx(W, s, k0), v[0][s]);
-                    }
-                }
+                ringPut(out, W, k0, k0 + 1 < W && lane < CPK_WAVE - 1, lane > 0, v[0], ringStates);
             }
         }
         roll_fence<!FAST>();
@@ -260,13 +300,7 @@ struct Sweep {
             fwdCells<1>(c, kk, kkR, v);
 #pragma unroll
             for (int s = 0; s < S; s++) cur[s + kkR[0]] = v[0][s];
-            if (ringStates > 0) {
-                ringSt(out + ringIdx(W, 0, k0), v[0][0]);
-                if (ringStates > 1) {
-#pragma unroll
-                    for (int s = 1; s < S; s++) ringSt(out + ringIdx(W, s, k0), v[0][s]);
-                }
-            }
+            ringPut(out, W, k0, k0 + 1 < hi && lane < CPK_WAVE - 1, k0 > lo && lane > 0, v[0], ringStates);
         }
     }
 
@@ -326,13 +360,8 @@ struct Sweep {
                 if (inA || inB) {
 #pragma unroll
                     for (int s = 0; s < S; s++) curL[s + kR] = v[0][s];
-                    if (rsL > 0) {
-                        ringSt(outL + ringIdx(WL, 0, k), v[0][0]);
-                        if (rsL > 1) {
-#pragma unroll
-                            for (int s = 1; s < S; s++) ringSt(outL + ringIdx(WL, s, k), v[0][s]);
-                        }
-                    }
+                    // the two diagonals' cells never pair: A's are lanes [0, r), B's [r, r + b)
+                    ringPut(outL, WL, k, inA ? lane + 1 < r : lane + 1 - r < b, inA ? lane > 0 : lane > r, v[0], rsL);
                 }
                 tail.has = false;
                 if (asc) lo = b;
@@ -1081,6 +1110,12 @@ cpecan_pairhmm_sweep(const KArgs a) {
         const bool traceRole = MODE == kModeTrace || (MODE == kModeFused && tk >= a.regionCount);  // wave-uniform
         const bool forwardRole = MODE == kModeForward || (MODE == kModeFused && !traceRole);
         const int ti = MODE == kModeFused ? tk - a.regionCount : tk;
+#ifdef CPK_FUSED_PRIO
+        if (MODE == kModeFused) {  // the forward sweeps are the producers of everything the items wait for
+            if (forwardRole) __builtin_amdgcn_s_setprio(CPK_FUSED_PRIO);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         const int r = traceRole ? a.items[ti].region : a.regionBase + tk;
         const int itemSeg = traceRole ? a.items[ti].seg : 0;
 
@@ -1166,7 +1201,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 double *o0 = sw.ringAt(g0);
                 if (lane < S) {
                     cur[lane] = startPrior[lane];
-                    sw.ringSt(o0 + lane, startPrior[lane]);
+                    sw.ringSt(o0 + sw.ringIdx(1, lane, 0), startPrior[lane]);
                 }
                 roll_fence<!FAST>();
                 sw.f1 = g0;
@@ -1199,6 +1234,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                         // fence is the wait, nothing else at workgroup scope -- they are where every XCD reads them, and the
                         // count goes out.  (An agent-scope release here writes back the XCD's whole L2: measured, 10 % slower.)
                         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every ring store of this wave is acknowledged
                         if (lane == 0) __hip_atomic_store(a.progress + r, si + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     continue;

@@ -37,7 +37,10 @@ __global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *r
             while (d > covTop && covSeg + 1 < rg.nSeg) covTop = sg[++covSeg].dTop;
             const bool all = d == 0 || (emitFrom - (int)d) % CPK_REFRESH_PERIOD == 0 || d >= covTop - 1;
             e.ringOff = pos;
-            pos += all ? w * S : w;
+            // every diagonal starts on an even double and its match row is padded to one: the one-launch form stores
+            // pairs of match cells, and a cell's other states, as aligned 16-byte writes (Sweep::ringPut)
+            const int32_t we = (w + 1) & ~1;
+            pos += all ? we + w * (S - 1) : we;
         } else {
             if (pos + w > rg.ringCap) pos = 0;
             e.ringOff = pos;
