@@ -1110,12 +1110,6 @@ cpecan_pairhmm_sweep(const KArgs a) {
         const bool traceRole = MODE == kModeTrace || (MODE == kModeFused && tk >= a.regionCount);  // wave-uniform
         const bool forwardRole = MODE == kModeForward || (MODE == kModeFused && !traceRole);
         const int ti = MODE == kModeFused ? tk - a.regionCount : tk;
-#ifdef CPK_FUSED_PRIO
-        if (MODE == kModeFused) {  // the forward sweeps are the producers of everything the items wait for
-            if (forwardRole) __builtin_amdgcn_s_setprio(CPK_FUSED_PRIO);
-            else __builtin_amdgcn_s_setprio(0);
-        }
-#endif
         const int r = traceRole ? a.items[ti].region : a.regionBase + tk;
         const int itemSeg = traceRole ? a.items[ti].seg : 0;
 
