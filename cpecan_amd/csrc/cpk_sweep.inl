@@ -102,8 +102,9 @@ struct Sweep {
         }
         typedef unsigned u4 __attribute__((ext_vector_type(4)));
         const unsigned lo = (unsigned)__double_as_longlong(v[0]), hi = (unsigned)((unsigned long long)__double_as_longlong(v[0]) >> 32);
-        const unsigned loN = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x130, 0xf, 0xf, false);  // wave_shl:1: lane i <- lane i + 1
-        const unsigned hiN = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x130, 0xf, 0xf, false);
+        // wave_shl:1: lane i <- lane i + 1 (0 where that lane is off or does not exist: bound_ctrl)
+        const unsigned loN = (unsigned)__builtin_amdgcn_update_dpp(0, (int)lo, 0x130, 0xf, 0xf, true);
+        const unsigned hiN = (unsigned)__builtin_amdgcn_update_dpp(0, (int)hi, 0x130, 0xf, 0xf, true);
         if (rs <= 0) return;
         const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)ring, 0, 0x7fffffff, 0x00020000);  // the region's ring: < 2 GiB (cpk_device_upload)
         const bool even = (k & 1) == 0;
@@ -111,7 +112,8 @@ struct Sweep {
         if (even && next) {
             __builtin_amdgcn_raw_buffer_store_b128(u4{lo, hi, loN, hiN}, rsrc, (int)at, 0, 16);  // aux 16 = sc1
         } else if (even || !prev) {
-            ringSt(out + k, v[0]);
+            typedef unsigned u2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(u2{lo, hi}, rsrc, (int)at, 0, 16);
         }
         if (rs > 1) {
             const unsigned at2 = (unsigned)((out - ring) + ringIdx(W, 1, k)) * 8u;
