@@ -901,6 +901,41 @@ def test_cell_values_and_totals_match_oracle(case):
     assert np.all(np.abs(tot[mt] - otot[mt]) <= LOG_TOL * np.maximum(1.0, np.abs(otot[mt]))), float(np.max(np.abs(tot[mt] - otot[mt])))
 
 
+def test_one_launch_form_keeps_spare_slots_only_beside_a_live_batch(monkeypatch):
+    """The one-launch form of a split class fills every wave slot of the chip when the batch has the device to itself and
+    leaves one slot in every eighth CU free when another batch of the process has run there and is still alive (its list
+    gather and the next batch's table build need somewhere to run: DESIGN.md section 5).  Same lists either way."""
+    import torch
+    monkeypatch.delenv("CPECAN_SPLIT", raising=False)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    probs = [make_pair(4, i, 2000, 100) for i in range(420)]  # regions + segments > wave slots
+    sm = api.stateMachine5_construct()
+    p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=100)
+    arr, cnt, keep = api.Batch.prepare_problems(probs)
+
+    def one():
+        b = api.Batch(sm, p)
+        b.add_prepared(arr, cnt)
+        b.upload()
+        b.run()
+        b.download()
+        return b
+
+    alone = one()
+    beside = one()                       # planned while `alone` is alive
+    w_alone, w_beside = alone.stats().wavesPerLaunch, beside.stats().wavesPerLaunch
+    lists_alone = [alone.result(i) for i in range(cnt)]
+    lists_beside = [beside.result(i) for i in range(cnt)]
+    alone.close()
+    beside.close()
+    again = one()                        # nothing alive any more
+    w_again = again.stats().wavesPerLaunch
+    again.close()
+    assert w_alone == w_again and w_alone - w_beside == cus // 8, (w_alone, w_beside, w_again, cus)
+    for x, y in zip(lists_alone, lists_beside):
+        assert np.array_equal(x, y)
+
+
 # ---- batches as a pipeline: every batch on streams and events of its own (SURVEY 8d's host-to-host clock) ----
 def test_pipelined_batches_equal_unpipelined_ones():
     """Two batches in flight from one host thread -- batch k+1 is packed, planned and uploaded and batch k-1 is gathered and
