@@ -905,8 +905,10 @@ def test_one_launch_form_keeps_spare_slots_only_beside_a_live_batch(monkeypatch)
     """The one-launch form of a split class fills every wave slot of the chip when the batch has the device to itself and
     leaves one slot in every eighth CU free when another batch of the process has run there and is still alive (its list
     gather and the next batch's table build need somewhere to run: DESIGN.md section 5).  Same lists either way."""
+    import gc
     import torch
     monkeypatch.delenv("CPECAN_SPLIT", raising=False)
+    gc.collect()  # batches that earlier tests left to the collector count as alive until they are destroyed
     cus = torch.cuda.get_device_properties(0).multi_processor_count
     probs = [make_pair(4, i, 2000, 100) for i in range(420)]  # regions + segments > wave slots
     sm = api.stateMachine5_construct()
