@@ -148,7 +148,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="override the config's number of pairs (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host to host) measurements")
-    ap.add_argument("--e2e-batches", type=int, default=9, help="batches pushed through the pipeline (odd: the steady state is read over an even number of batch intervals)")
+    ap.add_argument("--e2e-batches", type=int, default=0, help="batches pushed through the pipeline (odd: the steady state is read over an even number of batch intervals); 0: nine, or as many as make the section last ~0.5 s (short batches: one hiccup of a few ms must not decide the figure)")
     ap.add_argument("--e2e-depth", type=int, default=0, help="batches in flight in the end-to-end pipeline; 0: two, or three where the host's packing and planning takes at least half as long as sweep + download and three batches fit in half the device memory")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend: nccl is RCCL; gloo only for the CPU dry run of the launcher (tests)")
@@ -338,7 +338,10 @@ def main():
         # download runs on the helper thread the library gives every batch).  Two in flight are enough where the sweep is
         # the longest stage (config B); where the host's packing and planning is (config 4), the latency of one batch --
         # upload tail + sweep + gather + fetch -- exceeds the host's interval and a third batch in flight hides it.
-        nb = max(3, args.e2e_batches)
+        nb = args.e2e_batches
+        if nb <= 0:
+            nb = max(9, min(201, int(0.5 / max(e2e["serial_s_per_batch"], 1e-4)))) | 1
+        nb = max(3, nb)
         depth = args.e2e_depth
         if depth < 2:
             total_mem = torch.cuda.get_device_properties(local_rank).total_memory
