@@ -897,7 +897,11 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             // two launches win.  The rings of whole regions are given up first when device memory is short (below).
             const bool manySegs = nSegClass * 4 >= n * 5;
             const bool wanted = env ? atoi(env) != 0 : manySegs;
-            const bool oneLaunch = nSegClass * 2 >= n * 7;  // 3.5 segments per region and more
+            // ... and up to ~4.5 rounds of forward sweeps: beyond, every region ticket is drawn before the first item anyway,
+            // the overlap is down to the seam between the two phases, and the launches' plain ring stores win against
+            // the one launch's write-through ones (2 kb pairs, band 100: 5000 / 6500 / 8000 pairs -8 / -8 / -2 % for the one
+            // launch, 10 000 pairs -- config B -- +1.7 %: 89.3 against 87.6 ms, and 90.2 against 87.3 ms per pipelined batch)
+            const bool oneLaunch = nSegClass * 2 >= n * 7 /* 3.5 segments per region and more */ && n * 2 < slots * 9;
             if (eligible && wanted) {
                 c.split = true;
                 // CPECAN_SPLIT=2 / 1: force the one-launch (kModeFused) / two-launch form
