@@ -92,7 +92,7 @@ EXPORTS = [
     "cpecan_mea_alignment", "cpecan_left_shift_alignment", "cpecan_get_shifted_mea_alignment",
     "cpecan_anchors_from_alignment", "cpecan_batch_set_match_gamma", "cpecan_batch_identity_scores",
     "cpecan_identity_scores", "cpecan_filter_pairs_ordered", "cpecan_batch_add_many",
-    "cpecan_filter_to_remove_overlap",
+    "cpecan_filter_to_remove_overlap", "cpecan_cache_trim",
 ]
 OP_MATCH, OP_INDEL_X, OP_INDEL_Y = 0, 1, 2
 POST_REWEIGHT, POST_MEA, POST_LEFT_SHIFT, POST_ORDERED = 1, 2, 4, 8
@@ -122,6 +122,8 @@ def lib():
     L.cpecan_split_points.restype = C.c_int64
     L.cpecan_split_points.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int, C.c_int, i64p]
     L.cpecan_device_count.restype = C.c_int
+    L.cpecan_cache_trim.restype = C.c_int64
+    L.cpecan_cache_trim.argtypes = [C.c_int]
     L.cpecan_last_error.restype = C.c_char_p
     L.cpecan_batch_create.argtypes = [C.POINTER(vp), C.POINTER(StateMachine), C.POINTER(PairwiseAlignmentParameters),
                                       C.c_int, C.c_int]
@@ -271,6 +273,11 @@ def getSplitPoints(anchorPairs, lX, lY, maxMatrixSize, raggedLeft, raggedRight):
 
 def device_count():
     return lib().cpecan_device_count()
+
+
+def cache_trim(device=-1):
+    """Idle device blocks of `device` (-1: every device) and idle host blocks go back to the driver; bytes released."""
+    return int(lib().cpecan_cache_trim(device))
 
 
 class Batch:

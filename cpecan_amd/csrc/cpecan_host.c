@@ -529,6 +529,7 @@ int64_t cpecan_filter_to_remove_overlap(const int64_t *pairs, int64_t n, int64_t
 
 int cpecan_device_count(void) { return cpk_device_count(); }
 int cpecan_current_device(void) { return cpk_current_device(); }
+int64_t cpecan_cache_trim(int device) { return cpk_cache_trim(device); }
 const char *cpecan_last_error(void) { return cpk_last_error(); }
 
 int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpecan_params *params, int emit,
@@ -590,7 +591,16 @@ void cpecan_batch_destroy(cpecan_batch *b) {
     free(b);
 }
 
+/* A download running on the helper thread (cpecan_batch_download_begin) rewrites the batch's result arrays, segment
+ * table and device order: until cpecan_batch_download_end every other entry point refuses the batch. */
+static int dl_busy(const cpecan_batch *b) {
+    if (!b || !b->dlActive || pthread_equal(pthread_self(), b->dlThread)) return 0;
+    cpk_set_error("the batch is being downloaded on its helper thread: call cpecan_batch_download_end first");
+    return 1;
+}
+
 int cpecan_batch_set_debug(cpecan_batch *b, int on) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || b->frozen) return CPECAN_ESTATE;
     b->debug = on != 0;
     return CPECAN_OK;
@@ -663,6 +673,7 @@ static int problem_valid(const cpecan_problem *it) {
 }
 
 int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *items, int64_t n) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || b->frozen) return CPECAN_ESTATE;
     if (n < 0 || (n > 0 && !items)) return CPECAN_EINVAL;
     if (n == 0) return b->nProblems;
@@ -797,6 +808,7 @@ int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *items, int6
 
 int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char *sY, int64_t lY,
                          const int64_t *anchors, int64_t nAnchors, int raggedLeft, int raggedRight) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     const cpecan_problem it = {sX, lX, sY, lY, anchors, nAnchors, raggedLeft ? 1 : 0, raggedRight ? 1 : 0};
     return cpecan_batch_add_many(b, &it, 1);
 }
@@ -838,6 +850,7 @@ int cpk_host_threads(void) {
 }
 
 int cpecan_batch_upload(cpecan_batch *b) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || b->frozen) return CPECAN_ESTATE;
     if (b->nRegions == 0) {
         if (cpk_device_count() < 1) {
@@ -1066,7 +1079,15 @@ int cpecan_batch_upload(cpecan_batch *b) {
                 sg[si].outCap = (int32_t)cap;
                 at += cap;
             }
-            if (at > g->outCap) g->outCap = (int32_t)imin(at, ((int64_t)1 << 31) - 1);
+            if (at > ((int64_t)1 << 31) - 1) {
+                /* segment offsets and the region's slice are 32-bit: threshold <= 0 on a region of more than 2^31 cells x
+                 * segments cannot be laid out (the reference would return a list of that many tuples) */
+                cpk_set_error("a region's output slice exceeds 2^31 triples (%lld): raise the threshold or split the region",
+                              (long long)at);
+                rc = CPECAN_EINVAL;
+                goto fail2;
+            }
+            if (at > g->outCap) g->outCap = (int32_t)at;
         }
         g->outOff = outAt;
         outAt += g->outCap;
@@ -1156,6 +1177,7 @@ fail1:
 }
 
 int cpecan_batch_run(cpecan_batch *b, void *stream) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || !b->frozen) return CPECAN_ESTATE;
     b->downloaded = 0;
     if (b->nRegions == 0) {
@@ -1301,6 +1323,7 @@ static int run_post(cpecan_batch *b) {
 }
 
 int cpecan_batch_set_post(cpecan_batch *b, int flags, double gapGamma) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b) return CPECAN_EINVAL;
     if (flags & ~(CPECAN_POST_REWEIGHT | CPECAN_POST_MEA | CPECAN_POST_LEFT_SHIFT | CPECAN_POST_ORDERED)) return CPECAN_EINVAL;
     if ((flags & CPECAN_POST_LEFT_SHIFT) && !(flags & CPECAN_POST_MEA)) return CPECAN_EINVAL;
@@ -1317,12 +1340,14 @@ int cpecan_batch_set_post(cpecan_batch *b, int flags, double gapGamma) {
 }
 
 int cpecan_batch_set_match_gamma(cpecan_batch *b, float matchGamma) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || !(matchGamma >= 0.0f)) return CPECAN_EINVAL;
     b->postMatchGamma = matchGamma;
     return CPECAN_OK;
 }
 
 int cpecan_batch_identity_scores(const cpecan_batch *b, int64_t problem, double *byIdentity, double *byIdentityIgnoringGaps) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || !b->downloaded) return CPECAN_ESTATE;
     if (problem < 0 || problem >= b->nProblems || b->emit == CPECAN_EMIT_FORWARD || b->emit == CPECAN_EMIT_EXPECT)
         return CPECAN_EINVAL;
@@ -1337,6 +1362,7 @@ int cpecan_batch_identity_scores(const cpecan_batch *b, int64_t problem, double 
 
 int cpecan_batch_scores(const cpecan_batch *b, int64_t problem, double *byPosterior, double *byPosteriorIgnoringGaps,
                         double *meaScore) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || !b->downloaded) return CPECAN_ESTATE;
     if (problem < 0 || problem >= b->nProblems || b->emit == CPECAN_EMIT_FORWARD || b->emit == CPECAN_EMIT_EXPECT)
         return CPECAN_EINVAL;
@@ -1347,6 +1373,7 @@ int cpecan_batch_scores(const cpecan_batch *b, int64_t problem, double *byPoster
 }
 
 int cpecan_batch_download(cpecan_batch *b) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || !b->ran) return CPECAN_ESTATE;
     free_results(b);
     b->stats.pairs = 0;
@@ -1488,6 +1515,7 @@ int cpecan_batch_download_end(cpecan_batch *b) {
 }
 
 int cpecan_batch_result(const cpecan_batch *b, int64_t problem, int which, const int32_t **triples, int64_t *n) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || !b->downloaded) return CPECAN_ESTATE;
     if (problem < 0 || problem >= b->nProblems || which < 0) return CPECAN_EINVAL;
     if (which >= b->nLists && !(which == 3 && (b->postFlags & (CPECAN_POST_MEA | CPECAN_POST_ORDERED)))) return CPECAN_EINVAL;
@@ -1497,6 +1525,7 @@ int cpecan_batch_result(const cpecan_batch *b, int64_t problem, int which, const
 }
 
 int cpecan_batch_forward_prob(const cpecan_batch *b, int64_t problem, double *logProb) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || !b->downloaded || b->emit != CPECAN_EMIT_FORWARD) return CPECAN_ESTATE;
     if (problem < 0 || problem >= b->nProblems || !logProb) return CPECAN_EINVAL;
     *logProb = b->forward[b->regions[b->problems[problem].firstRegion].devIndex];
@@ -1504,6 +1533,7 @@ int cpecan_batch_forward_prob(const cpecan_batch *b, int64_t problem, double *lo
 }
 
 int cpecan_batch_expectations(const cpecan_batch *b, cpecan_hmm *acc) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || !b->downloaded || b->emit != CPECAN_EMIT_EXPECT) return CPECAN_ESTATE;
     const int S = is_five(b->model.type) ? 5 : 3;
     if (!acc || acc->stateNumber != S) return CPECAN_EINVAL;
@@ -1516,6 +1546,7 @@ int cpecan_batch_expectations(const cpecan_batch *b, cpecan_hmm *acc) {
 }
 
 int cpecan_batch_stats(const cpecan_batch *b, cpecan_stats *s) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || !s) return CPECAN_EINVAL;
     *s = b->stats;
     return CPECAN_OK;
@@ -1523,6 +1554,7 @@ int cpecan_batch_stats(const cpecan_batch *b, cpecan_stats *s) {
 
 int cpecan_batch_debug_fetch(const cpecan_batch *b, int64_t problem, double *fbMatch, int64_t cells, double *totalUsed,
                              int64_t diagonals) {
+    if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || !b->downloaded || !b->debug) return CPECAN_ESTATE;
     if (problem < 0 || problem >= b->nProblems || b->problems[problem].nRegions != 1) return CPECAN_EINVAL;
     const HostRegion *r = &b->regions[b->problems[problem].firstRegion];

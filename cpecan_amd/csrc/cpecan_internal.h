@@ -133,6 +133,7 @@ void *cpk_host_alloc(size_t bytes);
 void cpk_host_free(void *p);
 void *cpk_host_grow(void *p, size_t usedBytes, size_t newBytes); /* NULL on failure: p is still valid then */
 int cpk_device_count(void);
+int64_t cpk_cache_trim(int device); /* idle device blocks of `device` (-1: all) and idle host blocks -> driver / OS; bytes */
 int cpk_current_device(void); /* the calling thread's current HIP device (0 when there is none) */
 const char *cpk_last_error(void);
 int cpk_device_create(CpkDevice **out, int device);

@@ -131,15 +131,42 @@ struct BlockCache {
 constexpr int kMaxDevices = 64;
 constexpr size_t kCacheMaxBlock = (size_t)256 << 30;  // the rings of a batch's split regions are ONE block (60 GB at config B)
 constexpr int kCacheMaxBlocks = 512;
-size_t cache_max_bytes() {
-    static const size_t v = [] {
+// What the idle blocks of one device may hold: CPECAN_CACHE_MB, default HALF of the device's memory (the process may
+// share the GPU with torch / RCCL allocations that cannot reclaim what this library hoards; cpecan_cache_trim gives
+// everything back on request, and the last batch to leave a device drops its large blocks, cpk_device_destroy).
+// The current device is `device`.
+size_t cache_max_bytes(int device) {
+    static const double envMb = [] {
         const char *mb = getenv("CPECAN_CACHE_MB");
-        return mb ? (size_t)(atof(mb) * 1048576.0) : ((size_t)256 << 30);
+        return mb ? atof(mb) : -1.0;
+    }();
+    if (envMb >= 0.0) return (size_t)(envMb * 1048576.0);
+    static std::atomic<size_t> half[kMaxDevices];
+    if (device < 0 || device >= kMaxDevices) return (size_t)16 << 30;
+    size_t v = half[device].load(std::memory_order_relaxed);
+    if (v == 0) {
+        size_t freeB = 0, totalB = 0;
+        if (hipMemGetInfo(&freeB, &totalB) != hipSuccess) {
+            (void)hipGetLastError();
+            totalB = (size_t)32 << 30;
+        }
+        v = totalB / 2 + 1;
+        half[device].store(v, std::memory_order_relaxed);
+    }
+    return v;
+}
+// idle blocks above this size go back to the driver when the last live batch of a device is destroyed
+// (CPECAN_CACHE_KEEP_MB, default 256; negative: keep everything, as rounds 1-2 did)
+double cache_keep_mb() {
+    static const double v = [] {
+        const char *mb = getenv("CPECAN_CACHE_KEEP_MB");
+        return mb ? atof(mb) : 256.0;
     }();
     return v;
 }
 std::mutex g_cacheMutex;
 BlockCache g_blockCache[kMaxDevices];
+std::atomic<int> g_liveShells[kMaxDevices];  // batches (device shells) created and not destroyed yet, per device
 // batches of this process that have run on a device and are not destroyed yet: the consumers of such a batch (list
 // gather, reweight, MEA, ...) may still have to run beside the sweep of the batch that is being planned
 static std::atomic<int> g_ranAlive[kMaxDevices];
@@ -196,13 +223,40 @@ void cache_free(int device, void *ptr, size_t bytes) {
     if (device >= 0 && device < kMaxDevices && bytes <= kCacheMaxBlock) {
         std::lock_guard<std::mutex> lock(g_cacheMutex);
         BlockCache &c = g_blockCache[device];
-        if (c.bytes + bytes <= cache_max_bytes() && (int)c.blocks.size() < kCacheMaxBlocks) {
+        if (c.bytes + bytes <= cache_max_bytes(device) && (int)c.blocks.size() < kCacheMaxBlocks) {
             c.blocks.push_back({ptr, bytes});
             c.bytes += bytes;
             return;
         }
     }
     (void)hipFree(ptr);
+}
+
+// Gives the idle blocks of `device` that are larger than keepBelow bytes back to the driver (hipFree waits for the
+// device).  The current device is `device`.  Returns the bytes freed.
+size_t cache_trim(int device, size_t keepBelow) {
+    if (device < 0 || device >= kMaxDevices) return 0;
+    std::vector<CachedBlock> drop;
+    {
+        std::lock_guard<std::mutex> lock(g_cacheMutex);
+        BlockCache &c = g_blockCache[device];
+        for (size_t i = 0; i < c.blocks.size();) {
+            if (c.blocks[i].bytes > keepBelow) {
+                drop.push_back(c.blocks[i]);
+                c.bytes -= c.blocks[i].bytes;
+                c.blocks[i] = c.blocks.back();
+                c.blocks.pop_back();
+            } else {
+                i++;
+            }
+        }
+    }
+    size_t freed = 0;
+    for (const CachedBlock &b : drop) {
+        (void)hipFree(b.ptr);
+        freed += b.bytes;
+    }
+    return freed;
 }
 }  // namespace
 
@@ -275,7 +329,11 @@ static void *host_alloc_impl(size_t bytes, bool mustPin) {
         int best = -1;
         for (int i = 0; i < (int)g_hostIdle.size(); i++)
             if (g_hostIdle[i].bytes >= bytes && g_hostIdle[i].bytes <= 2 * bytes + ((size_t)8 << 20) &&
-                (g_hostIdle[i].pinned || !mustPin) && (best < 0 || g_hostIdle[i].bytes < g_hostIdle[best].bytes))
+                // kernels store through the HOST pointer of a mustPin block: only hipHostMalloc'ed memory is guaranteed to
+                // map at the same device address; a range pinned later by hipHostRegister is not (no hipHostGetDevicePointer
+                // is ever asked for), so such blocks never serve a mustPin request
+                ((g_hostIdle[i].pinned && !g_hostIdle[i].registered) || !mustPin) &&
+                (best < 0 || g_hostIdle[i].bytes < g_hostIdle[best].bytes))
                 best = i;
         if (best >= 0) {
             HostBlock b = g_hostIdle[best];
@@ -325,6 +383,22 @@ extern "C" void cpk_host_free(void *p) {
     }
     if (b.ptr) host_release(b);
     else free(p);  // a small block
+}
+
+// Releases every idle host block (pinned ones included).  Returns the bytes released.
+static size_t host_trim(void) {
+    std::vector<HostBlock> drop;
+    {
+        std::lock_guard<std::mutex> lock(g_hostMutex);
+        drop.swap(g_hostIdle);
+        g_hostIdleBytes = 0;
+    }
+    size_t freed = 0;
+    for (const HostBlock &b : drop) {
+        host_release(b);
+        freed += b.bytes;
+    }
+    return freed;
 }
 
 // Grows a block to newBytes keeping its first usedBytes.  A block that is not pinned grows in place where the C library
@@ -509,6 +583,7 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
         if (!g_shells[device].empty()) {
             *out = g_shells[device].back();
             g_shells[device].pop_back();
+            g_liveShells[device]++;
             return CPECAN_OK;
         }
     }
@@ -517,8 +592,24 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
         shell_delete(d);  // whatever was created before the failure
         return rc;
     }
+    if (device < kMaxDevices) g_liveShells[device]++;
     *out = d;
     return CPECAN_OK;
+}
+
+// Idle device blocks of `device` (-1: every device) and idle host blocks go back to the driver / the OS.  For a process
+// that shares the GPU with another allocator (torch, RCCL): call it when a phase of alignment work is over.
+extern "C" int64_t cpk_cache_trim(int device) {
+    int64_t freed = 0;
+    const int n = cpk_device_count();
+    for (int dev = 0; dev < n && dev < kMaxDevices; dev++) {
+        if (device >= 0 && dev != device) continue;
+        DeviceGuard guard(dev);
+        if (guard.err != hipSuccess) continue;
+        freed += (int64_t)cache_trim(dev, 0);
+    }
+    freed += (int64_t)host_trim();
+    return freed;
 }
 
 // Waits for everything this batch has in flight: its sweep launches (the stop event on the caller's stream) and its own
@@ -561,6 +652,12 @@ extern "C" void cpk_device_destroy(CpkDevice *d) {
     if (!d) return;
     DeviceGuard guard(d->device);
     free_all(d);
+    if (d->device >= 0 && d->device < kMaxDevices) {
+        // the last batch to leave a device takes its large idle blocks with it (a config-B batch's rings are ONE block
+        // of 60 GB): what stays cached is what makes a loop of small calls cheap, not what starves torch or RCCL
+        const bool last = --g_liveShells[d->device] <= 0;
+        if (last && cache_keep_mb() >= 0.0) (void)cache_trim(d->device, (size_t)(cache_keep_mb() * 1048576.0));
+    }
     if (d->device < kMaxDevices) {  // keep the shell (streams, events) for the next batch on this device
         d->classes.clear();
         ran_set(d, false);

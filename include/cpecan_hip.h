@@ -140,6 +140,12 @@ int cpecan_device_count(void);
  * caller's CURRENT device, so in a one-process-per-GPU job they follow hipSetDevice / torch.cuda.set_device. */
 int cpecan_current_device(void);
 const char *cpecan_last_error(void);
+/* Device and pinned-host blocks of destroyed batches are recycled, not freed (hipFree waits for the whole device): up to
+ * CPECAN_CACHE_MB of idle device blocks per device (default: half of the device's memory) and CPECAN_HOST_CACHE_MB of
+ * idle host blocks (default 16 GiB).  The last live batch to leave a device already gives back every idle block above
+ * CPECAN_CACHE_KEEP_MB (default 256); this call gives back ALL idle blocks of `device` (-1: every device) and all idle
+ * host blocks, for a process that shares the GPU with another allocator (torch, RCCL).  Returns the bytes released. */
+int64_t cpecan_cache_trim(int device);
 
 /* ---- batch API ---- */
 /* Creates an empty batch bound to HIP device `device`. `emit` selects the emitter for every problem. */

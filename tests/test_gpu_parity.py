@@ -994,6 +994,11 @@ def test_pipelined_batches_equal_unpipelined_ones():
     prev.download_begin()
     with pytest.raises(api.CpecanError):
         prev.download_begin()  # one download at a time per batch
+    # while the helper thread rewrites the batch, every other entry point refuses it (CPECAN_ESTATE) instead
+    # of racing with it
+    for refused in (prev.download, lambda: prev.result(0), prev.run, prev.stats):
+        with pytest.raises(api.CpecanError):
+            refused()
     for k in range(1, len(jobs)):
         cur = start(k)
         cur.download_begin()
@@ -1005,6 +1010,19 @@ def test_pipelined_batches_equal_unpipelined_ones():
             assert g is not None and len(g) == len(w), (name, k)
             for i, (a, b) in enumerate(zip(g, w)):
                 assert np.array_equal(a, b), (name, "job", k, "problem", i, len(a), len(b))
+
+
+def test_cache_trim_gives_idle_blocks_back():
+    """idle device / host blocks of destroyed batches can be returned to the driver (cpecan_cache_trim), and
+    the library keeps working afterwards."""
+    sx, sy, a = make_pair(3, 0, 600, 20)
+    p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=20)
+    first = api.getAlignedPairsUsingAnchors(api.stateMachine5_construct(), sx, sy, a, p)
+    freed = api.cache_trim(0)
+    assert freed > 0  # the batch of the call above left its blocks in the cache
+    assert api.cache_trim(-1) == 0  # nothing idle is left
+    again = api.getAlignedPairsUsingAnchors(api.stateMachine5_construct(), sx, sy, a, p)
+    assert np.array_equal(first, again)
 
 
 def test_entry_points_leave_the_callers_current_device_alone():
