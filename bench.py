@@ -137,6 +137,26 @@ def cpu_model_name():
     return "unknown"
 
 
+def other_configs(names):
+    """Short passes of the other BASELINE configs, one child process each (this process keeps the GPU context; the
+    children are started, not exec'ed).  Per config: kernel-only cells/s, ms per step, roofline fraction, end-to-end cells/s."""
+    res = {}
+    for name in names:
+        t0 = time.perf_counter()
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "3", "--warmup", "1",
+               "--no-cpu-baseline", "--e2e-batches", "5", "--no-other-configs"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
+            d = json.loads(line)
+            res[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
+                         "frac": d["roofline"]["frac"], "value_e2e": d["value_e2e"],
+                         "workload": d["config"]["workload"], "wall_s": time.perf_counter() - t0}
+        except Exception as e:  # noqa: BLE001 -- a failed side pass must not lose the headline line
+            res[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,6 +168,8 @@ def main():
     ap.add_argument("--pairs", type=int, default=0, help="override the config's number of pairs (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host to host) measurements")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="the default run (config B, one GPU) appends short passes of configs A, 4 and 5 as `other_configs`; skip them")
     ap.add_argument("--e2e-batches", type=int, default=0, help="batches pushed through the pipeline (odd: the steady state is read over an even number of batch intervals); 0: nine, or as many as make the section last ~0.5 s (short batches: one hiccup of a few ms must not decide the figure)")
     ap.add_argument("--e2e-depth", type=int, default=0, help="batches in flight in the end-to-end pipeline; 0: two, or three where the host's packing and planning takes at least half as long as sweep + download and three batches fit in half the device memory")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -489,6 +511,14 @@ def main():
                     assert abs(acc.emissions[i] - oacc.E[i]) <= 1e-5 * abs(oacc.E[i]) + 1e-9, ("E", i)
                 assert abs(acc.likelihood - oacc.likelihood) <= 1e-9 * abs(oacc.likelihood)
                 out["parity_spot_check"] = "expectation counts of %d problems match the oracle to 1e-5" % nchk
+        if (args.config == "B" and world == 1 and not args.pairs and not args.no_other_configs and not args.no_e2e):
+            # the driver's default run sees the other BASELINE configs too -- short passes (3 steps, a
+            # five-batch pipeline) as child processes once this process has given its device memory back
+            if batch is not None:
+                batch.close()
+                batch = None
+            api.cache_trim(-1)
+            out["other_configs"] = other_configs(("A", "4", "5"))
         print(json.dumps(out), flush=True)
     if batch is not None:
         batch.close()
