@@ -34,7 +34,7 @@ for _p in (ROOT, os.path.join(ROOT, "tests")):
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 KERNEL_SOURCES = ["cpecan_kernels.hip", "cpk_device_common.inl", "cpk_sweep.inl", "cpk_team.inl", "cpk_packed.inl",
-                  "cpk_table_gather.inl", "cpk_post.inl", "cpecan_band.inl", "cpecan_internal.h"]
+                  "cpk_table_gather.inl", "cpk_post.inl", "cpk_cells.inl", "cpecan_band.inl", "cpecan_internal.h"]
 
 
 def kernel_source_hash():

@@ -3,6 +3,7 @@
  * Host-side glue only: list <-> array conversion, struct flattening, error mapping (st_errAbort semantics:
  * print and abort, as impl/pairwiseAligner.c:1044 and impl/stateMachine.c:36 do).
  */
+#include <ctype.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdlib.h>
@@ -816,27 +817,285 @@ Hmm *hmm_jsonParse(char *buf, size_t r) {
     return hmm;
 }
 
-/* The reference's per-diagonal emitters (impl/pairwiseAligner.c:666-689, :691-733, :735-746).  They read DpMatrix rows,
- * which this library never materialises on the host (the diagonals live in LDS): here they are the TOKENS by which a
- * caller of getPosteriorProbsWithBanding names the emitter -- recognised by address and routed to the device emitters.
- * Calling one directly aborts. */
+/* ---------------- DpDiagonal / DpMatrix / cell_* / diagonalCalculation* (inc/pairwiseAligner.h:186-237) ----------------
+ * The containers the reference's unit tests link (tests/pairwiseAlignerTest.c:155-324), with the reference's semantics
+ * (impl/pairwiseAligner.c:448-586).  They are host memory; every piece of DP arithmetic on them -- a cell's transition
+ * list, a diagonal's sweep, the posterior's exp -- is evaluated on the GPU through cpecan_ref_cells (one lane, the
+ * reference's order of operations): the library holds no CPU implementation of the recurrences.  The fold of a dot
+ * product is logAdd, which the reference itself exports as a host utility (:287-307) and so does this layer. */
+struct _dpDiagonal {
+    Diagonal diagonal;
+    int64_t stateNumber;
+    double *cells;
+};
+struct _dpMatrix {
+    DpDiagonal **diagonals;
+    int64_t diagonalNumber;
+    int64_t activeDiagonals;
+    int64_t stateNumber;
+};
+
+char *diagonal_getString(Diagonal diagonal) { /* impl/pairwiseAligner.c:75-78; the caller frees */
+    char *out = malloc(128);
+    if (!out) die("cpecan_hip: out of memory");
+    snprintf(out, 128, "Diagonal, xay: %lld xmyL %lld, xmyR: %lld", (long long)diagonal.xay, (long long)diagonal.xmyL,
+             (long long)diagonal.xmyR);
+    return out;
+}
+
+DpDiagonal *dpDiagonal_construct(Diagonal diagonal, int64_t stateNumber) { /* :454-461 */
+    DpDiagonal *d = malloc(sizeof *d);
+    const int64_t w = diagonal_getWidth(diagonal);
+    if (!d || w < 0) die("cpecan_hip: dpDiagonal_construct: out of memory or negative width");
+    d->diagonal = diagonal;
+    d->stateNumber = stateNumber;
+    d->cells = malloc(sizeof(double) * (size_t)(stateNumber * w > 0 ? stateNumber * w : 1));
+    if (!d->cells) die("cpecan_hip: out of memory");
+    return d;
+}
+DpDiagonal *dpDiagonal_clone(DpDiagonal *diagonal) {
+    DpDiagonal *c2 = dpDiagonal_construct(diagonal->diagonal, diagonal->stateNumber);
+    memcpy(c2->cells, diagonal->cells, sizeof(double) * (size_t)(diagonal_getWidth(diagonal->diagonal) * diagonal->stateNumber));
+    return c2;
+}
+bool dpDiagonal_equals(DpDiagonal *d1, DpDiagonal *d2) { /* :469-482 */
+    if (!diagonal_equals(d1->diagonal, d2->diagonal) || d1->stateNumber != d2->stateNumber) return 0;
+    for (int64_t i = 0; i < diagonal_getWidth(d1->diagonal) * d1->stateNumber; i++)
+        if (d1->cells[i] != d2->cells[i]) return 0;
+    return 1;
+}
+void dpDiagonal_destruct(DpDiagonal *dpDiagonal) {
+    free(dpDiagonal->cells);
+    free(dpDiagonal);
+}
+double *dpDiagonal_getCell(DpDiagonal *dpDiagonal, int64_t xmy) { /* NULL outside the band: how band edges reach the cell functions, :489-495 */
+    if (xmy < dpDiagonal->diagonal.xmyL || xmy > dpDiagonal->diagonal.xmyR) return NULL;
+    return &dpDiagonal->cells[((xmy - dpDiagonal->diagonal.xmyL) / 2) * dpDiagonal->stateNumber];
+}
+void dpDiagonal_zeroValues(DpDiagonal *diagonal) {
+    for (int64_t i = 0; i < diagonal_getWidth(diagonal->diagonal) * diagonal->stateNumber; i++) diagonal->cells[i] = LOG_ZERO;
+}
+void dpDiagonal_initialiseValues(DpDiagonal *diagonal, StateMachine *sM, double (*getStateValue)(StateMachine *, int64_t)) {
+    for (int64_t i = diagonal->diagonal.xmyL; i <= diagonal->diagonal.xmyR; i += 2) {
+        double *cell = dpDiagonal_getCell(diagonal, i);
+        for (int64_t j = 0; j < diagonal->stateNumber; j++) cell[j] = getStateValue(sM, j);
+    }
+}
+double cell_dotProduct(double *cell1, double *cell2, int64_t stateNumber) { /* :402-408 */
+    double totalProb = cell1[0] + cell2[0];
+    for (int64_t i = 1; i < stateNumber; i++) totalProb = logAdd(totalProb, cell1[i] + cell2[i]);
+    return totalProb;
+}
+double cell_dotProduct2(double *cell, StateMachine *sM, double (*getStateValue)(StateMachine *, int64_t)) { /* :410-416 */
+    double totalProb = cell[0] + getStateValue(sM, 0);
+    for (int64_t i = 1; i < sM->stateNumber; i++) totalProb = logAdd(totalProb, cell[i] + getStateValue(sM, i));
+    return totalProb;
+}
+double dpDiagonal_dotProduct(DpDiagonal *diagonal1, DpDiagonal *diagonal2) { /* :513-523 */
+    double totalProbability = LOG_ZERO;
+    for (int64_t xmy = diagonal1->diagonal.xmyL; xmy <= diagonal1->diagonal.xmyR; xmy += 2)
+        totalProbability = logAdd(totalProbability, cell_dotProduct(dpDiagonal_getCell(diagonal1, xmy), dpDiagonal_getCell(diagonal2, xmy),
+                                                                    diagonal1->stateNumber));
+    return totalProbability;
+}
+
+DpMatrix *dpMatrix_construct(int64_t diagonalNumber, int64_t stateNumber) { /* :540-548 */
+    DpMatrix *m = malloc(sizeof *m);
+    if (!m || diagonalNumber < 0) die("cpecan_hip: dpMatrix_construct: out of memory or negative size");
+    m->diagonalNumber = diagonalNumber;
+    m->diagonals = calloc((size_t)diagonalNumber + 1, sizeof(DpDiagonal *));
+    if (!m->diagonals) die("cpecan_hip: out of memory");
+    m->activeDiagonals = 0;
+    m->stateNumber = stateNumber;
+    return m;
+}
+void dpMatrix_destruct(DpMatrix *dpMatrix) {
+    free(dpMatrix->diagonals);
+    free(dpMatrix);
+}
+DpDiagonal *dpMatrix_getDiagonal(DpMatrix *dpMatrix, int64_t xay) {
+    if (xay < 0 || xay > dpMatrix->diagonalNumber) return NULL;
+    return dpMatrix->diagonals[xay];
+}
+int64_t dpMatrix_getActiveDiagonalNumber(DpMatrix *dpMatrix) { return dpMatrix->activeDiagonals; }
+DpDiagonal *dpMatrix_createDiagonal(DpMatrix *dpMatrix, Diagonal diagonal) { /* :567-576 */
+    if (diagonal.xay < 0 || diagonal.xay > dpMatrix->diagonalNumber || dpMatrix->diagonals[diagonal.xay] != NULL)
+        die("cpecan_hip: dpMatrix_createDiagonal: diagonal %lld out of range or already there", (long long)diagonal.xay);
+    DpDiagonal *d = dpDiagonal_construct(diagonal, dpMatrix->stateNumber);
+    dpMatrix->diagonals[diagonal.xay] = d;
+    dpMatrix->activeDiagonals++;
+    return d;
+}
+void dpMatrix_deleteDiagonal(DpMatrix *dpMatrix, int64_t xay) { /* :578-587 */
+    if (xay < 0 || xay > dpMatrix->diagonalNumber) die("cpecan_hip: dpMatrix_deleteDiagonal: diagonal %lld out of range", (long long)xay);
+    if (dpMatrix->diagonals[xay] != NULL) {
+        dpMatrix->activeDiagonals--;
+        dpDiagonal_destruct(dpMatrix->diagonals[xay]);
+        dpMatrix->diagonals[xay] = NULL;
+    }
+}
+
+/* a flat buffer of cells for cpecan_ref_cells: every distinct cell pointer of a call gets `S` doubles of it */
+typedef struct {
+    double *buf;
+    double **where; /* the host cell each slot mirrors */
+    int64_t nCells, cap;
+    int64_t S;
+} CellPack;
+static int32_t pack_cell(CellPack *pk, double *cell) {
+    if (!cell) return -1;
+    for (int64_t i = pk->nCells - 1; i >= 0 && i >= pk->nCells - 8; i--) /* a neighbour shared with the cell before */
+        if (pk->where[i] == cell) return (int32_t)(i * pk->S);
+    if (pk->nCells == pk->cap) {
+        pk->cap = pk->cap ? 2 * pk->cap : 64;
+        pk->buf = realloc(pk->buf, sizeof(double) * (size_t)(pk->cap * pk->S));
+        pk->where = realloc(pk->where, sizeof(double *) * (size_t)pk->cap);
+        if (!pk->buf || !pk->where) die("cpecan_hip: out of memory");
+    }
+    pk->where[pk->nCells] = cell;
+    memcpy(pk->buf + pk->nCells * pk->S, cell, sizeof(double) * (size_t)pk->S);
+    return (int32_t)(pk->nCells++ * pk->S);
+}
+static void unpack_cells(CellPack *pk) {
+    for (int64_t i = 0; i < pk->nCells; i++) memcpy(pk->where[i], pk->buf + i * pk->S, sizeof(double) * (size_t)pk->S);
+    free(pk->buf);
+    free(pk->where);
+}
+static void run_cells(StateMachine *sM, int mode, cpecan_cell_op *ops, int64_t n, CellPack *pk, const char *what) {
+    check(cpecan_ref_cells(flat_or_die(sM), mode, ops, n, pk->buf, pk->nCells * pk->S, 0.0), what);
+    unpack_cells(pk);
+}
+static void one_cell(StateMachine *sM, int mode, double *current, double *lower, double *middle, double *upper, Symbol cX, Symbol cY,
+                     const char *what) {
+    CellPack pk = {NULL, NULL, 0, 0, sM->stateNumber};
+    cpecan_cell_op op;
+    op.cur = pack_cell(&pk, current);
+    op.lower = pack_cell(&pk, lower);
+    op.middle = pack_cell(&pk, middle);
+    op.upper = pack_cell(&pk, upper);
+    op.cX = (int32_t)cX;
+    op.cY = (int32_t)cY;
+    run_cells(sM, mode, &op, 1, &pk, what);
+}
+void cell_calculateForward(StateMachine *sM, double *current, double *lower, double *middle, double *upper, Symbol cX, Symbol cY,
+                           void *extraArgs) { /* :387-390 */
+    (void)extraArgs;
+    one_cell(sM, CPECAN_CELLS_FORWARD, current, lower, middle, upper, cX, cY, "cell_calculateForward");
+}
+void cell_calculateBackward(StateMachine *sM, double *current, double *lower, double *middle, double *upper, Symbol cX, Symbol cY,
+                            void *extraArgs) { /* :397-400 */
+    (void)extraArgs;
+    one_cell(sM, CPECAN_CELLS_BACKWARD, current, lower, middle, upper, cX, cY, "cell_calculateBackward");
+}
+/* diagonalCalculation, :609-624: the cells of dpDiagonal in ascending x-y against dpDiagonalM1 / dpDiagonalM2 */
+static void diagonal_calculation(StateMachine *sM, int mode, DpDiagonal *dpDiagonal, DpDiagonal *m1, DpDiagonal *m2,
+                                 const SymbolString sX, const SymbolString sY, const char *what) {
+    const Diagonal dg = dpDiagonal->diagonal;
+    const int64_t w = diagonal_getWidth(dg);
+    if (w <= 0) return;
+    CellPack pk = {NULL, NULL, 0, 0, sM->stateNumber};
+    cpecan_cell_op *ops = malloc(sizeof *ops * (size_t)w);
+    if (!ops) die("cpecan_hip: out of memory");
+    int64_t k = 0;
+    for (int64_t xmy = dg.xmyL; xmy <= dg.xmyR; xmy += 2, k++) {
+        const int64_t x = diagonal_getXCoordinate(dg.xay, xmy), y = diagonal_getYCoordinate(dg.xay, xmy);
+        ops[k].cX = (int32_t)(x > 0 ? sX.sequence[x - 1] : n); /* getXCharacter, :597-607 */
+        ops[k].cY = (int32_t)(y > 0 ? sY.sequence[y - 1] : n);
+        ops[k].cur = pack_cell(&pk, dpDiagonal_getCell(dpDiagonal, xmy));
+        ops[k].lower = pack_cell(&pk, m1 ? dpDiagonal_getCell(m1, xmy - 1) : NULL);
+        ops[k].middle = pack_cell(&pk, m2 ? dpDiagonal_getCell(m2, xmy) : NULL);
+        ops[k].upper = pack_cell(&pk, m1 ? dpDiagonal_getCell(m1, xmy + 1) : NULL);
+    }
+    run_cells(sM, mode, ops, k, &pk, what);
+    free(ops);
+}
+void diagonalCalculationForward(StateMachine *sM, int64_t xay, DpMatrix *dpMatrix, const SymbolString sX, const SymbolString sY) {
+    diagonal_calculation(sM, CPECAN_CELLS_FORWARD, dpMatrix_getDiagonal(dpMatrix, xay), dpMatrix_getDiagonal(dpMatrix, xay - 1),
+                         dpMatrix_getDiagonal(dpMatrix, xay - 2), sX, sY, "diagonalCalculationForward");
+}
+void diagonalCalculationBackward(StateMachine *sM, int64_t xay, DpMatrix *dpMatrix, const SymbolString sX, const SymbolString sY) {
+    diagonal_calculation(sM, CPECAN_CELLS_BACKWARD, dpMatrix_getDiagonal(dpMatrix, xay), dpMatrix_getDiagonal(dpMatrix, xay - 1),
+                         dpMatrix_getDiagonal(dpMatrix, xay - 2), sX, sY, "diagonalCalculationBackward");
+}
+double diagonalCalculationTotalProbability(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix, DpMatrix *backwardDpMatrix,
+                                           const SymbolString sX, const SymbolString sY) { /* :636-653 */
+    DpDiagonal *forwardDiagonal = dpMatrix_getDiagonal(forwardDpMatrix, xay);
+    DpDiagonal *backDiagonal = dpMatrix_getDiagonal(backwardDpMatrix, xay);
+    double totalProbability = dpDiagonal_dotProduct(forwardDiagonal, backDiagonal);
+    forwardDiagonal = dpMatrix_getDiagonal(forwardDpMatrix, xay - 1);
+    backDiagonal = dpMatrix_getDiagonal(backwardDpMatrix, xay + 1);
+    if (backDiagonal != NULL && forwardDiagonal != NULL) { /* matches straddling the diagonal */
+        DpDiagonal *matchDiagonal = dpDiagonal_clone(backDiagonal);
+        dpDiagonal_zeroValues(matchDiagonal);
+        diagonal_calculation(sM, CPECAN_CELLS_FORWARD, matchDiagonal, NULL, forwardDiagonal, sX, sY, "diagonalCalculationTotalProbability");
+        totalProbability = logAdd(totalProbability, dpDiagonal_dotProduct(matchDiagonal, backDiagonal));
+        dpDiagonal_destruct(matchDiagonal);
+    }
+    return totalProbability;
+}
+
+/* The reference's per-diagonal emitters (impl/pairwiseAligner.c:666-689, :691-733, :735-746).  Passed to
+ * getPosteriorProbsWithBanding they are TOKENS: recognised by address and routed to the device emitters of the sweep
+ * kernels (the diagonals of that engine live in LDS, no DpMatrix exists).  Called directly with DpMatrix rows -- as the
+ * reference's test_diagonalDPCalculations does -- the match emitter works on those rows: exp() of every cell on the GPU
+ * (cpecan_ref_cells, mode posterior), threshold / clamp / floor as addPosteriorProb (:655-664). */
+static void posterior_list(StateMachine *sM, DpDiagonal *fD, DpDiagonal *bD, int64_t state, double totalProbability,
+                           PairwiseAlignmentParameters *p, stList *out, int needX, int needY) {
+    const Diagonal dg = fD->diagonal;
+    const int64_t w = diagonal_getWidth(dg);
+    if (w <= 0) return;
+    double *buf = malloc(sizeof(double) * 3 * (size_t)w);
+    cpecan_cell_op *ops = malloc(sizeof *ops * (size_t)w);
+    if (!buf || !ops) die("cpecan_hip: out of memory");
+    int64_t k = 0;
+    for (int64_t xmy = dg.xmyL; xmy <= dg.xmyR; xmy += 2, k++) {
+        buf[3 * k] = dpDiagonal_getCell(fD, xmy)[state];
+        buf[3 * k + 1] = dpDiagonal_getCell(bD, xmy)[state];
+        buf[3 * k + 2] = 0.0;
+        ops[k].cur = (int32_t)(3 * k);
+        ops[k].lower = (int32_t)(3 * k + 1);
+        ops[k].middle = -1;
+        ops[k].upper = (int32_t)(3 * k + 2);
+        ops[k].cX = ops[k].cY = 0;
+    }
+    check(cpecan_ref_cells(flat_or_die(sM), CPECAN_CELLS_POSTERIOR, ops, k, buf, 3 * k, totalProbability), "posterior probabilities");
+    k = 0;
+    for (int64_t xmy = dg.xmyL; xmy <= dg.xmyR; xmy += 2, k++) {
+        const int64_t x = diagonal_getXCoordinate(dg.xay, xmy), y = diagonal_getYCoordinate(dg.xay, xmy);
+        if ((needX && x <= 0) || (needY && y <= 0)) continue;
+        double pp = buf[3 * k + 2];
+        if (pp >= p->threshold) { /* addPosteriorProb */
+            if (pp > 1.0) pp = 1.0;
+            stList_append(out, stIntTuple_construct3((int64_t)floor(pp * PAIR_ALIGNMENT_PROB_1), x - 1, y - 1));
+        }
+    }
+    free(buf);
+    free(ops);
+}
 void diagonalCalculationPosteriorMatchProbs(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix, DpMatrix *backwardDpMatrix,
                                             const SymbolString sX, const SymbolString sY, double totalProbability,
                                             PairwiseAlignmentParameters *p, void *extraArgs) {
-    (void)sM; (void)xay; (void)forwardDpMatrix; (void)backwardDpMatrix; (void)sX; (void)sY; (void)totalProbability; (void)p; (void)extraArgs;
-    die("cpecan_hip: diagonalCalculationPosteriorMatchProbs is an emitter token for getPosteriorProbsWithBanding; the DP diagonals exist on the GPU only");
+    (void)sX; (void)sY;
+    if (!forwardDpMatrix || !backwardDpMatrix) die("cpecan_hip: diagonalCalculationPosteriorMatchProbs: no DpMatrix given");
+    posterior_list(sM, dpMatrix_getDiagonal(forwardDpMatrix, xay), dpMatrix_getDiagonal(backwardDpMatrix, xay), sM->matchState,
+                   totalProbability, p, (stList *)((void **)extraArgs)[0], 1, 1);
 }
 void diagonalCalculationPosteriorProbs(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix, DpMatrix *backwardDpMatrix,
                                        const SymbolString sX, const SymbolString sY, double totalProbability,
-                                       PairwiseAlignmentParameters *p, void *extraArgs) {
-    (void)sM; (void)xay; (void)forwardDpMatrix; (void)backwardDpMatrix; (void)sX; (void)sY; (void)totalProbability; (void)p; (void)extraArgs;
-    die("cpecan_hip: diagonalCalculationPosteriorProbs is an emitter token for getPosteriorProbsWithBanding; the DP diagonals exist on the GPU only");
+                                       PairwiseAlignmentParameters *p, void *extraArgs) { /* :691-733 */
+    (void)sX; (void)sY;
+    if (!forwardDpMatrix || !backwardDpMatrix) die("cpecan_hip: diagonalCalculationPosteriorProbs: no DpMatrix given");
+    DpDiagonal *fD = dpMatrix_getDiagonal(forwardDpMatrix, xay), *bD = dpMatrix_getDiagonal(backwardDpMatrix, xay);
+    posterior_list(sM, fD, bD, sM->matchState, totalProbability, p, (stList *)((void **)extraArgs)[0], 1, 1);
+    posterior_list(sM, fD, bD, sM->gapXState, totalProbability, p, (stList *)((void **)extraArgs)[2], 1, 0);
+    posterior_list(sM, fD, bD, sM->gapYState, totalProbability, p, (stList *)((void **)extraArgs)[4], 0, 1);
 }
 void diagonalCalculationExpectations(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix, DpMatrix *backwardDpMatrix,
                                      const SymbolString sX, const SymbolString sY, double totalProbability,
                                      PairwiseAlignmentParameters *p, void *extraArgs) {
     (void)sM; (void)xay; (void)forwardDpMatrix; (void)backwardDpMatrix; (void)sX; (void)sY; (void)totalProbability; (void)p; (void)extraArgs;
-    die("cpecan_hip: diagonalCalculationExpectations is an emitter token for getPosteriorProbsWithBanding; the DP diagonals exist on the GPU only");
+    die("cpecan_hip: diagonalCalculationExpectations is an emitter token for getPosteriorProbsWithBanding / getExpectationsUsingAnchors; "
+        "the expectation sums are accumulated by the device emitter only");
 }
 
 static char *chars_of(const SymbolString s) {
@@ -910,4 +1169,120 @@ void getPosteriorProbsWithBanding(StateMachine *sM, stList *anchorPairs, const S
     free(cX);
     free(cY);
     free(anchors);
+}
+
+
+/* getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps, impl/pairwiseAligner.c:1273-1326 (inc/pairwiseAligner.h:264):
+ * the rectangles of getSplitPoints, each aligned as a region of its own (ragged on the sides where it was cut) with its
+ * anchors rebased, and coordinateCorrectionFn(x1, y1, extraArgs) called after each -- in the reference that callback moves
+ * the region's pairs from the scratch lists of extraArgs into the caller's lists (:1411-1432).  Here every rectangle is
+ * one problem of ONE batch (one upload, one launch per size class, one download); the emitter's lists are then filled
+ * and the callback made rectangle by rectangle, in the reference's order. */
+void getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps(
+    StateMachine *sM, stList *anchorPairs, const char *sX, const char *sY, int64_t lX, int64_t lY, PairwiseAlignmentParameters *p,
+    bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd,
+    void (*diagonalPosteriorProbFn)(StateMachine *, int64_t, DpMatrix *, DpMatrix *, const SymbolString, const SymbolString, double,
+                                    PairwiseAlignmentParameters *, void *),
+    void (*coordinateCorrectionFn)(), void *extraArgs) {
+    int emit;
+    if (diagonalPosteriorProbFn == diagonalCalculationPosteriorMatchProbs) emit = CPECAN_EMIT_MATCH;
+    else if (diagonalPosteriorProbFn == diagonalCalculationPosteriorProbs) emit = CPECAN_EMIT_INDEL;
+    else if (diagonalPosteriorProbFn == diagonalCalculationExpectations) emit = CPECAN_EMIT_EXPECT;
+    else {
+        die("cpecan_hip: getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps: the emitter must be one of "
+            "diagonalCalculationPosteriorMatchProbs, diagonalCalculationPosteriorProbs, diagonalCalculationExpectations");
+        return;
+    }
+    cpecan_params q;
+    flatten_params(p, &q);
+    const int64_t maxMatrixSize = q.splitMatrixBiggerThanThis;
+    q.splitMatrixBiggerThanThis = INT64_MAX / 4; /* the rectangles are cut here, as the reference cuts them */
+    int64_t n;
+    int64_t *anchors = flatten_anchors(anchorPairs, &n);
+    int64_t *rect = malloc(sizeof(int64_t) * 4 * (size_t)(n + 2));
+    if (!rect) die("cpecan_hip: out of memory");
+    const int64_t nRect = cpecan_split_points(anchors, n, lX, lY, maxMatrixSize, alignmentHasRaggedLeftEnd, alignmentHasRaggedRightEnd, rect);
+    if (nRect < 0) die("cpecan_hip: getSplitPoints: invalid anchors");
+    cpecan_batch *b = NULL;
+    check(cpecan_batch_create(&b, flat_or_die(sM), &q, emit, cpecan_current_device()), "cpecan_batch_create");
+    int64_t j = 0;
+    int64_t *sub = malloc(sizeof(int64_t) * 3 * (size_t)(n ? n : 1));
+    if (!sub) die("cpecan_hip: out of memory");
+    for (int64_t i = 0; i < nRect; i++) {
+        const int64_t x1 = rect[4 * i], y1 = rect[4 * i + 1], x2 = rect[4 * i + 2], y2 = rect[4 * i + 3];
+        int64_t m = 0;
+        while (j < n && anchors[3 * j] + anchors[3 * j + 1] < x2 + y2) { /* :1299-1311 */
+            sub[3 * m] = anchors[3 * j] - x1;
+            sub[3 * m + 1] = anchors[3 * j + 1] - y1;
+            sub[3 * m + 2] = anchors[3 * j + 2];
+            m++;
+            j++;
+        }
+        if (cpecan_batch_add(b, sX + x1, x2 - x1, sY + y1, y2 - y1, sub, m, alignmentHasRaggedLeftEnd || i > 0,
+                             alignmentHasRaggedRightEnd || i < nRect - 1) < 0)
+            die("cpecan_hip: %s", cpecan_last_error());
+    }
+    if (nRect > 0) {
+        check(cpecan_batch_upload(b), "cpecan_batch_upload");
+        check(cpecan_batch_run(b, NULL), "cpecan_batch_run");
+        check(cpecan_batch_download(b), "cpecan_batch_download");
+    }
+    if (emit == CPECAN_EMIT_EXPECT && nRect > 0) {
+        cpecan_hmm acc;
+        to_flat((Hmm *)extraArgs, &acc);
+        check(cpecan_batch_expectations(b, &acc), "cpecan_batch_expectations");
+        from_flat(&acc, (Hmm *)extraArgs);
+    }
+    for (int64_t i = 0; i < nRect; i++) {
+        const int nLists = emit == CPECAN_EMIT_MATCH ? 1 : (emit == CPECAN_EMIT_INDEL ? 3 : 0);
+        for (int l = 0; l < nLists; l++) {
+            const int32_t *tr = NULL;
+            int64_t cnt = 0;
+            check(cpecan_batch_result(b, i, l, &tr, &cnt), "cpecan_batch_result");
+            append_reversed((stList *)((void **)extraArgs)[2 * l], tr, cnt); /* the emitter's own order, :813-841 */
+        }
+        if (coordinateCorrectionFn != NULL) ((void (*)(int64_t, int64_t, void *))coordinateCorrectionFn)(rect[4 * i], rect[4 * i + 1], extraArgs);
+    }
+    cpecan_batch_destroy(b);
+    free(sub);
+    free(rect);
+    free(anchors);
+}
+
+/* getIndelProbabilities / reweightAlignedPairs, impl/pairwiseAligner.c:1519-1548 (inc/pairwiseAligner.h:272-276): the two
+ * halves of reweightAlignedPairs2 for callers that hold the per-base arrays themselves -- integer list bookkeeping on the
+ * caller's lists; the fused form (reweightAlignedPairs2 above, cpecan_batch_set_post) runs on the device. */
+int64_t *getIndelProbabilities(stList *alignedPairs, int64_t seqLength, bool xIfTrueElseY) {
+    int64_t *indelProbs = malloc(sizeof(int64_t) * (size_t)(seqLength > 0 ? seqLength : 1));
+    if (!indelProbs) die("cpecan_hip: out of memory");
+    for (int64_t i = 0; i < seqLength; i++) indelProbs[i] = PAIR_ALIGNMENT_PROB_1;
+    for (int64_t i = 0; i < stList_length(alignedPairs); i++) {
+        stIntTuple *tp = stList_get(alignedPairs, i);
+        indelProbs[stIntTuple_get(tp, xIfTrueElseY ? 1 : 2)] -= stIntTuple_get(tp, 0);
+    }
+    for (int64_t i = 0; i < seqLength; i++)
+        if (indelProbs[i] < 0) indelProbs[i] = 0;
+    return indelProbs;
+}
+stList *reweightAlignedPairs(stList *alignedPairs, int64_t *indelProbsX, int64_t *indelProbsY, double gapGamma) {
+    stList *out = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    for (int64_t i = 0; i < stList_length(alignedPairs); i++) {
+        stIntTuple *aPair = stList_get(alignedPairs, i);
+        const int64_t x = stIntTuple_get(aPair, 1), y = stIntTuple_get(aPair, 2);
+        /* int64 - double * int64, truncated on the assignment: the reference's arithmetic (:1543) */
+        const int64_t updatedWeight = (int64_t)(stIntTuple_get(aPair, 0) - gapGamma * (indelProbsX[x] + indelProbsY[y]));
+        stList_append(out, stIntTuple_construct3(updatedWeight, x, y));
+    }
+    stList_destruct(alignedPairs); /* "destroys input aligned pairs in the process" */
+    return out;
+}
+int64_t getNumberOfMatchingAlignedPairs(char *subSeqX, char *subSeqY, stList *alignedPairs) { /* :1562-1570 */
+    int64_t matches = 0;
+    for (int64_t i = 0; i < stList_length(alignedPairs); i++) {
+        stIntTuple *aPair = stList_get(alignedPairs, i);
+        const int64_t x = stIntTuple_get(aPair, 1), y = stIntTuple_get(aPair, 2);
+        const int cx = toupper((unsigned char)subSeqX[x]), cy = toupper((unsigned char)subSeqY[y]);
+        matches += cx == cy && cx != 'N';
+    }
+    return matches;
 }

@@ -530,6 +530,35 @@ int64_t cpecan_filter_to_remove_overlap(const int64_t *pairs, int64_t n, int64_t
 int cpecan_device_count(void) { return cpk_device_count(); }
 int cpecan_current_device(void) { return cpk_current_device(); }
 int64_t cpecan_cache_trim(int device) { return cpk_cache_trim(device); }
+
+int cpecan_ref_cells(const cpecan_model *model, int mode, const cpecan_cell_op *ops, int64_t n, double *cells,
+                     int64_t nDoubles, double total) {
+    if (!model || !ops || !cells || n < 0 || nDoubles < 0 || mode < CPECAN_CELLS_FORWARD || mode > CPECAN_CELLS_POSTERIOR ||
+        model->type < CPECAN_FIVE_STATE || model->type > CPECAN_THREE_STATE_ASYM) {
+        cpk_set_error("cpecan_ref_cells: invalid arguments");
+        return CPECAN_EINVAL;
+    }
+    const int S = is_five(model->type) ? 5 : 3;
+    for (int64_t i = 0; i < n; i++) { /* every offset names a whole cell inside the buffer: the kernel trusts them */
+        const int32_t o[4] = {ops[i].cur, ops[i].lower, ops[i].middle, ops[i].upper};
+        for (int f = 0; f < 4; f++) {
+            const int need = mode == CPECAN_CELLS_POSTERIOR ? (f == 2 ? 0 : 1) : S;
+            const int may_be_null = mode != CPECAN_CELLS_POSTERIOR && f > 0;
+            if (need == 0 || (may_be_null && o[f] < 0)) continue;
+            if (o[f] < 0 || (int64_t)o[f] + need > nDoubles) {
+                cpk_set_error("cpecan_ref_cells: operation %lld names a cell outside the buffer", (long long)i);
+                return CPECAN_EINVAL;
+            }
+        }
+        if (mode != CPECAN_CELLS_POSTERIOR && (ops[i].cX < 0 || ops[i].cX > 4 || ops[i].cY < 0 || ops[i].cY > 4)) {
+            cpk_set_error("cpecan_ref_cells: operation %lld has a symbol outside 0..4", (long long)i);
+            return CPECAN_EINVAL;
+        }
+    }
+    CpkModel km;
+    kernel_model(model, 0.0, &km);
+    return cpk_ref_cells(cpk_current_device(), &km, mode, (const CpkCellOp *)ops, n, cells, nDoubles, total);
+}
 const char *cpecan_last_error(void) { return cpk_last_error(); }
 
 int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpecan_params *params, int emit,

@@ -127,7 +127,18 @@ typedef struct {
 /* Device-side mirror of a frozen batch; owned by the HIP TU. */
 typedef struct CpkDevice CpkDevice;
 
+/* One operation of cpk_ref_cells (cpk_cells.inl): offsets, in doubles, of the cells in the flat buffer; -1 = NULL.
+ * Layout shared with include/cpecan_hip.h's cpecan_cell_op. */
+typedef struct {
+    int32_t cur, lower, middle, upper;
+    int32_t cX, cY;
+} CpkCellOp;
+
 /* ---- implemented in cpecan_kernels.hip ---- */
+/* The reference's cell-level primitives on the current device: `n` operations applied in order by one lane to the
+ * `nDoubles` doubles of buf (copied up, changed in place, copied back).  mode 0 forward, 1 backward, 2 posterior. */
+int cpk_ref_cells(int device, const CpkModel *model, int mode, const CpkCellOp *ops, int64_t n, double *buf, int64_t nDoubles,
+                  double total);
 /* Host blocks of a batch: pinned and recycled when a HIP device is present, plain malloc below 256 KB or without a GPU. */
 void *cpk_host_alloc(size_t bytes);
 void cpk_host_free(void *p);

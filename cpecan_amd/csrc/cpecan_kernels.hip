@@ -75,6 +75,7 @@ extern "C" const char *cpk_last_error(void) { return g_err; }
 #include "cpk_table_gather.inl"
 #include "cpk_packed.inl"
 #include "cpk_post.inl"
+#include "cpk_cells.inl"
 
 // ------------------------------------------------------------------------------------------------
 // host side of the HIP TU: memory, launch, timing
@@ -1641,6 +1642,41 @@ extern "C" int cpk_device_debug_fetch(CpkDevice *d, double *fb, int64_t cells, d
     HIP_TRY(hipMemcpy(fb, d->dDbgFb, sizeof(double) * (size_t)cells, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(totals, d->dDbgTotals, sizeof(double) * (size_t)diags, hipMemcpyDeviceToHost));
     return CPECAN_OK;
+}
+
+// The reference's unit-test primitives (cpk_cells.inl): a few hundred cells at most, one lane, blocking copies.
+extern "C" int cpk_ref_cells(int device, const CpkModel *model, int mode, const CpkCellOp *ops, int64_t n, double *buf,
+                             int64_t nDoubles, double total) {
+    const int nDev = cpk_device_count();
+    if (nDev <= 0 || device < 0 || device >= nDev) {
+        cpk_set_error("no usable HIP device (count=%d, requested=%d): the HIP path has no CPU fallback", nDev, device);
+        return CPECAN_ENODEVICE;
+    }
+    if (n <= 0 || nDoubles <= 0) return CPECAN_OK;
+    CPK_ON_DEVICE(device);
+    void *dOps = nullptr, *dBuf = nullptr;
+    const size_t opBytes = sizeof(CpkCellOp) * (size_t)n, bufBytes = sizeof(double) * (size_t)nDoubles;
+    HIP_TRY(cache_alloc(device, &dOps, opBytes));
+    if (hipError_t e = cache_alloc(device, &dBuf, bufBytes); e != hipSuccess) {
+        cache_free(device, dOps, opBytes);
+        HIP_TRY(e);
+    }
+    int rc = CPECAN_OK;
+    hipError_t e = hipMemcpy(dOps, ops, opBytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dBuf, buf, bufBytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(cpecan_ref_cells, dim3(1), dim3(CPK_WAVE), 0, nullptr, *model, mode, (const CpkCellOp *)dOps, (int)n,
+                           (double *)dBuf, total);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(buf, dBuf, bufBytes, hipMemcpyDeviceToHost);  // waits for the kernel (null stream)
+    if (e != hipSuccess) {
+        cpk_set_error("cpk_ref_cells: %s", hipGetErrorString(e));
+        rc = CPECAN_EHIP;
+    }
+    cache_free(device, dOps, opBytes);
+    cache_free(device, dBuf, bufBytes);
+    return rc;
 }
 
 extern "C" int64_t cpk_device_bytes(const CpkDevice *d) { return d->bytes; }

@@ -15,9 +15,13 @@
  * sonLib linked into the same program takes precedence.
  *
  * Not provided: the lastz path of getAlignedPairs / getExpectations (beyond anchorMatrixBiggerThanThis the reference shells
- * out to lastz, impl/pairwiseAligner.c:1032-1042) and the host-side DpMatrix / DpDiagonal / cell_* primitives: the DP
- * diagonals never exist on the host.  sM->cellCalculate is a stub that aborts; getPosteriorProbsWithBanding accepts the
- * reference's three emitters (recognised by address, see below) and refuses foreign callbacks.
+ * out to lastz, impl/pairwiseAligner.c:1032-1042).  The primitives the reference's unit tests link (inc/pairwiseAligner.h:
+ * 186-237: DpDiagonal, DpMatrix, cell_calculateForward / Backward, cell_dotProduct[2], diagonalCalculationForward /
+ * Backward / TotalProbability, the per-diagonal emitters on DpMatrix rows) ARE provided: the containers are host memory
+ * with the reference's semantics, their DP arithmetic runs on the GPU (cpecan_ref_cells, one lane, the reference's order
+ * of operations -- the library holds no CPU implementation of the recurrences).  sM->cellCalculate itself, which takes an
+ * arbitrary per-transition callback, stays a stub that aborts; getPosteriorProbsWithBanding accepts the reference's three
+ * emitters (recognised by address, see below) and refuses foreign callbacks.
  */
 #ifndef CPECAN_DROPIN_H_
 #define CPECAN_DROPIN_H_
@@ -216,6 +220,7 @@ int64_t diagonal_getWidth(Diagonal diagonal);
 int64_t diagonal_getXCoordinate(int64_t xay, int64_t xmy);
 int64_t diagonal_getYCoordinate(int64_t xay, int64_t xmy);
 int64_t diagonal_equals(Diagonal diagonal1, Diagonal diagonal2);
+char *diagonal_getString(Diagonal diagonal); /* inc/pairwiseAligner.h:138; malloc'ed, the caller frees */
 
 typedef struct _band Band;
 Band *band_construct(stList *anchorPairs, int64_t lX, int64_t lY, int64_t expansion);
@@ -242,10 +247,12 @@ SymbolString symbolString_construct(const char *sequence, int64_t length); /* in
 double logAdd(double x, double y);
 
 /* inc/pairwiseAligner.h:245-248: the banded engine itself, one region, with the reference's emitter-callback signature.
- * The per-diagonal emitters of the reference read DpMatrix rows; this library keeps the DP diagonals on the GPU, so the
- * three emitters below are TOKENS: getPosteriorProbsWithBanding recognises them by address and runs the device emitter
- * (extraArgs as in the reference: {alignedPairs} / {alignedPairs, _, gapXPairs, _, gapYPairs} / Hmm*); any other callback
- * is refused (abort with a message).  Lists are appended in the reference emitter's own order. */
+ * The per-diagonal emitters of the reference read DpMatrix rows; the engine keeps its DP diagonals on the GPU, so as
+ * arguments of getPosteriorProbsWithBanding the three emitters below are TOKENS: recognised by address and routed to the
+ * device emitter (extraArgs as in the reference: {alignedPairs} / {alignedPairs, _, gapXPairs, _, gapYPairs} / Hmm*); any
+ * other callback is refused (abort with a message).  Lists are appended in the reference emitter's own order.  Called
+ * directly on DpMatrix rows (as the reference's test_diagonalDPCalculations does) the two posterior emitters work on those
+ * rows, their exp() on the GPU. */
 typedef struct _dpMatrix DpMatrix;
 void diagonalCalculationPosteriorMatchProbs(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix, DpMatrix *backwardDpMatrix,
                                             const SymbolString sX, const SymbolString sY, double totalProbability,
@@ -263,6 +270,46 @@ void getPosteriorProbsWithBanding(StateMachine *sM, stList *anchorPairs, const S
                                   void *extraArgs);
 stList *getSplitPoints(stList *anchorPairs, int64_t lX, int64_t lY, int64_t maxMatrixSize, bool alignmentHasRaggedLeftEnd,
                        bool alignmentHasRaggedRightEnd);
+/* inc/pairwiseAligner.h:264 (impl/pairwiseAligner.c:1273-1326): the rectangles of getSplitPoints as the problems of ONE
+ * batch; per rectangle the emitter's lists (extraArgs[0], [2], [4], or the Hmm) are filled and coordinateCorrectionFn
+ * (offsetX, offsetY, extraArgs) is called, in the reference's order.  Emitters as for getPosteriorProbsWithBanding. */
+void getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps(
+    StateMachine *sM, stList *anchorPairs, const char *sX, const char *sY, int64_t lX, int64_t lY, PairwiseAlignmentParameters *p,
+    bool alignmentHasRaggedLeftEnd, bool alignmentHasRaggedRightEnd,
+    void (*diagonalPosteriorProbFn)(StateMachine *, int64_t, DpMatrix *, DpMatrix *, const SymbolString, const SymbolString, double,
+                                    PairwiseAlignmentParameters *, void *),
+    void (*coordinateCorrectionFn)(), void *extraArgs);
+
+/* inc/pairwiseAligner.h:186-237: the containers and cell-level calculations the reference's unit tests link
+ * (impl/pairwiseAligner.c:382-416, :448-653); see the note at the top of this header */
+void cell_calculateForward(StateMachine *sM, double *current, double *lower, double *middle, double *upper, Symbol cX, Symbol cY, void *extraArgs);
+void cell_calculateBackward(StateMachine *sM, double *current, double *lower, double *middle, double *upper, Symbol cX, Symbol cY, void *extraArgs);
+double cell_dotProduct(double *cell1, double *cell2, int64_t stateNumber);
+double cell_dotProduct2(double *cell1, StateMachine *sM, double (*getStateValue)(StateMachine *, int64_t));
+typedef struct _dpDiagonal DpDiagonal;
+DpDiagonal *dpDiagonal_construct(Diagonal diagonal, int64_t stateNumber);
+DpDiagonal *dpDiagonal_clone(DpDiagonal *diagonal);
+bool dpDiagonal_equals(DpDiagonal *diagonal1, DpDiagonal *diagonal2);
+void dpDiagonal_destruct(DpDiagonal *dpDiagonal);
+double *dpDiagonal_getCell(DpDiagonal *dpDiagonal, int64_t xmy);
+double dpDiagonal_dotProduct(DpDiagonal *diagonal1, DpDiagonal *diagonal2);
+void dpDiagonal_zeroValues(DpDiagonal *diagonal);
+void dpDiagonal_initialiseValues(DpDiagonal *diagonal, StateMachine *sM, double (*getStateValue)(StateMachine *, int64_t));
+DpMatrix *dpMatrix_construct(int64_t diagonalNumber, int64_t stateNumber);
+void dpMatrix_destruct(DpMatrix *dpMatrix);
+DpDiagonal *dpMatrix_getDiagonal(DpMatrix *dpMatrix, int64_t xay);
+int64_t dpMatrix_getActiveDiagonalNumber(DpMatrix *dpMatrix);
+DpDiagonal *dpMatrix_createDiagonal(DpMatrix *dpMatrix, Diagonal diagonal);
+void dpMatrix_deleteDiagonal(DpMatrix *dpMatrix, int64_t xay);
+void diagonalCalculationForward(StateMachine *sM, int64_t xay, DpMatrix *dpMatrix, const SymbolString sX, const SymbolString sY);
+void diagonalCalculationBackward(StateMachine *sM, int64_t xay, DpMatrix *dpMatrix, const SymbolString sX, const SymbolString sY);
+double diagonalCalculationTotalProbability(StateMachine *sM, int64_t xay, DpMatrix *forwardDpMatrix, DpMatrix *backwardDpMatrix,
+                                           const SymbolString sX, const SymbolString sY);
+
+/* inc/pairwiseAligner.h:272-276, :287 (impl/pairwiseAligner.c:1519-1548, :1562-1570) */
+int64_t *getIndelProbabilities(stList *alignedPairs, int64_t seqLength, bool xIfTrueElseY);
+stList *reweightAlignedPairs(stList *alignedPairs, int64_t *indelProbsX, int64_t *indelProbsY, double gapGamma);
+int64_t getNumberOfMatchingAlignedPairs(char *subSeqX, char *subSeqY, stList *alignedPairs);
 
 #ifdef __cplusplus
 }

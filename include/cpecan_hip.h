@@ -132,6 +132,22 @@ int64_t cpecan_anchors_from_alignment(const int64_t *ops, int64_t nOps, int64_t 
  * larger in both coordinates.  pairs: n triples sorted by x, then y; out: room for n triples.  Returns the number kept. */
 int64_t cpecan_filter_to_remove_overlap(const int64_t *pairs, int64_t n, int64_t *out);
 
+/* The reference's cell-level primitives (inc/pairwiseAligner.h:186-237: cell_calculateForward / Backward,
+ * diagonalCalculationForward / Backward, the posterior of :683-685), which its unit tests link, evaluated on the caller's
+ * current device: `n` operations applied in order to the cells held in `cells` (nDoubles doubles, changed in place).
+ * An operation names its cells by offsets in doubles, -1 = NULL (the reference's out-of-band neighbour).
+ * mode 0: forward, current[to] = logAdd(current[to], from[..] + (eP + tP)) over the transition list
+ * (impl/pairwiseAligner.c:382-385; impl/stateMachine.c:450-480, :689-714); mode 1: backward, the same list scattered into
+ * the neighbours (:392-395); mode 2: cells[upper] = exp(cells[cur] + cells[lower] - total).  Not a hot-path entry point:
+ * one lane, blocking copies. */
+typedef struct cpecan_cell_op {
+    int32_t cur, lower, middle, upper;
+    int32_t cX, cY; /* symbols 0..4 (a c g t n) of the current cell */
+} cpecan_cell_op;
+enum { CPECAN_CELLS_FORWARD = 0, CPECAN_CELLS_BACKWARD = 1, CPECAN_CELLS_POSTERIOR = 2 };
+int cpecan_ref_cells(const cpecan_model *model, int mode, const cpecan_cell_op *ops, int64_t n, double *cells,
+                     int64_t nDoubles, double total);
+
 /* ---- device ---- */
 int cpecan_device_count(void);
 /* The calling thread's current HIP device (hipGetDevice).  Device rule of this library: a batch works on the device it

@@ -408,6 +408,222 @@ static void test_getPosteriorProbsWithBanding_gpu(void) {
     free(sY.sequence);
 }
 
+
+/* test_dpDiagonal / test_dpMatrix, tests/pairwiseAlignerTest.c:184-240: the containers (host memory, no GPU) */
+static void test_dp_containers(void) {
+    StateMachine *sM = stateMachine5_construct(fiveState);
+    Diagonal diagonal = diagonal_construct(3, -1, 1);
+    DpDiagonal *dpDiagonal = dpDiagonal_construct(diagonal, sM->stateNumber);
+    double *c1 = dpDiagonal_getCell(dpDiagonal, -1), *c2 = dpDiagonal_getCell(dpDiagonal, 1);
+    CHECK(c1 != NULL && c2 != NULL);
+    CHECK(dpDiagonal_getCell(dpDiagonal, 3) == NULL && dpDiagonal_getCell(dpDiagonal, -3) == NULL);
+    dpDiagonal_initialiseValues(dpDiagonal, sM, sM->endStateProb);
+    double totalProb = LOG_ZERO;
+    for (int64_t i = 0; i < sM->stateNumber; i++) {
+        CHECK(c1[i] == sM->endStateProb(sM, i) && c2[i] == sM->endStateProb(sM, i));
+        totalProb = logAdd(totalProb, 2 * c1[i]);
+        totalProb = logAdd(totalProb, 2 * c2[i]);
+    }
+    DpDiagonal *dpDiagonal2 = dpDiagonal_clone(dpDiagonal);
+    CHECK(dpDiagonal_equals(dpDiagonal, dpDiagonal2));
+    CHECK(fabs(totalProb - dpDiagonal_dotProduct(dpDiagonal, dpDiagonal2)) < 0.001);
+    dpDiagonal_zeroValues(dpDiagonal2);
+    CHECK(!dpDiagonal_equals(dpDiagonal, dpDiagonal2) && isinf(dpDiagonal_getCell(dpDiagonal2, 1)[0]));
+    dpDiagonal_destruct(dpDiagonal);
+    dpDiagonal_destruct(dpDiagonal2);
+
+    const int64_t lX = 3, lY = 2;
+    DpMatrix *dpMatrix = dpMatrix_construct(lX + lY, 5);
+    CHECK(dpMatrix_getActiveDiagonalNumber(dpMatrix) == 0);
+    for (int64_t i = -1; i <= lX + lY + 10; i++) CHECK(dpMatrix_getDiagonal(dpMatrix, i) == NULL);
+    for (int64_t i = 0; i <= lX + lY; i++) {
+        DpDiagonal *d = dpMatrix_createDiagonal(dpMatrix, diagonal_construct(i, -i, i));
+        CHECK(d == dpMatrix_getDiagonal(dpMatrix, i));
+        CHECK(dpMatrix_getActiveDiagonalNumber(dpMatrix) == i + 1);
+    }
+    for (int64_t i = lX + lY; i >= 0; i--) {
+        dpMatrix_deleteDiagonal(dpMatrix, i);
+        CHECK(dpMatrix_getDiagonal(dpMatrix, i) == NULL);
+        CHECK(dpMatrix_getActiveDiagonalNumber(dpMatrix) == i);
+    }
+    dpMatrix_destruct(dpMatrix);
+    char *str = diagonal_getString(diagonal_construct(30, -10, 30));
+    CHECK(strcmp(str, "Diagonal, xay: 30 xmyL -10, xmyR: 30") == 0);
+    free(str);
+    stateMachine_destruct(sM);
+}
+
+/* the list helpers of inc/pairwiseAligner.h:272-287: the two halves of reweightAlignedPairs2 and the identity count */
+static void test_list_helpers(void) {
+    stList *pairs = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    stList_append(pairs, stIntTuple_construct3(9000000, 0, 0));
+    stList_append(pairs, stIntTuple_construct3(4000000, 1, 1));
+    stList_append(pairs, stIntTuple_construct3(7000000, 1, 2));
+    stList_append(pairs, stIntTuple_construct3(2000000, 3, 2));
+    int64_t *ix = getIndelProbabilities(pairs, 4, 1), *iy = getIndelProbabilities(pairs, 3, 0);
+    CHECK(ix[0] == 1000000 && ix[1] == 0 /* clamped: 1e7 - 1.1e7 */ && ix[2] == 10000000 && ix[3] == 8000000);
+    CHECK(iy[0] == 1000000 && iy[1] == 6000000 && iy[2] == 1000000);
+    char sx[] = "ACnT", sy[] = "aCN";
+    CHECK(getNumberOfMatchingAlignedPairs(sx, sy, pairs) == 2); /* (0,0) A/a and (1,1) C/C; (1,2) C/N no; (3,2) T/N no */
+    stList *rw = reweightAlignedPairs(pairs, ix, iy, 0.5); /* consumes pairs */
+    CHECK(stList_length(rw) == 4);
+    const int64_t want[4] = {9000000 - 1000000, 4000000 - 3000000, 7000000 - 500000, 2000000 - 4500000};
+    for (int i = 0; i < 4; i++) CHECK(stIntTuple_get(stList_get(rw, i), 0) == want[i]);
+    stList_destruct(rw);
+    free(ix);
+    free(iy);
+}
+
+/* test_cell, tests/pairwiseAlignerTest.c:155-182: forward and backward through one cell and its three neighbours give the
+ * same total probability (cell arithmetic on the GPU through cpecan_ref_cells) */
+static void test_cell_gpu(StateMachine *sM) {
+    double lowerF[5], middleF[5], upperF[5], currentF[5], lowerB[5], middleB[5], upperB[5], currentB[5];
+    for (int64_t i = 0; i < sM->stateNumber; i++) {
+        middleF[i] = sM->startStateProb(sM, i);
+        middleB[i] = lowerF[i] = lowerB[i] = upperF[i] = upperB[i] = currentF[i] = LOG_ZERO;
+        currentB[i] = sM->endStateProb(sM, i);
+    }
+    const Symbol cX = a, cY = t;
+    cell_calculateForward(sM, lowerF, NULL, NULL, middleF, cX, cY, NULL);
+    cell_calculateForward(sM, upperF, middleF, NULL, NULL, cX, cY, NULL);
+    cell_calculateForward(sM, currentF, lowerF, middleF, upperF, cX, cY, NULL);
+    cell_calculateBackward(sM, currentB, lowerB, middleB, upperB, cX, cY, NULL);
+    cell_calculateBackward(sM, upperB, middleB, NULL, NULL, cX, cY, NULL);
+    cell_calculateBackward(sM, lowerB, NULL, NULL, middleB, cX, cY, NULL);
+    const double totalProbForward = cell_dotProduct2(currentF, sM, sM->endStateProb);
+    const double totalProbBackward = cell_dotProduct2(middleB, sM, sM->startStateProb);
+    CHECK(isfinite(totalProbForward) && fabs(totalProbForward - totalProbBackward) < 0.00001);
+}
+
+/* test_diagonalDPCalculations, tests/pairwiseAlignerTest.c:242-324, statement for statement: a complete matrix for
+ * AGCG / AGTTCG diagonal by diagonal through the DpMatrix API, forward == backward == every diagonal's total, and the four
+ * pairs.  SURVEY 8c recorded the reference's numbers for this input: total -17.519321161239 and the four scores. */
+static void test_diagonalDPCalculations_gpu(void) {
+    const char *sX = "AGCG", *sY = "AGTTCG";
+    const int64_t lX = 4, lY = 6;
+    SymbolString sX2 = symbolString_construct(sX, lX), sY2 = symbolString_construct(sY, lY);
+    StateMachine *sM = stateMachine5_construct(fiveState);
+    DpMatrix *fwd = dpMatrix_construct(lX + lY, sM->stateNumber), *bwd = dpMatrix_construct(lX + lY, sM->stateNumber);
+    stList *anchorPairs = stList_construct();
+    Band *band = band_construct(anchorPairs, lX, lY, 2);
+    BandIterator *bandIt = bandIterator_construct(band);
+    for (int64_t i = 0; i <= lX + lY; i++) {
+        Diagonal d = bandIterator_getNext(bandIt);
+        dpDiagonal_zeroValues(dpMatrix_createDiagonal(bwd, d));
+        dpDiagonal_zeroValues(dpMatrix_createDiagonal(fwd, d));
+    }
+    dpDiagonal_initialiseValues(dpMatrix_getDiagonal(fwd, 0), sM, sM->startStateProb);
+    dpDiagonal_initialiseValues(dpMatrix_getDiagonal(bwd, lX + lY), sM, sM->endStateProb);
+    for (int64_t i = 1; i <= lX + lY; i++) diagonalCalculationForward(sM, i, fwd, sX2, sY2);
+    for (int64_t i = lX + lY; i > 0; i--) diagonalCalculationBackward(sM, i, bwd, sX2, sY2);
+    const double totalProbForward = cell_dotProduct2(dpDiagonal_getCell(dpMatrix_getDiagonal(fwd, lX + lY), lX - lY), sM, sM->endStateProb);
+    const double totalProbBackward = cell_dotProduct2(dpDiagonal_getCell(dpMatrix_getDiagonal(bwd, 0), 0), sM, sM->startStateProb);
+    CHECK(fabs(totalProbForward - totalProbBackward) < 0.001);
+    CHECK(fabs(totalProbForward - (-17.519321161239)) < 1e-9); /* computeForwardProbability of the same input, SURVEY 8c */
+    for (int64_t i = 0; i <= lX + lY; i++)
+        CHECK(fabs(totalProbForward - diagonalCalculationTotalProbability(sM, i, fwd, bwd, sX2, sY2)) < 0.01);
+    stList *alignedPairs = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    void *extraArgs[1] = {alignedPairs};
+    PairwiseAlignmentParameters *p = pairwiseAlignmentBandingParameters_construct();
+    p->threshold = 0.2;
+    for (int64_t i = 1; i <= lX + lY; i++) diagonalCalculationPosteriorMatchProbs(sM, i, fwd, bwd, sX2, sY2, totalProbForward, p, extraArgs);
+    CHECK(stList_length(alignedPairs) == 4);
+    const int64_t want[4][3] = {{9944673, 0, 0}, {9259684, 1, 1}, {8665179, 2, 4}, {9893294, 3, 5}}; /* SURVEY 8c */
+    for (int64_t i = 0; i < stList_length(alignedPairs) && i < 4; i++) {
+        stIntTuple *pair = stList_get(alignedPairs, i);
+        CHECK(stIntTuple_get(pair, 1) == want[i][1] && stIntTuple_get(pair, 2) == want[i][2]);
+        CHECK(llabs((long long)(stIntTuple_get(pair, 0) - want[i][0])) <= 100); /* total of the last diagonal instead of per-diagonal totals: ~1e-5 */
+    }
+    /* and against the engine itself on the same input */
+    stList *engine = getAlignedPairsUsingAnchors(sM, sX, sY, anchorPairs, p, 0, 0);
+    CHECK(stList_length(engine) == 4);
+    stList_destruct(engine);
+    stList_destruct(alignedPairs);
+    for (int64_t i = 0; i <= lX + lY; i++) {
+        dpMatrix_deleteDiagonal(fwd, i);
+        dpMatrix_deleteDiagonal(bwd, i);
+    }
+    dpMatrix_destruct(fwd);
+    dpMatrix_destruct(bwd);
+    bandIterator_destruct(bandIt);
+    band_destruct(band);
+    stList_destruct(anchorPairs);
+    pairwiseAlignmentBandingParameters_destruct(p);
+    stateMachine_destruct(sM);
+    free(sX2.sequence);
+    free(sY2.sequence);
+}
+
+/* getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps (inc/pairwiseAligner.h:264) driven exactly as
+ * getAlignedPairsUsingAnchors drives it in the reference (impl/pairwiseAligner.c:1411-1444): scratch list + caller's list
+ * in extraArgs, a coordinate-correction callback that shifts and pops -- must equal getAlignedPairsUsingAnchors. */
+static int correctionCalls = 0;
+static int64_t consumed = 0; /* the minimal stList has no pop: the callback remembers how far it has read the scratch list */
+static void pop_and_shift(int64_t offsetX, int64_t offsetY, void *extraArgs) {
+    stList *sub = ((void **)extraArgs)[0], *all = ((void **)extraArgs)[1];
+    correctionCalls++;
+    for (int64_t k = stList_length(sub) - 1; k >= consumed; k--) { /* the reference pops from the end (:1415-1417) */
+        stIntTuple *i = stList_get(sub, k);
+        stList_append(all, stIntTuple_construct3(stIntTuple_get(i, 0), stIntTuple_get(i, 1) + offsetX, stIntTuple_get(i, 2) + offsetY));
+    }
+    consumed = stList_length(sub);
+}
+static void test_splitting_wrapper_gpu(void) {
+    /* two similar 600-base sequences with a 40-base insertion in Y in the middle: anchors around the gap, split at 10 x 10 */
+    enum { L = 600 };
+    static char sx[L + 1], sy[L + 41];
+    const char bases[4] = {'A', 'C', 'G', 'T'};
+    uint64_t z = 12345;
+    for (int i = 0; i < L; i++) {
+        z = z * 6364136223846793005ull + 1442695040888963407ull;
+        sx[i] = bases[(z >> 33) & 3];
+    }
+    sx[L] = 0;
+    memcpy(sy, sx, 300);
+    for (int i = 0; i < 40; i++) sy[300 + i] = bases[(i * 7 + 1) & 3];
+    memcpy(sy + 340, sx + 300, 300);
+    sy[L + 40] = 0;
+    stList *anchors = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    for (int x = 20; x < 290; x += 30) stList_append(anchors, stIntTuple_construct3(x, x, 10));
+    for (int x = 310; x < 590; x += 30) stList_append(anchors, stIntTuple_construct3(x, x + 40, 10));
+    StateMachine *sM = stateMachine5_construct(fiveState);
+    PairwiseAlignmentParameters *p = pairwiseAlignmentBandingParameters_construct();
+    p->splitMatrixBiggerThanThis = 100;
+    p->diagonalExpansion = 10;
+    stList *want = getAlignedPairsUsingAnchors(sM, sx, sy, anchors, p, 0, 0);
+    stList *splits = getSplitPoints(anchors, L, L + 40, 100, 0, 0);
+    CHECK(stList_length(splits) >= 2);
+    stList *sub = stList_construct();
+    stList *all = stList_construct3(0, (void (*)(void *))stIntTuple_destruct);
+    void *extraArgs[2] = {sub, all};
+    correctionCalls = 0;
+    getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps(sM, anchors, sx, sy, L, L + 40, p, 0, 0, diagonalCalculationPosteriorMatchProbs,
+                                                               NULL, extraArgs);
+    /* without a correction callback every rectangle's pairs stay in the scratch list, in rectangle coordinates */
+    CHECK(stList_length(sub) == stList_length(want) && correctionCalls == 0);
+    /* with the callback: called once per rectangle with the rectangle's origin, and the caller's list comes out as
+     * getAlignedPairsUsingAnchors builds it -- same triples, same order */
+    stList *sub2 = stList_construct();
+    void *extraArgs2[2] = {sub2, all};
+    consumed = 0;
+    getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps(sM, anchors, sx, sy, L, L + 40, p, 0, 0, diagonalCalculationPosteriorMatchProbs,
+                                                               (void (*)())pop_and_shift, extraArgs2);
+    CHECK(correctionCalls == stList_length(splits));
+    CHECK(stList_length(all) == stList_length(want) && stList_length(want) > 500);
+    for (int64_t i = 0; i < stList_length(all) && i < stList_length(want); i++)
+        for (int f = 0; f < 3; f++) CHECK(stIntTuple_get(stList_get(all, i), f) == stIntTuple_get(stList_get(want, i), f));
+    for (int64_t i = 0; i < stList_length(sub); i++) stIntTuple_destruct(stList_get(sub, i));
+    for (int64_t i = 0; i < stList_length(sub2); i++) stIntTuple_destruct(stList_get(sub2, i));
+    stList_destruct(sub);
+    stList_destruct(sub2);
+    stList_destruct(all);
+    stList_destruct(splits);
+    stList_destruct(want);
+    stList_destruct(anchors);
+    pairwiseAlignmentBandingParameters_destruct(p);
+    stateMachine_destruct(sM);
+}
+
 int main(int argc, char **argv) {
     const int gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
     test_bands();
@@ -420,9 +636,20 @@ int main(int argc, char **argv) {
     test_symbols();
     test_models();
     test_diagonal_logadd_dynamic_band_hmm_json();
+    test_dp_containers();
+    test_list_helpers();
     if (gpu) test_known_answers_gpu();
     if (gpu) test_getPosteriorProbsWithBanding_gpu();
     if (gpu) test_consumers_gpu();
+    if (gpu) {
+        StateMachine *sM5 = stateMachine5_construct(fiveState), *sM3 = stateMachine3_construct(threeState);
+        test_cell_gpu(sM5);
+        test_cell_gpu(sM3);
+        stateMachine_destruct(sM5);
+        stateMachine_destruct(sM3);
+        test_diagonalDPCalculations_gpu();
+        test_splitting_wrapper_gpu();
+    }
     printf("%s: %d failure(s)\n", gpu ? "gpu" : "cpu", failures);
     return failures != 0;
 }
