@@ -851,6 +851,8 @@ typedef struct {
 /* what planning keeps of a region's band walk */
 typedef struct {
     int64_t maxW, liveMax, fbMax, nSeg, refreshMax;
+    int smooth; /* both edges of the band move by exactly one x-y step per diagonal (fixed expansions do): the region may run
+                 * under the absolute-position sweeps (cpk_table_gather.inl, "positions") */
 } RegionPlan;
 
 static int by_cost_desc(const void *a, const void *b) {
@@ -950,6 +952,8 @@ int cpecan_batch_upload(cpecan_batch *b) {
             int64_t offAfter = 0;        /* cells before diagonal tracedBackTo + 1 */
             int64_t slot = 0; /* d % K without the division: this loop runs once per diagonal of the batch */
             int64_t maxW = 0;
+            int64_t prevLo = 0, prevHi = 0;
+            int smooth = !dynamic;
             const int64_t minBetween = p->minDiagsBetweenTraceBack, narrow = p->diagonalExpansion * 2 + 1;
             for (int64_t d = 0; d <= N && !bad; d++, slot = slot + 1 == K ? 0 : slot + 1) {
                 int64_t lo, hi;
@@ -962,6 +966,12 @@ int cpecan_batch_upload(cpecan_batch *b) {
                     bad = 1;
                     break;
                 }
+                if (d > 0) {
+                    const int64_t dl = lo - prevLo, dh = hi - prevHi;
+                    smooth &= (dl == 1 || dl == -1) && (dh == 1 || dh == -1);
+                }
+                prevLo = lo;
+                prevHi = hi;
                 histOff[slot] = cells;
                 histW[slot] = w;
                 if (d == 1) offAfter = cells; /* tracedBackTo == 0 for the first segment */
@@ -992,6 +1002,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
                 offAfter = histOff[tfSlot] + histW[tfSlot];
             }
             pl->maxW = maxW;
+            pl->smooth = smooth;
             if (bad) {
 #pragma omp critical(cpk_plan)
                 {
@@ -1084,6 +1095,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
         g->raggedLeft = r->raggedLeft;
         g->raggedRight = r->raggedRight;
         g->maxWidth = (int32_t)pl->maxW;
+        g->absOk = pl->smooth;
         /* ring: diagonals are laid down one after another and never straddle the end of the ring */
         g->ringCap = (int32_t)imin(pl->liveMax + pl->maxW, ((int64_t)1 << 31) - 1);
         g->dbgCellOff = dbgCells;

@@ -64,6 +64,7 @@ typedef struct {
     int32_t ringCap;          /* cells of forward ring the region needs: its longest live span + its widest diagonal */
     int32_t nAnchors;
     int32_t split;            /* set by the device layer: the region's tracebacks run as separate queue items */
+    int32_t absOk;            /* planning: the band's edges move by one x-y step per diagonal (absolute-position sweeps allowed) */
 } CpkRegion;
 
 /* Model constants as the kernels use them: per-state priors, named transitions and padded emissions. */

@@ -23,6 +23,7 @@ struct KArgs {
     KConsts kc;
     const CpkRegion *regions;
     const CpkDiag *diags;
+    const int32_t *dpos;  // per diagonal: positions of the absolute-position sweeps (cpk_table_gather.inl); null without them
     const CpkSegment *segs;
     const uint8_t *symbols;
     const CpkModel *model;
@@ -284,6 +285,9 @@ struct DiagCache {
     int base;  // diagonal held by lane 0
     int lane;
     int eXmyL, eWidth, eRing, eCell;
+    // absolute-position sweeps only: the region's slice of KArgs::dpos and the chunk's entries of it
+    const int32_t *posTable = nullptr;
+    int ePos = 0;
 
     __device__ __forceinline__ void load(int b) {
         base = b;
@@ -294,9 +298,15 @@ struct DiagCache {
         eWidth = e.y;
         eRing = e.z;
         eCell = e.w;
+        if (posTable) ePos = posTable[i];
         // consume the loaded registers here so the s_waitcnt for this load sits inside the (rare) refill branch;
         // otherwise hipcc puts a vmcnt(0) at the branch merge and every diagonal waits for its ring stores
-        asm volatile("" ::"v"(eXmyL), "v"(eWidth), "v"(eRing), "v"(eCell));
+        asm volatile("" ::"v"(eXmyL), "v"(eWidth), "v"(eRing), "v"(eCell), "v"(ePos));
+    }
+    __device__ __forceinline__ int posAt(int l) const { return __builtin_amdgcn_readlane(ePos, l); }
+    __device__ __forceinline__ int posGet(int d, bool descending) {
+        if (d < base || d >= base + CPK_WAVE) load(descending ? d - (CPK_WAVE - 1) : d);
+        return __builtin_amdgcn_readlane(ePos, __builtin_amdgcn_readfirstlane(d - base));
     }
     // entry held by lane l of the current chunk (l wave-uniform).  The hot loops walk a chunk with load() outside the
     // loop over its 64 diagonals: a lazy refill inside the loop costs a range check, a branch and a round of VGPR

@@ -7,7 +7,9 @@
 // (sc1, write-through / read-through) so that no L2 write-back or invalidate is needed around the hand-off
 // RDBL: a table entry's ringOff counts doubles (the ring of a split region keeps only the states that are read back,
 // cpk_table_gather.inl) instead of cells of S doubles
-template <int S, bool FAST, int ROWS = 2 * S + 1, bool COH = false, bool RDBL = false>
+// ABS: the rolling rows are indexed by a cell's POSITION (its matrix diagonal, cpk_table_gather.inl "positions") instead of
+// its rank on the anti-diagonal: neighbours sit at constant offsets, out-of-band ones read -inf without a range test
+template <int S, bool FAST, int ROWS = 2 * S + 1, bool COH = false, bool RDBL = false, bool ABS = false>
 struct Sweep {
     const KArgs &a;
     const KConsts &m;  // kernarg-resident constants
@@ -63,7 +65,7 @@ struct Sweep {
     // kernel and everything added to it per diagonal / per group is wave-uniform, so no per-access multiply is left.
     // sel(iR, wR): element offset of neighbour cell i of a diagonal with w cells (wR = w*R; w = 0: no such diagonal),
     // or the offset of the -inf guard (position 0) when the neighbour is outside the band.
-    __device__ __forceinline__ static int sel(int iR, int wR) { return ((unsigned)iR < (unsigned)wR) ? iR : -R; }
+    __device__ __forceinline__ static int sel(int iR, int wR) { return ABS ? iR : (((unsigned)iR < (unsigned)wR) ? iR : -R); }
     __device__ __forceinline__ double *fbuf1(int d) const { return roll + R + (d & 1) * S; }
     __device__ __forceinline__ double *bM1(int d) const { return roll + R + (d + 3) % 3; }
     __device__ __forceinline__ double *bG1(int d) const { return roll + R + 2 + (d & 1) * (S - 1); }
@@ -395,6 +397,199 @@ struct Sweep {
             tail.cur = cur;
             tail.out = out;
         }
+        f2 = f1;
+        f1 = g;
+    }
+
+    // =====================================================================================================================
+    // Absolute-position sweeps (ABS).  A cell of diagonal d with x-y = xmy lives at position p = (xmy - B) >> 1 of the row
+    // set of d's parity (rows (d & 1) * S + state), B an even base that changes rarely; the table builder lays the
+    // positions out per diagonal and per sweep direction (cpk_table_gather.inl, "positions": bit 15 of a diagonal's value
+    // = the base moves in front of it).  What that buys:
+    //  * the neighbours of a cell are at CONSTANT offsets -- the middle one (d -+ 2, same x-y) at the cell's own position,
+    //    in the same row set, so a diagonal's values replace those of d -+ 2 in place, position by position, whatever
+    //    the order of the groups; the two of d -+ 1 at p - 1 and p (d even) or p and p + 1 (d odd) of the other set --
+    //    no per-diagonal shifts, no range tests: a position outside the band holds -inf unless a band cell wrote it, and
+    //    the re-base below wipes what a rectangle of the band leaves behind before the next one can read it;
+    //  * a group shared by the last cells of one diagonal and the first cells of the next differs per lane in two LDS
+    //    offsets, the diagonal number and the first x: the traceback can stream cells across diagonals as the forward
+    //    sweep does (lane fill 80 % -> 95 %) for a dozen instructions per shared group instead of ~120
+    //    (profiles/r02_ab_traceback_stream.log).
+    // =====================================================================================================================
+    struct AbsDiag {       // one diagonal as the groups of its cells see it (wave-uniform; per lane in a shared group)
+        int d;             // the diagonal
+        int xlo;           // x of its first cell
+        int ownR;          // (position of its first cell - 1) * R: element offset of cell 0 from a row pointer at position 1
+        int W;
+        double *cur;       // row set of d's parity, position 1: the diagonal's values go there, over those of d -+ 2
+        const double *lu;  // the other row set, shifted by d's parity: the neighbour at x-y - 1 is at the cell's own offset,
+                           // the one at x-y + 1 R elements further
+    };
+    __device__ __forceinline__ AbsDiag absDiag(int d, const CpkDiag &g, int pLo) const {
+        AbsDiag c;
+        c.d = d;
+        c.xlo = (d + g.xmyL) >> 1;
+        c.ownR = (pLo - 1) * R;
+        c.W = g.width;
+        c.cur = roll + R + (d & 1) * S;
+        c.lu = roll + R + ((d + 1) & 1) * S + ((d & 1) - 1) * R;
+        return c;
+    }
+    // every position of every row: -inf (a region's forward sweep and a segment's traceback start from empty rows)
+    __device__ void absWipe() {
+        for (int i = lane; i < R * stride; i += CPK_WAVE) roll[i] = NEG_INF;
+        roll_fence<false>();
+    }
+    // Moves the W cells of diagonal dd (first cell at position pOld of its row set) by `delta` positions and sets every
+    // other position of that row set to -inf.  W = 0: the diagonal does not exist, the set is wiped.
+    __device__ void absMoveRows(int dd, int pOld, int W, int delta) {
+        double *set = roll + (dd & 1) * S;  // position 0
+        const int nG = (W + CPK_WAVE - 1) / CPK_WAVE;
+        if (delta != 0) {
+            for (int i = 0; i < nG; i++) {  // memmove order: towards higher positions from the top group down
+                const int k = (delta > 0 ? nG - 1 - i : i) * CPK_WAVE + lane;
+                const int src = (pOld + k) * R;
+                double v[S];
+                if (k < W) {
+#pragma unroll
+                    for (int st = 0; st < S; st++) v[st] = lds1(set + src + st);
+                }
+                roll_fence<false>();
+                if (k < W) {
+#pragma unroll
+                    for (int st = 0; st < S; st++) set[src + delta * R + st] = v[st];
+                }
+                roll_fence<false>();
+            }
+        }
+        const int pNew = pOld + delta;
+        for (int p = lane; p < stride; p += CPK_WAVE) {
+            if (p < pNew || p >= pNew + W) {
+#pragma unroll
+                for (int st = 0; st < S; st++) set[p * R + st] = NEG_INF;
+            }
+        }
+        roll_fence<false>();
+    }
+    // The base moves in front of diagonal d (first cell at position pLo under the new base): the two live diagonals --
+    // e1 (d - dir, first cell at p1 under the old base) and, where `have2`, e2 (d - 2 dir, at p2) -- move along, everything
+    // else becomes -inf.  dir = +1: forward sweep, -1: traceback.  Returns the shift in positions.
+    __device__ int absRebase(int d, const CpkDiag &g, int pLo, int dir, const CpkDiag &e1, int p1, bool have1, const CpkDiag &e2, int p2, bool have2) {
+        int delta = 0;
+        if (have1) {
+            const int bNew = g.xmyL - 2 * pLo - (d & 1), bOld = e1.xmyL - 2 * p1 - ((d - dir) & 1);
+            delta = (bOld - bNew) >> 1;  // both bases are even
+        }
+        absMoveRows(d - dir, p1, have1 ? e1.width : 0, delta);
+        absMoveRows(d - 2 * dir, p2, have2 ? e2.width : 0, delta);
+        return delta;
+    }
+
+    // ---- forward sweep as a stream of cells over absolute positions (cf. forwardStream) ----
+    struct AbsTail {
+        bool has;
+        int k0, n;   // leftover cells [k0, k0 + n) of diagonal c.d
+        int rs;
+        AbsDiag c;
+        double *out;
+    };
+    AbsTail atail{};
+    int apos1 = 0, apos2 = 0;  // first-cell positions of the diagonals d - 1 / d - 2 (f1 / f2) under the base in force
+
+    // cells [kb, kb + 64) of one diagonal, clipped to [kb, hi)
+    __device__ __forceinline__ void absFwdGroup(const AbsDiag &c, double *out, int rs, int kb, int hi) {
+        const int k0 = kb + lane;
+        if (k0 < hi) {
+            const int kk[1] = {k0};
+            const int kkR[1] = {c.ownR + kb * R + laneR};
+            FwdCtx f;
+            f.d = c.d;
+            f.xlo = c.xlo;
+            f.dlR = 0;
+            f.w1R = 0;
+            f.dmR = 0;
+            f.w2R = 0;
+            f.p1 = c.lu;
+            f.p2 = c.cur;
+            double v[1][S];
+            fwdCells<1>(f, kk, kkR, v);
+#pragma unroll
+            for (int st = 0; st < S; st++) c.cur[st + kkR[0]] = v[0][st];
+            ringPut(out, c.W, k0, k0 + 1 < hi && lane < CPK_WAVE - 1, lane > 0, v[0], rs);
+        }
+    }
+    __device__ void absFlushTail() {
+        if (!atail.has) return;
+        absFwdGroup(atail.c, atail.out, atail.rs, atail.k0, atail.k0 + atail.n);
+        atail.has = false;
+    }
+    // pos: the diagonal's entry of KArgs::dpos, forward half (position of its first cell | base-moves flag << 15)
+    __device__ void forwardStreamAbs(int d, const CpkDiag &g, int pos, int ringStates) {
+        const int W = g.width;
+        const int pLo = pos & 0x7fff;
+        if (pos & 0x8000) {  // rare: once per rectangle of the band
+            absFlushTail();
+            const int delta = absRebase(d, g, pLo, 1, f1, apos1, d >= 1, f2, apos2, d >= 2);
+            apos1 += delta;
+            apos2 += delta;
+        }
+        const AbsDiag c = absDiag(d, g, pLo);
+        double *out = ringAt(g);
+        int lo = 0;
+        if (atail.has) {
+            // Lanes [0, r) finish diagonal A = d - 1, lanes [r, r + b) start this one.  Its cells [0, b) read F[A] up to
+            // position pLo + b - 1 + (d & 1), which earlier groups must have written: below the first leftover cell of A.
+            // (They replace F[d - 2] = F[A - 1] at positions [pLo, pLo + b), below everything A's leftover cells read, and
+            // within the group every load precedes every store.)
+            const int r = atail.n;
+            const int b = CPK_WAVE - r < W ? CPK_WAVE - r : W;
+            if (c.ownR + (b + (d & 1)) * R < atail.c.ownR + atail.k0 * R) {
+                const bool inA = lane < r;
+                const bool inB = !inA && lane - r < b;
+                // idle lanes (a narrow diagonal) recompute this diagonal's first cell and store nothing
+                const int k = inA ? atail.k0 + lane : (inB ? lane - r : 0);
+                const int kR = inA ? atail.c.ownR + atail.k0 * R + laneR : (inB ? c.ownR - r * R + laneR : c.ownR);
+                FwdCtx m;
+                m.d = inA ? atail.c.d : c.d;
+                m.xlo = inA ? atail.c.xlo : c.xlo;
+                m.dlR = 0;
+                m.w1R = 0;
+                m.dmR = 0;
+                m.w2R = 0;
+                m.p1 = inA ? atail.c.lu : c.lu;
+                double *curL = inA ? atail.c.cur : c.cur;
+                m.p2 = curL;
+                double *outL = inA ? atail.out : out;
+                const int WL = inA ? atail.c.W : W;
+                const int rsL = inA ? atail.rs : ringStates;
+                const int kk[1] = {k};
+                const int kkR[1] = {kR};
+                double v[1][S];
+                fwdCells<1>(m, kk, kkR, v);
+                if (inA || inB) {
+#pragma unroll
+                    for (int st = 0; st < S; st++) curL[st + kR] = v[0][st];
+                    ringPut(outL, WL, k, inA ? lane + 1 < r : lane + 1 - r < b, inA ? lane > 0 : lane > r, v[0], rsL);
+                }
+                atail.has = false;
+                lo = b;
+            } else {
+                absFlushTail();
+            }
+        }
+        // whole groups now, the leftover waits for the next diagonal (ONE call site for the uniform group: code size)
+        const int nWhole = (W - lo) >> 6;
+        for (int i = 0; i < nWhole; i++, lo += CPK_WAVE) absFwdGroup(c, out, ringStates, lo, W);
+        if (W > lo) {
+            atail.has = true;
+            atail.k0 = lo;
+            atail.n = W - lo;
+            atail.rs = ringStates;
+            atail.c = c;
+            atail.out = out;
+        }
+        apos2 = apos1;
+        apos1 = pLo;
         f2 = f1;
         f1 = g;
     }

@@ -7,8 +7,54 @@
 // position follows the rule the kernels rely on: diagonals are laid end to end and never straddle the ring's end.
 // (In a pipeline of batches this kernel of batch k+1 runs on that batch's own stream; its 56 allocated VGPRs do not fit
 // in the 48 a resident sweep of batch k leaves free per lane, so it starts when that sweep drains: ~3 ms per config-B batch.)
+// ---- positions for the absolute-position sweeps (Sweep::forwardStreamAbs / tracebackAbs, cpk_sweep.inl) ----
+// Those sweeps keep the rolling rows indexed by a cell's matrix diagonal instead of its rank on the anti-diagonal:
+// position p = (xmy - B) >> 1 for an even base B that changes rarely, so that a cell's three neighbours sit at constant
+// offsets (d even: lower p-1, upper p; d odd: lower p, upper p+1; middle p) and out-of-band neighbours read the -inf a
+// position holds unless a band cell wrote it.  Two things need care, and both are decided HERE, per diagonal and per
+// sweep direction, so that the kernels only follow a flag:
+//  * the positions of three consecutive diagonals must fit the rows: [1, P - 2] with P = maxWidth + kAbsSlack positions
+//    (0 and P - 1 stay -inf);
+//  * a position vacated by the band keeps its last value.  Inside one rectangle of the band an in-band cell never has an
+//    out-of-band neighbour that was in the band before (such neighbours lie left of / below the rectangle); across
+//    rectangles it can -- exactly when an edge of the band turns back over positions it has left: the low edge after
+//    rising, the high edge after falling (with a fixed expansion both edges move by exactly 1 per diagonal).  At such a
+//    turn, or when an edge jumps, the sweep re-bases: it moves the two live diagonals to the new positions and wipes
+//    everything else (Sweep::absRebase).
+// dpos[d] = posF | flagF << 15 | posB << 16 | flagB << 31: position of the diagonal's first cell under the base of the
+// forward (ascending) / backward (descending) sweep when it computes d, and whether the base changed in front of d.
+constexpr int kAbsSlack = 6;
+__device__ __forceinline__ int abs_chain_step(int lo, int hi, int lo1, int hi1, int lo2, int hi2, int have, int P, int &B) {
+    // lo/hi: x-y range of the diagonal about to be computed; lo1/hi1, lo2/hi2: the one / two diagonals before it in sweep
+    // order (have = how many of them exist).  Returns the position of the first cell, bit 15 set when the base moved.
+    int needLo = lo, needHi = hi;
+    bool danger = have == 0;
+    if (have >= 1) {
+        needLo = lo1 < needLo ? lo1 : needLo;
+        needHi = hi1 > needHi ? hi1 : needHi;
+        const int dl = lo - lo1, dh = hi - hi1;
+        danger = danger || (dl != 1 && dl != -1) || (dh != 1 && dh != -1);
+        if (have >= 2) {
+            needLo = lo2 < needLo ? lo2 : needLo;
+            needHi = hi2 > needHi ? hi2 : needHi;
+            danger = danger || (lo < lo1 && lo1 > lo2) || (hi > hi1 && hi1 < hi2);  // an edge turns back over vacated positions
+        }
+    }
+    const bool fits = ((needLo - B) >> 1) >= 1 && ((needHi - B) >> 1) <= P - 2;
+    int flag = 0;
+    if (danger || !fits) {
+        const int span = ((needHi - needLo) >> 1) + 2;  // positions the three diagonals cover, mixed parity included
+        int slack = (P - 2) - span;
+        if (slack < 0) slack = 0;
+        B = needLo - 2 * (1 + slack / 2);
+        B -= B & 1;  // even (two's complement: rounds towards -infinity)
+        flag = 1;
+    }
+    return ((lo - B) >> 1) | (flag << 15);
+}
+
 __global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *regions, int nRegions, const cpk_anchor_t *anchors, int anchorStride,
-                                                              const CpkSegment *segs, int S, CpkDiag *diags, int64_t expansion, int dynamic) {
+                                                              const CpkSegment *segs, int S, CpkDiag *diags, int32_t *dpos, int64_t expansion, int dynamic) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nRegions) return;
     const CpkRegion rg = regions[i];
@@ -48,6 +94,27 @@ __global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *r
         }
         table[d] = e;
         cells += w;
+    }
+    if (!dpos || dynamic) return;
+    // the position chains of the absolute-position sweeps (see above); the entries just written are read back
+    int32_t *pt = dpos + rg.diagOff;
+    const int P = rg.maxWidth + kAbsSlack;
+    {
+        int B = 0, lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0;
+        for (int64_t d = 0; d <= N; d++) {
+            const int lo = table[d].xmyL, hi = lo + 2 * (table[d].width - 1);
+            pt[d] = abs_chain_step(lo, hi, lo1, hi1, lo2, hi2, d >= 2 ? 2 : (int)d, P, B);
+            lo2 = lo1; hi2 = hi1; lo1 = lo; hi1 = hi;
+        }
+    }
+    {
+        int B = 0, lo1 = 0, hi1 = 0, lo2 = 0, hi2 = 0;
+        for (int64_t d = N; d >= 0; d--) {
+            const int lo = table[d].xmyL, hi = lo + 2 * (table[d].width - 1);
+            const int v = abs_chain_step(lo, hi, lo1, hi1, lo2, hi2, N - d >= 2 ? 2 : (int)(N - d), P, B);
+            pt[d] = (pt[d] & 0xffff) | (v << 16);
+            lo2 = lo1; hi2 = hi1; lo1 = lo; hi1 = hi;
+        }
     }
 }
 

@@ -609,7 +609,11 @@ static void test_splitting_wrapper_gpu(void) {
     getPosteriorProbsWithBandingSplittingAlignmentsByLargeGaps(sM, anchors, sx, sy, L, L + 40, p, 0, 0, diagonalCalculationPosteriorMatchProbs,
                                                                (void (*)())pop_and_shift, extraArgs2);
     CHECK(correctionCalls == stList_length(splits));
-    CHECK(stList_length(all) == stList_length(want) && stList_length(want) > 500);
+    /* anchors 30 apart and split at 100 cells: only ~10 x 10 boxes around the anchors are aligned, one rectangle each */
+    CHECK(stList_length(all) == stList_length(want) && stList_length(want) > 100);
+    if (stList_length(all) != stList_length(want) || stList_length(want) <= 100)
+        fprintf(stderr, "splitting wrapper: %lld pairs through the wrapper, %lld from getAlignedPairsUsingAnchors, %lld rectangles\n",
+                (long long)stList_length(all), (long long)stList_length(want), (long long)stList_length(splits));
     for (int64_t i = 0; i < stList_length(all) && i < stList_length(want); i++)
         for (int f = 0; f < 3; f++) CHECK(stIntTuple_get(stList_get(all, i), f) == stIntTuple_get(stList_get(want, i), f));
     for (int64_t i = 0; i < stList_length(sub); i++) stIntTuple_destruct(stList_get(sub, i));
