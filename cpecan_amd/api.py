@@ -92,7 +92,7 @@ EXPORTS = [
     "cpecan_mea_alignment", "cpecan_left_shift_alignment", "cpecan_get_shifted_mea_alignment",
     "cpecan_anchors_from_alignment", "cpecan_batch_set_match_gamma", "cpecan_batch_identity_scores",
     "cpecan_identity_scores", "cpecan_filter_pairs_ordered", "cpecan_batch_add_many",
-    "cpecan_filter_to_remove_overlap", "cpecan_cache_trim",
+    "cpecan_filter_to_remove_overlap", "cpecan_cache_trim", "cpecan_ref_cells",
 ]
 OP_MATCH, OP_INDEL_X, OP_INDEL_Y = 0, 1, 2
 POST_REWEIGHT, POST_MEA, POST_LEFT_SHIFT, POST_ORDERED = 1, 2, 4, 8

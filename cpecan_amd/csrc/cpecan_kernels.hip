@@ -100,6 +100,7 @@ struct LaunchClass {
     bool split = false;
     bool dense = false;  // three-state match kernels allocated for three waves per SIMD (WPS = 3)
     bool fused = false;  // split, as ONE launch (kModeFused): regions and their traceback items in one queue
+    bool abs = false;    // split, with the sweeps over absolute positions (cpk_sweep.inl "Absolute-position sweeps")
     KernelFn fnTrace = nullptr;
     int wavesTrace = 0;
     int64_t itemBase = 0, itemCount = 0;  // its items in dItems
@@ -483,6 +484,7 @@ struct CpkDevice {
     // device buffers
     CpkRegion *dRegions = nullptr;
     CpkDiag *dDiags = nullptr;
+    int32_t *dDiagPos = nullptr;  // positions of the absolute-position sweeps, one word per diagonal (fixed expansions only)
     CpkSegment *dSegs = nullptr;
     uint8_t *dSymbols = nullptr;
     CpkModel *dModel = nullptr;
@@ -628,7 +630,7 @@ static void free_all(CpkDevice *d) {
     cache_free(d->device, d->dCompact, d->compactBytes);
     cache_free(d->device, d->dChunks, d->chunkBytes);
     d->compactBytes = d->chunkBytes = 0;
-    d->dRegions = nullptr; d->dDiags = nullptr; d->dSegs = nullptr; d->dSymbols = nullptr; d->dModel = nullptr;
+    d->dRegions = nullptr; d->dDiags = nullptr; d->dDiagPos = nullptr; d->dSegs = nullptr; d->dSymbols = nullptr; d->dModel = nullptr;
     d->dRing = d->dC = d->dM = d->dTotals = d->dGroll = d->dBring = nullptr;
     d->dCand = nullptr;
     d->dForward = nullptr;
@@ -720,16 +722,32 @@ static int64_t split_ring_doubles(const CpkRegion &rg, int S) {
     return ((int64_t)rg.cells + (N + 1) + (int64_t)(S - 1) * rg.maxWidth * fullDiags + S + 1) & ~(int64_t)1;
 }
 // dense: the three-state match kernels allocated for three waves per SIMD (cpk_sweep.inl, WPS)
-static KernelFn pick_fused_kernel(const CpkGeometry &g, bool dense) {
+static KernelFn pick_fused_kernel(const CpkGeometry &g, bool dense, bool abs) {
     const bool fast = !g.useGlobalRoll;
+    if (abs && fast) {
+        if (g.nStates == 5) return cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeFused, CPK_SWEEP_WAVES, true>;
+        return dense ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeFused, 3, true>
+                     : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeFused, CPK_SWEEP_WAVES, true>;
+    }
     if (g.nStates == 5)
         return fast ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeFused> : cpecan_pairhmm_sweep<5, false, CPECAN_EMIT_MATCH, kModeFused>;
     if (dense)
         return fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeFused, 3> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeFused, 3>;
     return fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeFused> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeFused>;
 }
-static void pick_split_kernels(const CpkGeometry &g, bool dense, KernelFn *fwd, KernelFn *trace) {
+static void pick_split_kernels(const CpkGeometry &g, bool dense, bool abs, KernelFn *fwd, KernelFn *trace) {
     const bool fast = !g.useGlobalRoll;
+    if (abs && fast) {
+        if (g.nStates == 5) {
+            *fwd = cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeForward, CPK_SWEEP_WAVES, true>;
+            *trace = cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeTrace, CPK_SWEEP_WAVES, true>;
+        } else {
+            *fwd = cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeForward, CPK_SWEEP_WAVES, true>;
+            *trace = dense ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeTrace, 3, true>
+                           : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeTrace, CPK_SWEEP_WAVES, true>;
+        }
+        return;
+    }
     if (g.nStates == 5) {
         *fwd = fast ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeForward> : cpecan_pairhmm_sweep<5, false, CPECAN_EMIT_MATCH, kModeForward>;
         *trace = fast ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeTrace> : cpecan_pairhmm_sweep<5, false, CPECAN_EMIT_MATCH, kModeTrace>;
@@ -860,7 +878,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         c.geo.fbCells = geo->pFbCells[k];
         c.geo.maxRefresh = geo->pMaxRefresh[k];
         c.geo.refreshCells = (int64_t)GW * geo->pMaxRefresh[k];
-        c.ldsBytes = sizeof(double) * (size_t)(kLdsCubics + 40 + kLdsWeights + (expect ? kExpectCopies * 80 : 0)) +
+        c.ldsBytes = sizeof(double) * (size_t)(kLdsCubics + kLdsEm + kLdsWeights + (expect ? kExpectCopies * 80 : 0)) +
                      (size_t)G * pack_group_bytes(S, GW);
         int perCU = 0;
         if (int rc = wavesPerCU(c.fn, c.ldsBytes, &perCU)) return rc;
@@ -890,6 +908,23 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         c.geo.fbCells = geo->wFbCells[k];
         c.geo.seqLdsBytes = geo->wSeqLdsBytes[k];
         c.geo.rollStride = c.geo.maxWidth + 1;
+        // Will the class run split (its tracebacks as queue items; decided below, once the occupancy is known)?  Then, with
+        // a fixed expansion and bands whose edges move one step per diagonal (CpkRegion::absOk), its sweeps index the
+        // rolling rows by absolute position (cpk_sweep.inl): the rows need a few positions of slack.
+        // CPECAN_ABS=0: never (A/B runs, tests of the other form).
+        int64_t nSegClass = 0;
+        bool absOk = geo->emit == CPECAN_EMIT_MATCH && !dynamic;
+        for (int64_t di = regionAt; di < regionAt + geo->nWide[k]; di++) {
+            nSegClass += regions[di].nSeg;
+            absOk = absOk && regions[di].absOk;
+        }
+        {
+            const char *env = getenv("CPECAN_SPLIT"), *absEnv = getenv("CPECAN_ABS");
+            const bool splitLikely = geo->emit == CPECAN_EMIT_MATCH && (!geo->debug || env) && nSegClass > 0 &&
+                                     (env ? atoi(env) != 0 : nSegClass * 4 >= (int64_t)geo->nWide[k] * 5);
+            c.abs = splitLikely && absOk && !(absEnv && atoi(absEnv) == 0);
+            if (c.abs) c.geo.rollStride = c.geo.maxWidth + kAbsSlack;
+        }
         c.geo.refreshCells = (int64_t)c.geo.maxWidth * c.geo.maxRefresh;
         if (c.geo.refreshCells < 1) c.geo.refreshCells = 1;
         c.geo.rollDoubles = (int64_t)(2 * S + 1) * c.geo.rollStride;
@@ -897,6 +932,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         const size_t header = sizeof(double) * (lds_header_doubles(geo->emit) + lds_stage_doubles(geo->emit));
         const size_t fastLds = header + sizeof(double) * (size_t)c.geo.rollDoubles + (size_t)((c.geo.seqLdsBytes + 15) / 16 * 16);
         c.geo.useGlobalRoll = fastLds + 16 > 64 * 1024;
+        if (c.geo.useGlobalRoll) c.abs = false;  // absolute positions are a form of the LDS rows
         c.ldsBytes = c.geo.useGlobalRoll ? header : fastLds;
         c.fn = pick_kernel(c.geo);
         if (!c.fn) {
@@ -977,15 +1013,15 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         {
             // Split the class when its regions do not fill the chip and have tracebacks to hand out: the segments of a
             // region are independent once its forward values exist.  CPECAN_SPLIT=1 / 0 (tests, diagnostics): always / never.
-            int64_t nSegClass = 0, maxRing = 0;
+            int64_t maxRing = 0;
             for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++) {
-                nSegClass += regions[di].nSeg;
                 const int64_t rd = split_ring_doubles(regions[di], S);
                 if (rd > maxRing) maxRing = rd;
             }
             const char *env = getenv("CPECAN_SPLIT");
             const int64_t slots = (int64_t)perCU * d->numCUs;
-            const bool eligible = c.threads == CPK_WAVE && geo->emit == CPECAN_EMIT_MATCH && !geo->debug && nSegClass > 0;
+            // (debug buffers: split only where CPECAN_SPLIT asks for it -- the per-cell parity tests of the split forms)
+            const bool eligible = c.threads == CPK_WAVE && geo->emit == CPECAN_EMIT_MATCH && (!geo->debug || env) && nSegClass > 0;
             // Regions with tracebacks to hand out (1.25 segments on average and more) run split whenever their rings fit:
             // measured against one wave per region on 600 to 10 000 pairs of 1-4 kb and bands of 55-124 cells per diagonal,
             // one of the two split forms won every time (tools/split_forms.py, profiles/r02_split_forms.txt).  Which one:
@@ -1006,7 +1042,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                 // (the one-launch form addresses a region's ring with 32-bit byte offsets: Sweep::ringPut)
                 c.fused = (env ? atoi(env) == 2 : oneLaunch) && maxRing < ((int64_t)1 << 28);
                 if (c.fused) {
-                    c.fn = pick_fused_kernel(c.geo, c.dense);
+                    c.fn = pick_fused_kernel(c.geo, c.dense, c.abs);
                     // One CU in eight keeps a wave slot (and its 19 KB of LDS) free: a launch that fills every slot to its
                     // end starves the small kernels of the batch before it -- the list consumers need a few KB of LDS --
                     // until it drains, and a pipeline two batches deep then idles between sweeps (82 ms measured).
@@ -1018,12 +1054,14 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                     c.waves = (int)wt;
                     c.subSlots = wt;
                 } else {
-                    pick_split_kernels(c.geo, c.dense, &c.fn, &c.fnTrace);
+                    pick_split_kernels(c.geo, c.dense, c.abs, &c.fn, &c.fnTrace);
                     int64_t wt = slots < nSegClass ? slots : nSegClass;
                     c.wavesTrace = (int)wt;
                     if (wt > c.subSlots) c.subSlots = wt;
                 }
                 c.itemCount = nSegClass;
+            } else {
+                c.abs = false;  // one wave per region: the other form of the rows (its LDS keeps the slack, harmlessly)
             }
         }
         c.ringEl = c.geo.ringCells * S;
@@ -1043,7 +1081,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     // its own is one wave's worth; where a class still asks for more than the device has free, it keeps as many
     // waves as fit and the rest of its regions queue behind them.
     {
-        double fixed = (double)sizeof(CpkRegion) * geo->nRegions + (double)sizeof(CpkDiag) * nDiags +
+        double fixed = (double)sizeof(CpkRegion) * geo->nRegions + (double)(sizeof(CpkDiag) + sizeof(int32_t)) * nDiags +
                        (double)sizeof(CpkSegment) * nSegs + (double)nSymbolBytes + 24.0 * nAnchors +
                        2.0 * 12.0 * nLists * outTriplesPerList /* the triples and their compact copy */;
         size_t freeB = 0, totalB = 0;
@@ -1064,6 +1102,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                 if (!c.split) continue;
                 c.split = false;
                 c.fused = false;
+                c.abs = false;
                 c.fn = c.dense ? pick_dense_kernel(c.geo) : pick_kernel(c.geo);
                 c.fnTrace = nullptr;
                 c.subSlots = c.waves;
@@ -1146,6 +1185,12 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
 
     if (int rc = dev_alloc(d, &d->dRegions, (size_t)geo->nRegions)) return rc;
     if (int rc = dev_alloc(d, &d->dDiags, (size_t)nDiags)) return rc;
+    {
+        bool anyAbs = false;
+        for (const LaunchClass &c : d->classes) anyAbs = anyAbs || c.abs;
+        if (anyAbs)
+            if (int rc = dev_alloc(d, &d->dDiagPos, (size_t)nDiags)) return rc;
+    }
     if (int rc = dev_alloc(d, &d->dSegs, (size_t)nSegs)) return rc;
     if (int rc = dev_alloc(d, &d->dSymbols, (size_t)nSymbolBytes)) return rc;
     if (int rc = dev_alloc(d, &d->dModel, 1)) return rc;
@@ -1235,7 +1280,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             if (int rc = staged_h2d(d, dAnchors, anchors, sizeof(cpk_anchor_t) * (size_t)anchorStride * (size_t)nAnchors, &stageAt)) return rc;
         if (int rc = staged_h2d(d, d->dSegs, segs, sizeof(CpkSegment) * (size_t)nSegs, &stageAt)) return rc;  // the builder reads the schedule
         hipLaunchKernelGGL(cpecan_build_diag_table, dim3((unsigned)((geo->nRegions + 63) / 64)), dim3(64), 0, io,
-                           d->dRegions, geo->nRegions, dAnchors, anchorStride, d->dSegs, geo->nStates, d->dDiags, expansion, dynamic);
+                           d->dRegions, geo->nRegions, dAnchors, anchorStride, d->dSegs, geo->nStates, d->dDiags, d->dDiagPos, expansion, dynamic);
         HIP_TRY(hipGetLastError());
         if (int rc = staged_h2d(d, d->dSymbols, symbols, (size_t)nSymbolBytes, &stageAt)) return rc;
         if (int rc = staged_h2d(d, d->dModel, model, sizeof(CpkModel), &stageAt)) return rc;
@@ -1295,6 +1340,7 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
     a.kc = d->kc;
     a.regions = d->dRegions;
     a.diags = d->dDiags;
+    a.dpos = d->dDiagPos;
     a.segs = d->dSegs;
     a.symbols = d->dSymbols;
     a.model = d->dModel;

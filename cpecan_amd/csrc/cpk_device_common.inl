@@ -82,21 +82,40 @@ struct __attribute__((aligned(16))) Cubic {
 #define CPK_LOGADD_EXACT 0
 #endif
 
+// Shipped form: dc = min(|x - y|, 7.75) falls into one of 16 buckets of width 0.5 -- the thresholds 1.0, 2.5, 4.5, 7.5 are all
+// multiples of 0.5 -- and the bucket is floor(2 dc): one multiply and one conversion, both exact (round 2 found the segment
+// from the bit pattern of dc in four integer instructions).  The table holds, per bucket, its segment's cubic as TWO
+// 16-byte halves in two arrays of 16 rows: {c3, c2} at element 2 b, {c1 - 1, c0} at element 32 + 2 b.  An array of 16 rows of
+// 16 bytes covers the 64 banks exactly once, so each of the two ds_read_b128 of a logAdd is conflict-free whatever
+// buckets the lanes hit (one row of 32 bytes per bucket is not: rows 8 apart share banks -- measured, 26 such rows: config
+// B 88 -> 100 ms, profiles/r03_ab_cubic_table_forms.txt).
+#if CPK_LOGADD_EXACT
+constexpr int kCubicDoubles = 24;  // 5 rows of {c3, c2, c1, c0}, padded
+#else
+constexpr int kCubicDoubles = 64;  // 16 x {c3, c2}, then 16 x {c1 - 1, c0}
+#endif
 __device__ __forceinline__ void fill_cubics(double *t) {
     const float c[16] = {-0.009350833524763f, 0.130659527668286f, 0.498799810682272f, 0.693203116424741f,
                          -0.014532321752540f, 0.139942324101744f, 0.495635523139337f, 0.692140569840976f,
                          -0.004605031767994f, 0.063427417320019f, 0.695956496475118f, 0.514272634594009f,
                          -0.000458661602210f, 0.009695946122598f, 0.930734667215156f, 0.168037164329057f};
-    const int l = threadIdx.x;
-    if (l < 16) {
+    for (int l = threadIdx.x; l < kCubicDoubles; l += CPK_WAVE) {
+        int seg, coef;  // segment 0..3 (4: d >= 7.5, all zeros: the result is hi) and coefficient 0..3 = c3, c2, c1, c0
+        if (CPK_LOGADD_EXACT) {
+            seg = l >> 2;
+            coef = l & 3;
+        } else {
+            const int bucket = (l & 31) >> 1;  // [0, 1) | [1, 2.5) | [2.5, 4.5) | [4.5, 7.5) | [7.5, 8) in steps of 0.5
+            seg = bucket >= 15 ? 4 : bucket >= 9 ? 3 : bucket >= 5 ? 2 : bucket >= 2 ? 1 : 0;
+            coef = (l >> 5) * 2 + (l & 1);
+        }
+        const int idx = seg * 4 + coef;
         float v = c[0];
 #pragma unroll
-        for (int i = 1; i < 16; i++) v = l == i ? c[i] : v;
-        double w = (double)v;
-        if (!CPK_LOGADD_EXACT && (l & 3) == 2) w = w - 1.0;  // Q(d) = P(d) - d
+        for (int i = 1; i < 16; i++) v = idx == i ? c[i] : v;
+        double w = seg >= 4 ? 0.0 : (double)v;
+        if (!CPK_LOGADD_EXACT && seg < 4 && coef == 2) w = w - 1.0;  // Q(d) = P(d) - d
         t[l] = w;
-    } else if (l < 20) {
-        t[l] = 0.0;  // row 4: d >= 7.5, the result is hi
     }
 }
 
@@ -132,19 +151,21 @@ __device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
     return (d < 7.5) ? r : hi;
 }
 #else
-// Row of dc in [0, 8]: the number of thresholds T in {1.0, 2.5, 4.5, 7.5} with dc >= T.  Their bit patterns are
-// multiples of 2^49, so with hs = bits(dc) >> 49 and b = max(hs - (bits(1.0) >> 49) + 1, 0) (at most 25 for dc <= 8)
-// the row is the number of set bits of {0, 10, 17, 23} below position b: shift, saturating subtract, v_bfe, v_bcnt.
-__device__ __forceinline__ int cubic_row(double dc) {
-    const unsigned hs = (unsigned)((unsigned long long)__double_as_longlong(dc) >> 32) >> 17;
-    const unsigned b = __builtin_elementwise_sub_sat(hs, (0x3FF00000u >> 17) - 1u);
-    return __builtin_popcount(__builtin_amdgcn_ubfe((1u << 0) | (1u << 10) | (1u << 17) | (1u << 23), 0u, b));
+constexpr double kLogAddClamp = 7.75;  // any value in [7.5, 8): the last bucket, whose row is all zeros
+struct __attribute__((aligned(16))) CubicHalf {
+    double a, b;
+};
+__device__ __forceinline__ Cubic cubic_fetch(const Cubic *tab, double dc) {
+    const unsigned bucket = (unsigned)(dc * 2.0);  // v_mul_f64, v_cvt_u32_f64: exact (truncation of an exact product)
+    const CubicHalf *t = reinterpret_cast<const CubicHalf *>(tab);
+    const CubicHalf h = t[bucket], l = t[16 + bucket];
+    return Cubic{h.a, h.b, l.a, l.b};
 }
 
 __device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
     const double hi = __builtin_fmax(x, y);
-    const double dc = __builtin_fmin(__builtin_fabs(x - y), 8.0);
-    const Cubic q = tab[cubic_row(dc)];
+    const double dc = __builtin_fmin(__builtin_fabs(x - y), kLogAddClamp);
+    const Cubic q = cubic_fetch(tab, dc);
     double r = __builtin_fma(q.c3, dc, q.c2);
     r = __builtin_fma(r, dc, q.c1);
     r = __builtin_fma(r, dc, q.c0);
@@ -227,10 +248,10 @@ __device__ __forceinline__ void logadd_n(const Cubic *tab, double (&acc)[N], con
 #pragma unroll
     for (int i = 0; i < N; i++) {
         hi[i] = __builtin_fmax(acc[i], t[i]);
-        dc[i] = __builtin_fmin(__builtin_fabs(acc[i] - t[i]), 8.0);
+        dc[i] = __builtin_fmin(__builtin_fabs(acc[i] - t[i]), kLogAddClamp);
     }
 #pragma unroll
-    for (int i = 0; i < N; i++) q[i] = tab[cubic_row(dc[i])];
+    for (int i = 0; i < N; i++) q[i] = cubic_fetch(tab, dc[i]);
     double r[N];
 #pragma unroll
     for (int i = 0; i < N; i++) r[i] = __builtin_fma(q[i].c3, dc[i], q[i].c2);
@@ -344,12 +365,13 @@ struct DiagCache {
 #ifndef CPK_SWEEP_WAVES
 #define CPK_SWEEP_WAVES 2  // waves per SIMD the sweep kernel's registers are allocated for
 #endif
-constexpr int kLdsCubics = 24;  // 5 rows x 4 coefficients (4 cubics + the all-zero row), padded to 64 bytes
+constexpr int kLdsCubics = kCubicDoubles;  // the logAdd table (fill_cubics)
+constexpr int kLdsEm = 0;  // (rounds 1-2 kept 40 doubles of plain emissions here; every reader uses the (emission + transition) table)
 // doubles of LDS in front of the rolling rows: cubics + emissions (+ expectation sums for that emitter only)
 constexpr int kExpectCopies = 4;  // emission-expectation sums are kept in 4 LDS copies (lane & 3): fewer atomic collisions
 constexpr int kLdsWeights = 168;  // (emission + transition) sums, see Sweep::wt: 25*5 + 5*4 + 5*4 = 165, padded
 __host__ __device__ constexpr int lds_header_doubles(int emit) {
-    return kLdsCubics + 40 + kLdsWeights + (emit == CPECAN_EMIT_EXPECT ? kExpectCopies * 80 : 0);
+    return kLdsCubics + kLdsEm + kLdsWeights + (emit == CPECAN_EMIT_EXPECT ? kExpectCopies * 80 : 0);
 }
 // doubles of LDS behind the rolling rows for the candidate staging rings (16-byte Candidates, 128 per list; none for
 // the forward-only and expectation emitters)

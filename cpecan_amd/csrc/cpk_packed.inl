@@ -44,14 +44,10 @@ cpecan_pairhmm_packed(const KArgs a) {
 
     fill_cubics(lds);
     const Cubic *lg = reinterpret_cast<const Cubic *>(lds);
-    double *wt = lds + kLdsCubics + 40;
+    double *wt = lds + kLdsCubics + kLdsEm;
     fill_weights<S>(wt, m, a.kc, lane);
     constexpr bool kExpect = EMIT == CPECAN_EMIT_EXPECT;
-    double *em = lds + kLdsCubics;
-    if (kExpect) {  // raw emissions are only needed to tell N from ACGT: the events use the weight table
-        if (lane < 25) em[lane] = m.matchEm[lane];
-    }
-    double *eLds = lds + kLdsCubics + 40 + kLdsWeights;  // expectation emitter: emission sums of this wave, four copies
+    double *eLds = lds + kLdsCubics + kLdsEm + kLdsWeights;  // expectation emitter: emission sums of this wave, four copies
     if (kExpect)
         for (int i = lane; i < kExpectCopies * 80; i += CPK_WAVE) eLds[i] = 0.0;
     constexpr int kNT = S == 5 ? 13 : 9;
@@ -59,7 +55,7 @@ cpecan_pairhmm_packed(const KArgs a) {
 #pragma unroll
     for (int i = 0; i < kNT; i++) tAcc[i] = 0.0;
     double likelihood = 0.0;
-    uint8_t *mine = reinterpret_cast<uint8_t *>(lds + kLdsCubics + 40 + kLdsWeights + (kExpect ? kExpectCopies * 80 : 0)) +
+    uint8_t *mine = reinterpret_cast<uint8_t *>(lds + kLdsCubics + kLdsEm + kLdsWeights + (kExpect ? kExpectCopies * 80 : 0)) +
                     (size_t)g * pack_group_bytes(S, GW);
     double *rows = reinterpret_cast<double *>(mine);                                   // rolling buffers
     int4 *ebuf = reinterpret_cast<int4 *>(mine + pack_rows_bytes(S, GW));              // table entries of the chunk

@@ -92,6 +92,9 @@ struct Sweep {
     // DPP and writes both as one aligned 16 bytes, the neighbour writes nothing, and a cell's other states leave as
     // 16-byte writes too (S - 1 is even, their run starts on an even double).
     __device__ __forceinline__ void ringPut(double *out, int W, int k, bool next, bool prev, const double (&v)[S], int rs) const {
+#ifdef CPK_TIMING_NO_RING_STORES  // timing experiment (tools/ab_build.sh): what the forward sweep costs without its stores
+        if (a.geo.maxWidth >= 0) return;
+#endif
         if (!(COH && CPK_COH_ST && CPK_COH_PAIRS)) {
             if (rs > 0) {
                 ringSt(out + ringIdx(W, 0, k), v[0]);
@@ -499,7 +502,11 @@ struct Sweep {
     // cells [kb, kb + 64) of one diagonal, clipped to [kb, hi)
     __device__ __forceinline__ void absFwdGroup(const AbsDiag &c, double *out, int rs, int kb, int hi) {
         const int k0 = kb + lane;
+#ifdef CPK_TIMING_LANES  // timing experiment: only the first CPK_TIMING_LANES lanes of every group work (results invalid)
+        if (k0 < hi && lane < CPK_TIMING_LANES) {
+#else
         if (k0 < hi) {
+#endif
             const int kk[1] = {k0};
             const int kkR[1] = {c.ownR + kb * R + laneR};
             FwdCtx f;
@@ -517,6 +524,33 @@ struct Sweep {
             for (int st = 0; st < S; st++) c.cur[st + kkR[0]] = v[0][st];
             ringPut(out, c.W, k0, k0 + 1 < hi && lane < CPK_WAVE - 1, lane > 0, v[0], rs);
         }
+    }
+    // cells [kb, kb + 128) of one diagonal, clipped to [kb, hi): two cells per lane, 64 apart, in lock-step
+    __device__ __forceinline__ void absFwdGroup2(const AbsDiag &c, double *out, int rs, int kb, int hi) {
+        const int k0 = kb + lane, k1 = k0 + CPK_WAVE;
+        const bool on1 = k1 < hi;
+        // lanes without a second cell recompute their first one (k0 < hi holds for every lane: hi - kb > 64)
+        const int kk[2] = {k0, on1 ? k1 : k0};
+        const int kkR[2] = {c.ownR + kb * R + laneR, c.ownR + (on1 ? kb + CPK_WAVE : kb) * R + laneR};
+        FwdCtx f;
+        f.d = c.d;
+        f.xlo = c.xlo;
+        f.dlR = 0;
+        f.w1R = 0;
+        f.dmR = 0;
+        f.w2R = 0;
+        f.p1 = c.lu;
+        f.p2 = c.cur;
+        double v[2][S];
+        fwdCells<2>(f, kk, kkR, v);
+#pragma unroll
+        for (int st = 0; st < S; st++) c.cur[st + kkR[0]] = v[0][st];
+        if (on1) {
+#pragma unroll
+            for (int st = 0; st < S; st++) c.cur[st + kkR[1]] = v[1][st];
+        }
+        ringPut(out, c.W, k0, lane < CPK_WAVE - 1, lane > 0, v[0], rs);
+        if (on1) ringPut(out, c.W, k1, k1 + 1 < hi && lane < CPK_WAVE - 1, lane > 0, v[1], rs);
     }
     __device__ void absFlushTail() {
         if (!atail.has) return;
@@ -536,6 +570,21 @@ struct Sweep {
         const AbsDiag c = absDiag(d, g, pLo);
         double *out = ringAt(g);
         int lo = 0;
+#if defined(CPK_ABS_FWD_FORM) && CPK_ABS_FWD_FORM > 0
+        // timing experiments (tools/ab_build.sh): no streaming; FORM 2: pairs of groups in lock-step (two cells per lane)
+        for (; CPK_ABS_FWD_FORM == 2 && W - lo > CPK_WAVE; lo += 2 * CPK_WAVE) absFwdGroup2(c, out, ringStates, lo, W);
+#ifdef CPK_TIMING_GROUP_REPEAT  // timing experiment: every group computed CPK_TIMING_GROUP_REPEAT times (0: not at all)
+        for (; lo < W; lo += CPK_WAVE)
+            for (int rep = 0; rep < CPK_TIMING_GROUP_REPEAT; rep++) absFwdGroup(c, out, ringStates, lo, W);
+#else
+        for (; lo < W; lo += CPK_WAVE) absFwdGroup(c, out, ringStates, lo, W);
+#endif
+        apos2 = apos1;
+        apos1 = pLo;
+        f2 = f1;
+        f1 = g;
+        return;
+#endif
         if (atail.has) {
             // Lanes [0, r) finish diagonal A = d - 1, lanes [r, r + b) start this one.  Its cells [0, b) read F[A] up to
             // position pLo + b - 1 + (d & 1), which earlier groups must have written: below the first leftover cell of A.
@@ -950,6 +999,294 @@ struct Sweep {
         for (int l = 0; l < (CANDS ? NL : 0); l++) flush(l, pend[l]);
     }
 
+    // ---- traceback of one segment over absolute positions, as a STREAM of cells (cf. traceback above: same arithmetic,
+    // same candidate filter, same series for the totals).  Diagonals of 101-151 cells fill groups of 64 lanes to 80 %; here
+    // the last cells of a diagonal (fewer than 64) may wait and share a group with the first cells of the next lower one:
+    // lanes [0, off) finish diagonal A, lanes [off, 64) start B = A - 1.  Legal when B's cells in that group only read cells
+    // of A that earlier groups wrote (their neighbours at x-y -+ 1 lie below A's waiting cells); B[B] replaces B[A + 1] in
+    // place at B's first positions, below everything A's waiting cells read, and within a group every load precedes every
+    // store.  Visit order is kept (A's cells before B's, each by ascending x-y), so the candidate list is unchanged.
+    // A refresh diagonal finishes its own cells before its dot products, the top diagonal of the segment is never shared,
+    // and no diagonal waits in front of one that moves the base.  `off` also shifts the lanes of the prefetched F rows.
+    template <int NL, bool CANDS>
+    __device__ void tracebackAbs(const CpkSegment &sg, const double *endPrior, double *dbgFb, int (&nCand)[NL]) {
+        const int J = sg.nRefresh;
+        const float logThr = (float)log(m.threshold);
+        int pend[NL], head[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) nCand[l] = pend[l] = head[l] = 0;
+        auto flush = [&](int l, int n) {
+            if (lane < n) {
+                cand[(size_t)l * a.geo.fbCells + nCand[l] + lane] = stage[l * kStage + ((head[l] + lane) & (kStage - 1))];
+            }
+            head[l] = (head[l] + n) & (kStage - 1);
+            pend[l] -= n;
+            nCand[l] += n;
+        };
+        float lastMax = -__builtin_huge_valf();
+        double ep[S];
+#pragma unroll
+        for (int st = 0; st < S; st++) ep[st] = endPrior[st];
+#pragma unroll
+        for (int st = 0; st < S; st++) asm volatile("" : "+v"(ep[st]));
+        absWipe();  // nothing above the top diagonal exists: its neighbours read -inf
+        CpkDiag gb{}, ga{};      // table entries of d2+1 and d2+2 ...
+        int posb = 0, posa = 0;  // ... and the positions of their first cells under the base in force
+        CpkDiag g = dc.get(sg.dTop, true);
+        int gpos = dc.posGet(sg.dTop, true) >> 16;  // backward half of the diagonal's positions
+        CpkDiag gnext = sg.dTop >= 1 ? dc.get(sg.dTop - 1, true) : CpkDiag{};
+        int gnpos = sg.dTop >= 1 ? dc.posGet(sg.dTop - 1, true) >> 16 : 0;
+        int off = 0;        // lane of the current diagonal's cell 0 in its first group
+        bool carry = false; // lanes [0, off) of that group hold the last cells of the diagonal above:
+        AbsDiag tl{};       //   its context,
+        int tlK0 = 0, tlCellOff = 0, tlJr = 0;
+        bool tlEmit = false, tlFeeds = false;
+        double fTail[NL];   //   and its F values
+#pragma unroll
+        for (int l = 0; l < NL; l++) fTail[l] = 0.0;
+        double fmCur[NL][kPrefetch];
+        auto loadRows = [&](const CpkDiag &gd, int offd, double (&dst)[NL][kPrefetch]) {
+            const double *src = ringAt(gd);
+#pragma unroll
+            for (int l = 0; l < NL; l++)
+#pragma unroll
+                for (int q = 0; q < kPrefetch; q++) {
+                    int k = q * CPK_WAVE - offd + lane;
+                    k = k < 0 ? 0 : k;
+                    dst[l][q] = ringLd(src + ringIdx(gd.width, l, k < gd.width ? k : gd.width - 1));
+                }
+        };
+        loadRows(g, 0, fmCur);
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+#pragma unroll
+            for (int q = 0; q < kPrefetch; q++) asm volatile("" : "+v"(fmCur[l][q]));
+        int untilRefresh = sg.dTop - sg.tbFrom;
+        int jr = 0;
+        for (int d2 = sg.dTop; d2 > sg.tbPrev;) {
+          dc.load(d2 - 2 - (CPK_WAVE - 1));
+          for (int ci = CPK_WAVE - 1; ci >= 0 && d2 > sg.tbPrev; ci--, d2--) {
+            const bool seeded = d2 == sg.dTop;
+            const int W = g.width;
+            const bool emit = d2 <= sg.tbFrom;
+            const bool refresh = untilRefresh == 0;
+            const bool feeds = untilRefresh == 1 && d2 - 1 > sg.tbPrev;
+            const int jrNext = jr;
+            const int pLo = gpos & 0x7fff;
+            if ((gpos & 0x8000) && !seeded) {  // rare; never with cells of the diagonal above waiting (carryNext below)
+                const int delta = absRebase(d2, g, pLo, -1, gb, posb, true, ga, posa, d2 + 2 <= sg.dTop);
+                posb += delta;
+                posa += delta;
+            }
+            const AbsDiag cx = absDiag(d2, g, pLo);
+            // groups of this diagonal: qT whole ones (the first may be shared with the diagonal above), then r cells
+            const int qT = (off + W) >> 6, r = (off + W) & (CPK_WAVE - 1);
+            bool carryNext = false;
+            if (!seeded && !refresh && d2 - 1 > sg.tbPrev && r > 0 && qT >= 1 && qT < kPrefetch && !(gnpos & 0x8000)) {
+                const int bN = CPK_WAVE - r < gnext.width ? CPK_WAVE - r : gnext.width;
+                // the next diagonal's cells [0, bN) read this one up to position pLoN + bN - 1 + ((d2 - 1) & 1): below the
+                // first waiting cell, which sits at position pLo + qT * 64 - off
+                carryNext = (gnpos & 0x7fff) + bN + ((d2 - 1) & 1) - 1 < pLo + qT * CPK_WAVE - off;
+            }
+            const int offNext = carryNext ? r : 0;
+            double fmNext[NL][kPrefetch];
+            loadRows(gnext, offNext, fmNext);
+            const CpkDiag gnext2 = dc.at(ci);
+            const int gnpos2 = dc.posAt(ci) >> 16;
+            const double *fsrc = ringAt(g);
+            const float keepFrom = lastMax + logThr - kCandMargin;
+            double rfC[S][kPrefetch];
+            if (refresh) {
+#pragma unroll
+                for (int q = 0; q < kPrefetch; q++) {
+                    const int k = q * CPK_WAVE - off + lane;
+#pragma unroll
+                    for (int s2 = NL; s2 < S; s2++) rfC[s2][q] = (unsigned)k < (unsigned)W ? ringLd(fsrc + ringIdx(W, s2, k)) : 0.0;
+                }
+            }
+            // One group of 64 cells: lane by lane cell k0 of diagonal t (wave-uniform except in the shared group).  Control
+            // flow is wave-uniform (the candidate counts must stay identical in every lane): lanes that are not `on`
+            // recompute a cell of their diagonal and have their stores masked.
+            auto group = [&](const AbsDiag &t, int k0, int kR0, bool on, const double (&f0)[NL], bool tEmit, bool tFeeds, int tJr,
+                             int tCellOff, bool anyEmit) {
+                double v[1][S];
+                if (seeded) {
+#pragma unroll
+                    for (int st = 0; st < S; st++) v[0][st] = ep[st];
+                } else {
+                    BwdCtx c;
+                    c.d2 = t.d;
+                    c.xlo = t.xlo;
+                    c.dbR = 0;
+                    c.wBR = 0;
+                    c.daR = 0;
+                    c.wAR = 0;
+                    c.pb = t.lu;
+                    c.pa = t.cur;
+                    const int kk[1] = {k0};
+                    const int kkR[1] = {kR0};
+                    bwdCells<1>(c, kk, kkR, v);
+                }
+                if (on) {
+#pragma unroll
+                    for (int st = 0; st < S; st++) t.cur[st + kR0] = v[0][st];
+                }
+                if (tFeeds && on) mbuf[(size_t)k0 * J + tJr] = f0[0] + v[0][0];
+                if (anyEmit) {
+                    const int x = t.xlo + k0, y = t.d - x;
+                    double fbv[NL];
+#pragma unroll
+                    for (int l = 0; l < NL; l++) fbv[l] = f0[l] + v[0][l];
+                    if (on && tEmit && dbgFb) dbgFb[tCellOff + k0] = fbv[0];
+#pragma unroll
+                    for (int l = 0; l < (CANDS ? NL : 0); l++) {
+                        const bool cell = l == 0 ? (x > 0 && y > 0) : (l == 1 ? x > 0 : y > 0);
+                        const bool keep = on && tEmit && cell && (float)fbv[l] >= keepFrom;
+                        const unsigned long long mask = __ballot(keep);
+                        if (keep) {
+                            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                            Candidate cd;
+                            cd.fb = fbv[l];
+                            cd.x = x;
+                            cd.y = y;
+                            stage[l * kStage + ((head[l] + pend[l] + rank) & (kStage - 1))] = cd;
+                        }
+                        pend[l] += __popcll(mask);
+                        if (pend[l] >= CPK_WAVE) flush(l, CPK_WAVE);
+                    }
+                }
+            };
+            // the shared group: lanes [0, off) finish the diagonal above, the others start this one
+            if (carry) {
+                const bool inA = lane < off;
+                const int b = CPK_WAVE - off < W ? CPK_WAVE - off : W;
+                const bool on = lane < off + b;
+                AbsDiag mx;
+                mx.d = inA ? tl.d : cx.d;
+                mx.xlo = inA ? tl.xlo : cx.xlo;
+                mx.ownR = 0;
+                mx.W = 0;
+                mx.cur = inA ? tl.cur : cx.cur;
+                mx.lu = inA ? tl.lu : cx.lu;
+                // lanes past the end of a narrow diagonal recompute its first cell
+                const int k0 = inA ? tlK0 + lane : (on ? lane - off : 0);
+                const int kR0 = inA ? tl.ownR + tlK0 * R + laneR : (on ? cx.ownR - off * R + laneR : cx.ownR);
+                double f0[NL];
+#pragma unroll
+                for (int l = 0; l < NL; l++) f0[l] = inA ? fTail[l] : fmCur[l][0];
+                group(mx, k0, kR0, on, f0, inA ? tlEmit : emit, inA ? tlFeeds : feeds, inA ? tlJr : jrNext, inA ? tlCellOff : g.cellOff,
+                      tlEmit || emit);
+            }
+            // this diagonal's own groups; its last cells wait for the next diagonal when they may (carryNext)
+            const int nNow = carryNext ? qT : qT + (r > 0 ? 1 : 0);
+#pragma unroll
+            for (int q = 0; q < kPrefetch; q++) {
+                if (q >= (carry ? 1 : 0) && q < nNow) {
+                    double f0[NL];
+#pragma unroll
+                    for (int l = 0; l < NL; l++) f0[l] = fmCur[l][q];
+                    const int kb = q * CPK_WAVE - off;
+                    const int k0 = kb + lane;
+                    const bool on = k0 < W;
+                    group(cx, on ? k0 : W - 1, on ? cx.ownR + kb * R + laneR : cx.ownR + (W - 1) * R, on, f0, emit, feeds, jrNext, g.cellOff, emit);
+                }
+            }
+            for (int q = kPrefetch; q < nNow; q++) {  // diagonals wider than the prefetch load F on the spot
+                const int kb = q * CPK_WAVE - off;
+                const int k0 = kb + lane;
+                const bool on = k0 < W;
+                double f0[NL];
+#pragma unroll
+                for (int l = 0; l < NL; l++) f0[l] = ((emit || feeds) && on) ? ringLd(fsrc + ringIdx(W, l, k0)) : 0.0;
+                group(cx, on ? k0 : W - 1, on ? cx.ownR + kb * R + laneR : cx.ownR + (W - 1) * R, on, f0, emit, feeds, jrNext, g.cellOff, emit);
+            }
+            roll_fence<false>();
+            if (refresh) {
+                float diagMax = -__builtin_huge_valf();
+                auto dotCell = [&](int k, const double (&fRow)[S]) {
+                    const int kR = cx.ownR + k * R;
+                    double t = fRow[0] + cx.cur[kR];
+                    const int x = cx.xlo + k, y = d2 - x;
+                    const float fbf = (x > 0 && y > 0) ? (float)t : -__builtin_huge_valf();
+#pragma unroll
+                    for (int s2 = 1; s2 < S; s2++) t = logadd(lg, t, fRow[s2] + cx.cur[s2 + kR]);
+                    cbuf[(size_t)k * J + jr] = t;
+                    return fbf;
+                };
+#pragma unroll
+                for (int q = 0; q < kPrefetch; q++) {
+                    const int k = q * CPK_WAVE - off + lane;
+                    float fbf = -__builtin_huge_valf();
+                    if (q * CPK_WAVE - off < W) {  // wave-uniform
+                        if ((unsigned)k < (unsigned)W) {
+                            double fRow[S];
+#pragma unroll
+                            for (int s2 = 0; s2 < S; s2++) fRow[s2] = s2 < NL ? fmCur[s2][q] : rfC[s2][q];
+                            fbf = dotCell(k, fRow);
+                        }
+                        if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
+                    }
+                }
+                for (int kb = kPrefetch * CPK_WAVE - off; kb < W; kb += CPK_WAVE) {
+                    const int k = kb + lane;
+                    float fbf = -__builtin_huge_valf();
+                    if (k < W) {
+                        double fRow[S];
+#pragma unroll
+                        for (int s2 = 0; s2 < S; s2++) fRow[s2] = ringLd(fsrc + ringIdx(W, s2, k));
+                        fbf = dotCell(k, fRow);
+                    }
+                    if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
+                }
+                if (CANDS) lastMax = fmaxf(diagMax, lastMax - 1.0f);
+            }
+            // the cells that wait: their context and their F values (group qT of this diagonal's prefetched rows)
+            if (carryNext) {
+                tl = cx;
+                tlK0 = qT * CPK_WAVE - off;
+                tlEmit = emit;
+                tlFeeds = feeds;
+                tlJr = jrNext;
+                tlCellOff = g.cellOff;
+#pragma unroll
+                for (int l = 0; l < NL; l++) {
+                    double f = fmCur[l][kPrefetch - 1];
+#pragma unroll
+                    for (int q = kPrefetch - 2; q >= 1; q--) f = qT == q ? fmCur[l][q] : f;
+                    fTail[l] = f;
+                }
+            }
+            carry = carryNext;
+            off = offNext;
+            // slide the window of table entries, positions and prefetched F rows down one diagonal
+            ga = gb;
+            posa = posb;
+            gb = g;
+            posb = pLo;
+            g = gnext;
+            gpos = gnpos;
+            gnext = gnext2;
+            gnpos = gnpos2;
+#pragma unroll
+            for (int l = 0; l < NL; l++)
+#pragma unroll
+                for (int q = 0; q < kPrefetch; q++) {
+                    asm volatile("" : "+v"(fmNext[l][q]));
+                    fmCur[l][q] = fmNext[l][q];
+                }
+            if (refresh) {
+                untilRefresh = CPK_REFRESH_PERIOD - 1;
+                jr++;
+            } else {
+                untilRefresh--;
+            }
+          }
+        }
+#pragma unroll
+        for (int l = 0; l < (CANDS ? NL : 0); l++) flush(l, pend[l]);
+    }
+
     // ---- expectation step (diagonalCalculationExpectations, pairwiseAligner.c:735-746; updateExpectations :418-432).
     // Second backward sweep of the segment, run once the totals are known.  For every emitted diagonal d2, every cell
     // of B[d2] and every transition into it: p = exp(F_nbr[from] + B[to] + (eP + tP) - total) with the neighbours
@@ -1252,9 +1589,12 @@ constexpr int kModeWhole = 0, kModeForward = 1, kModeTrace = 2, kModeFused = 3;
 // WPS: waves per SIMD the registers are allocated for.  Two everywhere (the five-state match kernel needs ~230 VGPRs)
 // except the three-state match kernels of classes with more regions than two waves per SIMD hold: at 168 VGPRs (a
 // handful of spills) three fit, and a queue that long runs 9-34 % faster with them (cpk_device_upload).
-template <int S, bool FAST, int EMIT, int MODE = kModeWhole, int WPS = CPK_SWEEP_WAVES>
+// ABS: the sweeps of a split class over absolute positions (Sweep::forwardStreamAbs / tracebackAbs): match emitter, LDS rows,
+// fixed expansion (KArgs::dpos holds the positions)
+template <int S, bool FAST, int EMIT, int MODE = kModeWhole, int WPS = CPK_SWEEP_WAVES, bool ABS = false>
 __global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 cpecan_pairhmm_sweep(const KArgs a) {
+    static_assert(!ABS || (FAST && MODE != kModeWhole && EMIT == CPECAN_EMIT_MATCH), "absolute positions: split classes of the match emitter");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const CpkModel &m = *a.model;
@@ -1264,15 +1604,10 @@ cpecan_pairhmm_sweep(const KArgs a) {
     // LDS (doubles): logAdd cubics | emission tables | expectation sums | rolling buffers (FAST) | symbol strings (FAST)
     fill_cubics(lds);
     const Cubic *lg = reinterpret_cast<const Cubic *>(lds);
-    double *em = lds + kLdsCubics;
-    if (lane < 25) em[lane] = m.matchEm[lane];
-    if (lane < 5) {
-        em[25 + lane] = m.gapXEm[lane];
-        em[30 + lane] = m.gapYEm[lane];
-    }
-    double *wt = lds + kLdsCubics + 40;
+    double *em = lds + kLdsCubics;  // (no plain emission table any more: kLdsEm == 0, every term reads `wt`)
+    double *wt = lds + kLdsCubics + kLdsEm;
     fill_weights<S>(wt, m, a.kc, lane);
-    double *eLds = lds + kLdsCubics + 40 + kLdsWeights;  // emission-expectation sums of this wave (expectation emitter)
+    double *eLds = lds + kLdsCubics + kLdsEm + kLdsWeights;  // emission-expectation sums of this wave (expectation emitter)
     if (EMIT == CPECAN_EMIT_EXPECT)
         for (int i = lane; i < kExpectCopies * 80; i += CPK_WAVE) eLds[i] = 0.0;
     constexpr int kNT = S == 5 ? 13 : 9;
@@ -1320,9 +1655,9 @@ cpecan_pairhmm_sweep(const KArgs a) {
             roll_fence<false>();
         }
         const CpkDiag *table = a.diags + rg.diagOff;
-        Sweep<S, FAST, 2 * S + 1, MODE == kModeFused, MODE != kModeWhole> sw{a,
+        Sweep<S, FAST, 2 * S + 1, MODE == kModeFused, MODE != kModeWhole, ABS> sw{a,
                           a.kc,
-                          DiagCache{table, N, 0, lane, 0, 0, 0, 0},
+                          DiagCache{table, N, 0, lane, 0, 0, 0, 0, ABS ? a.dpos + rg.diagOff : nullptr, 0},
                           FAST ? seqLds : gx,
                           FAST ? seqLds + ((lX + 3) >> 1) : gy,
                           roll,
@@ -1389,6 +1724,11 @@ cpecan_pairhmm_sweep(const KArgs a) {
             if (!traceRole) {
                 const CpkDiag g0 = sw.dc.get(0, false);
                 double *cur = sw.fbuf1(0);
+                if (ABS) {  // empty rows, the single cell of diagonal 0 at its position
+                    sw.absWipe();
+                    sw.apos1 = sw.apos2 = sw.dc.posGet(0, false) & 0x7fff;
+                    cur += (sw.apos1 - 1) * R;
+                }
                 double *o0 = sw.ringAt(g0);
                 if (lane < S) {
                     cur[lane] = startPrior[lane];
@@ -1414,11 +1754,13 @@ cpecan_pairhmm_sweep(const KArgs a) {
                     for (; d <= dEnd; d++) {
                         while (d > emitFrom) emitFrom = a.segs[rg.segOff + ++emitSeg].tbFrom;  // the last segment ends at N
                         const bool all = EMIT != CPECAN_EMIT_MATCH || (emitFrom - d) % CPK_REFRESH_PERIOD == 0 || d >= sg.dTop - 1;
-                        if (FAST) sw.forwardStream(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
+                        if (ABS) sw.forwardStreamAbs(d, sw.dc.at(d - sw.dc.base), sw.dc.posAt(d - sw.dc.base), all ? S : 1);
+                        else if (FAST) sw.forwardStream(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
                         else sw.forward(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
                     }
                 }
-                if (FAST && !traceRole) sw.flushTail();  // the traceback needs every cell of dTop
+                if (ABS && !traceRole) sw.absFlushTail();
+                else if (FAST && !traceRole) sw.flushTail();  // the traceback needs every cell of dTop
                 if (forwardRole) {  // the tracebacks of this region are items of their own (of the next launch, or of this one)
                     if (MODE == kModeFused) {
                         // the ring stores are device-scope write-through (Sweep::ringSt): once they are acknowledged -- this
@@ -1450,7 +1792,8 @@ cpecan_pairhmm_sweep(const KArgs a) {
 #endif
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
                 int nCand[NL];
-                sw.template traceback<NL, EMIT != CPECAN_EMIT_EXPECT>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
+                if (ABS) sw.template tracebackAbs<NL, true>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
+                else sw.template traceback<NL, EMIT != CPECAN_EMIT_EXPECT>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
                 roll_fence<true>();  // candidate / cbuf / mbuf stores of all lanes are complete before they are re-read
                 sw.foldTotals(sg, table);
                 if (a.geo.debug & 1) {

@@ -18,7 +18,7 @@
 constexpr int kTeamGroups = 3;  // 64-cell groups a wave handles per diagonal at most: bands up to 64 * T * kTeamGroups cells
 constexpr int kTeamXchg = 32;   // doubles of LDS for the exchange area (counts, maxima, the region ticket)
 
-__host__ __device__ constexpr int team_header_doubles() { return kLdsCubics + 40 + kLdsWeights + kTeamXchg; }
+__host__ __device__ constexpr int team_header_doubles() { return kLdsCubics + kLdsEm + kLdsWeights + kTeamXchg; }
 
 template <int S, int T>
 __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a) {
@@ -32,18 +32,12 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
     // LDS (doubles): logAdd cubics | emissions | weights | exchange area | rolling rows | symbol strings
     if (wave == 0) {
         fill_cubics(lds);
-        double *em0 = lds + kLdsCubics;
-        if (lane < 25) em0[lane] = m.matchEm[lane];
-        if (lane < 5) {
-            em0[25 + lane] = m.gapXEm[lane];
-            em0[30 + lane] = m.gapYEm[lane];
-        }
-        fill_weights<S>(lds + kLdsCubics + 40, m, a.kc, lane);
+        fill_weights<S>(lds + kLdsCubics + kLdsEm, m, a.kc, lane);
     }
     const Cubic *lg = reinterpret_cast<const Cubic *>(lds);
     double *em = lds + kLdsCubics;
-    double *wt = lds + kLdsCubics + 40;
-    int *xi = reinterpret_cast<int *>(lds + kLdsCubics + 40 + kLdsWeights);  // [0]: ticket, [8 + parity * T + w]: counts
+    double *wt = lds + kLdsCubics + kLdsEm;
+    int *xi = reinterpret_cast<int *>(lds + kLdsCubics + kLdsEm + kLdsWeights);  // [0]: ticket, [8 + parity * T + w]: counts
     float *xf = reinterpret_cast<float *>(xi + 8 + 2 * T);                   // [parity * T + w]: maxima
     double *roll = lds + team_header_doubles();
     uint8_t *seqLds = reinterpret_cast<uint8_t *>(roll + (size_t)R * stride);

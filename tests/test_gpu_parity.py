@@ -856,12 +856,19 @@ def test_packed_kernel_expectations(force_packed, mtype):
 
 
 # ---- per-cell log-space values: sharper than any posterior (they see every logAdd of both sweeps) ----
+@pytest.mark.parametrize("form", ["whole", "split_abs", "fused_abs", "split_dense_rows"])
 @pytest.mark.parametrize("case", ["tiny5", "tiny3", "full200", "A_1kb", "B_2kb", "short_tracebacks", "asym_ragged"])
-def test_cell_values_and_totals_match_oracle(case):
+def test_cell_values_and_totals_match_oracle(case, form, monkeypatch):
     """F.match + B.match of every emitted cell and the total probability used on every emitted diagonal (the debug
     buffers of the sweep kernel) against the oracle's trace of the same problem: equal to LOG_TOL (tests/parity.py), i.e.
-    ~1e-12 relative -- seven orders inside the north star's 1e-5.  Multi-segment tracebacks, both state counts, ragged ends."""
+    ~1e-12 relative -- seven orders inside the north star's 1e-5.  Multi-segment tracebacks, both state counts, ragged ends.
+    form: one wave per region; the split forms (tracebacks as queue items: two launches / one launch), whose sweeps index
+    the rolling rows by absolute position (round 3); the two-launch form with the rows indexed by rank (CPECAN_ABS=0)."""
     from parity import LOG_TOL
+    if form != "whole" and case in ("tiny5", "tiny3", "full200"):
+        pytest.skip("single-segment problems run one wave per region")
+    monkeypatch.setenv("CPECAN_SPLIT", {"whole": "0", "split_abs": "1", "fused_abs": "2", "split_dense_rows": "1"}[form])
+    monkeypatch.setenv("CPECAN_ABS", "0" if form == "split_dense_rows" else "1")
     rl = rr = False
     if case == "tiny5":
         mtype, (sx, sy, a), pkw = 0, ("AGCG", "AGTTCG", ()), dict(threshold=0.2)
@@ -1160,6 +1167,13 @@ def test_split_classes_equal_whole_region_waves(monkeypatch):
         split, st1 = _run_batch(mtype, problems, **pkw)
         assert st1.cells == st0.cells
         for a, b in zip(split, whole):
+            assert np.array_equal(a, b)
+        # the same two launches with the rolling rows indexed by rank instead of absolute position (CPECAN_ABS=0)
+        monkeypatch.setenv("CPECAN_ABS", "0")
+        ranked, st3 = _run_batch(mtype, problems, **pkw)
+        monkeypatch.delenv("CPECAN_ABS")
+        assert st3.cells == st0.cells
+        for a, b in zip(ranked, whole):
             assert np.array_equal(a, b)
         # ... and as ONE launch (CPECAN_SPLIT=2: regions and their traceback items in one queue, an item waits for its
         # region's forward wave to pass its segment)
