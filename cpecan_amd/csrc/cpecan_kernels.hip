@@ -1147,7 +1147,9 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     }
     d->totalWaves = 0;
     {
-        int64_t oRing = 0, oCand = 0, oRef = 0, oTot = 0, oBring = 0, oGroll = 0, oExpect = 0;
+        // (the rings start 64 doubles into their block and the block ends 256 doubles behind them: the streamed traceback's
+        // prefetch reads up to 63 words in front of a diagonal's row and up to 191 behind it, Sweep::tracebackAbs)
+        int64_t oRing = 64, oCand = 0, oRef = 0, oTot = 0, oBring = 0, oGroll = 0, oExpect = 0;
         for (LaunchClass &c : d->classes) {
             c.oRing = oRing;
             c.oCand = oCand;
@@ -1171,7 +1173,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                     HIP_TRY(hipFuncSetAttribute((const void *)c.fnTrace, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.ldsBytes));
             }
         }
-        if (int rc = dev_alloc(d, &d->dRing, (size_t)oRing)) return rc;
+        if (int rc = dev_alloc(d, &d->dRing, (size_t)oRing + 256)) return rc;
         if (int rc = dev_alloc(d, &d->dCand, (size_t)oCand)) return rc;
         if (int rc = dev_alloc(d, &d->dC, (size_t)oRef)) return rc;
         if (int rc = dev_alloc(d, &d->dM, (size_t)oRef)) return rc;

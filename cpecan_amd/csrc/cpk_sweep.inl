@@ -1000,14 +1000,19 @@ struct Sweep {
     }
 
     // ---- traceback of one segment over absolute positions, as a STREAM of cells (cf. traceback above: same arithmetic,
-    // same candidate filter, same series for the totals).  Diagonals of 101-151 cells fill groups of 64 lanes to 80 %; here
-    // the last cells of a diagonal (fewer than 64) may wait and share a group with the first cells of the next lower one:
-    // lanes [0, off) finish diagonal A, lanes [off, 64) start B = A - 1.  Legal when B's cells in that group only read cells
-    // of A that earlier groups wrote (their neighbours at x-y -+ 1 lie below A's waiting cells); B[B] replaces B[A + 1] in
-    // place at B's first positions, below everything A's waiting cells read, and within a group every load precedes every
-    // store.  Visit order is kept (A's cells before B's, each by ascending x-y), so the candidate list is unchanged.
-    // A refresh diagonal finishes its own cells before its dot products, the top diagonal of the segment is never shared,
-    // and no diagonal waits in front of one that moves the base.  `off` also shifts the lanes of the prefetched F rows.
+    // same candidate filter, same series for the totals).  The last cells of a diagonal (fewer than 64) may wait and share
+    // a group with the first cells of the next lower one: lanes [0, off) finish diagonal A, lanes [off, 64) start B = A - 1.
+    // Legal when B's cells in that group only read cells of A that earlier groups wrote (their neighbours at x-y -+ 1 lie
+    // below A's waiting cells); B[B] replaces B[A + 1] in place at B's first positions, below everything A's waiting cells
+    // read, and within a group every load precedes every store.  Visit order is kept (A's cells before B's, each by
+    // ascending x-y), so the candidate list is unchanged.
+    // These sweeps are bound by the NUMBER of instructions a wave issues, so the loop is laid out
+    // for few of them per diagonal: the top diagonal (end prior, no neighbours) is peeled off; what only some diagonals do
+    // -- the straddle series of a diagonal above a refresh point, the dot products of a refresh point -- runs as a pass
+    // of its own behind the diagonal's groups, and such diagonals finish all their cells first; a waiting tail and the
+    // diagonal it joins are of the same kind (both emitted or both not), so a group has no per-lane flags; the prefetch
+    // of the next diagonal's F rows is three loads off one per-lane address (lanes outside the row read neighbouring ring
+    // words, which the ring's padding makes legal, and ignore them).
     template <int NL, bool CANDS>
     __device__ void tracebackAbs(const CpkSegment &sg, const double *endPrior, double *dbgFb, int (&nCand)[NL]) {
         const int J = sg.nRefresh;
@@ -1024,56 +1029,186 @@ struct Sweep {
             nCand[l] += n;
         };
         float lastMax = -__builtin_huge_valf();
-        double ep[S];
-#pragma unroll
-        for (int st = 0; st < S; st++) ep[st] = endPrior[st];
-#pragma unroll
-        for (int st = 0; st < S; st++) asm volatile("" : "+v"(ep[st]));
+        float keepFrom = lastMax;
         absWipe();  // nothing above the top diagonal exists: its neighbours read -inf
-        CpkDiag gb{}, ga{};      // table entries of d2+1 and d2+2 ...
-        int posb = 0, posa = 0;  // ... and the positions of their first cells under the base in force
-        CpkDiag g = dc.get(sg.dTop, true);
-        int gpos = dc.posGet(sg.dTop, true) >> 16;  // backward half of the diagonal's positions
-        CpkDiag gnext = sg.dTop >= 1 ? dc.get(sg.dTop - 1, true) : CpkDiag{};
-        int gnpos = sg.dTop >= 1 ? dc.posGet(sg.dTop - 1, true) >> 16 : 0;
-        int off = 0;        // lane of the current diagonal's cell 0 in its first group
-        bool carry = false; // lanes [0, off) of that group hold the last cells of the diagonal above:
-        AbsDiag tl{};       //   its context,
-        int tlK0 = 0, tlCellOff = 0, tlJr = 0;
-        bool tlEmit = false, tlFeeds = false;
-        double fTail[NL];   //   and its F values
-#pragma unroll
-        for (int l = 0; l < NL; l++) fTail[l] = 0.0;
+        // F rows of the emitted states, lane <-> cell k = q * 64 - off + lane of group q; unclamped (see above)
         double fmCur[NL][kPrefetch];
         auto loadRows = [&](const CpkDiag &gd, int offd, double (&dst)[NL][kPrefetch]) {
-            const double *src = ringAt(gd);
+            static_assert(NL == 1, "the unclamped prefetch addresses the match row (cell k at element k)");
+#ifdef CPK_TIMING_HOT_ROWS  // timing experiment: every prefetch reads the same (cache-hot) words -- results invalid
+            const double *src = ring + lane + (offd & 1);
+#else
+            const double *src = ringAt(gd) + (lane - offd);  // lane - offd may be negative: the ring is padded in front
+#endif
+#ifdef CPK_TIMING_NO_PREFETCH  // timing experiment: no F rows at all
 #pragma unroll
-            for (int l = 0; l < NL; l++)
+            for (int q = 0; q < kPrefetch; q++) dst[0][q] = (double)(src != nullptr);
+#else
+#pragma unroll
+            for (int q = 0; q < kPrefetch; q++) dst[0][q] = ringLd(src + q * CPK_WAVE);
+#endif
+        };
+        // posterior candidates of one group of an emitted diagonal: fb = F + B of the NL emitted states
+        auto emitCells = [&](int d, int x, bool on, const double (&f0)[NL], const double (&v)[S], int dbgAt) {
+            const int y = d - x;
+            double fbv[NL];
+#pragma unroll
+            for (int l = 0; l < NL; l++) fbv[l] = f0[l] + v[l];
+            if (dbgFb && on) dbgFb[dbgAt] = fbv[0];
+#pragma unroll
+            for (int l = 0; l < (CANDS ? NL : 0); l++) {
+                const bool cell = l == 0 ? (x > 0 && y > 0) : (l == 1 ? x > 0 : y > 0);
+                const bool keep = on && cell && (float)fbv[l] >= keepFrom;
+                const unsigned long long mask = __ballot(keep);
+                if (keep) {
+                    const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                    Candidate cd;
+                    cd.fb = fbv[l];
+                    cd.x = x;
+                    cd.y = y;
+                    stage[l * kStage + ((head[l] + pend[l] + rank) & (kStage - 1))] = cd;
+                }
+                pend[l] += __popcll(mask);
+                if (pend[l] >= CPK_WAVE) flush(l, CPK_WAVE);
+            }
+        };
+        // a refresh point: per-cell dot products over the states (cell_dotProduct, pairwiseAligner.c:402-408) into cbuf and,
+        // for the candidate bound, the diagonal's largest F.m + B.m (renewed as max(this, old - 1): :834 bounds the drift)
+        // rfC: the remaining states of F[d] (rows NL..S-1), prefetched before the diagonal's groups; fm: its emitted states
+        auto dotCell = [&](const AbsDiag &cx, int k, const double (&fRow)[S], int jr) {
+            const int kR = cx.ownR + k * R;
+            double t = fRow[0] + cx.cur[kR];
+            const int x = cx.xlo + k, y = cx.d - x;
+            const float fbf = (x > 0 && y > 0) ? (float)t : -__builtin_huge_valf();
+#pragma unroll
+            for (int s2 = 1; s2 < S; s2++) t = logadd(lg, t, fRow[s2] + cx.cur[s2 + kR]);
+#ifndef CPK_TIMING_NO_SERIES_STORES  // (timing experiment: without the scattered stores of the totals' series)
+            cbuf[(size_t)k * J + jr] = t;
+#endif
+            return fbf;
+        };
+        auto refreshDots = [&](const AbsDiag &cx, const CpkDiag &g, int off, int jr, const double (&fm)[NL][kPrefetch],
+                               const double (&rfC)[S][kPrefetch]) {
+            const int W = g.width;
+            const double *fsrc = ringAt(g);
+            float diagMax = -__builtin_huge_valf();
+#pragma unroll
+            for (int q = 0; q < kPrefetch; q++) {
+                const int k = q * CPK_WAVE - off + lane;
+                float fbf = -__builtin_huge_valf();
+                if (q * CPK_WAVE - off < W) {  // wave-uniform
+                    if ((unsigned)k < (unsigned)W) {
+                        double fRow[S];
+#pragma unroll
+                        for (int s2 = 0; s2 < S; s2++) fRow[s2] = s2 < NL ? fm[s2][q] : rfC[s2][q];
+                        fbf = dotCell(cx, k, fRow, jr);
+                    }
+                    if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
+                }
+            }
+            for (int kb = kPrefetch * CPK_WAVE - off; kb < W; kb += CPK_WAVE) {  // diagonals wider than the prefetch
+                const int k = kb + lane;
+                float fbf = -__builtin_huge_valf();
+                if (k < W) {
+                    double fRow[S];
+#pragma unroll
+                    for (int s2 = 0; s2 < S; s2++) fRow[s2] = ringLd(fsrc + ringIdx(W, s2, k));
+                    fbf = dotCell(cx, k, fRow, jr);
+                }
+                if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
+            }
+            if (CANDS) {
+                lastMax = fmaxf(diagMax, lastMax - 1.0f);
+                keepFrom = lastMax + logThr - kCandMargin;
+            }
+        };
+        auto loadRefreshRows = [&](const CpkDiag &g, int off, double (&rfC)[S][kPrefetch]) {
+            const double *fsrc = ringAt(g);
+#pragma unroll
+            for (int q = 0; q < kPrefetch; q++) {
+                const int k = q * CPK_WAVE - off + lane;
+#pragma unroll
+                for (int s2 = NL; s2 < S; s2++) rfC[s2][q] = (unsigned)k < (unsigned)g.width ? ringLd(fsrc + ringIdx(g.width, s2, k)) : 0.0;
+            }
+        };
+
+        // ---- the top diagonal: every cell gets the end-state prior (pairwiseAligner.c:798-799); nothing is read
+        CpkDiag g = dc.get(sg.dTop, true);
+        int gpos = dc.posGet(sg.dTop, true) >> 16;  // backward half of the diagonal's positions
+        int untilRefresh = sg.dTop - sg.tbFrom;  // diagonals until the next refresh point (every 10th emitted one, from tbFrom)
+        int jr = 0;                              // ... and its index
+        {
+            const int W = g.width;
+            const AbsDiag cx = absDiag(sg.dTop, g, gpos & 0x7fff);
+            const bool emit = sg.dTop <= sg.tbFrom;  // the last segment of a region: the top diagonal is tbFrom (and a refresh point)
+            const double *fsrc = ringAt(g);
+            double ep[S];
+#pragma unroll
+            for (int st = 0; st < S; st++) ep[st] = endPrior[st];
+            const bool feedsTop = untilRefresh == 1 && sg.dTop - 1 > sg.tbPrev;  // (traceBackDiagonals == 0 only)
+            for (int kb = 0; kb < W; kb += CPK_WAVE) {
+                const int k0 = kb + lane;
+                const bool on = k0 < W;
+                if (on) {
+#pragma unroll
+                    for (int st = 0; st < S; st++) cx.cur[st + cx.ownR + k0 * R] = ep[st];
+                }
+                if (emit || feedsTop) {
+                    double f0[NL];
+#pragma unroll
+                    for (int l = 0; l < NL; l++) f0[l] = ringLd(fsrc + ringIdx(W, l, on ? k0 : W - 1));
+                    if (feedsTop && on) mbuf[(size_t)k0 * J + jr] = f0[0] + ep[0];
+                    if (emit) emitCells(sg.dTop, cx.xlo + k0, on, f0, ep, g.cellOff + k0);  // keepFrom is still -inf: every cell
+                }
+            }
+            roll_fence<false>();
+            if (untilRefresh == 0) {
+                double fm[NL][kPrefetch], rfC[S][kPrefetch];
 #pragma unroll
                 for (int q = 0; q < kPrefetch; q++) {
-                    int k = q * CPK_WAVE - offd + lane;
-                    k = k < 0 ? 0 : k;
-                    dst[l][q] = ringLd(src + ringIdx(gd.width, l, k < gd.width ? k : gd.width - 1));
+                    const int k = q * CPK_WAVE + lane;
+#pragma unroll
+                    for (int l = 0; l < NL; l++) fm[l][q] = ringLd(fsrc + ringIdx(W, l, k < W ? k : W - 1));
                 }
-        };
+                loadRefreshRows(g, 0, rfC);
+                refreshDots(cx, g, 0, jr, fm, rfC);
+                untilRefresh = CPK_REFRESH_PERIOD - 1;
+                jr++;
+            } else {
+                untilRefresh--;
+            }
+        }
+
+        // ---- the diagonals below it
+        CpkDiag gb = g, ga{};                       // table entries of d2 + 1 and d2 + 2 ...
+        int posb = gpos & 0x7fff, posa = 0;          // ... and the positions of their first cells under the base in force
+        g = sg.dTop >= 1 ? dc.get(sg.dTop - 1, true) : CpkDiag{};
+        gpos = sg.dTop >= 1 ? dc.posGet(sg.dTop - 1, true) >> 16 : 0;
+        CpkDiag gnext = sg.dTop >= 2 ? dc.get(sg.dTop - 2, true) : CpkDiag{};
+        int gnpos = sg.dTop >= 2 ? dc.posGet(sg.dTop - 2, true) >> 16 : 0;
+        int off = 0;         // lane of the current diagonal's cell 0 in its first group
+        bool carry = false;  // lanes [0, off) of that group hold the last cells of the diagonal above:
+        AbsDiag tl{};        //   its context,
+        int tlK0 = 0, tlCellOff = 0;
+        double fTail[NL];    //   and its F values
+#pragma unroll
+        for (int l = 0; l < NL; l++) fTail[l] = 0.0;
         loadRows(g, 0, fmCur);
 #pragma unroll
         for (int l = 0; l < NL; l++)
 #pragma unroll
             for (int q = 0; q < kPrefetch; q++) asm volatile("" : "+v"(fmCur[l][q]));
-        int untilRefresh = sg.dTop - sg.tbFrom;
-        int jr = 0;
-        for (int d2 = sg.dTop; d2 > sg.tbPrev;) {
-          dc.load(d2 - 2 - (CPK_WAVE - 1));
+        for (int d2 = sg.dTop - 1; d2 > sg.tbPrev;) {
+          dc.load(d2 - 2 - (CPK_WAVE - 1));  // the chunk of table entries that ends at d2 - 2
           for (int ci = CPK_WAVE - 1; ci >= 0 && d2 > sg.tbPrev; ci--, d2--) {
-            const bool seeded = d2 == sg.dTop;
             const int W = g.width;
             const bool emit = d2 <= sg.tbFrom;
             const bool refresh = untilRefresh == 0;
+            // "Matches straddling diagonal r" (pairwiseAligner.c:643-651) is F[r+1].m + B[r+1].m of every cell: the
+            // diagonal above a refresh point writes that series (see traceback above)
             const bool feeds = untilRefresh == 1 && d2 - 1 > sg.tbPrev;
-            const int jrNext = jr;
             const int pLo = gpos & 0x7fff;
-            if ((gpos & 0x8000) && !seeded) {  // rare; never with cells of the diagonal above waiting (carryNext below)
+            if (gpos & 0x8000) {  // rare; never with cells of the diagonal above waiting (carryNext below)
                 const int delta = absRebase(d2, g, pLo, -1, gb, posb, true, ga, posa, d2 + 2 <= sg.dTop);
                 posb += delta;
                 posa += delta;
@@ -1082,7 +1217,8 @@ struct Sweep {
             // groups of this diagonal: qT whole ones (the first may be shared with the diagonal above), then r cells
             const int qT = (off + W) >> 6, r = (off + W) & (CPK_WAVE - 1);
             bool carryNext = false;
-            if (!seeded && !refresh && d2 - 1 > sg.tbPrev && r > 0 && qT >= 1 && qT < kPrefetch && !(gnpos & 0x8000)) {
+            if (!refresh && !feeds && r > 0 && qT >= 1 && qT < kPrefetch && d2 - 1 > sg.tbPrev && (d2 - 1 <= sg.tbFrom) == emit &&
+                !(gnpos & 0x8000)) {
                 const int bN = CPK_WAVE - r < gnext.width ? CPK_WAVE - r : gnext.width;
                 // the next diagonal's cells [0, bN) read this one up to position pLoN + bN - 1 + ((d2 - 1) & 1): below the
                 // first waiting cell, which sits at position pLo + qT * 64 - off
@@ -1090,75 +1226,47 @@ struct Sweep {
             }
             const int offNext = carryNext ? r : 0;
             double fmNext[NL][kPrefetch];
-            loadRows(gnext, offNext, fmNext);
+            loadRows(gnext, offNext, fmNext);  // one diagonal of arithmetic covers the round trip
             const CpkDiag gnext2 = dc.at(ci);
             const int gnpos2 = dc.posAt(ci) >> 16;
-            const double *fsrc = ringAt(g);
-            const float keepFrom = lastMax + logThr - kCandMargin;
-            double rfC[S][kPrefetch];
-            if (refresh) {
-#pragma unroll
-                for (int q = 0; q < kPrefetch; q++) {
-                    const int k = q * CPK_WAVE - off + lane;
-#pragma unroll
-                    for (int s2 = NL; s2 < S; s2++) rfC[s2][q] = (unsigned)k < (unsigned)W ? ringLd(fsrc + ringIdx(W, s2, k)) : 0.0;
-                }
-            }
-            // One group of 64 cells: lane by lane cell k0 of diagonal t (wave-uniform except in the shared group).  Control
-            // flow is wave-uniform (the candidate counts must stay identical in every lane): lanes that are not `on`
-            // recompute a cell of their diagonal and have their stores masked.
-            auto group = [&](const AbsDiag &t, int k0, int kR0, bool on, const double (&f0)[NL], bool tEmit, bool tFeeds, int tJr,
-                             int tCellOff, bool anyEmit) {
+            double rfC[S][kPrefetch];  // a refresh point reads every state of F[d2]: requested here, used behind the groups
+#ifndef CPK_TIMING_NO_PASSES
+            if (refresh) loadRefreshRows(g, off, rfC);
+#endif
+            // One group of 64 cells: lane by lane cell k0 of diagonal t (wave-uniform except in the shared group); lanes that
+            // are not `on` compute a cell of their diagonal all the same and store nothing.
+            auto group = [&](const AbsDiag &t, int k0, int kR0, bool on, const double (&f0)[NL], int tCellOff) {
+#ifdef CPK_TIMING_TRACE_REPEAT  // timing experiment: every traceback group computed this many times (0: not at all)
+              for (int rep = 0; rep < CPK_TIMING_TRACE_REPEAT; rep++) {
+#endif
+                BwdCtx c;
+                c.d2 = t.d;
+                c.xlo = t.xlo;
+                c.dbR = 0;
+                c.wBR = 0;
+                c.daR = 0;
+                c.wAR = 0;
+                c.pb = t.lu;
+                c.pa = t.cur;
+                const int kk[1] = {k0};
+                const int kkR[1] = {kR0};
                 double v[1][S];
-                if (seeded) {
-#pragma unroll
-                    for (int st = 0; st < S; st++) v[0][st] = ep[st];
-                } else {
-                    BwdCtx c;
-                    c.d2 = t.d;
-                    c.xlo = t.xlo;
-                    c.dbR = 0;
-                    c.wBR = 0;
-                    c.daR = 0;
-                    c.wAR = 0;
-                    c.pb = t.lu;
-                    c.pa = t.cur;
-                    const int kk[1] = {k0};
-                    const int kkR[1] = {kR0};
-                    bwdCells<1>(c, kk, kkR, v);
-                }
+                bwdCells<1>(c, kk, kkR, v);
                 if (on) {
 #pragma unroll
                     for (int st = 0; st < S; st++) t.cur[st + kR0] = v[0][st];
                 }
-                if (tFeeds && on) mbuf[(size_t)k0 * J + tJr] = f0[0] + v[0][0];
-                if (anyEmit) {
-                    const int x = t.xlo + k0, y = t.d - x;
-                    double fbv[NL];
-#pragma unroll
-                    for (int l = 0; l < NL; l++) fbv[l] = f0[l] + v[0][l];
-                    if (on && tEmit && dbgFb) dbgFb[tCellOff + k0] = fbv[0];
-#pragma unroll
-                    for (int l = 0; l < (CANDS ? NL : 0); l++) {
-                        const bool cell = l == 0 ? (x > 0 && y > 0) : (l == 1 ? x > 0 : y > 0);
-                        const bool keep = on && tEmit && cell && (float)fbv[l] >= keepFrom;
-                        const unsigned long long mask = __ballot(keep);
-                        if (keep) {
-                            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32),
-                                                                       __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                            Candidate cd;
-                            cd.fb = fbv[l];
-                            cd.x = x;
-                            cd.y = y;
-                            stage[l * kStage + ((head[l] + pend[l] + rank) & (kStage - 1))] = cd;
-                        }
-                        pend[l] += __popcll(mask);
-                        if (pend[l] >= CPK_WAVE) flush(l, CPK_WAVE);
-                    }
-                }
+#ifdef CPK_TIMING_TRACE_NO_EMIT
+                if (emit && a.geo.maxWidth < 0) emitCells(t.d, t.xlo + k0, on, f0, v[0], tCellOff + k0);
+#else
+                if (emit) emitCells(t.d, t.xlo + k0, on, f0, v[0], tCellOff + k0);
+#endif
+#ifdef CPK_TIMING_TRACE_REPEAT
+              }
+#endif
             };
-            // the shared group: lanes [0, off) finish the diagonal above, the others start this one
-            if (carry) {
+            int q0 = 0;
+            if (carry) {  // the shared group: lanes [0, off) finish the diagonal above, the others start this one
                 const bool inA = lane < off;
                 const int b = CPK_WAVE - off < W ? CPK_WAVE - off : W;
                 const bool on = lane < off + b;
@@ -1169,27 +1277,27 @@ struct Sweep {
                 mx.W = 0;
                 mx.cur = inA ? tl.cur : cx.cur;
                 mx.lu = inA ? tl.lu : cx.lu;
-                // lanes past the end of a narrow diagonal recompute its first cell
+                // lanes past the end of a narrow diagonal compute its first cell
                 const int k0 = inA ? tlK0 + lane : (on ? lane - off : 0);
                 const int kR0 = inA ? tl.ownR + tlK0 * R + laneR : (on ? cx.ownR - off * R + laneR : cx.ownR);
                 double f0[NL];
 #pragma unroll
                 for (int l = 0; l < NL; l++) f0[l] = inA ? fTail[l] : fmCur[l][0];
-                group(mx, k0, kR0, on, f0, inA ? tlEmit : emit, inA ? tlFeeds : feeds, inA ? tlJr : jrNext, inA ? tlCellOff : g.cellOff,
-                      tlEmit || emit);
+                group(mx, k0, kR0, on, f0, inA ? tlCellOff : g.cellOff);
+                q0 = 1;
             }
             // this diagonal's own groups; its last cells wait for the next diagonal when they may (carryNext)
             const int nNow = carryNext ? qT : qT + (r > 0 ? 1 : 0);
 #pragma unroll
             for (int q = 0; q < kPrefetch; q++) {
-                if (q >= (carry ? 1 : 0) && q < nNow) {
+                if (q >= q0 && q < nNow) {
                     double f0[NL];
 #pragma unroll
                     for (int l = 0; l < NL; l++) f0[l] = fmCur[l][q];
                     const int kb = q * CPK_WAVE - off;
                     const int k0 = kb + lane;
                     const bool on = k0 < W;
-                    group(cx, on ? k0 : W - 1, on ? cx.ownR + kb * R + laneR : cx.ownR + (W - 1) * R, on, f0, emit, feeds, jrNext, g.cellOff, emit);
+                    group(cx, on ? k0 : W - 1, on ? cx.ownR + kb * R + laneR : cx.ownR + (W - 1) * R, on, f0, g.cellOff);
                 }
             }
             for (int q = kPrefetch; q < nNow; q++) {  // diagonals wider than the prefetch load F on the spot
@@ -1198,56 +1306,30 @@ struct Sweep {
                 const bool on = k0 < W;
                 double f0[NL];
 #pragma unroll
-                for (int l = 0; l < NL; l++) f0[l] = ((emit || feeds) && on) ? ringLd(fsrc + ringIdx(W, l, k0)) : 0.0;
-                group(cx, on ? k0 : W - 1, on ? cx.ownR + kb * R + laneR : cx.ownR + (W - 1) * R, on, f0, emit, feeds, jrNext, g.cellOff, emit);
+                for (int l = 0; l < NL; l++) f0[l] = ringLd(ringAt(g) + ringIdx(W, l, on ? k0 : W - 1));
+                group(cx, on ? k0 : W - 1, on ? cx.ownR + kb * R + laneR : cx.ownR + (W - 1) * R, on, f0, g.cellOff);
             }
-            roll_fence<false>();
-            if (refresh) {
-                float diagMax = -__builtin_huge_valf();
-                auto dotCell = [&](int k, const double (&fRow)[S]) {
-                    const int kR = cx.ownR + k * R;
-                    double t = fRow[0] + cx.cur[kR];
-                    const int x = cx.xlo + k, y = d2 - x;
-                    const float fbf = (x > 0 && y > 0) ? (float)t : -__builtin_huge_valf();
-#pragma unroll
-                    for (int s2 = 1; s2 < S; s2++) t = logadd(lg, t, fRow[s2] + cx.cur[s2 + kR]);
-                    cbuf[(size_t)k * J + jr] = t;
-                    return fbf;
-                };
-#pragma unroll
-                for (int q = 0; q < kPrefetch; q++) {
-                    const int k = q * CPK_WAVE - off + lane;
-                    float fbf = -__builtin_huge_valf();
-                    if (q * CPK_WAVE - off < W) {  // wave-uniform
-                        if ((unsigned)k < (unsigned)W) {
-                            double fRow[S];
-#pragma unroll
-                            for (int s2 = 0; s2 < S; s2++) fRow[s2] = s2 < NL ? fmCur[s2][q] : rfC[s2][q];
-                            fbf = dotCell(k, fRow);
-                        }
-                        if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
+#ifdef CPK_TIMING_NO_PASSES  // timing experiment: neither the straddle series nor the dot products
+            if ((feeds || refresh) && a.geo.maxWidth < 0) {
+#else
+            if (feeds || refresh) {  // one diagonal in five: all its cells are done (no tail waits), a pass of its own follows
+#endif
+                roll_fence<false>();
+                if (feeds) {
+                    const double *fsrc = ringAt(g);
+                    for (int kb = -off; kb < W; kb += CPK_WAVE) {
+                        const int k = kb + lane;
+#ifndef CPK_TIMING_NO_SERIES_STORES
+                        if ((unsigned)k < (unsigned)W) mbuf[(size_t)k * J + jr] = ringLd(fsrc + ringIdx(W, 0, k)) + cx.cur[cx.ownR + k * R];
+#endif
                     }
                 }
-                for (int kb = kPrefetch * CPK_WAVE - off; kb < W; kb += CPK_WAVE) {
-                    const int k = kb + lane;
-                    float fbf = -__builtin_huge_valf();
-                    if (k < W) {
-                        double fRow[S];
-#pragma unroll
-                        for (int s2 = 0; s2 < S; s2++) fRow[s2] = ringLd(fsrc + ringIdx(W, s2, k));
-                        fbf = dotCell(k, fRow);
-                    }
-                    if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
-                }
-                if (CANDS) lastMax = fmaxf(diagMax, lastMax - 1.0f);
+                if (refresh) refreshDots(cx, g, off, jr, fmCur, rfC);
             }
             // the cells that wait: their context and their F values (group qT of this diagonal's prefetched rows)
             if (carryNext) {
                 tl = cx;
                 tlK0 = qT * CPK_WAVE - off;
-                tlEmit = emit;
-                tlFeeds = feeds;
-                tlJr = jrNext;
                 tlCellOff = g.cellOff;
 #pragma unroll
                 for (int l = 0; l < NL; l++) {
@@ -1268,6 +1350,8 @@ struct Sweep {
             gpos = gnpos;
             gnext = gnext2;
             gnpos = gnpos2;
+            // The empty asm consumes the prefetched registers HERE, one whole diagonal after their loads were issued and
+            // before the next prefetch goes out (left to itself hipcc waits at the first use, behind the next prefetch).
 #pragma unroll
             for (int l = 0; l < NL; l++)
 #pragma unroll
@@ -1792,7 +1876,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
 #endif
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
                 int nCand[NL];
-                if (ABS) sw.template tracebackAbs<NL, true>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
+                if constexpr (ABS) sw.template tracebackAbs<NL, true>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
                 else sw.template traceback<NL, EMIT != CPECAN_EMIT_EXPECT>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
                 roll_fence<true>();  // candidate / cbuf / mbuf stores of all lanes are complete before they are re-read
                 sw.foldTotals(sg, table);
