@@ -563,7 +563,8 @@ struct Sweep {
         const int pLo = pos & 0x7fff;
         if (pos & 0x8000) {  // rare: once per rectangle of the band
             absFlushTail();
-            const int delta = absRebase(d, g, pLo, 1, f1, apos1, d >= 1, f2, apos2, d >= 2);
+            const CpkDiag e1 = dc.table[d >= 1 ? d - 1 : 0], e2 = dc.table[d >= 2 ? d - 2 : 0];  // (not kept in registers)
+            const int delta = absRebase(d, g, pLo, 1, e1, apos1, d >= 1, e2, apos2, d >= 2);
             apos1 += delta;
             apos2 += delta;
         }
@@ -571,7 +572,10 @@ struct Sweep {
         double *out = ringAt(g);
         int lo = 0;
 #if defined(CPK_ABS_FWD_FORM) && CPK_ABS_FWD_FORM > 0
-        // timing experiments (tools/ab_build.sh): no streaming; FORM 2: pairs of groups in lock-step (two cells per lane)
+        // timing experiments (tools/ab_build.sh): no streaming; FORM 2: pairs of groups in lock-step (two cells per lane).
+        // Measured (profiles/r03_forward_what_bounds_it.txt, r03_ab_forward_pairs_under_subscribed.txt): the pairs are 6 %
+        // slower with every wave slot busy and within 1.5 % of the stream on launches with fewer regions than slots (1250 /
+        // 2500 config-B pairs, config A) -- two cells per lane buy nothing on this kernel.
         for (; CPK_ABS_FWD_FORM == 2 && W - lo > CPK_WAVE; lo += 2 * CPK_WAVE) absFwdGroup2(c, out, ringStates, lo, W);
 #ifdef CPK_TIMING_GROUP_REPEAT  // timing experiment: every group computed CPK_TIMING_GROUP_REPEAT times (0: not at all)
         for (; lo < W; lo += CPK_WAVE)
@@ -581,8 +585,6 @@ struct Sweep {
 #endif
         apos2 = apos1;
         apos1 = pLo;
-        f2 = f1;
-        f1 = g;
         return;
 #endif
         if (atail.has) {
@@ -639,8 +641,6 @@ struct Sweep {
         }
         apos2 = apos1;
         apos1 = pLo;
-        f2 = f1;
-        f1 = g;
     }
 
     // Puts diagonal d of the forward ring back into its rolling buffer (after a traceback used the buffers).
@@ -1029,7 +1029,7 @@ struct Sweep {
             nCand[l] += n;
         };
         float lastMax = -__builtin_huge_valf();
-        float keepFrom = lastMax;
+        double keepFrom = lastMax;  // compared in double: one instruction per group instead of a conversion and a compare
         absWipe();  // nothing above the top diagonal exists: its neighbours read -inf
         // F rows of the emitted states, lane <-> cell k = q * 64 - off + lane of group q; unclamped (see above)
         double fmCur[NL][kPrefetch];
@@ -1058,7 +1058,7 @@ struct Sweep {
 #pragma unroll
             for (int l = 0; l < (CANDS ? NL : 0); l++) {
                 const bool cell = l == 0 ? (x > 0 && y > 0) : (l == 1 ? x > 0 : y > 0);
-                const bool keep = on && cell && (float)fbv[l] >= keepFrom;
+                const bool keep = on && cell && fbv[l] >= keepFrom;
                 const unsigned long long mask = __ballot(keep);
                 if (keep) {
                     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
@@ -1082,9 +1082,7 @@ struct Sweep {
             const float fbf = (x > 0 && y > 0) ? (float)t : -__builtin_huge_valf();
 #pragma unroll
             for (int s2 = 1; s2 < S; s2++) t = logadd(lg, t, fRow[s2] + cx.cur[s2 + kR]);
-#ifndef CPK_TIMING_NO_SERIES_STORES  // (timing experiment: without the scattered stores of the totals' series)
             cbuf[(size_t)k * J + jr] = t;
-#endif
             return fbf;
         };
         auto refreshDots = [&](const AbsDiag &cx, const CpkDiag &g, int off, int jr, const double (&fm)[NL][kPrefetch],
@@ -1119,7 +1117,7 @@ struct Sweep {
             }
             if (CANDS) {
                 lastMax = fmaxf(diagMax, lastMax - 1.0f);
-                keepFrom = lastMax + logThr - kCandMargin;
+                keepFrom = (double)(lastMax + logThr - kCandMargin);
             }
         };
         auto loadRefreshRows = [&](const CpkDiag &g, int off, double (&rfC)[S][kPrefetch]) {
@@ -1180,8 +1178,7 @@ struct Sweep {
         }
 
         // ---- the diagonals below it
-        CpkDiag gb = g, ga{};                       // table entries of d2 + 1 and d2 + 2 ...
-        int posb = gpos & 0x7fff, posa = 0;          // ... and the positions of their first cells under the base in force
+        int posb = gpos & 0x7fff, posa = 0;  // positions of the first cells of d2 + 1 and d2 + 2 under the base in force
         g = sg.dTop >= 1 ? dc.get(sg.dTop - 1, true) : CpkDiag{};
         gpos = sg.dTop >= 1 ? dc.posGet(sg.dTop - 1, true) >> 16 : 0;
         CpkDiag gnext = sg.dTop >= 2 ? dc.get(sg.dTop - 2, true) : CpkDiag{};
@@ -1209,7 +1206,9 @@ struct Sweep {
             const bool feeds = untilRefresh == 1 && d2 - 1 > sg.tbPrev;
             const int pLo = gpos & 0x7fff;
             if (gpos & 0x8000) {  // rare; never with cells of the diagonal above waiting (carryNext below)
-                const int delta = absRebase(d2, g, pLo, -1, gb, posb, true, ga, posa, d2 + 2 <= sg.dTop);
+                const bool have2 = d2 + 2 <= sg.dTop;
+                const CpkDiag gb = dc.table[d2 + 1], ga = dc.table[have2 ? d2 + 2 : d2 + 1];  // (not kept in registers: once per rectangle)
+                const int delta = absRebase(d2, g, pLo, -1, gb, posb, true, ga, posa, have2);
                 posb += delta;
                 posa += delta;
             }
@@ -1315,13 +1314,16 @@ struct Sweep {
             if (feeds || refresh) {  // one diagonal in five: all its cells are done (no tail waits), a pass of its own follows
 #endif
                 roll_fence<false>();
-                if (feeds) {
+                if (feeds) {  // F.m of the cells from the prefetched registers, B.m from the rows
+#pragma unroll
+                    for (int q = 0; q < kPrefetch; q++) {
+                        const int k = q * CPK_WAVE - off + lane;
+                        if ((unsigned)k < (unsigned)W) mbuf[(size_t)k * J + jr] = fmCur[0][q] + cx.cur[cx.ownR + k * R];
+                    }
                     const double *fsrc = ringAt(g);
-                    for (int kb = -off; kb < W; kb += CPK_WAVE) {
+                    for (int kb = kPrefetch * CPK_WAVE - off; kb < W; kb += CPK_WAVE) {
                         const int k = kb + lane;
-#ifndef CPK_TIMING_NO_SERIES_STORES
-                        if ((unsigned)k < (unsigned)W) mbuf[(size_t)k * J + jr] = ringLd(fsrc + ringIdx(W, 0, k)) + cx.cur[cx.ownR + k * R];
-#endif
+                        if (k < W) mbuf[(size_t)k * J + jr] = ringLd(fsrc + ringIdx(W, 0, k)) + cx.cur[cx.ownR + k * R];
                     }
                 }
                 if (refresh) refreshDots(cx, g, off, jr, fmCur, rfC);
@@ -1342,9 +1344,7 @@ struct Sweep {
             carry = carryNext;
             off = offNext;
             // slide the window of table entries, positions and prefetched F rows down one diagonal
-            ga = gb;
             posa = posb;
-            gb = g;
             posb = pLo;
             g = gnext;
             gpos = gnpos;
@@ -1824,6 +1824,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
             }
             int d = 1;
             int emitSeg = 0, emitFrom = a.segs[rg.segOff].tbFrom;  // the segment whose traceback emits diagonal d: the first with tbFrom >= d
+            int toRefresh = (emitFrom - 1) % CPK_REFRESH_PERIOD;    // (emitFrom - d) mod 10 as a countdown: no division per diagonal
             const int siFirst = traceRole ? itemSeg : 0, siEnd = traceRole ? itemSeg + 1 : rg.nSeg;
             for (int si = siFirst; si < siEnd; si++) {
                 const CpkSegment sg = a.segs[rg.segOff + si];
@@ -1836,8 +1837,12 @@ cpecan_pairhmm_sweep(const KArgs a) {
                     sw.dc.load(d);  // table entries of diagonals d .. d+63
                     const int dEnd = d + CPK_WAVE - 1 < sg.dTop ? d + CPK_WAVE - 1 : sg.dTop;
                     for (; d <= dEnd; d++) {
-                        while (d > emitFrom) emitFrom = a.segs[rg.segOff + ++emitSeg].tbFrom;  // the last segment ends at N
-                        const bool all = EMIT != CPECAN_EMIT_MATCH || (emitFrom - d) % CPK_REFRESH_PERIOD == 0 || d >= sg.dTop - 1;
+                        if (d > emitFrom) {
+                            while (d > emitFrom) emitFrom = a.segs[rg.segOff + ++emitSeg].tbFrom;  // the last segment ends at N
+                            toRefresh = (emitFrom - d) % CPK_REFRESH_PERIOD;
+                        }
+                        const bool all = EMIT != CPECAN_EMIT_MATCH || toRefresh == 0 || d >= sg.dTop - 1;
+                        toRefresh = toRefresh == 0 ? CPK_REFRESH_PERIOD - 1 : toRefresh - 1;
                         if (ABS) sw.forwardStreamAbs(d, sw.dc.at(d - sw.dc.base), sw.dc.posAt(d - sw.dc.base), all ? S : 1);
                         else if (FAST) sw.forwardStream(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
                         else sw.forward(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
