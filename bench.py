@@ -299,7 +299,12 @@ def main():
 
     total_cells, total_pairs = cells, len(mine)
     per_rank_cells = [cells]
+    per_rank_ms = [elapsed / args.steps * 1e3]
     if world > 1:
+        tr = torch.zeros(world, dtype=torch.float64, device=red_dev)
+        tr[rank] = elapsed / args.steps * 1e3
+        dist.all_reduce(tr, op=dist.ReduceOp.SUM)
+        per_rank_ms = [float(v) for v in tr.tolist()]  # every rank's own time per step (the line's time is their maximum)
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -320,7 +325,10 @@ def main():
 
     # ---- SURVEY 8d's wall clock: problems resident in host memory -> result lists materialised in host memory ----
     e2e = {"plan_upload_s": upload_s, "download_and_assemble_s": d2h_s, "pairs_emitted": int(st.pairs),
-           "device_bytes": int(st.deviceBytes), "waves": int(st.wavesPerLaunch)}
+           "device_bytes": int(st.deviceBytes), "waves": int(st.wavesPerLaunch),
+           # which form the widest size class ran in: the split forms hold whole regions' forward values (cpecan_hip.h)
+           "launch_form": {0: "one wave per region", 1: "two launches", 2: "one launch"}[int(st.launchForm) & 3] +
+                          (", absolute positions" if int(st.launchForm) & 4 else "")}
     value_e2e = None
     if not args.no_e2e:
         # the timed batch goes first: a config-B batch in its one-launch form holds the forward values of every region
@@ -459,6 +467,7 @@ def main():
                 "pairs_total": total_pairs,
                 "cells_total": total_cells,
                 "cells_per_rank": per_rank_cells,
+                "ms_per_step_per_rank": per_rank_ms,
                 "world_size": world,
                 "parallelism": "pairs dealt longest-first over %d GPU(s), no data-path collective" % world
                                if scaling == "strong" else "every GPU its own batch, no data-path collective",

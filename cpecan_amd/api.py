@@ -75,7 +75,7 @@ class Stats(C.Structure):
         ("problems", C.c_int64), ("regions", C.c_int64), ("cells", C.c_int64), ("diagonals", C.c_int64),
         ("pairs", C.c_int64), ("deviceBytes", C.c_int64),
         ("kernelMs", C.c_double), ("h2dMs", C.c_double), ("d2hMs", C.c_double),
-        ("launches", C.c_int32), ("wavesPerLaunch", C.c_int32),
+        ("launches", C.c_int32), ("wavesPerLaunch", C.c_int32), ("launchForm", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

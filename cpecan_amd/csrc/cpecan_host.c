@@ -1194,6 +1194,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
     if (rc != CPECAN_OK) goto fail2;
     b->stats.deviceBytes = cpk_device_bytes(b->dev);
     b->stats.wavesPerLaunch = cpk_device_waves(b->dev);
+    b->stats.launchForm = cpk_device_form(b->dev);
     b->frozen = 1;
     free(diagStart);
     free(segStart);

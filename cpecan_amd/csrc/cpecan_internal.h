@@ -161,6 +161,7 @@ int cpk_device_upload(CpkDevice *dev, const CpkGeometry *geo, const CpkModel *mo
 double cpk_device_h2d_ms(CpkDevice *dev); /* the upload's copy time; waits for the copies */
 int cpk_device_update_regions(CpkDevice *dev, const CpkRegion *regions, const CpkSegment *segs, int64_t outTriplesPerList);
 int cpk_device_run(CpkDevice *dev, void *stream);
+int cpk_device_form(const CpkDevice *dev); /* CPECAN_FORM_* of the batch's last (widest) size class */
 /* Once more on the stream of the last run (after an output overflow); kernel times of a batch's launches add up. */
 int cpk_device_rerun(CpkDevice *dev);
 /* Blocks until the run is complete and copies back the per-region counts and per-segment start offsets (and the

@@ -1112,6 +1112,10 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             }
         };
         planSplit();
+        // The rings of whole regions are a fixed share of the device at most (CPECAN_SPLIT_BUDGET_FRAC, default 0.45: two
+        // pipelined batches fit whatever is free at this moment), so that the same batch always runs in the same form.
+        double splitBudget = 0.45 * (double)totalB;
+        if (const char *fr = getenv("CPECAN_SPLIT_BUDGET_FRAC")) splitBudget = atof(fr) * (double)totalB;
         double need = 0, floorNeed = 0;
         auto tally = [&]() {
             need = floorNeed = fixed;
@@ -1121,7 +1125,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             }
         };
         tally();
-        if (need > budget) {  // whole-region rings are a luxury: give them up before giving up resident waves
+        if (need > budget || need > splitBudget) {  // whole-region rings are a luxury: give them up before giving up resident waves
             unsplit();
             tally();
         }
@@ -1728,4 +1732,9 @@ extern "C" int cpk_ref_cells(int device, const CpkModel *model, int mode, const 
 }
 
 extern "C" int64_t cpk_device_bytes(const CpkDevice *d) { return d->bytes; }
+extern "C" int cpk_device_form(const CpkDevice *d) {
+    if (d->classes.empty()) return CPECAN_FORM_WHOLE;
+    const LaunchClass &c = d->classes.back();
+    return (c.split ? (c.fused ? CPECAN_FORM_FUSED : CPECAN_FORM_SPLIT) : CPECAN_FORM_WHOLE) | (c.abs ? CPECAN_FORM_ABS : 0);
+}
 extern "C" int cpk_device_waves(const CpkDevice *d) { return d->totalWaves; }

@@ -96,7 +96,15 @@ typedef struct cpecan_stats {
     double h2dMs, d2hMs;   /* last upload / download */
     int32_t launches;      /* kernel launches in the last run (1 unless output overflow forced a re-run) */
     int32_t wavesPerLaunch;
+    /* How the widest size class of the batch runs (CPECAN_FORM_*): one wave per region, or its tracebacks as queue items
+     * of a second launch / of the same launch; | CPECAN_FORM_ABS: sweeps over absolute positions.  The split forms keep
+     * the forward values of whole regions (68 GB at BASELINE config B) and are only taken while the batch stays under
+     * CPECAN_SPLIT_BUDGET_FRAC (default 0.45) of the device's memory, so that two pipelined batches fit. */
+    int32_t launchForm;
+    int32_t reserved;
 } cpecan_stats;
+
+enum { CPECAN_FORM_WHOLE = 0, CPECAN_FORM_SPLIT = 1, CPECAN_FORM_FUSED = 2, CPECAN_FORM_ABS = 4 };
 
 /* ---- model / parameter helpers (stateMachine.c / pairwiseAligner.c defaults) ---- */
 int cpecan_model_default(cpecan_model *m, int32_t type);          /* stateMachine5/3_construct, stateMachine.c:482,716 */
