@@ -497,6 +497,7 @@ struct CpkDevice {
     void *hostCounts = nullptr;  // the block of the host pool that holds the three
     CpkItem *dItems = nullptr;
     int *dProgress = nullptr;  // fused classes: per region, segments whose forward values are complete (+ an error word)
+    bool fusedRetried = false; // a fused class timed out once and runs as two launches now (cpk_device_download)
     int32_t *dCompact = nullptr; CpkChunk *dChunks = nullptr; int64_t compactCap = 0, chunkCap = 0;
     unsigned int *dQueue = nullptr;
     double *dDbgFb = nullptr, *dDbgTotals = nullptr;
@@ -820,6 +821,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     CPK_ON_DEVICE(d->device);
     free_all(d);
     d->kernelMsAccum = 0.0;
+    d->fusedRetried = false;
     d->geo = *geo;
     d->kc = KConsts{model->matchContinue, model->matchFromShortX, model->matchFromShortY, model->matchFromLongX,
                     model->matchFromLongY, model->shortOpenX, model->shortOpenY, model->shortExtendX,
@@ -1042,6 +1044,11 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                 // (the one-launch form addresses a region's ring with 32-bit byte offsets: Sweep::ringPut)
                 c.fused = (env ? atoi(env) == 2 : oneLaunch) && maxRing < ((int64_t)1 << 28);
                 if (c.fused) {
+                    // an item polls this often (s_sleep between polls: seconds in all) for its region's forward values; a
+                    // count that never comes is reported and the class re-run in two launches (cpk_device_download).
+                    // CPECAN_FUSED_SPIN: tests force that path with a bound of a few polls.
+                    const char *spinEnv = getenv("CPECAN_FUSED_SPIN");
+                    c.geo.fusedSpin = spinEnv ? atoi(spinEnv) : (1 << 24);
                     c.fn = pick_fused_kernel(c.geo, c.dense, c.abs);
                     // One CU in eight keeps a wave slot (and its 19 KB of LDS) free: a launch that fills every slot to its
                     // end starves the small kernels of the batch before it -- the list consumers need a few KB of LDS --
@@ -1453,8 +1460,24 @@ extern "C" int cpk_device_download(CpkDevice *d, int32_t *counts, int32_t *segSt
         HIP_TRY(hipMemcpyAsync(&err, d->dProgress + d->geo.nRegions, sizeof(int), hipMemcpyDeviceToHost, io));
         HIP_TRY(hipStreamSynchronize(io));
         if (err) {
-            cpk_set_error("fused launch: a traceback item waited in vain for its region's forward sweep");
-            return CPECAN_EHIP;
+            // An item gave up waiting for its region's forward values (a bounded poll).  The rings of the class are whole:
+            // run it again as two launches -- all forward sweeps, then all items -- which needs no hand-off inside a launch.
+            bool any = false;
+            for (LaunchClass &c : d->classes) {
+                if (!c.fused) continue;
+                any = true;
+                c.fused = false;
+                pick_split_kernels(c.geo, c.dense, c.abs, &c.fn, &c.fnTrace);
+                c.wavesTrace = c.waves;
+                if (c.waves > c.regionCount) c.waves = c.regionCount;
+            }
+            if (!any || d->fusedRetried) {
+                cpk_set_error("fused launch: a traceback item waited in vain for its region's forward sweep");
+                return CPECAN_EHIP;
+            }
+            d->fusedRetried = true;
+            if (int rc = cpk_device_rerun(d)) return rc;
+            return cpk_device_download(d, counts, segStarts, segCounts, expect, kernelMs, d2hMs);
         }
     }
     // written by the sweeps straight into pinned host memory; complete with the stop event

@@ -1669,6 +1669,12 @@ constexpr int kEmitForward = 3;
 //                 or done: no deadlock whatever the number of resident waves.  The tracebacks of a region's first
 //                 segments then run beside the forward sweeps of the class instead of behind the slowest of them.
 constexpr int kModeWhole = 0, kModeForward = 1, kModeTrace = 2, kModeFused = 3;
+// kModeFused hands the forward ring from wave to wave inside one launch with sc1 (device-scope write-through / read-through)
+// accesses and a flag behind an acknowledged-stores wait: the hand-off MI355X_MICROARCH.md lists for gfx942 / gfx950, outside
+// what the HIP memory model promises in general.  This translation unit is gfx950 code; refuse anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "cpecan_kernels.hip: the one-launch hand-off (kModeFused) relies on gfx942 / gfx950 sc1 semantics"
+#endif
 
 // WPS: waves per SIMD the registers are allocated for.  Two everywhere (the five-state match kernel needs ~230 VGPRs)
 // except the three-state match kernels of classes with more regions than two waves per SIMD hold: at 168 VGPRs (a
@@ -1865,7 +1871,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                     // wait until the region's forward wave has passed this segment's top diagonal (bounded: a count that
                     // never comes is reported, not waited for)
                     int seen = 0;
-                    for (int spin = 0; spin < (1 << 24); spin++) {
+                    for (int spin = 0; spin < a.geo.fusedSpin; spin++) {
                         seen = __hip_atomic_load(a.progress + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         if (seen > si) break;
                         __builtin_amdgcn_s_sleep(16);

@@ -1019,6 +1019,21 @@ def test_pipelined_batches_equal_unpipelined_ones():
                 assert np.array_equal(a, b), (name, "job", k, "problem", i, len(a), len(b))
 
 
+def test_one_launch_form_times_out_into_two_launches(monkeypatch):
+    """an item of the one-launch form that gives up waiting for its region's forward values (here: after a
+    single poll, CPECAN_FUSED_SPIN=1) is reported by the launch, and the download runs the class again as two launches
+    instead of failing -- same lists as one wave per region."""
+    probs = [make_pair(4, i, 2000, 60) for i in range(24)]
+    monkeypatch.setenv("CPECAN_SPLIT", "0")
+    whole, st0 = _run_batch(0, probs, diagonalExpansion=60)
+    monkeypatch.setenv("CPECAN_SPLIT", "2")
+    monkeypatch.setenv("CPECAN_FUSED_SPIN", "1")
+    fused, st1 = _run_batch(0, probs, diagonalExpansion=60)
+    assert st1.launches >= 1 and st1.cells == st0.cells
+    for a, b in zip(fused, whole):
+        assert np.array_equal(a, b)
+
+
 def test_cache_trim_gives_idle_blocks_back():
     """idle device / host blocks of destroyed batches can be returned to the driver (cpecan_cache_trim), and
     the library keeps working afterwards."""
