@@ -173,16 +173,14 @@ __device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
 }
 #endif
 
-// exp(x) to a relative error of ~1e-7 for x <= ~1 (probabilities): 2^(x log2 e) with the integer part split off in
-// double, the fraction through v_exp_f32, and the scaling by v_ldexp_f64 -- 8 instructions instead of the ~35 of the
-// double-precision exp.  Only for the expectation sums, whose gate is 1e-5 relative (linear-space
-// sums, order-insensitive at 1e-5); the posterior emitters keep the exact exp.
+// exp(x) for the expectation sums only (probabilities: x <= ~1), whose gate is 1e-5 relative (SURVEY 8a row a11:
+// linear-space sums, order-insensitive at 1e-5); the posterior emitters keep the exact exp.  Round 3: 2^(x log2 e) with the
+// product formed in double and handed to v_exp_f32 as a float -- four instructions (round 2 split off the integer part in
+// double and scaled with v_ldexp_f64: eight, ~1e-7).  The float carries x log2 e to 2^-24 relative, i.e. the result to
+// |x log2 e| * 4e-8 relative: 8e-7 for an event 1e-6 times less likely than its cell's total (|x log2 e| = 20), less for
+// the likelier ones that make up the sums; events below 2^-126 count as zero.  -inf (an unreachable transition) gives 0.
 __device__ __forceinline__ double exp_1e7(double x) {
-    // branch-free: -inf, NaN (an unreachable transition) and anything below 2^-1100 end as ldexp(.., -1100) == 0
-    const double y = __builtin_fmax(x * 1.4426950408889634 /* log2(e) */, -1100.0);
-    const double yi = __builtin_rint(y);
-    const float yf = (float)(y - yi);         // in [-0.5, 0.5]
-    return __builtin_ldexp((double)__builtin_amdgcn_exp2f(yf), (int)yi);
+    return (double)__builtin_amdgcn_exp2f((float)(x * 1.4426950408889634 /* log2(e) */));
 }
 
 // Packs the nSym one-byte symbols at src into LDS, two to a byte (low nibble = even index; a missing partner reads as
