@@ -1380,85 +1380,132 @@ struct Sweep {
     // tAcc: per-lane sums, one per transition in list order; eLds: [state*16 + cX*4 + cY] in LDS (fp64 LDS atomics).
     static constexpr int kNT = S == 5 ? 13 : 9;
 
-    // One group of 64 cells of one emitted diagonal, as the expectation step sees it.
-    struct ExpItem {
-        int d2, kb, W, xlo, dl, dm, w1, w2, w2Load, cellOff;
+    // One emitted diagonal as the expectation step sees it (wave-uniform).
+    struct ExpDiag {
+        int d2, W, xlo, dl, dm, w1, w2, w2Load, cellOff;
         const double *f1, *f2;
         int jt;  // refresh point whose total normalises the diagonal
+    };
+    // One item of the step: up to 64 CELLS, the last nA cells [kA, kA + nA) of diagonal A and the first nB cells of the
+    // next lower diagonal B.  (Round 3: the step has no dependency between cells, so it streams them across diagonals;
+    // rounds 1-2 gave every diagonal groups of its own -- BASELINE config 5's 36-cell diagonals filled them to 56 %.)
+    struct ExpItem {
+        ExpDiag A, B;
+        int kA, nA, nB;
         bool valid;
     };
-    // What the step reads for its cell: B of the cell, F[d2-1] at the lower / upper neighbour, F[d2-2] at the middle one.
+    // What the step keeps per lane for its cell: B of the cell, F[d2-1] at the lower / upper neighbour, F[d2-2] at the
+    // middle one, the total of its diagonal, and the cell itself (coordinates, which neighbours exist, first cell of its
+    // diagonal or not).
     struct ExpLoads {
         double v[S], fL[S], fU[S], fM[S];
         double total;
+        // the cell's coordinates (both below 2^30) with four flags in their top bits -- x: 30 = lower neighbour in the band,
+        // 31 = upper; y: 30 = middle, 31 = cell 0 of its diagonal.  A lane without a cell has no flag set.
+        unsigned x, y;
     };
 
     __device__ void expectations(const CpkSegment &sg, double (&tAcc)[kNT], double *eLds, double &likelihood) {
         const int bBase = dc.table[sg.tbPrev + 1].cellOff;
-        // The step has no dependency between cells: it is a stream of (diagonal, group) items.  Three items are in
-        // flight: the loads of an item (16 values per cell) are issued two items before its events are computed, i.e.
-        // ~500 vector instructions ahead -- one item of lead (~250 instructions, round 1) is shorter than a loaded HBM
-        // round trip, and the waves of this emitter waited 47 % of their cycles.  The pass stores nothing to global
-        // memory, and every load is unconditional (an item behind the last one reads valid words it never uses), so
-        // the wait in front of an item's events can count the younger loads and leave them in flight.
-        auto first_of = [&](int d2) {
-            ExpItem it{};
-            it.valid = d2 > sg.tbPrev;
-            const int dd = it.valid ? d2 : sg.tbPrev + 1;  // behind the last diagonal: the last one again, never used
+        // kDepth items are in flight: the loads of an item (16 values per cell) are issued kDepth - 1 items before its
+        // events are computed.  The pass stores nothing to global memory, and every load is unconditional (a lane without
+        // a cell, an item behind the last one: valid words that are never used), so the wait in front of an item's events
+        // can count the younger loads and leave them in flight.
+        auto diag_of = [&](int d2) {
+            ExpDiag e;
+            const int dd = d2 > sg.tbPrev ? d2 : sg.tbPrev + 1;  // behind the last diagonal: the last one again, never used
             const CpkDiag g = dc.get(dd, true);
             const CpkDiag g1 = dc.get(dd - 1, true);      // F[d2-1]: always alive (d2-1 >= tbPrev)
             const bool haveM2 = dd - 2 >= sg.tbPrev;      // F[d2-2] is gone at d2 == tbPrev+1 (:843-845)
             const CpkDiag g2 = haveM2 ? dc.get(dd - 2, true) : g1;
-            it.d2 = dd;
-            it.kb = 0;
-            it.W = g.width;
-            it.xlo = (dd + g.xmyL) >> 1;
-            it.dl = (g.xmyL - 1 - g1.xmyL) >> 1;  // lower neighbour (d2-1, xmy-1) is cell k+dl of F[d2-1]
-            it.dm = (g.xmyL - g2.xmyL) >> 1;      // middle neighbour (d2-2, xmy) is cell k+dm of F[d2-2]
-            it.w1 = g1.width;
-            it.w2 = haveM2 ? g2.width : 0;
-            it.w2Load = g2.width;                 // the row the middle loads read (g1's when F[d2-2] is gone: unused then)
-            it.cellOff = g.cellOff;
-            it.f1 = ringAt(g1);
-            it.f2 = ringAt(g2);
-            it.jt = (sg.tbFrom - dd) / CPK_REFRESH_PERIOD;  // its total is loaded with the item's other values (issue)
+            e.d2 = dd;
+            e.W = g.width;
+            e.xlo = (dd + g.xmyL) >> 1;
+            e.dl = (g.xmyL - 1 - g1.xmyL) >> 1;  // lower neighbour (d2-1, xmy-1) is cell k+dl of F[d2-1]
+            e.dm = (g.xmyL - g2.xmyL) >> 1;      // middle neighbour (d2-2, xmy) is cell k+dm of F[d2-2]
+            e.w1 = g1.width;
+            e.w2 = haveM2 ? g2.width : 0;
+            e.w2Load = g2.width;                 // the row the middle loads read (g1's when F[d2-2] is gone: unused then)
+            e.cellOff = g.cellOff;
+            e.f1 = ringAt(g1);
+            e.f2 = ringAt(g2);
+            e.jt = (sg.tbFrom - dd) / CPK_REFRESH_PERIOD;
+            return e;
+        };
+        // the stream's cursor: the next cell to hand out is cell curK of diagonal cur.d2 (curValid: there is one)
+        ExpDiag cur = diag_of(sg.tbFrom);
+        int curK = 0;
+        bool curValid = sg.tbFrom > sg.tbPrev;
+        auto next_item = [&]() {
+            ExpItem it;
+            it.valid = curValid;
+            it.A = cur;
+            it.kA = curK;
+            it.nA = curValid ? (cur.W - curK < CPK_WAVE ? cur.W - curK : CPK_WAVE) : 0;
+            it.B = cur;
+            it.nB = 0;
+            if (!curValid) return it;
+            if (curK + it.nA < cur.W) {  // diagonal A goes on in the next item
+                curK += it.nA;
+                return it;
+            }
+            // A is finished: the first cells of the diagonal below share the item
+            if (cur.d2 - 1 > sg.tbPrev) {
+                cur = diag_of(cur.d2 - 1);
+                const int room = CPK_WAVE - it.nA;
+                it.B = cur;
+                it.nB = cur.W < room ? cur.W : room;
+                curK = it.nB;
+                if (curK >= cur.W) {  // B fits whole: the cursor moves on to the diagonal below it (a third diagonal never shares)
+                    if (cur.d2 - 1 > sg.tbPrev) {
+                        cur = diag_of(cur.d2 - 1);
+                        curK = 0;
+                    } else {
+                        curValid = false;
+                    }
+                }
+            } else {
+                curValid = false;
+            }
             return it;
         };
-        auto next_of = [&](const ExpItem &it) {
-            if (!it.valid) return it;
-            if (it.kb + CPK_WAVE < it.W) {
-                ExpItem n = it;
-                n.kb += CPK_WAVE;
-                return n;
-            }
-            return first_of(it.d2 - 1);
-        };
         auto issue = [&](const ExpItem &it, ExpLoads &L) {
-            int k = it.kb + lane;
-            k = k < it.W ? k : it.W - 1;  // lanes past the end re-read the last cell
-            const int kL = k + it.dl, kU = k + it.dl + 1, kM = k + it.dm;
-            const int qL = (unsigned)kL < (unsigned)it.w1 ? kL : 0, qU = (unsigned)kU < (unsigned)it.w1 ? kU : 0;
-            const int qM = (unsigned)kM < (unsigned)it.w2Load ? kM : 0;
-            const int gN = it.W - it.kb < CPK_WAVE ? it.W - it.kb : CPK_WAVE;
-            const double *bo = bring + (size_t)(it.cellOff - bBase + it.kb) * S + (k - it.kb);
-            L.total = ld_self(totals + it.jt);
+            const bool inA = lane < it.nA;
+            const bool has = lane < it.nA + it.nB;
+            // per lane: the diagonal of its cell (lanes without a cell read B's first cell and use nothing)
+            const int W = inA ? it.A.W : it.B.W, d2 = inA ? it.A.d2 : it.B.d2, xlo = inA ? it.A.xlo : it.B.xlo;
+            const int dl = inA ? it.A.dl : it.B.dl, dm = inA ? it.A.dm : it.B.dm;
+            const int w1 = inA ? it.A.w1 : it.B.w1, w2 = inA ? it.A.w2 : it.B.w2, w2Load = inA ? it.A.w2Load : it.B.w2Load;
+            const int cellOff = inA ? it.A.cellOff : it.B.cellOff, jt = inA ? it.A.jt : it.B.jt;
+            const double *f1 = inA ? it.A.f1 : it.B.f1, *f2 = inA ? it.A.f2 : it.B.f2;
+            int k = inA ? it.kA + lane : (has ? lane - it.nA : 0);
+            k = k < W ? k : W - 1;
+            const int kL = k + dl, kU = k + dl + 1, kM = k + dm;
+            const bool okL = (unsigned)kL < (unsigned)w1, okU = (unsigned)kU < (unsigned)w1, okM = (unsigned)kM < (unsigned)w2;
+            const int qL = okL ? kL : 0, qU = okU ? kU : 0;
+            const int qM = (unsigned)kM < (unsigned)w2Load ? kM : 0;
+            // the traceback kept B per group of gN cells, state-major (traceback: `bring`)
+            const int kb = k & ~(CPK_WAVE - 1);
+            const int gN = W - kb < CPK_WAVE ? W - kb : CPK_WAVE;
+            const double *bo = bring + (size_t)(cellOff - bBase + kb) * S + (k - kb);
+            L.total = ld_self(totals + jt);
+            const int x = xlo + k;
+            L.x = (unsigned)x | (has && okL ? 1u << 30 : 0u) | (has && okU ? 1u << 31 : 0u);
+            L.y = (unsigned)(d2 - x) | (has && okM ? 1u << 30 : 0u) | (has && k == 0 ? 1u << 31 : 0u);
 #pragma unroll
             for (int s = 0; s < S; s++) {
                 // 5 states: the lower block reads M, sX, lX, the upper block M, sY, lY; 3 states: all three
                 const bool needL = S == 3 || s == 0 || s == 1 || s == 3, needU = S == 3 || s == 0 || s == 2 || s == 4;
                 L.v[s] = ld_self(bo + s * gN);
-                L.fL[s] = needL ? ld_self(it.f1 + ringIdx(it.w1, s, qL)) : 0.0;
-                L.fU[s] = needU ? ld_self(it.f1 + ringIdx(it.w1, s, qU)) : 0.0;
-                L.fM[s] = ld_self(it.f2 + ringIdx(it.w2Load, s, qM));
+                L.fL[s] = needL ? ld_self(f1 + ringIdx(w1, s, qL)) : 0.0;
+                L.fU[s] = needU ? ld_self(f1 + ringIdx(w1, s, qU)) : 0.0;
+                L.fM[s] = ld_self(f2 + ringIdx(w2Load, s, qM));
             }
         };
-        auto events = [&](const ExpItem &cur, const ExpLoads &Lc) {
-            if (cur.kb == 0) likelihood += Lc.total;  // once per diagonal (:743)
-            const int k = cur.kb + lane;
-            if (k < cur.W) {
-                const int kL = k + cur.dl, kU = k + cur.dl + 1, kM = k + cur.dm;
-                const bool okL = (unsigned)kL < (unsigned)cur.w1, okU = (unsigned)kU < (unsigned)cur.w1,
-                           okM = (unsigned)kM < (unsigned)cur.w2;
+        auto events = [&](const ExpLoads &Lc) {
+            if (Lc.y >> 31) likelihood += Lc.total;  // once per diagonal (:743), by the lane of its first cell: summed over lanes at the end
+            const bool okL = (Lc.x >> 30) & 1u, okU = Lc.x >> 31, okM = (Lc.y >> 30) & 1u;
+            if (okL || okU || okM) {  // (a cell none of whose neighbours is in the band has no event)
                 double fL[S], fU[S], fM[S];
 #pragma unroll
                 for (int s = 0; s < S; s++) {
@@ -1466,8 +1513,7 @@ struct Sweep {
                     fU[s] = okU ? Lc.fU[s] : NEG_INF;
                     fM[s] = okM ? Lc.fM[s] : NEG_INF;
                 }
-                const int x = cur.xlo + k, y = cur.d2 - x;
-                const int cX = symX(x), cY = symY(y);
+                const int cX = symX((int)(Lc.x & 0x3fffffffu)), cY = symY((int)(Lc.y & 0x3fffffffu));
                 // (emission + transition) sums of the events, from the same LDS table as the sweeps (Sweep::wt)
                 const double *wM = wt + (cX * 5 + cY) * kWM, *wX = wt + 25 * kWM + cX * kWG, *wY = wt + 25 * kWM + 5 * kWG + cY * kWG;
                 const bool acgt = cX < CPK_SYM_N && cY < CPK_SYM_N;
@@ -1518,17 +1564,18 @@ struct Sweep {
 #define CPK_EXP_DEPTH 4
 #endif
         constexpr int kDepth = CPK_EXP_DEPTH;
-        ExpItem it[kDepth];
+        bool valid[kDepth];
         ExpLoads L[kDepth];
-        it[0] = first_of(sg.tbFrom);
 #pragma unroll
-        for (int j = 1; j < kDepth; j++) it[j] = next_of(it[j - 1]);
-#pragma unroll
-        for (int j = 0; j < kDepth; j++) issue(it[j], L[j]);
-        for (bool more = it[0].valid; more;) {
+        for (int j = 0; j < kDepth; j++) {
+            const ExpItem it = next_item();
+            valid[j] = it.valid;
+            issue(it, L[j]);
+        }
+        for (bool more = valid[0]; more;) {
 #pragma unroll
             for (int j = 0; j < kDepth; j++) {
-                if (!it[j].valid) {  // wave-uniform: the items behind it are invalid as well
+                if (!valid[j]) {  // wave-uniform: the items behind it are invalid as well
                     more = false;
                     break;
                 }
@@ -1537,9 +1584,10 @@ struct Sweep {
                     asm volatile("" : "+v"(L[j].v[s]), "+v"(L[j].fL[s]), "+v"(L[j].fU[s]), "+v"(L[j].fM[s]));
                 }
                 asm volatile("" : "+v"(L[j].total));
-                events(it[j], L[j]);
-                it[j] = next_of(it[(j + kDepth - 1) % kDepth]);  // the item behind the youngest one in flight
-                issue(it[j], L[j]);
+                events(L[j]);
+                const ExpItem it = next_item();  // the item behind the youngest one in flight
+                valid[j] = it.valid;
+                issue(it, L[j]);
             }
         }
     }
@@ -1950,6 +1998,11 @@ cpecan_pairhmm_sweep(const KArgs a) {
             for (int k = 0; k < kExpectCopies; k++) e += eLds[k * 80 + i];
             dst[25 + i] = e;
         }
-        if (lane == 0) dst[105] = likelihood;
+        {  // every lane holds the totals of the diagonals whose first cell it computed (Sweep::expectations)
+            double v = likelihood;
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            if (lane == 0) dst[105] = v;
+        }
     }
 }
