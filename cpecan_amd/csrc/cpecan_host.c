@@ -996,6 +996,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
                 pl->fbMax = imax(pl->fbMax, fbCells);
                 pl->nSeg++;
                 sg++;
+
                 /* the next segment starts from tbFrom: remember the cell offsets of tbFrom and tbFrom + 1 */
                 tracedBackTo = tf;
                 offTracedBackTo = histOff[tfSlot];

@@ -94,6 +94,7 @@ struct LaunchClass {
     int threads = CPK_WAVE;  // threads per workgroup: one wave, or the waves of a team
     int64_t subSlots = 0;  // scratch slots: one per wave (sweep) or one per region group of a wave (packed)
     size_t ldsBytes = 0;
+    size_t ldsBytesFwd = 0;  // split, two launches: the forward launch's own LDS size (no candidate ring)
     int regionBase = 0, regionCount = 0;
     // A SPLIT class (fewer regions than wave slots): launch 1 = forward sweeps of whole regions into per-REGION rings,
     // launch 2 = one queue item per (region, traceback segment); see kModeForward / kModeTrace in cpk_sweep.inl.
@@ -736,14 +737,18 @@ static KernelFn pick_fused_kernel(const CpkGeometry &g, bool dense, bool abs) {
         return fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeFused, 3> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeFused, 3>;
     return fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeFused> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeFused>;
 }
-static void pick_split_kernels(const CpkGeometry &g, bool dense, bool abs, KernelFn *fwd, KernelFn *trace) {
+static void pick_split_kernels(const CpkGeometry &g, bool dense, bool abs, KernelFn *fwd, KernelFn *trace, bool fwd3 = false) {
     const bool fast = !g.useGlobalRoll;
     if (abs && fast) {
+        // fwd3: the forward launch has no candidate ring and 120 VGPRs or fewer; where its LDS lets nine or more waves
+        // onto a CU it runs the build for three waves per SIMD (profiles/r03_occupancy_3_waves_per_simd.txt)
         if (g.nStates == 5) {
-            *fwd = cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeForward, CPK_SWEEP_WAVES, true>;
+            *fwd = fwd3 ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeForward, 3, true>
+                        : cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeForward, CPK_SWEEP_WAVES, true>;
             *trace = cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeTrace, CPK_SWEEP_WAVES, true>;
         } else {
-            *fwd = cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeForward, CPK_SWEEP_WAVES, true>;
+            *fwd = fwd3 ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeForward, 3, true>
+                        : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeForward, CPK_SWEEP_WAVES, true>;
             *trace = dense ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeTrace, 3, true>
                            : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeTrace, CPK_SWEEP_WAVES, true>;
         }
@@ -1065,12 +1070,35 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                     int64_t wt = slots < nSegClass ? slots : nSegClass;
                     c.wavesTrace = (int)wt;
                     if (wt > c.subSlots) c.subSlots = wt;
+                    // the forward launch: no candidate ring in its LDS, and with absolute positions few enough registers
+                    // for three waves per SIMD -- more waves per CU where that LDS allows them (CPECAN_FWD3=0: never)
+                    c.ldsBytesFwd = c.geo.useGlobalRoll ? c.ldsBytes : c.ldsBytes - sizeof(double) * lds_stage_doubles(geo->emit);
+                    const char *f3e = getenv("CPECAN_FWD3");
+                    if (c.abs && !(f3e && atoi(f3e) == 0) && (160 * 1024) / c.ldsBytesFwd >= 9) {
+                        KernelFn f3 = nullptr, tr = nullptr;
+                        pick_split_kernels(c.geo, c.dense, c.abs, &f3, &tr, true);
+                        int p3 = 0;
+                        if (int rc = wavesPerCU(f3, c.ldsBytesFwd, &p3)) return rc;
+                        if (p3 > perCU) {
+                            c.fn = f3;
+                            int64_t wf = (int64_t)p3 * d->numCUs;
+                            if (wf > n) wf = n;
+                            const int64_t rounds = (n + wf - 1) / wf, even = (n + rounds - 1) / rounds;
+                            if (even >= 1 && even < wf) wf = even;
+                            c.waves = (int)wf;  // forward waves touch no per-slot scratch: subSlots stays as it is
+                        }
+                    }
                 }
                 c.itemCount = nSegClass;
             } else {
                 c.abs = false;  // one wave per region: the other form of the rows (its LDS keeps the slack, harmlessly)
             }
         }
+        if (getenv("CPECAN_TRACE_HOST"))
+            fprintf(stderr, "cpecan class %d: %d regions, widest diagonal %d, LDS %zu B (forward launch %zu B), waves %d / %d, %s%s%s\n", k,
+                    c.regionCount, c.geo.maxWidth, c.ldsBytes, c.ldsBytesFwd, c.waves, c.wavesTrace,
+                    c.split ? (c.fused ? "one launch" : "two launches") : "one wave per region", c.abs ? ", absolute positions" : "",
+                    c.dense ? ", three waves per SIMD" : "");
         c.ringEl = c.geo.ringCells * S;
         c.candEl = c.geo.fbCells * nCandLists;
         c.refEl = c.geo.refreshCells;
@@ -1418,7 +1446,7 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
         }
         hipStream_t cs = onCaller ? st : d->sideStream[i];
         if (!onCaller) HIP_TRY(hipStreamWaitEvent(cs, d->evStart, 0));
-        hipLaunchKernelGGL(c.fn, dim3((unsigned)c.waves), dim3((unsigned)c.threads), c.ldsBytes, cs, p);
+        hipLaunchKernelGGL(c.fn, dim3((unsigned)c.waves), dim3((unsigned)c.threads), (c.split && !c.fused && c.ldsBytesFwd) ? c.ldsBytesFwd : c.ldsBytes, cs, p);
         HIP_TRY(hipGetLastError());
         if (c.split && !c.fused) {  // the tracebacks of the class's regions, one queue item each, behind the forward launch
             KArgs t = p;

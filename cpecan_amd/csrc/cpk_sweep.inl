@@ -1756,7 +1756,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
     constexpr int kHeader = lds_header_doubles(EMIT);
     double *roll = FAST ? (lds + kHeader) : (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles);
     Candidate *stageLds = reinterpret_cast<Candidate *>(lds + kHeader + (FAST ? (size_t)(2 * S + 1) * stride : 0));
-    constexpr int kStageDoubles = lds_stage_doubles(EMIT);
+    constexpr int kStageDoubles = MODE == kModeForward ? 0 : lds_stage_doubles(EMIT);  // a forward launch stages no candidates
     uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + kHeader + (size_t)(2 * S + 1) * stride + kStageDoubles);
     // every rolling cell starts as -inf; position 0 of each row is never written again (the guard)
     for (int i = lane; i < (2 * S + 1) * stride; i += CPK_WAVE) roll[i] = NEG_INF;

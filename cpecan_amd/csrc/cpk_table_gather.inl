@@ -23,7 +23,10 @@
 //    everything else (Sweep::absRebase).
 // dpos[d] = posF | flagF << 15 | posB << 16 | flagB << 31: position of the diagonal's first cell under the base of the
 // forward (ascending) / backward (descending) sweep when it computes d, and whether the base changed in front of d.
-constexpr int kAbsSlack = 6;
+#ifndef CPK_ABS_SLACK
+#define CPK_ABS_SLACK 6
+#endif
+constexpr int kAbsSlack = CPK_ABS_SLACK;  // three consecutive diagonals span at most maxWidth + 3 positions, one -inf position at either end, one to spare
 __device__ __forceinline__ int abs_chain_step(int lo, int hi, int lo1, int hi1, int lo2, int hi2, int have, int P, int &B) {
     // lo/hi: x-y range of the diagonal about to be computed; lo1/hi1, lo2/hi2: the one / two diagonals before it in sweep
     // order (have = how many of them exist).  Returns the position of the first cell, bit 15 set when the base moved.

@@ -9,9 +9,9 @@ CFG=${2:-B}
 OUT=$R/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py --config $CFG --steps 5 --warmup 2 > $OUT/bench.json.log 2>&1
+python3 $R/bench.py --config $CFG --steps 5 --warmup 2 --no-other-configs > $OUT/bench.json.log 2>&1
 grep '^{' $OUT/bench.json.log > $OUT/bench.json
-B="python3 $R/bench.py --config $CFG --no-cpu-baseline --no-e2e"
+B="python3 $R/bench.py --config $CFG --no-cpu-baseline --no-e2e --no-other-configs"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- $B --steps 3 --warmup 1 > $OUT/stats.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- $B --steps 1 --warmup 0 > $OUT/fetch.log 2>&1
 timeout -k 10 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- $B --steps 1 --warmup 0 > $OUT/write.log 2>&1
