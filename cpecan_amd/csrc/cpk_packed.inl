@@ -29,8 +29,11 @@ __host__ __device__ constexpr int pack_group_bytes(int S, int gw) {  // a multip
     return pack_rows_bytes(S, gw) + 16 * kPackChunk + 2 * pack_win_bytes(gw) + 16 * 2 * gw;
 }
 
+#ifndef CPK_PACKED_WAVES
+#define CPK_PACKED_WAVES 2  // waves per SIMD the packed kernel's registers are allocated for (3: 73-84 spilled VGPRs, measured slower)
+#endif
 template <int S, int GW, int EMIT>  // EMIT: CPECAN_EMIT_MATCH or CPECAN_EMIT_EXPECT
-__global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(2, 2)))
+__global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(CPK_PACKED_WAVES, CPK_PACKED_WAVES)))
 cpecan_pairhmm_packed(const KArgs a) {
     constexpr int G = CPK_WAVE / GW;
     constexpr int R = 2 * S + 1;
