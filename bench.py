@@ -526,7 +526,7 @@ def main():
             if batch is not None:
                 batch.close()
                 batch = None
-            api.cache_trim(-1)
+            api.cache_trim(local_rank)  # (not -1: that would touch -- and create a context on -- every GPU of the node)
             out["other_configs"] = other_configs(("A", "4", "5"))
         print(json.dumps(out), flush=True)
     if batch is not None:

@@ -609,6 +609,10 @@ extern "C" int64_t cpk_cache_trim(int device) {
     const int n = cpk_device_count();
     for (int dev = 0; dev < n && dev < kMaxDevices; dev++) {
         if (device >= 0 && dev != device) continue;
+        {  // a device this process never used has nothing cached: do not create a context on it
+            std::lock_guard<std::mutex> lock(g_cacheMutex);
+            if (g_blockCache[dev].blocks.empty()) continue;
+        }
         DeviceGuard guard(dev);
         if (guard.err != hipSuccess) continue;
         freed += (int64_t)cache_trim(dev, 0);
