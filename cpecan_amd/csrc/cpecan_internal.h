@@ -97,6 +97,8 @@ typedef struct {
     int32_t seqLdsBytes;  /* fast path: bytes of LDS for the two padded symbol strings of the largest region */
     int32_t debug;
     int32_t fusedSpin;    /* one-launch form: polls of an item for its region's forward values before it gives up (reported, re-run in two launches) */
+    int32_t expInSweep;   /* expectation emitter: the events are formed inside the traceback (every diagonal of the class fits one 64-lane group) */
+    int32_t reserved0;
     int64_t ringCells;    /* forward ring capacity per slot, in cells */
     int64_t fbCells;      /* posterior-candidate scratch per slot, in cells (most emitted cells of one segment) */
     int64_t refreshCells; /* c/m scratch per slot = maxWidth * maxRefresh (each) */

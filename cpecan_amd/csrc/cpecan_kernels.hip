@@ -776,6 +776,9 @@ static KernelFn pick_dense_kernel(const CpkGeometry &g) {  // one wave per regio
 
 static KernelFn pick_kernel(const CpkGeometry &g) {
     const bool fast = !g.useGlobalRoll;  // second template argument = FAST (LDS rolling buffers + LDS symbol strings)
+    if (g.emit == CPECAN_EMIT_EXPECT && fast && g.expInSweep)
+        return g.nStates == 5 ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, false, true>
+                              : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, false, true>;
 #define CPK_PICK(E)                                                                                          \
     if (g.emit == (E)) {                                                                                     \
         if (g.nStates == 5) return fast ? cpecan_pairhmm_sweep<5, true, (E)> : cpecan_pairhmm_sweep<5, false, (E)>; \
@@ -945,6 +948,16 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         c.geo.useGlobalRoll = fastLds + 16 > 64 * 1024;
         if (c.geo.useGlobalRoll) c.abs = false;  // absolute positions are a form of the LDS rows
         c.ldsBytes = c.geo.useGlobalRoll ? header : fastLds;
+        {
+            // Expectation emitter, every diagonal of the class within two 64-lane groups: the events are formed inside the
+            // traceback (Sweep::tracebackExpect) from three forward diagonals kept in LDS, instead of a second pass over B
+            // values parked in global memory.  CPECAN_EXP_INSWEEP=0 (tests, A/B runs): the second pass everywhere.
+            const char *env = getenv("CPECAN_EXP_INSWEEP");
+            c.geo.expInSweep = expect && !c.geo.useGlobalRoll && c.geo.maxWidth <= 2 * CPK_WAVE /* Sweep::kExpGroups */ && !(env && atoi(env) == 0);
+            if (c.geo.expInSweep)
+                c.ldsBytes += sizeof(double) * (size_t)3 * (c.geo.maxWidth + 1) * S + sizeof(double) * kExpectWinCopies * 80 -
+                              sizeof(double) * (size_t)(lds_header_doubles(geo->emit) - lds_header_doubles(geo->emit, true));
+        }
         c.fn = pick_kernel(c.geo);
         if (!c.fn) {
             cpk_set_error("no kernel for emitter %d", geo->emit);
@@ -1099,15 +1112,15 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             }
         }
         if (getenv("CPECAN_TRACE_HOST"))
-            fprintf(stderr, "cpecan class %d: %d regions, widest diagonal %d, LDS %zu B (forward launch %zu B), waves %d / %d, %s%s%s\n", k,
+            fprintf(stderr, "cpecan class %d: %d regions, widest diagonal %d, LDS %zu B (forward launch %zu B), waves %d / %d, %s%s%s%s\n", k,
                     c.regionCount, c.geo.maxWidth, c.ldsBytes, c.ldsBytesFwd, c.waves, c.wavesTrace,
                     c.split ? (c.fused ? "one launch" : "two launches") : "one wave per region", c.abs ? ", absolute positions" : "",
-                    c.dense ? ", three waves per SIMD" : "");
+                    c.dense ? ", three waves per SIMD" : "", c.geo.expInSweep ? ", expectation events inside the traceback" : "");
         c.ringEl = c.geo.ringCells * S;
         c.candEl = c.geo.fbCells * nCandLists;
         c.refEl = c.geo.refreshCells;
         c.totEl = c.geo.maxRefresh;
-        c.bringEl = expect ? c.geo.fbCells * S : 0;
+        c.bringEl = expect ? (c.geo.expInSweep ? (int64_t)c.geo.maxRefresh * 96 /* Sweep::kWinDoubles */ : c.geo.fbCells * S) : 0;
         c.grollEl = (c.geo.useGlobalRoll && c.threads == CPK_WAVE) ? c.geo.rollDoubles : 0;
         d->classes.push_back(c);
     }

@@ -367,9 +367,14 @@ constexpr int kLdsCubics = kCubicDoubles;  // the logAdd table (fill_cubics)
 constexpr int kLdsEm = 0;  // (rounds 1-2 kept 40 doubles of plain emissions here; every reader uses the (emission + transition) table)
 // doubles of LDS in front of the rolling rows: cubics + emissions (+ expectation sums for that emitter only)
 constexpr int kExpectCopies = 4;  // emission-expectation sums are kept in 4 LDS copies (lane & 3): fewer atomic collisions
+// ... and so are the sums of one refresh window (Sweep::tracebackExpect): fp64 as well -- ds_add_f32 is the slow one on
+// gfx950 (20 000 config-5 pairs: 95 ms with fp32 window sums in 2, 4 or 8 copies, 70 ms with fp64 ones in 2 or 4)
+constexpr int kExpectWinCopies = 2;
+// (a class whose events are formed inside the traceback adds to the kernel's emission sums once per window only: one copy)
+__host__ __device__ constexpr int lds_expect_copies(bool inSweep) { return inSweep ? 1 : kExpectCopies; }
 constexpr int kLdsWeights = 168;  // (emission + transition) sums, see Sweep::wt: 25*5 + 5*4 + 5*4 = 165, padded
-__host__ __device__ constexpr int lds_header_doubles(int emit) {
-    return kLdsCubics + kLdsEm + kLdsWeights + (emit == CPECAN_EMIT_EXPECT ? kExpectCopies * 80 : 0);
+__host__ __device__ constexpr int lds_header_doubles(int emit, bool inSweep = false) {
+    return kLdsCubics + kLdsEm + kLdsWeights + (emit == CPECAN_EMIT_EXPECT ? lds_expect_copies(inSweep) * 80 : 0);
 }
 // doubles of LDS behind the rolling rows for the candidate staging rings (16-byte Candidates, 128 per list; none for
 // the forward-only and expectation emitters)

@@ -1592,6 +1592,354 @@ struct Sweep {
         }
     }
 
+    // ---- expectation step inside the traceback (classes whose diagonals fit one 64-lane group).
+    // expectations() above is a second pass: it reads B of every emitted cell back from `bring` (40 bytes a cell written,
+    // 40 read) and gathers 11 forward values per cell from the ring (88 bytes).  Here the events of a diagonal are formed
+    // right behind its backward cells: B is still in registers and the forward rows F[d2], F[d2-1], F[d2-2] sit in LDS,
+    // each diagonal of the ring read ONCE (coalesced, a diagonal ahead).  What is not known yet is the normaliser: the total
+    // of the diagonal's refresh window comes out of foldTotals() once the segment is done (its sequential logAdd folds
+    // are the reference's order, :513-523 / :649, and the cubic logAdd makes the order matter at the 1e-4 level).  So the
+    // events of window j are summed against a provisional reference ref_j (an fp32 log-sum-exp of the cell dot products of the
+    // window's refresh diagonal, within ~1e-3 of the total), the window's sums go to global memory (96 doubles per ten
+    // diagonals), and scaleWindows() multiplies them by exp(ref_j - total_j) afterwards: exp(x - total) =
+    // exp(x - ref) * exp(ref - total).  The events are exp2f-accurate as in expectations(), their sums fp64.
+    double *frow = nullptr;  // LDS: F of three diagonals, slot-major, position-major inside [position][S], position 0 = -inf guard
+    double *eWin = nullptr;  // LDS: emission sums of the current window, kWinCopies copies of [state*16 + cX*4 + cY]
+    static constexpr int kWinDoubles = 96;  // a window's record: kNT transition sums | [13] ref | [14] diagonals | [16, 96) emission sums
+
+    static constexpr int kWinCopies = kExpectWinCopies;  // LDS copies of the window's emission sums (lane & 1)
+    static constexpr int kExpGroups = 2;  // 64-lane groups per diagonal tracebackExpect() is unrolled for (class: <= 128 cells)
+    __device__ void tracebackExpect(const CpkSegment &sg, const double *endPrior, double *dbgFb) {
+        const int J = sg.nRefresh;
+        const int FS = (a.geo.maxWidth + 1) * S;  // doubles per F slot
+        double *wsum = bring;                     // the window records take the place of the B values
+        double ep[S];
+#pragma unroll
+        for (int s = 0; s < S; s++) ep[s] = endPrior[s];
+#pragma unroll
+        for (int s = 0; s < S; s++) asm volatile("" : "+v"(ep[s]));
+        // cell 0 of F[d2], F[d2-1], F[d2-2] (rotated every diagonal)
+        double *pF0 = frow + S, *pF1 = frow + FS + S, *pF2 = frow + 2 * FS + S;
+        // a diagonal of the ring -> registers (lanes past its end re-read its last cell) -> an F slot
+        auto loadF = [&](const CpkDiag &gd, double (&f)[kExpGroups][S]) {
+            const double *src = ringAt(gd);
+#pragma unroll
+            for (int q = 0; q < kExpGroups; q++) {
+                if (q > 0 && q * CPK_WAVE >= gd.width) break;  // wave-uniform
+                const int k = q * CPK_WAVE + lane < gd.width ? q * CPK_WAVE + lane : gd.width - 1;
+#pragma unroll
+                for (int s = 0; s < S; s++) f[q][s] = ringLd(src + ringIdx(gd.width, s, k));
+            }
+        };
+        auto storeF = [&](double *cell0, int Wd, const double (&f)[kExpGroups][S]) {
+#pragma unroll
+            for (int q = 0; q < kExpGroups; q++) {
+                const int k = q * CPK_WAVE + lane;
+                if (k < Wd) {
+#pragma unroll
+                    for (int s = 0; s < S; s++) cell0[k * S + s] = f[q][s];
+                }
+            }
+        };
+        CpkDiag gb{}, ga{};  // table entries of d2+1 and d2+2
+        CpkDiag g = dc.get(sg.dTop, true);
+        CpkDiag g1 = dc.get(sg.dTop >= 1 ? sg.dTop - 1 : 0, true);
+        CpkDiag g2 = dc.get(sg.dTop >= 2 ? sg.dTop - 2 : 0, true);
+        double fN[kExpGroups][S];
+#pragma unroll
+        for (int q = 0; q < kExpGroups; q++)
+#pragma unroll
+            for (int s = 0; s < S; s++) fN[q][s] = 0.0;
+        loadF(g, fN);
+        storeF(pF0, g.width, fN);
+        loadF(g1, fN);
+        storeF(pF1, g1.width, fN);
+        loadF(g2, fN);  // F[dTop-2]: stored at the top of the first diagonal
+        double tW[kNT];  // this lane's transition sums of the current window
+#pragma unroll
+        for (int i = 0; i < kNT; i++) tW[i] = 0.0;
+        double ref = 0.0;  // the window's provisional normaliser (set on its refresh diagonal, before its first event)
+        int jw = 0, nWin = 0;  // the window's index (= its refresh point's) and its diagonals so far
+        // Global stores wait a diagonal in registers and go out at the top of the next one, in front of its F request: the
+        // wait for a request counts the stores issued after it as well (loads and stores share vmcnt on gfx9 and complete
+        // out of order, so hipcc waits for all of them), and a write acknowledgement is the slowest thing there is to
+        // wait for.  Issued first, they have the whole diagonal.
+        double pendM[kExpGroups], pendC[kExpGroups], pendRec[3];
+        int pendMW = 0, pendMj = 0, pendCW = 0, pendCj = 0, pendRj = -1;  // widths (0: nothing pending), series indices; window (-1: none)
+        auto issueStores = [&]() {
+            if (pendMW > 0) {
+#pragma unroll
+                for (int q = 0; q < kExpGroups; q++)
+                    if (q * CPK_WAVE + lane < pendMW) mbuf[(size_t)(q * CPK_WAVE + lane) * J + pendMj] = pendM[q];
+                pendMW = 0;
+            }
+            if (pendCW > 0) {
+#pragma unroll
+                for (int q = 0; q < kExpGroups; q++)
+                    if (q * CPK_WAVE + lane < pendCW) cbuf[(size_t)(q * CPK_WAVE + lane) * J + pendCj] = pendC[q];
+                pendCW = 0;
+            }
+            if (pendRj >= 0) {
+                double *rec = wsum + (size_t)pendRj * kWinDoubles;
+                if (lane < 16) rec[lane] = pendRec[0];
+                rec[16 + lane] = pendRec[1];
+                if (lane < 16) rec[80 + lane] = pendRec[2];
+                pendRj = -1;
+            }
+        };
+        int untilRefresh = sg.dTop - sg.tbFrom;
+        int jr = 0;
+        for (int d2 = sg.dTop; d2 > sg.tbPrev;) {
+          dc.load(d2 - 3 - (CPK_WAVE - 1));  // table entries of the 64 diagonals ending at d2-3: one new entry per diagonal
+          for (int ci = CPK_WAVE - 1; ci >= 0 && d2 > sg.tbPrev; ci--, d2--) {
+            const bool seeded = d2 == sg.dTop;
+            const int W = g.width;
+            const bool emit = d2 <= sg.tbFrom;
+            const bool refresh = untilRefresh == 0;
+            const bool feeds = untilRefresh == 1 && d2 - 1 > sg.tbPrev;  // see traceback(): the straddle series of the refresh point below
+            // F[d2-2] arrives (its loads went out a diagonal ago) and takes the slot F[d2+1] has left; F[d2-3] is requested
+#pragma unroll
+            for (int q = 0; q < kExpGroups; q++)
+#pragma unroll
+                for (int s = 0; s < S; s++) asm volatile("" : "+v"(fN[q][s]));
+            storeF(pF2, g2.width, fN);
+            issueStores();
+            const CpkDiag g3 = dc.at(ci);  // entry of d2-3 (of diagonal 0 below it: never used then)
+            loadF(g3, fN);
+            double *curM = bM1(d2), *curG = bG1(d2);
+            const int xlo = (d2 + g.xmyL) >> 1;
+            BwdCtx c;
+            c.d2 = d2;
+            c.xlo = xlo;
+            c.dbR = ((g.xmyL - 1 - gb.xmyL) >> 1) * R;
+            c.wBR = gb.width * R;
+            c.daR = ((g.xmyL - ga.xmyL) >> 1) * R;
+            c.wAR = d2 + 2 <= sg.dTop ? ga.width * R : 0;
+            c.pb = bG1(d2 + 1);
+            c.pa = bM1(d2 + 2);
+            // backward cells of the diagonal, a group of 64 at a time; v stays in registers for the events
+            double v[kExpGroups][S];
+#pragma unroll
+            for (int q = 0; q < kExpGroups; q++) {
+                if (q * CPK_WAVE < W) {  // wave-uniform
+                    const int k0 = q * CPK_WAVE + lane;
+                    const bool on = k0 < W;
+                    if (seeded) {
+#pragma unroll
+                        for (int s = 0; s < S; s++) v[q][s] = ep[s];  // (pairwiseAligner.c:798-799)
+                    } else {
+                        const int kk[1] = {on ? k0 : W - 1};
+                        const int kkR[1] = {on ? k0 * R : (W - 1) * R};
+                        double vv[1][S];
+                        bwdCells<1>(c, kk, kkR, vv);
+#pragma unroll
+                        for (int s = 0; s < S; s++) v[q][s] = vv[0][s];
+                    }
+                    if (on) {
+                        curM[k0 * R] = v[q][0];
+#pragma unroll
+                        for (int s = 1; s < S; s++) curG[s + k0 * R] = v[q][s];
+                    }
+                } else {
+#pragma unroll
+                    for (int s = 0; s < S; s++) v[q][s] = NEG_INF;
+                }
+            }
+            roll_fence<false>();  // the B rows for the next diagonal, the F slot for this one
+            if (feeds || refresh || (emit && dbgFb)) {
+                float tMax = -__builtin_huge_valf();
+#pragma unroll
+                for (int q = 0; q < kExpGroups; q++) {
+                    if (q * CPK_WAVE < W) {
+                        const int k0 = q * CPK_WAVE + lane;
+                        const bool on = k0 < W;
+                        const double *myF = pF0 + (on ? k0 : W - 1) * S;
+                        const double fb0 = lds1(myF) + v[q][0];
+                        if (feeds) pendM[q] = fb0;
+                        if (emit && on && dbgFb) dbgFb[g.cellOff + k0] = fb0;
+                        if (refresh) {
+                            // cell dot products over states (cell_dotProduct, pairwiseAligner.c:402-408): the series foldTotals() folds
+                            double t = fb0;
+#pragma unroll
+                            for (int s = 1; s < S; s++) t = logadd(lg, t, lds1(myF + s) + v[q][s]);
+                            pendC[q] = t;
+                            if (on) tMax = fmaxf(tMax, (float)t);
+                        }
+                    }
+                }
+                if (feeds) {
+                    pendMW = W;
+                    pendMj = jr;
+                }
+                if (refresh) {
+                    pendCW = W;
+                    pendCj = jr;
+                    // ref = log of the sum of the cells' exp(dot product) in fp32, within ~1e-3 of the total that the sequential fp64
+                    // folds will give: the events that carry the sums then have an exp2f argument near 0, as in expectations()
+                    const float tm = wave_max_f32(tMax);
+                    float es = 0.0f;
+#pragma unroll
+                    for (int q = 0; q < kExpGroups; q++)
+                        if (q * CPK_WAVE + lane < W) es += __builtin_amdgcn_exp2f((float)(pendC[q] - (double)tm) * 1.44269504f);
+#pragma unroll
+                    for (int off = 32; off > 0; off >>= 1) es += __shfl_xor(es, off);
+                    ref = (double)tm + (double)(__builtin_amdgcn_logf(es) * 0.693147181f);
+                    if (!(ref > -1e300 && ref < 1e300)) ref = 0.0;  // a diagonal without any probability: every event is exp(-inf) whatever the reference
+                    jw = jr;
+                }
+            }
+            if (emit) {
+                // the events into the cells of d2 (updateExpectations, :418-432), against ref instead of the total
+                const int dl = (g.xmyL - 1 - g1.xmyL) >> 1, dm = (g.xmyL - g2.xmyL) >> 1;
+                const int w1 = g1.width, w2 = d2 - 2 >= sg.tbPrev ? g2.width : 0;  // F[d2-2] is gone at d2 == tbPrev+1 (:843-845)
+#pragma unroll
+                for (int q = 0; q < kExpGroups; q++) {
+                    if (q * CPK_WAVE >= W) break;  // wave-uniform
+                    const int k0 = q * CPK_WAVE + lane;
+                    const bool on = k0 < W;
+                    const int kL = k0 + dl, kM = k0 + dm;
+                    const int iL = (unsigned)kL < (unsigned)w1 ? kL * S : -S, iU = (unsigned)(kL + 1) < (unsigned)w1 ? (kL + 1) * S : -S;
+                    const int iM = (unsigned)kM < (unsigned)w2 ? kM * S : -S;
+                    double fL[S], fU[S], fM[S];
+#pragma unroll
+                    for (int s = 0; s < S; s++) {
+                        const bool needL = S == 3 || s == 0 || s == 1 || s == 3, needU = S == 3 || s == 0 || s == 2 || s == 4;
+                        fL[s] = needL ? lds1(pF1 + iL + s) : 0.0;
+                        fU[s] = needU ? lds1(pF1 + iU + s) : 0.0;
+                        fM[s] = lds1(pF2 + iM + s);
+                    }
+                    const int x = xlo + (on ? k0 : W - 1), y = d2 - x;
+                    const int cX = symX(x), cY = symY(y);
+                    const double *wM = wt + (cX * 5 + cY) * kWM, *wX = wt + 25 * kWM + cX * kWG, *wY = wt + 25 * kWM + 5 * kWG + cY * kWG;
+                    double vr[S];  // B - ref; a lane without a cell has no event
+#pragma unroll
+                    for (int s = 0; s < S; s++) vr[s] = on ? v[q][s] - ref : NEG_INF;
+                    double eAcc[S];  // this cell's events summed per target state: one LDS atomic per state, not per event
+#pragma unroll
+                    for (int s = 0; s < S; s++) eAcc[s] = 0.0;
+                    auto event = [&](int ti, double from, int to, double w) {
+                        const double p = exp_1e7(from + w + vr[to]);
+                        tW[ti] += p;
+                        eAcc[to] += p;
+                    };
+                    // the (emission + transition) sums of the events, fetched together: one LDS round trip, not one per event
+                    double w[kNT];
+#pragma unroll
+                    for (int i = 0; i < kWG; i++) w[i] = tab1(wX + i);
+#pragma unroll
+                    for (int i = 0; i < kWM; i++) w[kWG + i] = tab1(wM + i);
+#pragma unroll
+                    for (int i = 0; i < kWG; i++) w[kWG + kWM + i] = tab1(wY + i);
+                    if (S == 5) {  // the list order of expectations()
+                        event(0, fL[0], 1, w[0]);
+                        event(1, fL[1], 1, w[1]);
+                        event(2, fL[0], 3, w[2]);
+                        event(3, fL[3], 3, w[3]);
+                        event(4, fM[0], 0, w[4]);
+                        event(5, fM[1], 0, w[5]);
+                        event(6, fM[2], 0, w[6]);
+                        event(7, fM[3], 0, w[7]);
+                        event(8, fM[4], 0, w[8]);
+                        event(9, fU[0], 2, w[9]);
+                        event(10, fU[2], 2, w[10]);
+                        event(11, fU[0], 4, w[11]);
+                        event(12, fU[4], 4, w[12]);
+                    } else {
+                        event(0, fL[0], 1, w[0]);
+                        event(1, fL[1], 1, w[1]);
+                        event(2, fL[2], 1, w[2]);
+                        event(3, fM[0], 0, w[3]);
+                        event(4, fM[1], 0, w[4]);
+                        event(5, fM[2], 0, w[5]);
+                        event(6, fU[0], 2, w[6]);
+                        event(7, fU[2], 2, w[7]);
+                        event(8, fU[1], 2, w[8]);
+                    }
+                    if (on && cX < CPK_SYM_N && cY < CPK_SYM_N) {  // emissions are counted for ACGT x ACGT cells only (:429)
+                        double *copy = eWin + (lane & (kWinCopies - 1)) * 80 + cX * 4 + cY;
+#pragma unroll
+                        for (int s = 0; s < S; s++) atomicAdd(&copy[s * 16], eAcc[s]);
+                    }
+                }
+                nWin++;
+                if (untilRefresh == 1 || d2 == sg.tbPrev + 1 || (refresh && CPK_REFRESH_PERIOD == 1)) {
+                    // the window ends here (the next diagonal is a refresh point, or the segment's last): its record
+                    double mine = lane == kNT ? ref : (double)nWin;  // [13] = ref, [14] = diagonals, [15] unused
+#pragma unroll
+                    for (int i = 0; i < kNT; i++) {
+                        double t = tW[i];
+#pragma unroll
+                        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
+                        if (lane == i) mine = t;
+                        tW[i] = 0.0;
+                    }
+                    pendRec[0] = mine;
+                    roll_fence<false>();
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {  // emission sums [lane] and [64 + lane]
+                        const int e = h * CPK_WAVE + lane;
+                        double sum = 0.0;
+                        if (e < 80) {
+#pragma unroll
+                            for (int k = 0; k < kWinCopies; k++) {
+                                sum += eWin[k * 80 + e];
+                                eWin[k * 80 + e] = 0.0;
+                            }
+                        }
+                        pendRec[1 + h] = sum;
+                    }
+                    roll_fence<false>();
+                    pendRj = jw;
+                    nWin = 0;
+                }
+            }
+            // slide the window of table entries and F slots down one diagonal
+            ga = gb;
+            gb = g;
+            g = g1;
+            g1 = g2;
+            g2 = g3;
+            double *t = pF0;
+            pF0 = pF1;
+            pF1 = pF2;
+            pF2 = t;
+            if (refresh) {
+                untilRefresh = CPK_REFRESH_PERIOD - 1;
+                jr++;
+            } else {
+                untilRefresh--;
+            }
+          }
+        }
+        issueStores();
+#pragma unroll
+        for (int q = 0; q < kExpGroups; q++)
+#pragma unroll
+            for (int s = 0; s < S; s++) asm volatile("" : "+v"(fN[q][s]));  // the last request is never used: let it land
+    }
+
+    // The window records of tracebackExpect(), scaled by exp(ref - total) now that foldTotals() has the totals, into the
+    // kernel's sums: one lane per window.  likelihood: the total in force, once per emitted diagonal (:743).
+    __device__ void scaleWindows(const CpkSegment &sg, double (&tAcc)[kNT], double *eLds, double &likelihood) {
+        const int J = sg.nRefresh;
+        const double *wsum = bring;
+        for (int j0 = 0; j0 < J; j0 += CPK_WAVE) {
+            const int j = j0 + lane;
+            const bool on = j < J;
+            const double *rec = wsum + (size_t)(on ? j : 0) * kWinDoubles;
+            const double total = ld_self(totals + (on ? j : 0));
+            const double c = on ? exp(ld_self(rec + kNT) - total) : 0.0;
+            if (on) likelihood += ld_self(rec + kNT + 1) * total;
+#pragma unroll
+            for (int i = 0; i < kNT; i++) tAcc[i] += c * ld_self(rec + i);
+            double *copy = eLds;  // (one copy in this variant: lds_expect_copies)
+            for (int e = 0; e < S * 16; e++) {
+                const double p = c * ld_self(rec + 16 + e);
+                if (on) atomicAdd(&copy[e], p);
+            }
+        }
+    }
+
     // ---- total probability at every refresh point of the segment: one lane per refresh point, each doing the
     // reference's sequential folds (dpDiagonal_dotProduct :513-523, then the straddle term :649).
     // TEAM: called by one wave of a multi-wave workgroup (no workgroup barrier at the end, a wave-level fence instead)
@@ -1729,10 +2077,13 @@ constexpr int kModeWhole = 0, kModeForward = 1, kModeTrace = 2, kModeFused = 3;
 // handful of spills) three fit, and a queue that long runs 9-34 % faster with them (cpk_device_upload).
 // ABS: the sweeps of a split class over absolute positions (Sweep::forwardStreamAbs / tracebackAbs): match emitter, LDS rows,
 // fixed expansion (KArgs::dpos holds the positions)
-template <int S, bool FAST, int EMIT, int MODE = kModeWhole, int WPS = CPK_SWEEP_WAVES, bool ABS = false>
+// INSWEEP: expectation emitter, every diagonal of the class within one 64-lane group: the events are formed inside the
+// traceback (Sweep::tracebackExpect / scaleWindows) instead of in a second pass (Sweep::expectations)
+template <int S, bool FAST, int EMIT, int MODE = kModeWhole, int WPS = CPK_SWEEP_WAVES, bool ABS = false, bool INSWEEP = false>
 __global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 cpecan_pairhmm_sweep(const KArgs a) {
     static_assert(!ABS || (FAST && MODE != kModeWhole && EMIT == CPECAN_EMIT_MATCH), "absolute positions: split classes of the match emitter");
+    static_assert(!INSWEEP || (FAST && MODE == kModeWhole && EMIT == CPECAN_EMIT_EXPECT), "in-sweep events: expectation emitter, LDS rows");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
     const CpkModel &m = *a.model;
@@ -1746,20 +2097,29 @@ cpecan_pairhmm_sweep(const KArgs a) {
     double *wt = lds + kLdsCubics + kLdsEm;
     fill_weights<S>(wt, m, a.kc, lane);
     double *eLds = lds + kLdsCubics + kLdsEm + kLdsWeights;  // emission-expectation sums of this wave (expectation emitter)
+    constexpr int kECopies = lds_expect_copies(INSWEEP);
     if (EMIT == CPECAN_EMIT_EXPECT)
-        for (int i = lane; i < kExpectCopies * 80; i += CPK_WAVE) eLds[i] = 0.0;
+        for (int i = lane; i < kECopies * 80; i += CPK_WAVE) eLds[i] = 0.0;
     constexpr int kNT = S == 5 ? 13 : 9;
     double tAcc[kNT];
 #pragma unroll
     for (int i = 0; i < kNT; i++) tAcc[i] = 0.0;
     double likelihood = 0.0;
-    constexpr int kHeader = lds_header_doubles(EMIT);
+    constexpr int kHeader = lds_header_doubles(EMIT, INSWEEP);
     double *roll = FAST ? (lds + kHeader) : (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles);
     Candidate *stageLds = reinterpret_cast<Candidate *>(lds + kHeader + (FAST ? (size_t)(2 * S + 1) * stride : 0));
     constexpr int kStageDoubles = MODE == kModeForward ? 0 : lds_stage_doubles(EMIT);  // a forward launch stages no candidates
     uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + kHeader + (size_t)(2 * S + 1) * stride + kStageDoubles);
     // every rolling cell starts as -inf; position 0 of each row is never written again (the guard)
     for (int i = lane; i < (2 * S + 1) * stride; i += CPK_WAVE) roll[i] = NEG_INF;
+    // expectation step inside the traceback (Sweep::tracebackExpect): three F slots and the window's emission sums behind the strings
+    constexpr bool expInSweep = INSWEEP;
+    double *frowLds = reinterpret_cast<double *>(seqLds + (a.geo.seqLdsBytes + 15) / 16 * 16);
+    double *eWinLds = reinterpret_cast<double *>(frowLds + 3 * (a.geo.maxWidth + 1) * S);
+    if (expInSweep) {
+        for (int i = lane; i < 3 * (a.geo.maxWidth + 1) * S; i += CPK_WAVE) frowLds[i] = NEG_INF;
+        for (int i = lane; i < kExpectWinCopies * 80; i += CPK_WAVE) eWinLds[i] = 0;
+    }
     __syncthreads();
 
     const size_t slot = blockIdx.x;
@@ -1814,7 +2174,14 @@ cpecan_pairhmm_sweep(const KArgs a) {
                           N,
                           CpkDiag{},
                           CpkDiag{}};
-        if (EMIT == CPECAN_EMIT_EXPECT) sw.bring = a.bring + slot * (size_t)a.geo.fbCells * S;
+        if (EMIT == CPECAN_EMIT_EXPECT) {
+            // B of a segment's emitted cells (expectations()) or its window records (tracebackExpect())
+            sw.bring = a.bring + slot * (size_t)(expInSweep ? (int64_t)a.geo.maxRefresh * sw.kWinDoubles : a.geo.fbCells * S);
+            if (expInSweep) {
+                sw.frow = frowLds;
+                sw.eWin = eWinLds;
+            }
+        }
         constexpr int NL = EMIT == CPECAN_EMIT_INDEL ? 3 : 1;
         int count[NL];
 #pragma unroll
@@ -1936,6 +2303,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
                 int nCand[NL];
                 if constexpr (ABS) sw.template tracebackAbs<NL, true>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
+                else if constexpr (INSWEEP) sw.tracebackExpect(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr);
                 else sw.template traceback<NL, EMIT != CPECAN_EMIT_EXPECT>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
                 roll_fence<true>();  // candidate / cbuf / mbuf stores of all lanes are complete before they are re-read
                 sw.foldTotals(sg, table);
@@ -1943,7 +2311,10 @@ cpecan_pairhmm_sweep(const KArgs a) {
                     for (int d2 = sg.tbPrev + 1 + lane; d2 <= sg.tbFrom; d2 += CPK_WAVE)
                         a.dbgTotals[rg.dbgDiagOff + d2] = ld_self(sw.totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
                 }
-                if (EMIT == CPECAN_EMIT_EXPECT) sw.expectations(sg, tAcc, eLds, likelihood);
+                if (EMIT == CPECAN_EMIT_EXPECT) {
+                    if constexpr (INSWEEP) sw.scaleWindows(sg, tAcc, eLds, likelihood);
+                    else sw.expectations(sg, tAcc, eLds, likelihood);
+                }
 #pragma unroll
                 for (int l = 0; l < (EMIT == CPECAN_EMIT_EXPECT ? 0 : NL); l++) {
                     if (traceRole) {
@@ -1995,7 +2366,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
         }
         for (int i = lane; i < 80; i += CPK_WAVE) {
             double e = 0.0;
-            for (int k = 0; k < kExpectCopies; k++) e += eLds[k * 80 + i];
+            for (int k = 0; k < kECopies; k++) e += eLds[k * 80 + i];
             dst[25 + i] = e;
         }
         {  // every lane holds the totals of the diagonals whose first cell it computed (Sweep::expectations)

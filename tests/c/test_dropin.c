@@ -165,8 +165,9 @@ static void test_known_answers_gpu(void) {
     CHECK(fabs(computeForwardProbability(sx, sy, anchors, p, sM3, 1, 1) + 20.651524037167) < 1e-11);
     Hmm *h = hmm_constructEmpty(0.0, fiveState);
     getExpectationsUsingAnchors(sM5, h, "AGCG", "AGTTCG", anchors, p, 0, 0);
-    CHECK(fabs(h->likelihood + 175.193211612) < 1e-8 && fabs(hmm_getTransition(h, 0, 0) - 3.010391804) < 1e-8);
-    CHECK(fabs(hmm_getTransition(h, 0, 1) - 0.000751913) < 1e-8 && fabs(hmm_getEmissionsExpectation(h, 0, a, a) - 0.994467322) < 1e-8);
+    /* (the events are exp2f of an fp32 argument: ~1e-7 relative each, against north_star's 1e-5) */
+    CHECK(fabs(h->likelihood + 175.193211612) < 1e-8 && fabs(hmm_getTransition(h, 0, 0) - 3.010391804) < 1e-7);
+    CHECK(fabs(hmm_getTransition(h, 0, 1) - 0.000751913) < 1e-8 && fabs(hmm_getEmissionsExpectation(h, 0, a, a) - 0.994467322) < 1e-7);
     hmm_destruct(h);
     stList *m, *gx, *gy;
     getAlignedPairsWithIndelsUsingAnchors(sM3, "ACGTACGTTTACG", "ACGTCGTTTAACG", anchors, p, &m, &gx, &gy, 0, 0);
