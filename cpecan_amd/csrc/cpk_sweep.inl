@@ -2077,6 +2077,9 @@ constexpr int kModeWhole = 0, kModeForward = 1, kModeTrace = 2, kModeFused = 3;
 // handful of spills) three fit, and a queue that long runs 9-34 % faster with them (cpk_device_upload).
 // ABS: the sweeps of a split class over absolute positions (Sweep::forwardStreamAbs / tracebackAbs): match emitter, LDS rows,
 // fixed expansion (KArgs::dpos holds the positions)
+#ifndef CPK_INSWEEP_PLAIN_FWD
+#define CPK_INSWEEP_PLAIN_FWD 1  // bands this narrow have no whole group in front of a tail: the plain per-diagonal forward (1.2 % faster, config 5)
+#endif
 // INSWEEP: expectation emitter, every diagonal of the class within one 64-lane group: the events are formed inside the
 // traceback (Sweep::tracebackExpect / scaleWindows) instead of in a second pass (Sweep::expectations)
 template <int S, bool FAST, int EMIT, int MODE = kModeWhole, int WPS = CPK_SWEEP_WAVES, bool ABS = false, bool INSWEEP = false>
@@ -2265,12 +2268,12 @@ cpecan_pairhmm_sweep(const KArgs a) {
                         const bool all = EMIT != CPECAN_EMIT_MATCH || toRefresh == 0 || d >= sg.dTop - 1;
                         toRefresh = toRefresh == 0 ? CPK_REFRESH_PERIOD - 1 : toRefresh - 1;
                         if (ABS) sw.forwardStreamAbs(d, sw.dc.at(d - sw.dc.base), sw.dc.posAt(d - sw.dc.base), all ? S : 1);
-                        else if (FAST) sw.forwardStream(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
+                        else if (FAST && !(INSWEEP && CPK_INSWEEP_PLAIN_FWD)) sw.forwardStream(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
                         else sw.forward(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
                     }
                 }
                 if (ABS && !traceRole) sw.absFlushTail();
-                else if (FAST && !traceRole) sw.flushTail();  // the traceback needs every cell of dTop
+                else if (FAST && !(INSWEEP && CPK_INSWEEP_PLAIN_FWD) && !traceRole) sw.flushTail();  // the traceback needs every cell of dTop
                 if (forwardRole) {  // the tracebacks of this region are items of their own (of the next launch, or of this one)
                     if (MODE == kModeFused) {
                         // the ring stores are device-scope write-through (Sweep::ringSt): once they are acknowledged -- this
