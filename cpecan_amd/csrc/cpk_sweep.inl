@@ -1069,20 +1069,48 @@ struct Sweep {
                     stage[l * kStage + ((head[l] + pend[l] + rank) & (kStage - 1))] = cd;
                 }
                 pend[l] += __popcll(mask);
-                if (pend[l] >= CPK_WAVE) flush(l, CPK_WAVE);
+                // a full staging half goes out at the END of the diagonal (behind the wait for the prefetch, see below);
+                // here only when the next group's candidates might not fit any more
+                if (pend[l] > kStage - CPK_WAVE) flush(l, CPK_WAVE);
             }
         };
         // a refresh point: per-cell dot products over the states (cell_dotProduct, pairwiseAligner.c:402-408) into cbuf and,
         // for the candidate bound, the diagonal's largest F.m + B.m (renewed as max(this, old - 1): :834 bounds the drift)
         // rfC: the remaining states of F[d] (rows NL..S-1), prefetched before the diagonal's groups; fm: its emitted states
-        auto dotCell = [&](const AbsDiag &cx, int k, const double (&fRow)[S], int jr) {
+        // Global stores of the two series wait in registers (the first kPrefetch groups of a diagonal) and go out at the END
+        // of the diagonal, behind the wait for the prefetched F rows and in front of the next prefetch: that wait counts
+        // every store issued since (loads and stores share vmcnt on gfx9 and complete out of order, hipcc waits for all),
+        // and a write acknowledgement is the slowest thing there is to wait for.  Issued there, they have a whole diagonal.
+        double pendM[kPrefetch], pendC[kPrefetch];
+        int pendMW = 0, pendMOff = 0, pendMj = 0, pendCW = 0, pendCOff = 0, pendCj = 0;  // widths (0: nothing waits), first lanes, series indices
+        auto issueStores = [&]() {
+            if (pendMW > 0) {
+#pragma unroll
+                for (int q = 0; q < kPrefetch; q++) {
+                    const int k = q * CPK_WAVE - pendMOff + lane;
+                    if ((unsigned)k < (unsigned)pendMW) mbuf[(size_t)k * J + pendMj] = pendM[q];
+                }
+                pendMW = 0;
+            }
+            if (pendCW > 0) {
+#pragma unroll
+                for (int q = 0; q < kPrefetch; q++) {
+                    const int k = q * CPK_WAVE - pendCOff + lane;
+                    if ((unsigned)k < (unsigned)pendCW) cbuf[(size_t)k * J + pendCj] = pendC[q];
+                }
+                pendCW = 0;
+            }
+#pragma unroll
+            for (int l = 0; l < (CANDS ? NL : 0); l++)
+                if (pend[l] >= CPK_WAVE) flush(l, CPK_WAVE);
+        };
+        auto dotCell = [&](const AbsDiag &cx, int k, const double (&fRow)[S], double &t) {
             const int kR = cx.ownR + k * R;
-            double t = fRow[0] + cx.cur[kR];
+            t = fRow[0] + cx.cur[kR];
             const int x = cx.xlo + k, y = cx.d - x;
             const float fbf = (x > 0 && y > 0) ? (float)t : -__builtin_huge_valf();
 #pragma unroll
             for (int s2 = 1; s2 < S; s2++) t = logadd(lg, t, fRow[s2] + cx.cur[s2 + kR]);
-            cbuf[(size_t)k * J + jr] = t;
             return fbf;
         };
         auto refreshDots = [&](const AbsDiag &cx, const CpkDiag &g, int off, int jr, const double (&fm)[NL][kPrefetch],
@@ -1099,7 +1127,7 @@ struct Sweep {
                         double fRow[S];
 #pragma unroll
                         for (int s2 = 0; s2 < S; s2++) fRow[s2] = s2 < NL ? fm[s2][q] : rfC[s2][q];
-                        fbf = dotCell(cx, k, fRow, jr);
+                        fbf = dotCell(cx, k, fRow, pendC[q]);
                     }
                     if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
                 }
@@ -1111,10 +1139,15 @@ struct Sweep {
                     double fRow[S];
 #pragma unroll
                     for (int s2 = 0; s2 < S; s2++) fRow[s2] = ringLd(fsrc + ringIdx(W, s2, k));
-                    fbf = dotCell(cx, k, fRow, jr);
+                    double tk;
+                    fbf = dotCell(cx, k, fRow, tk);
+                    cbuf[(size_t)k * J + jr] = tk;
                 }
                 if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
             }
+            pendCW = W;
+            pendCOff = off;
+            pendCj = jr;
             if (CANDS) {
                 lastMax = fmaxf(diagMax, lastMax - 1.0f);
                 keepFrom = (double)(lastMax + logThr - kCandMargin);
@@ -1170,6 +1203,7 @@ struct Sweep {
                 }
                 loadRefreshRows(g, 0, rfC);
                 refreshDots(cx, g, 0, jr, fm, rfC);
+                issueStores();
                 untilRefresh = CPK_REFRESH_PERIOD - 1;
                 jr++;
             } else {
@@ -1318,8 +1352,11 @@ struct Sweep {
 #pragma unroll
                     for (int q = 0; q < kPrefetch; q++) {
                         const int k = q * CPK_WAVE - off + lane;
-                        if ((unsigned)k < (unsigned)W) mbuf[(size_t)k * J + jr] = fmCur[0][q] + cx.cur[cx.ownR + k * R];
+                        pendM[q] = (unsigned)k < (unsigned)W ? fmCur[0][q] + cx.cur[cx.ownR + k * R] : 0.0;
                     }
+                    pendMW = W;
+                    pendMOff = off;
+                    pendMj = jr;
                     const double *fsrc = ringAt(g);
                     for (int kb = kPrefetch * CPK_WAVE - off; kb < W; kb += CPK_WAVE) {
                         const int k = kb + lane;
@@ -1359,6 +1396,7 @@ struct Sweep {
                     asm volatile("" : "+v"(fmNext[l][q]));
                     fmCur[l][q] = fmNext[l][q];
                 }
+            issueStores();
             if (refresh) {
                 untilRefresh = CPK_REFRESH_PERIOD - 1;
                 jr++;
