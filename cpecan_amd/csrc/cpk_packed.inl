@@ -221,6 +221,20 @@ cpecan_pairhmm_packed(const KArgs a) {
                 nCand += n;
             };
             float lastMax = -__builtin_huge_valf();
+            // Values of the two series wait a block (kAhead steps) in registers and go to global memory at the top of the
+            // next one, behind its wait for the requested F values and in front of the next request: that wait counts every
+            // store issued since as well, and a write acknowledgement is the slowest thing there is to wait for.  A group
+            // has at most one refresh point and one diagonal above one in a block (period 10 > kAhead).
+            double pendM = 0.0, pendC = 0.0;
+            int pendMj = -1, pendCj = -1;  // series index, -1: nothing waits
+            auto issueStores = [&]() {
+                if (pendMj >= 0) mbuf[(size_t)c * J + pendMj] = pendM;
+                if (pendCj >= 0) cbuf[(size_t)c * J + pendCj] = pendC;
+                pendMj = pendCj = -1;
+                if (!kExpect && __ballot(pend >= GW)) {
+                    if (pend >= GW) flush(GW);
+                }
+            };
             const int bBase = (kExpect && segOn) ? table[sg.tbPrev + 1].cellOff : 0;
             int d2 = segOn ? sg.dTop : 0;
             CpkDiag eb{}, ea{};  // entries of d2+1, d2+2
@@ -273,6 +287,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                       asm volatile("" : "+v"(rfN[s2]));
                       rf[s2] = rfN[s2];
                   }
+                  issueStores();
                   if (i0 + kAhead < kPackChunk) request(i0 + kAhead, d2 - kAhead);  // a group's d2 falls by one per active step
 #pragma unroll
                   for (int j = 0; j < kAhead; j++) {
@@ -321,7 +336,10 @@ cpecan_pairhmm_packed(const KArgs a) {
                         for (int s = 1; s < S; s++) curG[s + c * R] = v[0][s];
                     }
                     const double fbv = f0 + v[0][0];
-                    if (feeds && on) mbuf[(size_t)c * J + jrNext] = fbv;
+                    if (feeds && on) {
+                        pendM = fbv;
+                        pendMj = jrNext;
+                    }
                     if (kExpect && emit && on) {  // kept for the expectation step
                         double *bo = bring + (size_t)(e.cellOff - bBase + c) * S;
 #pragma unroll
@@ -339,8 +357,8 @@ cpecan_pairhmm_packed(const KArgs a) {
                             stage[(head + pend + __popcll(mask & belowMe)) & (kStageP - 1)] = cd;
                         }
                         pend += __popcll(mask & groupBits);
-                        if (__ballot(pend >= GW)) {
-                            if (pend >= GW) flush(GW);
+                        if (__ballot(pend > kStageP - GW)) {  // the next step's candidates might not fit: now (else at the top of the next block)
+                            if (pend > kStageP - GW) flush(GW);
                         }
                     }
                     if (__ballot(refresh)) {
@@ -351,7 +369,8 @@ cpecan_pairhmm_packed(const KArgs a) {
 #pragma unroll
                             for (int s2 = 1; s2 < S; s2++)
                                 t = logadd(lg, t, rf[s2] + v[0][s2]);
-                            cbuf[(size_t)c * J + jr] = t;
+                            pendC = t;
+                            pendCj = jr;
                             if (!kExpect && x > 0 && y > 0) fbf = (float)fbv;
                         }
                         const float diagMax = group_max_f32<GW>(fbf);
@@ -365,6 +384,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                   }
                 }
             }
+            issueStores();
             if (!kExpect && __ballot(pend > 0)) flush(pend);
             roll_fence<true>();  // candidate / cbuf / mbuf stores of the group's lanes are visible to each other
             // ---------------- totals at the refresh points (:636-653): lane c takes points c, c + GW, ... ----------------
