@@ -1664,8 +1664,20 @@ static int post_core(PostScratch &sc, int32_t *dTriples, const CpkPostJob *job) 
         if (int rc = sc.alloc(&dPrev, (size_t)job->chainSlots)) return rc;
         if (int rc = sc.alloc(&dNext, (size_t)job->chainSlots)) return rc;
         if (int rc = sc.alloc(&dChosen, (size_t)job->chainSlots)) return rc;
-        hipLaunchKernelGGL(cpecan_post_ordered, dim3(laneBlocks), dim3(64), 0, st, dProblems, nP, dTriples, dSeq,
-                           dBest, dPrev, dNext, dChosen, job->matchGamma, dMea, dCounts);
+        const char *lanesEnv = getenv("CPECAN_POST_LANES");  // 1: one lane per problem (the form of rounds 1-2; tests, A/B runs)
+        if (lanesEnv && atoi(lanesEnv) != 0) {
+            hipLaunchKernelGGL(cpecan_post_ordered, dim3(laneBlocks), dim3(64), 0, st, dProblems, nP, dTriples, dSeq,
+                               dBest, dPrev, dNext, dChosen, job->matchGamma, dMea, dCounts);
+        } else {
+            // one wave per problem: the pairs in column order take four more words a pair
+            int32_t *dSortX = nullptr, *dSortY = nullptr;
+            double *dSortW = nullptr;
+            if (int rc = sc.alloc(&dSortX, (size_t)job->chainSlots)) return rc;
+            if (int rc = sc.alloc(&dSortY, (size_t)job->chainSlots)) return rc;
+            if (int rc = sc.alloc(&dSortW, (size_t)job->chainSlots)) return rc;
+            hipLaunchKernelGGL(cpecan_post_ordered_wave, dim3((unsigned)nP), dim3(64), 0, st, dProblems, dTriples, dSeq, dBest,
+                               dPrev, dNext, dSortX, dSortY, dSortW, dChosen, job->matchGamma, dMea, dCounts);
+        }
         HIP_TRY(hipGetLastError());
     }
     if ((job->flags & kPostOrdered) || dChars) {

@@ -207,10 +207,15 @@ struct OrderedStairs {
     int len;
     int lastY, lastI;  // the last entry, in registers: the usual pair needs nothing else of the staircase
     double lastS;
+    bool writer = true;  // false: the lanes of a wave run the staircase in step and only lane 0 stores (cpecan_post_ordered_wave)
+    // (A value loaded on a rare path is CONSUMED there -- the empty asm: where such a path joins the usual one hipcc
+    // otherwise waits with vmcnt(0) for a register that may have been loaded, i.e. on EVERY pair, and in the wave kernel
+    // that wait includes the acknowledgements of the stores of the pair before: measured 1.4 us a pair.)
     __device__ __forceinline__ void reloadLast() {
         lastY = len > 0 ? stairY[len - 1] : -1;
         lastI = len > 0 ? stairI[len - 1] : -1;
         lastS = len > 0 ? best[lastI] : 0.0;
+        asm volatile("" ::"v"(lastY), "v"(lastI), "v"(lastS));
     }
     // number of entries with y' < y
     __device__ __forceinline__ int below(int y) const {
@@ -221,21 +226,35 @@ struct OrderedStairs {
             if (stairY[mid] < y) lo = mid + 1;
             else hi = mid;
         }
+        asm volatile("" ::"v"(lo));
         return lo;
     }
     // best chain end with y' < y: the last entry below y (the highest score; of equal scores only the smaller y is kept)
     __device__ __forceinline__ int query(int y) const {
         const int pos = below(y);
-        return pos == 0 ? -1 : (pos == len ? lastI : stairI[pos - 1]);
+        if (pos == 0) return -1;
+        if (pos == len) return lastI;
+        const int i = stairI[pos - 1];
+        asm volatile("" ::"v"(i));
+        return i;
     }
     // pair i (end y, chain score si, of the current column -- later than every entry's) becomes a chain end
     __device__ __forceinline__ void insert(int y, int i, double si) {
         const int pos = below(y);
         // an end at a smaller y with at least this score is preferred wherever both are candidates
-        if (pos > 0 && (pos == len ? lastS : best[stairI[pos - 1]]) >= si) return;
+        if (pos > 0) {
+            double before = lastS;
+            if (pos != len) {
+                before = best[stairI[pos - 1]];
+                asm volatile("" ::"v"(before));
+            }
+            if (before >= si) return;
+        }
         if (pos == len) {  // appended behind everything: no entry to compare with, nothing to move
-            stairY[len] = y;
-            stairI[len] = i;
+            if (writer) {
+                stairY[len] = y;
+                stairI[len] = i;
+            }
             len++;
             lastY = y;
             lastI = i;
@@ -252,17 +271,25 @@ struct OrderedStairs {
         const int shift = pos + 1 - q;
         if (shift > 0) {
             for (int k = len - 1; k >= q; k--) {
-                stairY[k + 1] = stairY[k];
-                stairI[k + 1] = stairI[k];
+                const int ty = stairY[k], ti = stairI[k];
+                if (writer) {
+                    stairY[k + 1] = ty;
+                    stairI[k + 1] = ti;
+                }
             }
         } else if (shift < 0) {
             for (int k = q; k < len; k++) {
-                stairY[k + shift] = stairY[k];
-                stairI[k + shift] = stairI[k];
+                const int ty = stairY[k], ti = stairI[k];
+                if (writer) {
+                    stairY[k + shift] = ty;
+                    stairI[k + shift] = ti;
+                }
             }
         }
-        stairY[pos] = y;
-        stairI[pos] = i;
+        if (writer) {
+            stairY[pos] = y;
+            stairI[pos] = i;
+        }
         len += shift;
         reloadLast();
     }
@@ -318,6 +345,259 @@ __global__ void __launch_bounds__(64) cpecan_post_ordered(const CpkPostProblem *
             count++;
         }
     counts[2 * p] = count;
+}
+
+// The same filter with one WAVE per problem (round 3).  One lane per problem left every step of the chain a round trip to
+// global memory of a lane of its own (64 scattered accesses per wave instruction): 21.7 ms for the 50 000 cigars of the
+// realign benchmark, as long as the DP kernels.  Here the parallel parts are the wave's -- the pairs that reach
+// matchGamma are counted per X column (LDS atomics), the columns' starts come from a prefix sum, the pairs are scattered
+// into column order (kept in list order inside a column), the chosen pairs are compacted -- and the chain itself, which
+// is a sequence, runs on values the wave already holds: 64 sorted pairs at a time in registers (read by lane index), the
+// last staircase entry in registers, the scores of a column's pairs in LDS; scores, predecessors and staircase entries
+// go to global memory as stores nobody waits for.  Every lane runs the chain in step with the same values and lane 0
+// alone stores; a wave's memory operations complete in order, so what lane 0 stored is what every lane reads back.
+// The walk back along the predecessors goes through LDS a tile of kPostTile places at a time (a predecessor is always an
+// earlier place).  Same arithmetic and tie-breaks as cpecan_post_ordered: identical lists.
+constexpr int kPostTile = 2048;  // words of LDS: the column counters (sequences up to that long; longer ones count in global memory), then the tiles of the walk back
+__global__ void __launch_bounds__(64) cpecan_post_ordered_wave(const CpkPostProblem *problems, const int32_t *triples,
+                                                               int32_t *seqScratch, double *best, int32_t *prev, int32_t *sortI,
+                                                               int32_t *sortX, int32_t *sortY, double *sortW, uint8_t *chosen,
+                                                               double matchGamma, int32_t *out, int32_t *counts) {
+    __shared__ int32_t tile[kPostTile];
+    __shared__ double colS[CPK_WAVE];  // scores and y of the pairs of the column being scored (a ring: longer columns re-read memory)
+    __shared__ int32_t colY[CPK_WAVE];
+    const int lane = threadIdx.x;
+    const CpkPostProblem pb = problems[blockIdx.x];
+    const int32_t *pairs = triples + 3 * pb.off[0];
+    const int n = pb.n[0], lX = pb.lX, lY = pb.lY;
+    int32_t *gcol = seqScratch + pb.seqOff;  // lX words: pairs per X column, then the columns' fill pointers
+    int32_t *stairY = gcol + lX, *stairI = stairY + lY;
+    int32_t *col = lX <= kPostTile ? tile : gcol;
+    double *bs = best + pb.chainOff;
+    int32_t *pv = prev + pb.chainOff;
+    int32_t *sI = sortI + pb.chainOff, *sX = sortX + pb.chainOff, *sY = sortY + pb.chainOff;
+    double *sW = sortW + pb.chainOff;  // the pair's weight as the chain adds it: score / PROB_1 (:393), divided once here, by a lane of its own
+    uint8_t *ch = chosen + pb.chainOff;
+    auto qualifies = [&](int w) {  // :393
+        const double wd = (double)w / (double)CPECAN_PROB_1;
+        return wd >= matchGamma && wd > 0.0;
+    };
+    for (int x = lane; x < lX; x += CPK_WAVE) col[x] = 0;
+    for (int i = lane; i < n; i += CPK_WAVE) ch[i] = 0;
+    __syncthreads();
+    for (int i = lane; i < n; i += CPK_WAVE)
+        if (qualifies(pairs[3 * i])) atomicAdd(&col[pairs[3 * i + 1]], 1);
+    __syncthreads();
+    int m = 0;  // pairs that take part
+    for (int x0 = 0; x0 < lX; x0 += CPK_WAVE) {  // exclusive prefix sum over the columns
+        const int x = x0 + lane;
+        const int c = x < lX ? col[x] : 0;
+        int incl = c;
+#pragma unroll
+        for (int off = 1; off < CPK_WAVE; off <<= 1) {
+            const int t = __shfl_up(incl, off);
+            if (lane >= off) incl += t;
+        }
+        if (x < lX) col[x] = m + incl - c;
+        m += __shfl(incl, CPK_WAVE - 1);
+    }
+    __syncthreads();
+    for (int i = lane; i < n; i += CPK_WAVE) {
+        const int w = pairs[3 * i];
+        if (qualifies(w)) {
+            const int x = pairs[3 * i + 1];
+            const int pos = atomicAdd(&col[x], 1);
+            sI[pos] = i;
+            sX[pos] = x;
+            sY[pos] = pairs[3 * i + 2];
+            sW[pos] = (double)w / (double)CPECAN_PROB_1;
+        }
+    }
+    __syncthreads();
+    // inside a column the pairs go back into list order (the atomics hand out places in any order): the lane of a
+    // column's first place sorts it by insertion -- columns hold a pair or two
+    for (int k0 = 0; k0 < m; k0 += CPK_WAVE) {
+        const int k = k0 + lane;
+        if (k < m && (k == 0 || sX[k - 1] != sX[k])) {
+            const int x = sX[k];
+            int e = k + 1;
+            while (e < m && sX[e] == x) e++;
+            for (int a2 = k + 1; a2 < e; a2++) {
+                const int i = sI[a2], y = sY[a2];
+                const double w = sW[a2];
+                int b = a2 - 1;
+                while (b >= k && sI[b] > i) {
+                    sI[b + 1] = sI[b];
+                    sY[b + 1] = sY[b];
+                    sW[b + 1] = sW[b];
+                    b--;
+                }
+                sI[b + 1] = i;
+                sY[b + 1] = y;
+                sW[b + 1] = w;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the chain (:389-427), column by column: every pair of a column is scored before any of them is inserted.
+    // Nothing in the usual step touches memory: the 64 sorted pairs of the current chunk are in registers (lane j <-> place
+    // base + j), their scores and predecessors are collected in registers the same way (v_writelane) and leave as one
+    // coalesced store per chunk, appended staircase entries likewise 64 at a time, a column's scores wait for its
+    // inserts in registers (one pair) or LDS.  A step that needs the staircase in memory (a pair that does not extend
+    // the alignment: binary search, entries dropped or moved) first flushes what the registers hold.
+    // (With a store per pair the loop ran at 1.4 us a pair: hipcc waits with vmcnt(0) wherever a rarely loaded value may
+    // join the usual path, and that wait includes the acknowledgement of the store just issued.)
+    OrderedStairs st{pairs, bs, stairY, stairI, 0, -1, -1, 0.0, lane == 0};
+    int cx = 0, cy = 0, cwLo = 0, cwHi = 0;  // the chunk's pairs
+    int pvR = 0, bsLo = 0, bsHi = 0;    // ... their predecessors and scores
+    int syR = 0, siR = 0, sBase = 0;    // staircase entries [sBase, st.len) that are not in memory yet: lane j <-> entry sBase + j
+    int base = 0, done = 0;             // the chunk's first place; places of it scored so far
+    auto flushStairs = [&]() {
+        if (sBase + lane < st.len) {
+            stairY[sBase + lane] = syR;
+            stairI[sBase + lane] = siR;
+        }
+        sBase = st.len;
+    };
+    auto flushChunk = [&]() {
+        if (lane < done) {
+            pv[base + lane] = pvR;
+            bs[base + lane] = __hiloint2double(bsHi, bsLo);
+        }
+    };
+    auto scoreOf = [&](int from) {  // chain score of an earlier place
+        if (from >= base) {
+            const int j = __builtin_amdgcn_readfirstlane(from - base);
+            return __hiloint2double(__builtin_amdgcn_readlane(bsHi, j), __builtin_amdgcn_readlane(bsLo, j));
+        }
+        const double v = bs[from];
+        asm volatile("" ::"v"(v));
+        return v;
+    };
+    auto insert = [&](int y, int k, double sc) {
+        if (st.len == 0 || st.lastY < y) {  // the pair extends the alignment: appended, or dominated by the last end
+            if (st.len > 0 && st.lastS >= sc) return;
+            if (st.len - sBase == CPK_WAVE) flushStairs();
+            const int j = __builtin_amdgcn_readfirstlane(st.len - sBase);
+            syR = (lane == j ? y : syR);
+            siR = (lane == j ? k : siR);
+            st.len++;
+            st.lastY = y;
+            st.lastI = k;
+            st.lastS = sc;
+            return;
+        }
+        flushStairs();
+        flushChunk();
+        st.insert(y, k, sc);
+        sBase = st.len;
+    };
+    int colX = -1, colK = 0, colN = 0, firstY = 0;  // the column being scored: its x, first place, pairs so far
+    double firstS = 0.0;
+    auto finishColumn = [&]() {
+        if (colN == 1) {
+            insert(firstY, colK, firstS);
+        } else if (colN > 1) {
+            const bool ring = colN <= CPK_WAVE;  // else the ring has wrapped: re-read what the chunk stores hold
+            if (!ring) {
+                flushChunk();
+                __syncthreads();
+            }
+            for (int q = 0; q < colN; q++) {
+                const int yq = ring ? colY[q] : sY[colK + q];
+                const double sq = ring ? colS[q] : bs[colK + q];
+                insert(yq, colK + q, sq);
+            }
+        }
+    };
+    for (base = 0; base < m; base += CPK_WAVE) {
+        {
+            const int k = base + lane < m ? base + lane : m - 1;
+            cx = sX[k];
+            cy = sY[k];
+            const double wk = sW[k];
+            cwLo = __double2loint(wk);
+            cwHi = __double2hiint(wk);
+            asm volatile("" ::"v"(cx), "v"(cy), "v"(cwLo), "v"(cwHi));
+        }
+        const int cnt = m - base < CPK_WAVE ? m - base : CPK_WAVE;
+        for (done = 0; done < cnt; done++) {
+            const int x = __builtin_amdgcn_readlane(cx, done), y = __builtin_amdgcn_readlane(cy, done);
+            const double w = __hiloint2double(__builtin_amdgcn_readlane(cwHi, done), __builtin_amdgcn_readlane(cwLo, done));
+            if (x != colX) {
+                finishColumn();
+                colX = x;
+                colK = base + done;
+                colN = 0;
+            }
+            int from;  // best chain end with y' < y
+            if (st.len == 0) {
+                from = -1;
+            } else if (st.lastY < y) {
+                from = st.lastI;
+            } else {
+                flushStairs();
+                from = st.query(y);
+            }
+            const double sFrom = from < 0 ? 0.0 : (from == st.lastI ? st.lastS : scoreOf(from));
+            const double sc = sFrom + w * 1.0;  // :404
+            pvR = (lane == done ? from : pvR);
+            bsLo = (lane == done ? __double2loint(sc) : bsLo);
+            bsHi = (lane == done ? __double2hiint(sc) : bsHi);
+            if (colN == 0) {  // (most columns hold one pair: it stays in registers)
+                firstY = y;
+                firstS = sc;
+            } else if (lane == 0) {
+                if (colN == 1) {
+                    colY[0] = firstY;
+                    colS[0] = firstS;
+                }
+                colY[colN & (CPK_WAVE - 1)] = y;
+                colS[colN & (CPK_WAVE - 1)] = sc;
+            }
+            colN++;
+        }
+        done = cnt;
+        flushChunk();
+    }
+    done = 0;  // (nothing of a chunk is pending any more)
+    finishColumn();
+    flushStairs();
+    __syncthreads();
+    // ---- the chain's pairs (:437-475): walked back from the best end and marked in place (predecessor p -> -3 - p <= -2)
+    for (int k = st.lastI; k >= 0;) {
+        const int t0 = k - (kPostTile - 1) > 0 ? k - (kPostTile - 1) : 0;
+        for (int j = lane; j <= k - t0; j += CPK_WAVE) tile[j] = pv[t0 + j];
+        __syncthreads();
+        const int top = k;
+        while (k >= t0) {
+            const int p = tile[k - t0];
+            if (lane == 0) tile[k - t0] = -3 - p;
+            k = p;
+        }
+        __syncthreads();
+        for (int j = lane; j <= top - t0; j += CPK_WAVE) pv[t0 + j] = tile[j];
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int k = lane; k < m; k += CPK_WAVE)
+        if (pv[k] <= -2) ch[sI[k]] = 1;
+    __syncthreads();
+    int32_t *o = out + 3 * pb.meaOut;
+    int count = 0;
+    for (int top = n; top > 0; top -= CPK_WAVE) {  // the list conversions of :621-651 and :582 reverse the list three times
+        const int i = top - 1 - lane;
+        const bool sel = i >= 0 && ch[i] == 1;
+        const unsigned long long mask = __ballot(sel);
+        if (sel) {
+            const int at2 = count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            o[3 * at2] = pairs[3 * i];
+            o[3 * at2 + 1] = pairs[3 * i + 1];
+            o[3 * at2 + 2] = pairs[3 * i + 2];
+        }
+        count += __popcll(mask);
+    }
+    if (lane == 0) counts[2 * blockIdx.x] = count;
 }
 
 // Scores of the final list (list 0, or the ordered alignment when fromOut): scoreByPosteriorProbability[IgnoringGaps]

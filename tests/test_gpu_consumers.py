@@ -198,6 +198,29 @@ def test_filter_pairs_ordered_vs_oracle():
             assert all(u[1] < v[1] and u[2] < v[2] for u, v in zip(chain, chain[1:]))  # checkAlignment's property
 
 
+def test_filter_pairs_ordered_wave_and_lane_kernels_agree(monkeypatch):
+    """One wave per problem (default) against one lane per problem (CPECAN_POST_LANES=1) and the oracle: columns of more
+    than 64 pairs, a list longer than the 2047 chain slots the wave keeps in LDS, lists in shuffled order."""
+    rng = random.Random(37)
+    cases = []
+    lX, lY = 3, 200  # every cell of three columns: 200 pairs a column
+    cases.append(([(rng.randrange(1, 10000001), x, y) for x in range(lX) for y in range(lY)], lX, lY))
+    lX = lY = 3000  # a noisy diagonal and scattered pairs: ~5000 in all
+    cells = {(i, min(lY - 1, max(0, i + rng.randrange(-3, 4)))) for i in range(lX) for _ in range(2)}
+    cells |= {(rng.randrange(lX), rng.randrange(lY)) for _ in range(1500)}
+    cells = list(cells)
+    rng.shuffle(cells)
+    cases.append(([(rng.randrange(1, 10000001), x, y) for x, y in cells], lX, lY))
+    cases.append(([(rng.randrange(0, 3) * 5000000, x, y) for x, y in cells[:2500]], lX, lY))  # many exact ties
+    for pairs, lX, lY in cases:
+        for gamma in (0.0, 0.4):
+            want = _as_tuples(ob.filter_pairs_ordered(pairs, lX, lY, gamma))
+            monkeypatch.delenv("CPECAN_POST_LANES", raising=False)
+            assert _as_tuples(api.filterPairwiseAlignmentToMakePairsOrdered(pairs, "A" * lX, "A" * lY, gamma)) == want
+            monkeypatch.setenv("CPECAN_POST_LANES", "1")
+            assert _as_tuples(api.filterPairwiseAlignmentToMakePairsOrdered(pairs, "A" * lX, "A" * lY, gamma)) == want
+
+
 def test_identity_scores_vs_oracle():
     rng = random.Random(29)
     p = api.pairwiseAlignmentBandingParameters_construct()

@@ -4,7 +4,7 @@
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 N=${1:-50000}
 OUT=$R/gpurun_out/realign_prof
-mkdir -p $OUT
+rm -rf $OUT/prof; mkdir -p $OUT
 D=$(python3 - $N <<PY
 import sys
 sys.path.insert(0, "$R/tools")
