@@ -6,16 +6,17 @@ src=gpurun_out/$tag
 cp $src/bench.json profiles/${tag}_bench.json
 cp $src/traffic.json profiles/${tag}_traffic.json
 cp $src/compute.json profiles/${tag}_compute.json
-cp $src/stats/*/*_kernel_stats.csv profiles/${tag}_kernel_stats.csv
+cp "$(ls -t $src/stats/*/*_kernel_stats.csv | head -1)" profiles/${tag}_kernel_stats.csv   # the newest run: gpurun merges into what earlier calls left
 python3 - $src profiles/$tag <<'PY'
-import csv, glob, sys
+import csv, glob, os, sys
 src, dst = sys.argv[1], sys.argv[2]
-kt = glob.glob(src + '/stats/*/*_kernel_trace.csv')[0]
+newest = lambda pat: max(glob.glob(pat), key=os.path.getmtime)
+kt = newest(src + '/stats/*/*_kernel_trace.csv')
 rows = list(csv.DictReader(open(kt)))
 keep = [r for r in rows if 'pairhmm' in r['Kernel_Name']]
 w = csv.DictWriter(open(dst + '_kernel_trace.csv', 'w', newline=''), fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
 for name in ('fetch', 'write', 'valu', 'lds'):
-    f = glob.glob(src + '/' + name + '/*/*_counter_collection.csv')[0]
+    f = newest(src + '/' + name + '/*/*_counter_collection.csv')
     rows = list(csv.DictReader(open(f)))
     keep = [r for r in rows if 'pairhmm' in r['Kernel_Name']]
     w = csv.DictWriter(open(dst + '_pmc_' + name + '.csv', 'w', newline=''), fieldnames=rows[0].keys()); w.writeheader(); w.writerows(keep)
