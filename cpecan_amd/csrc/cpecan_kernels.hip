@@ -951,12 +951,18 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         {
             // Expectation emitter, every diagonal of the class within two 64-lane groups: the events are formed inside the
             // traceback (Sweep::tracebackExpect) from three forward diagonals kept in LDS, instead of a second pass over B
-            // values parked in global memory.  CPECAN_EXP_INSWEEP=0 (tests, A/B runs): the second pass everywhere.
+            // values parked in global memory.  CPECAN_EXP_INSWEEP=0 (tests, A/B runs): the second pass everywhere; 2: inside
+            // the traceback whatever the LDS costs.
             const char *env = getenv("CPECAN_EXP_INSWEEP");
             c.geo.expInSweep = expect && !c.geo.useGlobalRoll && c.geo.maxWidth <= 2 * CPK_WAVE /* Sweep::kExpGroups */ && !(env && atoi(env) == 0);
-            if (c.geo.expInSweep)
-                c.ldsBytes += sizeof(double) * (size_t)3 * (c.geo.maxWidth + 1) * S + sizeof(double) * kExpectWinCopies * 80 -
-                              sizeof(double) * (size_t)(lds_header_doubles(geo->emit) - lds_header_doubles(geo->emit, true));
+            if (c.geo.expInSweep) {
+                const size_t with = c.ldsBytes + sizeof(double) * (size_t)3 * (c.geo.maxWidth + 1) * S + sizeof(double) * kExpectWinCopies * 80 -
+                                    sizeof(double) * (size_t)(lds_header_doubles(geo->emit) - lds_header_doubles(geo->emit, true));
+                // ... as long as the three forward diagonals in LDS do not cost a resident wave: the kernel's registers
+                // allow eight per CU (five-state: bands up to 74 cells, three-state: up to ~120; measured at 66 and 106)
+                if (with <= 160 * 1024 / 8 || (env && atoi(env) >= 2)) c.ldsBytes = with;
+                else c.geo.expInSweep = 0;
+            }
         }
         c.fn = pick_kernel(c.geo);
         if (!c.fn) {
