@@ -927,6 +927,31 @@ def test_cell_values_and_totals_match_oracle(case, form, monkeypatch):
     assert np.all(np.abs(tot[mt] - otot[mt]) <= LOG_TOL * np.maximum(1.0, np.abs(otot[mt]))), float(np.max(np.abs(tot[mt] - otot[mt])))
 
 
+@pytest.mark.parametrize("second_pass", [False, True])
+def test_expectation_emitter_cell_values_match_oracle(second_pass, monkeypatch):
+    """The same debug buffers under the expectation emitter, whose traceback is a function of its own when the events are
+    formed inside it (Sweep::tracebackExpect: forward rows in LDS, stores deferred by a diagonal) -- one and two groups per
+    diagonal, several segments -- and under its second-pass form."""
+    from parity import LOG_TOL
+    monkeypatch.setenv("CPECAN_EXP_INSWEEP", "0" if second_pass else "2")
+    for mtype, (sx, sy, a), pkw in ((0, make_pair(3, 1, 600, 10), dict(diagonalExpansion=10, minDiagsBetweenTraceBack=50, traceBackDiagonals=7)),
+                                    (2, make_pair(2, 0, 1000, 50), dict(diagonalExpansion=50)),
+                                    (0, make_pair(5, 0, 1200, 30), dict(diagonalExpansion=30))):
+        p = api.pairwiseAlignmentBandingParameters_construct(**pkw)
+        _, tr = ob.aligned_pairs_traced(ob.model(mtype), sx, sy, a, ob.params(**pkw), False, False)
+        with api.Batch(_sm(mtype), p, emit=api.EMIT_EXPECT, debug=True) as b:
+            b.add(sx, sy, a, False, False)
+            b.upload()
+            b.run()
+            b.download()
+            fb, tot = b.debug_fetch(0, tr["n_cells"], tr["n_diagonals"])
+        ofb, otot = tr["fb_match"], tr["total_used"]
+        m = ~np.isnan(ofb) & ~np.isinf(ofb)
+        assert np.all(np.abs(fb[m] - ofb[m]) <= LOG_TOL * np.maximum(1.0, np.abs(ofb[m]))), float(np.max(np.abs(fb[m] - ofb[m])))
+        mt = ~np.isnan(otot)
+        assert mt.any() and np.all(np.abs(tot[mt] - otot[mt]) <= LOG_TOL * np.maximum(1.0, np.abs(otot[mt])))
+
+
 def test_one_launch_form_keeps_spare_slots_only_beside_a_live_batch(monkeypatch):
     """The one-launch form of a split class fills every wave slot of the chip when the batch has the device to itself and
     leaves one slot in every eighth CU free when another batch of the process has run there and is still alive (its list
