@@ -1701,8 +1701,18 @@ static int post_core(PostScratch &sc, int32_t *dTriples, const CpkPostJob *job) 
         if (int rc = sc.alloc(&dBest, (size_t)job->chainSlots)) return rc;
         if (int rc = sc.alloc(&dPrev, (size_t)job->chainSlots)) return rc;
         if (int rc = sc.alloc(&dRecord, (size_t)job->chainSlots)) return rc;
-        hipLaunchKernelGGL(cpecan_post_mea, dim3(laneBlocks), dim3(64), 0, st, dProblems, nP, dTriples, dCum, dBest,
-                           dPrev, dRecord, (float)job->gapGamma, dMea, dCounts, dScores);
+        const char *lanesEnv = getenv("CPECAN_POST_LANES");  // 1: one lane per problem (the form of rounds 1-2; tests, A/B runs)
+        if (lanesEnv && atoi(lanesEnv) != 0) {
+            hipLaunchKernelGGL(cpecan_post_mea, dim3(laneBlocks), dim3(64), 0, st, dProblems, nP, dTriples, dCum, dBest,
+                               dPrev, dRecord, (float)job->gapGamma, dMea, dCounts, dScores);
+        } else {
+            long long *dG = nullptr, *dH = nullptr, *dT = nullptr;  // the gap masses around every pair (cpecan_post_mea_wave)
+            if (int rc = sc.alloc(&dG, (size_t)job->chainSlots)) return rc;
+            if (int rc = sc.alloc(&dH, (size_t)job->chainSlots)) return rc;
+            if (int rc = sc.alloc(&dT, (size_t)job->chainSlots)) return rc;
+            hipLaunchKernelGGL(cpecan_post_mea_wave, dim3((unsigned)nP), dim3(64), 0, st, dProblems, dTriples, dCum, dBest, dPrev,
+                               dRecord, dG, dH, dT, (float)job->gapGamma, dMea, dCounts, dScores);
+        }
         HIP_TRY(hipGetLastError());
     } else if (job->flags & kPostLeftShift) {
         hipLaunchKernelGGL(cpecan_post_copy_chain, dim3((unsigned)nP), dim3(256), 0, st, dProblems, dTriples, dMea,

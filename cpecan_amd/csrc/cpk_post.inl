@@ -6,6 +6,7 @@
 // ------------------------------------------------------------------------------------------------
 constexpr int kPostReweight = 1, kPostMea = 2, kPostLeftShift = 4, kPostOrdered = 8;  // == CPECAN_POST_*
 constexpr int kPostScores = CPK_POST_SCORES;  // doubles per problem: see CpkPostJob.scores
+constexpr int kPostTile = 2048;  // words of LDS of the wave-per-problem consumers: column counters (ordered filter; longer sequences count in global memory), tiles of the walks back along the predecessors
 
 // reweightAlignedPairs2 (impl/pairwiseAligner.c:1519-1558) + scoreByPosteriorProbability[IgnoringGaps] (:1578-1597).
 // One workgroup per problem.  mass[] = PROB_1 minus the listed mass of every base of X then Y, floored at 0 when read
@@ -125,6 +126,230 @@ __global__ void __launch_bounds__(64) cpecan_post_mea(const CpkPostProblem *prob
     }
     counts[2 * p] = count;
     scores[kPostScores * p + 2] = top;
+}
+
+// The same chain with one WAVE per problem (round 3).  The lane-per-problem kernel above walks back through global memory
+// one pair at a time, every lane of a wave on a list of its own: 6.07 s for 10 000 config-4 pairs beside 30 ms of DP
+// (tools/mea_bench.py).  Here:
+//  * the gap masses become three 64-bit words per pair, computed by the wave in parallel from the cumulative arrays (two
+//    prefix sums): G = mass of the gaps in front of the pair (cum_x[x-1] + cum_y[y-1]), H = mass up to and including its
+//    own row and column (cum_x[x] + cum_y[y]), T = mass behind it; the gap between pair j and a later pair i is then
+//    G_i - H_j (:1621-1625 are differences of the same cumulative sums; integer arithmetic, exact);
+//  * the walk back of pair i runs 64 earlier pairs at a time, lane t on pair i-1-t: the most recent 64 pairs (coordinates,
+//    H, chain score, record flag) live in registers and move up one lane per pair, older ones are read from global memory,
+//    coalesced.  A walk ends at the first dominated pair that is a record (:1685): the lanes up to it take part, the
+//    reference's "first strictly greater" is the first lane holding the maximum;
+//  * scores, predecessors and record flags of the last 64 pairs leave as coalesced stores once per 64 pairs, and the walk
+//    back along the predecessors goes through LDS a tile at a time (cf. cpecan_post_ordered_wave).
+// Same float / double / int64 expressions per pair as above: identical alignments and scores.
+__global__ void __launch_bounds__(64) cpecan_post_mea_wave(const CpkPostProblem *problems, const int32_t *triples, long long *cum,
+                                                           double *best, int32_t *prev, uint8_t *record, long long *gapG,
+                                                           long long *gapH, long long *gapT, float gapGamma, int32_t *meaOut,
+                                                           int32_t *counts, double *scores) {
+    __shared__ int32_t tile[kPostTile];
+    const int lane = threadIdx.x;
+    const CpkPostProblem pb = problems[blockIdx.x];
+    const int32_t *pairs = triples + 3 * pb.off[0], *gx = triples + 3 * pb.off[1], *gy = triples + 3 * pb.off[2];
+    const int n = pb.n[0];
+    const int lX = pb.lX, lY = pb.lY;
+    long long *cx = cum + pb.seqOff, *cy = cx + lX;  // getCumulativeGapProbs (:1603-1619)
+    double *bs = best + pb.chainOff;
+    int32_t *pv = prev + pb.chainOff;
+    uint8_t *rec = record + pb.chainOff;
+    long long *G = gapG + pb.chainOff, *H = gapH + pb.chainOff, *T = gapT + pb.chainOff;
+    for (int i = lane; i < lX + lY; i += CPK_WAVE) cx[i] = 0;
+    __syncthreads();
+    for (int i = lane; i < pb.n[1]; i += CPK_WAVE)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&cx[gx[3 * i + 1]]), (unsigned long long)(long long)gx[3 * i]);
+    for (int i = lane; i < pb.n[2]; i += CPK_WAVE)
+        atomicAdd(reinterpret_cast<unsigned long long *>(&cy[gy[3 * i + 2]]), (unsigned long long)(long long)gy[3 * i]);
+    __syncthreads();
+    for (int a = 0; a < 2; a++) {  // inclusive prefix sums of both arrays
+        long long *c = a == 0 ? cx : cy;
+        const int len = a == 0 ? lX : lY;
+        long long carry = 0;
+        for (int i0 = 0; i0 < len; i0 += CPK_WAVE) {
+            const int i = i0 + lane;
+            long long v = i < len ? c[i] : 0;
+#pragma unroll
+            for (int off = 1; off < CPK_WAVE; off <<= 1) {
+                const long long t = __shfl_up(v, off);
+                if (lane >= off) v += t;
+            }
+            if (i < len) c[i] = carry + v;
+            carry += __shfl(v, CPK_WAVE - 1);
+        }
+    }
+    __syncthreads();
+    const long long endX = lX > 0 ? cx[lX - 1] : 0, endY = lY > 0 ? cy[lY - 1] : 0;
+    for (int i = lane; i <= n; i += CPK_WAVE) {
+        if (i == n) {  // the sentinel behind both sequences (:1652-1654)
+            G[i] = endX + endY;
+            H[i] = 0;
+            T[i] = 0;
+        } else {
+            const int x = pairs[3 * i + 1], y = pairs[3 * i + 2];
+            G[i] = (x > 0 ? cx[x - 1] : 0) + (y > 0 ? cy[y - 1] : 0);
+            H[i] = cx[x] + cy[y];
+            T[i] = (endX - cx[x]) + (endY - cy[y]);
+        }
+    }
+    __syncthreads();
+    // ---- the chain (:1656-1702)
+    double top = 0;
+    // the 64 pairs in front of pair i, lane t <-> pair i-1-t (rj < 0: no such pair)
+    int rx = 0, ry = 0, rrec = 0, rj = -1;
+    long long rH = 0;
+    double rbs = 0.0;
+    // results of the current chunk of 64 pairs, lane (i - base): stored once per chunk
+    double oBs = 0.0;
+    int oPv = 0, oRec = 0;
+    for (int base = 0; base <= n; base += CPK_WAVE) {
+        const int cnt = n + 1 - base < CPK_WAVE ? n + 1 - base : CPK_WAVE;
+        // the chunk's pairs: lane k holds pair base + k
+        int cw = 0, cx2 = lX, cy2 = lY;
+        long long cG, cH, cT;
+        {
+            const int i = base + lane <= n ? base + lane : n;
+            if (i < n) {
+                cw = pairs[3 * i];
+                cx2 = pairs[3 * i + 1];
+                cy2 = pairs[3 * i + 2];
+            }
+            cG = G[i];
+            cH = H[i];
+            cT = T[i];
+            asm volatile("" ::"v"(cw), "v"(cx2), "v"(cy2), "v"(cG), "v"(cH), "v"(cT));
+        }
+        for (int k = 0; k < cnt; k++) {
+            const int i = base + k;
+            const int w = __builtin_amdgcn_readlane(cw, k), x = __builtin_amdgcn_readlane(cx2, k), y = __builtin_amdgcn_readlane(cy2, k);
+            const long long Gi = __shfl(cG, k), Hi = __shfl(cH, k), Ti = __shfl(cT, k);
+            double score = (double)((float)w + (float)Gi * gapGamma);  // :1660-1661
+            int from = -1;
+            // The walk back, 64 pairs at a time: the ones in registers first, then older ones from memory, two chunks of
+            // loads in flight.  Every lane keeps the best of ITS pairs (strictly greater replaces: the more recent pair
+            // stays on a tie); the wave's maximum is formed once, behind the walk.
+            double bestV = -__builtin_huge_val();
+            int bestJ = -1;
+            auto take = [&](int j, int x2, int y2, int rc, long long Hj, double bj) {  // returns true when the walk ends in this chunk
+                const bool dom = j >= 0 && x2 < x && y2 < y;
+                const unsigned long long stops = __ballot(dom && rc != 0);  // :1685
+                const int stopLane = stops ? __builtin_ctzll(stops) : CPK_WAVE;
+                const float g = (float)(Gi - Hj) * gapGamma;
+                const long long sc = (long long)(((double)w + bj) + (double)g);  // :1673-1675
+                if (dom && lane <= stopLane && (double)sc > bestV) {
+                    bestV = (double)sc;
+                    bestJ = j;
+                }
+                return stops != 0;
+            };
+            struct Older {
+                int x2, y2, rc, j;
+                long long Hj;
+                double bj;
+            };
+            auto fetch = [&](int c) {  // pairs i-1-64c-lane
+                Older o;
+                o.j = i - 1 - (c * CPK_WAVE + lane);
+                const int jj = o.j >= 0 ? o.j : 0;
+                o.x2 = pairs[3 * jj + 1];
+                o.y2 = pairs[3 * jj + 2];
+                o.rc = rec[jj];
+                o.Hj = H[jj];
+                o.bj = bs[jj];
+                return o;
+            };
+            if (!take(rj, rx, ry, rrec, rH, rbs) && i - 1 - CPK_WAVE >= 0) {
+                Older o1 = fetch(1), o2 = fetch(2);  // (a chunk past the front of the list reads pair 0 and takes nothing)
+                for (int c = 1;; c += 2) {
+                    asm volatile("" ::"v"(o1.x2), "v"(o1.y2), "v"(o1.rc), "v"(o1.Hj), "v"(o1.bj));
+                    if (take(o1.j, o1.x2, o1.y2, o1.rc, o1.Hj, o1.bj) || i - 1 - (c + 1) * CPK_WAVE < 0) break;
+                    o1 = fetch(c + 2);
+                    asm volatile("" ::"v"(o2.x2), "v"(o2.y2), "v"(o2.rc), "v"(o2.Hj), "v"(o2.bj));
+                    if (take(o2.j, o2.x2, o2.y2, o2.rc, o2.Hj, o2.bj) || i - 1 - (c + 2) * CPK_WAVE < 0) break;
+                    o2 = fetch(c + 3);
+                }
+            }
+            {
+                double m = bestV;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off));
+                if (m > score) {  // the first pair of the walk -- the most recent one -- that holds the maximum
+                    score = m;
+                    from = wave_max_i32(bestV == m ? bestJ : -1);
+                }
+            }
+            const float tail = (float)Ti * gapGamma;
+            const double scEnd = score + (double)tail;  // :1695-1696
+            int r = 0;
+            if (scEnd >= top) {
+                top = scEnd;
+                r = 1;
+            }
+            if (lane == k) {
+                oBs = score;
+                oPv = from;
+                oRec = r;
+            }
+            // pair i joins the front of the register window
+            rx = __shfl_up(rx, 1);
+            ry = __shfl_up(ry, 1);
+            rrec = __shfl_up(rrec, 1);
+            rj = __shfl_up(rj, 1);
+            rH = __shfl_up(rH, 1);
+            rbs = __shfl_up(rbs, 1);
+            if (lane == 0) {
+                rx = x;
+                ry = y;
+                rrec = r;
+                rj = i;
+                rH = Hi;
+                rbs = score;
+            }
+        }
+        if (lane < cnt) {
+            bs[base + lane] = oBs;
+            pv[base + lane] = oPv;
+            rec[base + lane] = (uint8_t)oRec;
+        }
+    }
+    __syncthreads();
+    // ---- the alignment (:1704-1714): the chain from the sentinel's predecessor, marked in place (p -> -3 - p <= -2)
+    for (int k = n; k >= 0;) {
+        const int t0 = k - (kPostTile - 1) > 0 ? k - (kPostTile - 1) : 0;
+        for (int j = lane; j <= k - t0; j += CPK_WAVE) tile[j] = pv[t0 + j];
+        __syncthreads();
+        const int hi = k;
+        bool first = k == n;
+        while (k >= t0) {
+            const int p = tile[k - t0];
+            if (!first && lane == 0) tile[k - t0] = -3 - p;  // (the sentinel itself is not part of the alignment)
+            first = false;
+            k = p;
+        }
+        __syncthreads();
+        for (int j = lane; j <= hi - t0; j += CPK_WAVE) pv[t0 + j] = tile[j];
+        __syncthreads();
+    }
+    int32_t *out = meaOut + 3 * pb.meaOut;
+    int count = 0;
+    for (int i0 = 0; i0 < n; i0 += CPK_WAVE) {  // back to front == built reversed, then flipped (:1714): ascending pairs
+        const int i = i0 + lane;
+        const bool sel = i < n && pv[i] <= -2;
+        const unsigned long long mask = __ballot(sel);
+        if (sel) {
+            const int at = count + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+            out[3 * at] = pairs[3 * i];
+            out[3 * at + 1] = pairs[3 * i + 1];
+            out[3 * at + 2] = pairs[3 * i + 2];
+        }
+        count += __popcll(mask);
+    }
+    if (lane == 0) {
+        counts[2 * blockIdx.x] = count;
+        scores[kPostScores * blockIdx.x + 2] = top;
+    }
 }
 
 // LEFT_SHIFT without MEA: list 0 is the chain to shift; put it where the MEA stage would have put its alignment.
@@ -358,7 +583,6 @@ __global__ void __launch_bounds__(64) cpecan_post_ordered(const CpkPostProblem *
 // alone stores; a wave's memory operations complete in order, so what lane 0 stored is what every lane reads back.
 // The walk back along the predecessors goes through LDS a tile of kPostTile places at a time (a predecessor is always an
 // earlier place).  Same arithmetic and tie-breaks as cpecan_post_ordered: identical lists.
-constexpr int kPostTile = 2048;  // words of LDS: the column counters (sequences up to that long; longer ones count in global memory), then the tiles of the walk back
 __global__ void __launch_bounds__(64) cpecan_post_ordered_wave(const CpkPostProblem *problems, const int32_t *triples,
                                                                int32_t *seqScratch, double *best, int32_t *prev, int32_t *sortI,
                                                                int32_t *sortX, int32_t *sortY, double *sortW, uint8_t *chosen,

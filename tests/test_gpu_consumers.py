@@ -113,6 +113,36 @@ def test_mea_and_left_shift_vs_oracle():
     assert got[:, 1:].tolist() == want[:, 1:].tolist()  # scores may differ by one unit of 1e-7 (device exp vs libm)
 
 
+def test_mea_wave_and_lane_kernels_agree_on_long_walks(monkeypatch):
+    """getMaximalExpectedAccuracyPairwiseAlignment with one wave per problem (default) against one lane per problem
+    (CPECAN_POST_LANES=1) and the oracle, on lists built so that the walk back from a pair runs over hundreds of earlier
+    pairs (few records): beyond the 64 pairs the wave keeps in registers, with exact ties in the weights."""
+    rng = random.Random(41)
+    cases = []
+    for lX, lY, n_pairs, coarse in ((400, 380, 900, False), (300, 320, 700, True), (70, 60, 64, False), (1500, 1500, 2600, False)):
+        cells = set()
+        for i in range(min(lX, lY)):  # a noisy diagonal, then scattered pairs; list order = anti-diagonal, as the emitters give it
+            cells.add((i, min(lY - 1, max(0, i + rng.randrange(-2, 3)))))
+        while len(cells) < n_pairs:
+            cells.add((rng.randrange(lX), rng.randrange(lY)))
+        cells = sorted(cells, key=lambda c: (c[0] + c[1], -(c[0] - c[1])))
+        pairs = [((rng.randrange(1, 6) * 2000000) if coarse else rng.randrange(1, 10000001), x, y) for x, y in cells]
+        # heavy gap mass: extending the chain soon stops setting records, so later walks run far back
+        gx = [(rng.randrange(1000000, 9000000), x, rng.randrange(lY)) for x in range(lX) for _ in range(2)]
+        gy = [(rng.randrange(1000000, 9000000), rng.randrange(lX), y) for y in range(lY) for _ in range(2)]
+        cases.append((pairs, gx, gy, lX, lY))
+    gamma = float(np.float32(0.5))
+    for pairs, gx, gy, lX, lY in cases:
+        want, want_score = ob.mea_alignment(pairs, gx, gy, lX, lY, gamma)
+        for lanes in (None, "1"):
+            if lanes:
+                monkeypatch.setenv("CPECAN_POST_LANES", lanes)
+            else:
+                monkeypatch.delenv("CPECAN_POST_LANES", raising=False)
+            got, score = api.getMaximalExpectedAccuracyPairwiseAlignment(pairs, gx, gy, lX, lY, gapGamma=gamma)
+            assert (np.asarray(got).reshape(-1, 3).astype(np.int64) == want).all() and score == want_score, (lX, lanes)
+
+
 def test_consumer_argument_errors():
     p = api.pairwiseAlignmentBandingParameters_construct()
     with api.Batch(_sm(0), p) as b:
