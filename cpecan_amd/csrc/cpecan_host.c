@@ -1028,10 +1028,8 @@ int cpecan_batch_upload(cpecan_batch *b) {
      * kernel; they come first in the device order.  Within each class: longest first (the work queues are LPT). */
     {
         const char *env = getenv("CPECAN_PACKED"); /* diagnostic: 0 = one wave per region for every region */
-        /* the packed kernel stages symbol windows assuming a band whose bounds never move backwards: true for a fixed
-         * expansion, not for per-anchor expansions */
-        const int enabled = (b->emit == CPECAN_EMIT_MATCH || b->emit == CPECAN_EMIT_EXPECT) && !b->debug && !dynamic &&
-                            !(env && atoi(env) == 0);
+        /* (bands with per-anchor expansions run the packed kernel's DYN variant: their edges may move backwards) */
+        const int enabled = (b->emit == CPECAN_EMIT_MATCH || b->emit == CPECAN_EMIT_EXPECT) && !b->debug && !(env && atoi(env) == 0);
         const int64_t minCount = (env && atoi(env) >= 2) ? 1 : 64; /* a launch is not worth fewer regions (2: always, for tests) */
         int64_t perClass[4] = {0, 0, 0, 0};
         for (int64_t i = 0; i < b->nRegions; i++) {

@@ -701,16 +701,18 @@ static void dev_release(CpkDevice *d, void *p) {
         }
 }
 
-static KernelFn pick_packed_kernel(const CpkGeometry &g, int cls) {  // class k: groups of 8 << k lanes
+static KernelFn pick_packed_kernel(const CpkGeometry &g, int cls, bool dynamic) {  // class k: groups of 8 << k lanes
     const bool five = g.nStates == 5;
-#define CPK_PICK_PACKED(E)                                                                                         \
-    if (g.emit == (E)) switch (cls) {                                                                              \
-            case 0: return five ? cpecan_pairhmm_packed<5, 8, (E)> : cpecan_pairhmm_packed<3, 8, (E)>;             \
-            case 1: return five ? cpecan_pairhmm_packed<5, 16, (E)> : cpecan_pairhmm_packed<3, 16, (E)>;           \
-            case 2: return five ? cpecan_pairhmm_packed<5, 32, (E)> : cpecan_pairhmm_packed<3, 32, (E)>;           \
+#define CPK_PICK_PACKED(E, D)                                                                                               \
+    if (g.emit == (E) && dynamic == (D)) switch (cls) {                                                                     \
+            case 0: return five ? cpecan_pairhmm_packed<5, 8, (E), (D)> : cpecan_pairhmm_packed<3, 8, (E), (D)>;            \
+            case 1: return five ? cpecan_pairhmm_packed<5, 16, (E), (D)> : cpecan_pairhmm_packed<3, 16, (E), (D)>;          \
+            case 2: return five ? cpecan_pairhmm_packed<5, 32, (E), (D)> : cpecan_pairhmm_packed<3, 32, (E), (D)>;          \
         }
-    CPK_PICK_PACKED(CPECAN_EMIT_MATCH)
-    CPK_PICK_PACKED(CPECAN_EMIT_EXPECT)
+    CPK_PICK_PACKED(CPECAN_EMIT_MATCH, false)
+    CPK_PICK_PACKED(CPECAN_EMIT_EXPECT, false)
+    CPK_PICK_PACKED(CPECAN_EMIT_MATCH, true)  // per-anchor expansions
+    CPK_PICK_PACKED(CPECAN_EMIT_EXPECT, true)
 #undef CPK_PICK_PACKED
     return nullptr;
 }
@@ -881,7 +883,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         LaunchClass c;
         c.packed = true;
         c.k = k;
-        c.fn = pick_packed_kernel(*geo, k);
+        c.fn = pick_packed_kernel(*geo, k, dynamic != 0);
         if (!c.fn) {
             cpk_set_error("no packed kernel for emitter %d", geo->emit);
             return CPECAN_EINVAL;

@@ -11,7 +11,7 @@
 // phases -- forward sweep of segment i, traceback of segment i, totals, emission -- each over its own diagonals; a
 // group that has nothing to do in a phase idles (regions are handed out sorted by size, so neighbours are alike).
 // Arithmetic: the sweep kernel's own cell functions (fwdCellsSym / bwdCellsSym), same order, bit-identical results.
-// Match emitter only; symbols are read from global memory (one byte per symbol).
+// Match and expectation emitters; symbols are staged per chunk of 64 diagonals into two LDS windows (one byte per symbol).
 // ------------------------------------------------------------------------------------------------
 template <int GW>
 __device__ __forceinline__ float group_max_f32(float v) {
@@ -32,7 +32,11 @@ __host__ __device__ constexpr int pack_group_bytes(int S, int gw) {  // a multip
 #ifndef CPK_PACKED_WAVES
 #define CPK_PACKED_WAVES 2  // waves per SIMD the packed kernel's registers are allocated for (3: 73-84 spilled VGPRs, measured slower)
 #endif
-template <int S, int GW, int EMIT>  // EMIT: CPECAN_EMIT_MATCH or CPECAN_EMIT_EXPECT
+// DYN: bands with per-anchor expansions (band_constructDynamic, pairwiseAligner.c:184-234).  Their edges may move BACK where
+// an anchor brings a larger expansion, so the symbols a chunk of 64 diagonals needs do not start at its first diagonal's:
+// the windows start at the minimum over the chunk's diagonals, and a cell outside a window (a chunk whose band wanders
+// further than the window holds: never with a fixed expansion) reads its symbol from global memory.
+template <int S, int GW, int EMIT, bool DYN = false>  // EMIT: CPECAN_EMIT_MATCH or CPECAN_EMIT_EXPECT
 __global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(CPK_PACKED_WAVES, CPK_PACKED_WAVES)))
 cpecan_pairhmm_packed(const KArgs a) {
     constexpr int G = CPK_WAVE / GW;
@@ -102,6 +106,17 @@ cpecan_pairhmm_packed(const KArgs a) {
         auto bG1 = [&](int d) { return rows + R + 2 + (d & 1) * (S - 1); };
         auto ringAt = [&](const CpkDiag &e) { return ring + (size_t)e.ringOff * S; };
         auto unpack = [](const int4 &t) { return CpkDiag{t.x, t.y, t.z, t.w}; };
+        // the symbol of padded position p of X / Y for a cell of the staged chunk (windows from x0 / y0)
+        auto symAtX = [&](int p, int x0) -> int {
+            const int q = p - x0;
+            if (!DYN || (unsigned)q < (unsigned)kWin) return xwin[q];
+            return gx[p < 0 ? 0 : (p > rg.lX + 1 ? rg.lX + 1 : p)];
+        };
+        auto symAtY = [&](int p, int y0) -> int {
+            const int q = p - y0;
+            if (!DYN || (unsigned)q < (unsigned)kWin) return ywin[q];
+            return gy[p < 0 ? 0 : (p > rg.lY + 1 ? rg.lY + 1 : p)];
+        };
         // Stages the table entries of `cnt` (<= 64) diagonals first, first + step, ... into ebuf and the X / Y symbols
         // their cells use (shifted by `shift`: the backward step reads the symbols of (x+1, y+1)) into the two windows.
         // One global round trip per 64 diagonals instead of three per diagonal.
@@ -109,6 +124,7 @@ cpecan_pairhmm_packed(const KArgs a) {
         // clamped instead of predicated): as loops of load-then-store the compiler waited for each in turn, ~30 global
         // round trips in a row per chunk.
         auto stage_chunk = [&](bool on, int first, int step, int cnt, int shift, int &x0, int &y0) {
+            int xMin = 0x7fffffff, yMin = 0x7fffffff;  // DYN: the lowest x and y of the chunk's cells
             {
                 int4 t[kPackChunk / GW];
 #pragma unroll
@@ -117,9 +133,23 @@ cpecan_pairhmm_packed(const KArgs a) {
                     int dd = first + step * (i < cnt ? i : (cnt > 0 ? cnt - 1 : 0));
                     dd = dd < 0 ? 0 : (dd > N ? N : dd);
                     t[j] = *reinterpret_cast<const int4 *>(table + dd);  // N = 0 for a group without a region: entry 0 of a valid table
+                    if (DYN) {
+                        const int xl = (dd + t[j].x) >> 1;
+                        xMin = xl < xMin ? xl : xMin;
+                        const int yl = dd - (xl + t[j].y - 1);
+                        yMin = yl < yMin ? yl : yMin;
+                    }
                 }
 #pragma unroll
                 for (int j = 0; j < kPackChunk / GW; j++) ebuf[c + j * GW] = on ? t[j] : int4{0, 1, 0, 0};
+                if (DYN) {
+#pragma unroll
+                    for (int off = GW / 2; off > 0; off >>= 1) {
+                        const int ox = __shfl_xor(xMin, off), oy = __shfl_xor(yMin, off);
+                        xMin = ox < xMin ? ox : xMin;
+                        yMin = oy < yMin ? oy : yMin;
+                    }
+                }
             }
             // both ends of the chunk bound the coordinates in between (x and y never decrease with the diagonal)
             int dA = step > 0 ? first : first - (cnt - 1), dB = step > 0 ? first + (cnt - 1) : first;
@@ -128,9 +158,9 @@ cpecan_pairhmm_packed(const KArgs a) {
             const CpkDiag eA = unpack(ebuf[step > 0 ? 0 : (cnt > 0 ? cnt - 1 : 0)]);
             const CpkDiag eB = unpack(ebuf[step > 0 ? (cnt > 0 ? cnt - 1 : 0) : 0]);
             const int xloA = (dA + eA.xmyL) >> 1, xloB = (dB + eB.xmyL) >> 1;
-            x0 = xloA + shift;
-            y0 = dA - (xloA + eA.width - 1) + shift;
-            const int x1 = xloB + eB.width - 1 + shift, y1 = dB - xloB + shift;
+            x0 = (DYN ? xMin : xloA) + shift;
+            y0 = (DYN ? yMin : dA - (xloA + eA.width - 1)) + shift;
+            const int x1 = DYN ? rg.lX + 1 : xloB + eB.width - 1 + shift, y1 = DYN ? rg.lY + 1 : dB - xloB + shift;
             constexpr int kWinIter = (kWin + GW - 1) / GW;
             uint8_t bx[kWinIter], by[kWinIter];
 #pragma unroll
@@ -188,7 +218,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                     fc.p1 = fbuf1(d - 1);
                     fc.p2 = fbuf1(d - 2);
                     const int x = fc.xlo + c, y = d - x;
-                    const int cX[1] = {on ? xwin[x - x0] : CPK_SYM_N}, cY[1] = {on ? ywin[y - y0] : CPK_SYM_N};
+                    const int cX[1] = {on ? symAtX(x, x0) : CPK_SYM_N}, cY[1] = {on ? symAtY(y, y0) : CPK_SYM_N};
                     const int kR[1] = {c * R};
                     double v[1][S];
                     sw.template fwdCellsSym<1>(fc, cX, cY, kR, v);
@@ -321,7 +351,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                     bc.pa = bM1(d2 + 2);
                     const int x = bc.xlo + c, y = d2 - x;
                     // symbols of the source cells (x+1, .) and (., y+1): the windows are staged one to the right
-                    const int cX1[1] = {on ? xwin[x + 1 - x0] : CPK_SYM_N}, cY1[1] = {on ? ywin[y + 1 - y0] : CPK_SYM_N};
+                    const int cX1[1] = {on ? symAtX(x + 1, x0) : CPK_SYM_N}, cY1[1] = {on ? symAtY(y + 1, y0) : CPK_SYM_N};
                     const int kR[1] = {c * R};
                     double v[1][S];
                     sw.template bwdCellsSym<1>(bc, cX1, cY1, kR, v);
@@ -458,7 +488,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                                 fM[s] = okM ? ld_self(f2 + SW::ringIdx(w2, s, qM)) : NEG_INF;
                             }
                             const int x = xlo + c, y = e2d - x;
-                            const int cX = xwin[x - x0], cY = ywin[y - y0];
+                            const int cX = symAtX(x, x0), cY = symAtY(y, y0);
                             constexpr int kWM = SW::kWM, kWG = SW::kWG;
                             const double *wM = wt + (cX * 5 + cY) * kWM, *wX = wt + 25 * kWM + cX * kWG,
                                          *wY = wt + 25 * kWM + 5 * kWG + cY * kWG;

@@ -776,6 +776,46 @@ def test_packed_kernel_realign_sample(force_packed, mtype):
     assert st.regions >= len(problems)
 
 
+@pytest.mark.parametrize("mtype", [0, 2])
+def test_packed_kernel_per_anchor_expansions(force_packed, mtype):
+    """dynamicAnchorExpansion (band_constructDynamic, pairwiseAligner.c:184-234) through the packed kernel's DYN variant:
+    every anchor brings an expansion of its own (0-24: group widths 8 to 32), so the band's edges move back where a larger
+    one follows a smaller one; dense and sparse anchors (a sparse stretch makes the band wander further than a symbol window
+    holds: those cells read global memory), short traceback schedules, match and expectation emitters."""
+    rng = random.Random(57 + mtype)
+    probs, raggeds = [], []
+    for k in range(40):
+        sx = _rand_seq(rng, rng.randrange(1, 700))
+        sy = _evolve(rng, sx) or "A"
+        anchors, x, y = [], -1, -1
+        while True:
+            step = rng.randrange(1, 5) if k % 3 else rng.randrange(1, 4)
+            x += step
+            y += step if rng.random() < 0.8 else rng.randrange(1, 5)
+            if x >= len(sx) or y >= len(sy):
+                break
+            anchors.append((x, y, 2 * rng.randrange(0, 13)))
+        probs.append((sx, sy, anchors))
+        raggeds.append((rng.random() > 0.5, rng.random() > 0.5))
+    tbd = rng.randrange(2, 12)
+    worst, st = _check_batch(mtype, probs, raggeds, dynamicAnchorExpansion=1, traceBackDiagonals=tbd,
+                             minDiagsBetweenTraceBack=tbd + rng.randrange(20, 150), splitMatrixBiggerThanThis=10 ** 12)
+    # and the expectation emitter on the same bands, against the oracle
+    kw = dict(dynamicAnchorExpansion=1)
+    acc_g, acc_o = api.hmm_constructEmpty(1e-12, mtype), ob.hmm(mtype, 1e-12)
+    with api.Batch(_sm(mtype), api.pairwiseAlignmentBandingParameters_construct(**kw), emit=api.EMIT_EXPECT) as b:
+        for (sx, sy, a), (rl, rr) in zip(probs, raggeds):
+            b.add(sx, sy, a, rl, rr)
+        b.upload()
+        b.run()
+        b.download()
+        b.expectations(acc_g)
+    om = ob.model(mtype)
+    for (sx, sy, a), (rl, rr) in zip(probs, raggeds):
+        ob.expectations(om, acc_o, sx, sy, a, ob.params(**kw), rl, rr)
+    _assert_hmm_close(acc_g, acc_o, acc_g.stateNumber)
+
+
 def test_packed_kernel_random_narrow_bands(force_packed):
     """Group widths 8, 16 and 32; random anchors and traceback schedules; mixed with wide regions in one batch."""
     rng = random.Random(91)
