@@ -1727,6 +1727,8 @@ struct Sweep {
         };
         int untilRefresh = sg.dTop - sg.tbFrom;
         int jr = 0;
+        // B.match rows of d2, d2+1, d2+2 (bM1: a ring of three; rotated every diagonal instead of two divisions by 3)
+        double *pM0 = bM1(sg.dTop), *pM1 = bM1(sg.dTop + 1), *pM2 = bM1(sg.dTop + 2);
         for (int d2 = sg.dTop; d2 > sg.tbPrev;) {
           dc.load(d2 - 3 - (CPK_WAVE - 1));  // table entries of the 64 diagonals ending at d2-3: one new entry per diagonal
           for (int ci = CPK_WAVE - 1; ci >= 0 && d2 > sg.tbPrev; ci--, d2--) {
@@ -1744,7 +1746,7 @@ struct Sweep {
             issueStores();
             const CpkDiag g3 = dc.at(ci);  // entry of d2-3 (of diagonal 0 below it: never used then)
             loadF(g3, fN);
-            double *curM = bM1(d2), *curG = bG1(d2);
+            double *curM = pM0, *curG = bG1(d2);
             const int xlo = (d2 + g.xmyL) >> 1;
             BwdCtx c;
             c.d2 = d2;
@@ -1754,7 +1756,7 @@ struct Sweep {
             c.daR = ((g.xmyL - ga.xmyL) >> 1) * R;
             c.wAR = d2 + 2 <= sg.dTop ? ga.width * R : 0;
             c.pb = bG1(d2 + 1);
-            c.pa = bM1(d2 + 2);
+            c.pa = pM2;
             // backward cells of the diagonal, a group of 64 at a time; v stays in registers for the events
             double v[kExpGroups][S];
 #pragma unroll
@@ -1778,9 +1780,6 @@ struct Sweep {
 #pragma unroll
                         for (int s = 1; s < S; s++) curG[s + k0 * R] = v[q][s];
                     }
-                } else {
-#pragma unroll
-                    for (int s = 0; s < S; s++) v[q][s] = NEG_INF;
                 }
             }
             roll_fence<false>();  // the B rows for the next diagonal, the F slot for this one
@@ -1849,9 +1848,10 @@ struct Sweep {
                     const int x = xlo + (on ? k0 : W - 1), y = d2 - x;
                     const int cX = symX(x), cY = symY(y);
                     const double *wM = wt + (cX * 5 + cY) * kWM, *wX = wt + 25 * kWM + cX * kWG, *wY = wt + 25 * kWM + 5 * kWG + cY * kWG;
-                    double vr[S];  // B - ref; a lane without a cell has no event
+                    double vr[S];  // B - ref; a lane without a cell has no event (its reference is +inf: every exponent -inf)
+                    const double refL = on ? ref : __builtin_huge_val();
 #pragma unroll
-                    for (int s = 0; s < S; s++) vr[s] = on ? v[q][s] - ref : NEG_INF;
+                    for (int s = 0; s < S; s++) vr[s] = v[q][s] - refL;
                     double eAcc[S];  // this cell's events summed per target state: one LDS atomic per state, not per event
 #pragma unroll
                     for (int s = 0; s < S; s++) eAcc[s] = 0.0;
@@ -1941,6 +1941,10 @@ struct Sweep {
             pF0 = pF1;
             pF1 = pF2;
             pF2 = t;
+            t = pM2;  // d2 - 1 takes the row of d2 + 2
+            pM2 = pM1;
+            pM1 = pM0;
+            pM0 = t;
             if (refresh) {
                 untilRefresh = CPK_REFRESH_PERIOD - 1;
                 jr++;
