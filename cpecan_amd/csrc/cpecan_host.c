@@ -533,7 +533,8 @@ int64_t cpecan_cache_trim(int device) { return cpk_cache_trim(device); }
 
 int cpecan_ref_cells(const cpecan_model *model, int mode, const cpecan_cell_op *ops, int64_t n, double *cells,
                      int64_t nDoubles, double total) {
-    if (!model || !ops || !cells || n < 0 || nDoubles < 0 || mode < CPECAN_CELLS_FORWARD || mode > CPECAN_CELLS_POSTERIOR ||
+    /* the kernel's operation count is an int */
+    if (!model || !ops || !cells || n < 0 || n > INT32_MAX || nDoubles < 0 || mode < CPECAN_CELLS_FORWARD || mode > CPECAN_CELLS_POSTERIOR ||
         model->type < CPECAN_FIVE_STATE || model->type > CPECAN_THREE_STATE_ASYM) {
         cpk_set_error("cpecan_ref_cells: invalid arguments");
         return CPECAN_EINVAL;
@@ -622,8 +623,12 @@ void cpecan_batch_destroy(cpecan_batch *b) {
 
 /* A download running on the helper thread (cpecan_batch_download_begin) rewrites the batch's result arrays, segment
  * table and device order: until cpecan_batch_download_end every other entry point refuses the batch. */
+static _Thread_local const cpecan_batch *tl_helperOf = NULL; /* set by the helper thread itself: the batch it downloads */
 static int dl_busy(const cpecan_batch *b) {
-    if (!b || !b->dlActive || pthread_equal(pthread_self(), b->dlThread)) return 0;
+    /* dlActive is written before pthread_create and after pthread_join only, both of which order it against the helper;
+     * the helper recognises itself by its own thread-local mark, not by comparing ids with a field pthread_create is
+     * still writing */
+    if (!b || !b->dlActive || tl_helperOf == b) return 0;
     cpk_set_error("the batch is being downloaded on its helper thread: call cpecan_batch_download_end first");
     return 1;
 }
@@ -1527,6 +1532,7 @@ int cpecan_batch_download(cpecan_batch *b) {
 
 static void *download_helper(void *arg) {
     cpecan_batch *b = arg;
+    tl_helperOf = b;
     b->dlResult = cpecan_batch_download(b);
     if (b->dlResult != CPECAN_OK) {
         strncpy(b->dlError, cpk_last_error(), sizeof b->dlError - 1);
@@ -1539,11 +1545,12 @@ int cpecan_batch_download_begin(cpecan_batch *b) {
     if (!b || !b->ran || b->dlActive) return CPECAN_ESTATE;
     b->dlResult = CPECAN_OK;
     b->dlError[0] = 0;
+    b->dlActive = 1;
     if (pthread_create(&b->dlThread, NULL, download_helper, b) != 0) {
+        b->dlActive = 0;
         cpk_set_error("cannot start the download helper thread");
         return CPECAN_ENOMEM;
     }
-    b->dlActive = 1;
     return CPECAN_OK;
 }
 

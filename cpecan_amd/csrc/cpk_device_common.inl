@@ -178,9 +178,12 @@ __device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
 // product formed in double and handed to v_exp_f32 as a float -- four instructions (round 2 split off the integer part in
 // double and scaled with v_ldexp_f64: eight, ~1e-7).  The float carries x log2 e to 2^-24 relative, i.e. the result to
 // |x log2 e| * 4e-8 relative: 8e-7 for an event 1e-6 times less likely than its cell's total (|x log2 e| = 20), less for
-// the likelier ones that make up the sums; events below 2^-126 count as zero.  -inf (an unreachable transition) gives 0.
+// the likelier ones that make up the sums; events below 2^-126 count as zero.  -inf (an unreachable transition) gives 0,
+// and so does NaN (-inf - -inf: a window reference or total of -inf, e.g. a zero-probability region under a loaded HMM
+// with -inf transitions): fmax returns its non-NaN operand, one instruction -- a NaN here would poison the sums of the
+// whole batch, whose per-wave partials are added up on the host.
 __device__ __forceinline__ double exp_1e7(double x) {
-    return (double)__builtin_amdgcn_exp2f((float)(x * 1.4426950408889634 /* log2(e) */));
+    return (double)__builtin_amdgcn_exp2f((float)__builtin_fmax(x * 1.4426950408889634 /* log2(e) */, -200.0));
 }
 
 // Packs the nSym one-byte symbols at src into LDS, two to a byte (low nibble = even index; a missing partner reads as

@@ -425,6 +425,16 @@ __global__ void __launch_bounds__(64) cpecan_post_left_shift(const CpkPostProble
 // every pair: 38.6 ms for the 50 000 cigars of the realign benchmark, more than the DP kernels.
 // Pairs of one X column are all scored before any of them is inserted (:389-409).
 // The reference's st_random() * 0.00001 per weight (:145) is left out.
+// Hand-off between the lanes of ONE wave through memory (cpecan_post_ordered_wave: lane 0, or one lane per entry,
+// stores; all 64 lanes load the same words later).  The hardware completes a wave's accesses to one address in order;
+// the fence makes the compiler keep that order too -- no load is hoisted over, and no store sunk below it (ADVICE r3:
+// without it, load-PRE over `if (writer) stairY[pos] = y; ... reloadLast()` could hand the other lanes the old value and
+// the wave's uniform control flow would diverge).  Wavefront scope: no instruction is emitted for it.
+__device__ __forceinline__ void wave_handoff_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct OrderedStairs {
     const int32_t *pairs;
     const double *best;
@@ -445,6 +455,7 @@ struct OrderedStairs {
     // number of entries with y' < y
     __device__ __forceinline__ int below(int y) const {
         if (len == 0 || lastY < y) return len;  // the usual case: the pair extends the alignment
+        wave_handoff_fence();  // the entries read below may have been stored by another lane of this wave
         int lo = 0, hi = len - 1;                         // stairY[hi] >= y
         while (lo < hi) {
             const int mid = (lo + hi) >> 1;
@@ -516,6 +527,7 @@ struct OrderedStairs {
             stairI[pos] = i;
         }
         len += shift;
+        wave_handoff_fence();  // the writer lane's stores above, every lane's loads below
         reloadLast();
     }
 };
@@ -713,6 +725,7 @@ __global__ void __launch_bounds__(64) cpecan_post_ordered_wave(const CpkPostProb
         }
         flushStairs();
         flushChunk();
+        wave_handoff_fence();  // st.insert reads entries and scores other lanes have just stored
         st.insert(y, k, sc);
         sBase = st.len;
     };
@@ -722,6 +735,7 @@ __global__ void __launch_bounds__(64) cpecan_post_ordered_wave(const CpkPostProb
         if (colN == 1) {
             insert(firstY, colK, firstS);
         } else if (colN > 1) {
+            wave_handoff_fence();  // lane 0 filled colY / colS, every lane reads them
             const bool ring = colN <= CPK_WAVE;  // else the ring has wrapped: re-read what the chunk stores hold
             if (!ring) {
                 flushChunk();
@@ -761,6 +775,7 @@ __global__ void __launch_bounds__(64) cpecan_post_ordered_wave(const CpkPostProb
                 from = st.lastI;
             } else {
                 flushStairs();
+                wave_handoff_fence();
                 from = st.query(y);
             }
             const double sFrom = from < 0 ? 0.0 : (from == st.lastI ? st.lastS : scoreOf(from));
@@ -783,6 +798,7 @@ __global__ void __launch_bounds__(64) cpecan_post_ordered_wave(const CpkPostProb
         }
         done = cnt;
         flushChunk();
+        wave_handoff_fence();  // scoreOf() of a later chunk reads these scores back, any lane's
     }
     done = 0;  // (nothing of a chunk is pending any more)
     finishColumn();

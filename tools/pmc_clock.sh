@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/pmc_clock
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $OUT
-timeout -k 10 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT.a.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/a -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs --no-e2e > $OUT.a.log 2>&1
 timeout -k 10 100 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE --output-format csv -d $OUT/b -- $R/tools/logadd_rate > $OUT.b.log 2>&1
 python3 - $OUT <<'PY'
 import csv, glob, sys

@@ -5,7 +5,7 @@ OUT=$R/gpurun_out/pmc_lat
 cd /tmp && export TMPDIR=/tmp
 mkdir -p $OUT
 run() { n=$1; shift
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python3 $R/bench.py --steps 1 --warmup 0 --pairs 4000 --no-cpu-baseline > $OUT.$n.log 2>&1 || { tail -5 $OUT.$n.log; return 1; }
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python3 $R/bench.py --steps 1 --warmup 0 --pairs 4000 --no-cpu-baseline --no-e2e > $OUT.$n.log 2>&1 || { tail -5 $OUT.$n.log; return 1; }
 }
 run a SQ_INST_LEVEL_LDS SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_UNALIGNED_STALL SQ_ACTIVE_INST_LDS SQ_WAVE_CYCLES && \
 run b SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VMEM SQ_WAVE_CYCLES && \

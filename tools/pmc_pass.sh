@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/${1:-pmc}
 cd /tmp && export TMPDIR=/tmp
 run() { # name counters...
   n=$1; shift
-  timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python3 $R/bench.py --steps 1 --warmup 0 --pairs 4000 --no-cpu-baseline > $OUT.$n.log 2>&1
+  timeout -k 10 200 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d $OUT/$n -- python3 $R/bench.py --steps 1 --warmup 0 --pairs 4000 --no-cpu-baseline --no-e2e > $OUT.$n.log 2>&1
 }
 mkdir -p $OUT
 run a SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU
