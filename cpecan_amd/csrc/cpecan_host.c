@@ -858,6 +858,8 @@ typedef struct {
     int64_t maxW, liveMax, fbMax, nSeg, refreshMax;
     int smooth; /* both edges of the band move by exactly one x-y step per diagonal (fixed expansions do): the region may run
                  * under the absolute-position sweeps (cpk_table_gather.inl, "positions") */
+    int64_t winBytes; /* LDS bytes of the largest symbol window of a traceback segment (both strings, two symbols per byte):
+                       * what the absolute-position sweeps stage per segment instead of the whole strings (cpk_sweep.inl) */
 } RegionPlan;
 
 static int by_cost_desc(const void *a, const void *b) {
@@ -935,7 +937,8 @@ int cpecan_batch_upload(cpecan_batch *b) {
     {
         /* cell offsets of the last traceBackDiagonals + 3 diagonals: the schedule looks that far back */
         const int64_t K = p->traceBackDiagonals + 3;
-        int64_t *histOff = malloc(sizeof(int64_t) * (size_t)K * 2), *histW = histOff ? histOff + K : NULL;
+        int64_t *histOff = malloc(sizeof(int64_t) * (size_t)K * 4), *histW = histOff ? histOff + K : NULL;
+        int64_t *histXlo = histOff ? histOff + 2 * K : NULL, *histYlo = histOff ? histOff + 3 * K : NULL;
         if (!histOff) {
 #pragma omp critical(cpk_plan)
             rc = CPECAN_ENOMEM;
@@ -958,6 +961,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
             int64_t slot = 0; /* d % K without the division: this loop runs once per diagonal of the batch */
             int64_t maxW = 0;
             int64_t prevLo = 0, prevHi = 0;
+            int64_t winXlo = 0, winYlo = 0; /* smallest x and y of diagonal tracedBackTo + 1 (symbol windows, RegionPlan::winBytes) */
             int smooth = !dynamic;
             const int64_t minBetween = p->minDiagsBetweenTraceBack, narrow = p->diagonalExpansion * 2 + 1;
             for (int64_t d = 0; d <= N && !bad; d++, slot = slot + 1 == K ? 0 : slot + 1) {
@@ -979,7 +983,13 @@ int cpecan_batch_upload(cpecan_batch *b) {
                 prevHi = hi;
                 histOff[slot] = cells;
                 histW[slot] = w;
-                if (d == 1) offAfter = cells; /* tracedBackTo == 0 for the first segment */
+                histXlo[slot] = (d + lo) >> 1;      /* x of the diagonal's first cell */
+                histYlo[slot] = d - ((d + hi) >> 1); /* y of its last cell: the smallest */
+                if (d == 1) {
+                    offAfter = cells; /* tracedBackTo == 0 for the first segment */
+                    winXlo = histXlo[slot];
+                    winYlo = histYlo[slot];
+                }
                 maxW = w > maxW ? w : maxW;
                 cells += w;
                 if (d == 0) continue;
@@ -999,6 +1009,13 @@ int cpecan_batch_upload(cpecan_batch *b) {
                 const int64_t tfSlot = tf % K; /* once per segment */
                 const int64_t fbCells = histOff[tfSlot] + histW[tfSlot] - offAfter;
                 pl->fbMax = imax(pl->fbMax, fbCells);
+                {
+                    /* the symbols the segment's diagonals tbPrev + 1 .. d touch, the kernel's arithmetic (cpk_sweep.inl,
+                     * "Symbol windows"): from the even index at or below the smallest x (y) to one past the largest */
+                    const int64_t x0 = winXlo & ~(int64_t)1, y0 = winYlo & ~(int64_t)1;
+                    const int64_t x1 = imin(((d + hi) >> 1) + 1, r->lX + 1), y1 = imin(d - ((d + lo) >> 1) + 1, r->lY + 1);
+                    pl->winBytes = imax(pl->winBytes, (x1 - x0 + 2) / 2 + (y1 - y0 + 2) / 2);
+                }
                 pl->nSeg++;
                 sg++;
 
@@ -1006,6 +1023,11 @@ int cpecan_batch_upload(cpecan_batch *b) {
                 tracedBackTo = tf;
                 offTracedBackTo = histOff[tfSlot];
                 offAfter = histOff[tfSlot] + histW[tfSlot];
+                if (tf < d) { /* diagonal tf + 1 has been walked already: within the last K */
+                    const int64_t s1 = (tf + 1) % K;
+                    winXlo = histXlo[s1];
+                    winYlo = histYlo[s1];
+                }
             }
             pl->maxW = maxW;
             pl->smooth = smooth;
@@ -1150,6 +1172,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
             geo.wRingCells[k] = imax(geo.wRingCells[k], pl->liveMax + pl->maxW);
             geo.wFbCells[k] = imax(geo.wFbCells[k], pl->fbMax);
             geo.wSeqLdsBytes[k] = (int32_t)imax(geo.wSeqLdsBytes[k], imin((r->lX + 3) / 2 + (r->lY + 3) / 2, (int64_t)1 << 30));
+            geo.wWinLdsBytes[k] = (int32_t)imax(geo.wWinLdsBytes[k], imin(pl->winBytes, (int64_t)1 << 30));
         }
     }
     for (int k = 0; k < 3; k++)

@@ -115,6 +115,7 @@ typedef struct {
      * get nor multiplies everybody's scratch.  The scalar fields above are filled per launch from these. */
     int32_t nWide[CPK_WIDE_CLASSES];
     int32_t wMaxWidth[CPK_WIDE_CLASSES], wMaxRefresh[CPK_WIDE_CLASSES], wSeqLdsBytes[CPK_WIDE_CLASSES];
+    int32_t wWinLdsBytes[CPK_WIDE_CLASSES]; /* the same for a class that stages symbol windows per traceback segment (absolute positions) */
     int64_t wRingCells[CPK_WIDE_CLASSES], wFbCells[CPK_WIDE_CLASSES];
 } CpkGeometry;
 

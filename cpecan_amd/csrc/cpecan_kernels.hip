@@ -886,7 +886,8 @@ static KernelFn pick_fused_kernel(const CpkGeometry &g, bool dense, bool abs) {
         return fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeFused, 3> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeFused, 3>;
     return fast ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeFused> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeFused>;
 }
-static void pick_split_kernels(const CpkGeometry &g, bool dense, bool abs, KernelFn *fwd, KernelFn *trace, bool fwd3 = false) {
+static void pick_split_kernels(const CpkGeometry &g, bool dense, bool abs, KernelFn *fwd, KernelFn *trace, bool fwd3 = false,
+                               bool trace3 = false) {
     const bool fast = !g.useGlobalRoll;
     if (abs && fast) {
         // fwd3: the forward launch has no candidate ring and 120 VGPRs or fewer; where its LDS lets nine or more waves
@@ -894,7 +895,10 @@ static void pick_split_kernels(const CpkGeometry &g, bool dense, bool abs, Kerne
         if (g.nStates == 5) {
             *fwd = fwd3 ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeForward, 3, true>
                         : cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeForward, CPK_SWEEP_WAVES, true>;
-            *trace = cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeTrace, CPK_SWEEP_WAVES, true>;
+            // trace3 (round 4): the traceback launch built for three waves per SIMD (168 VGPRs), for classes whose LDS lets
+            // nine or more waves onto a CU
+            *trace = trace3 ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeTrace, 3, true>
+                            : cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeTrace, CPK_SWEEP_WAVES, true>;
         } else {
             *fwd = fwd3 ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeForward, 3, true>
                         : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeForward, CPK_SWEEP_WAVES, true>;
@@ -1056,6 +1060,18 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         c.bringEl = expect ? c.geo.fbCells * S : 0;
         d->classes.push_back(c);
     }
+    // The LDS of one wave of the class: tables, rolling rows, candidate stage, symbols -- by the form of its sweeps.
+    // Absolute positions (cpk_sweep.inl): two arrays of S rows with a few positions of slack, a stage of 64
+    // candidates, and the symbols of one traceback segment at a time instead of both whole strings.
+    auto setForm = [&](LaunchClass &cc, bool abs) {
+        cc.abs = abs;
+        cc.geo.rollStride = cc.geo.maxWidth + (abs ? kAbsSlack : 1);
+        cc.geo.seqLdsBytes = abs ? geo->wWinLdsBytes[cc.k] : geo->wSeqLdsBytes[cc.k];
+        cc.geo.rollDoubles = (int64_t)(abs ? 2 * S : 2 * S + 1) * cc.geo.rollStride;
+        const size_t header = sizeof(double) * (lds_header_doubles(geo->emit) + lds_stage_doubles(geo->emit, abs));
+        cc.ldsBytes = cc.geo.useGlobalRoll ? header
+                                           : header + sizeof(double) * (size_t)cc.geo.rollDoubles + (size_t)((cc.geo.seqLdsBytes + 15) / 16 * 16);
+    };
     for (int k = 0; k < CPK_WIDE_CLASSES; k++) {  // then the wide ones: the sweep kernel, one region per wave at a time
         if (geo->nWide[k] <= 0) continue;
         LaunchClass c;
@@ -1082,17 +1098,16 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             const bool splitLikely = geo->emit == CPECAN_EMIT_MATCH && (!geo->debug || env) && nSegClass > 0 &&
                                      (env ? atoi(env) != 0 : nSegClass * 4 >= (int64_t)geo->nWide[k] * 5);
             c.abs = splitLikely && absOk && !(absEnv && atoi(absEnv) == 0);
-            if (c.abs) c.geo.rollStride = c.geo.maxWidth + kAbsSlack;
         }
         c.geo.refreshCells = (int64_t)c.geo.maxWidth * c.geo.maxRefresh;
         if (c.geo.refreshCells < 1) c.geo.refreshCells = 1;
-        c.geo.rollDoubles = (int64_t)(2 * S + 1) * c.geo.rollStride;
-        // LDS budget: beyond 64 KiB per wave (rolling buffers + symbol strings) the class takes the global-memory path
-        const size_t header = sizeof(double) * (lds_header_doubles(geo->emit) + lds_stage_doubles(geo->emit));
-        const size_t fastLds = header + sizeof(double) * (size_t)c.geo.rollDoubles + (size_t)((c.geo.seqLdsBytes + 15) / 16 * 16);
-        c.geo.useGlobalRoll = fastLds + 16 > 64 * 1024;
-        if (c.geo.useGlobalRoll) c.abs = false;  // absolute positions are a form of the LDS rows
-        c.ldsBytes = c.geo.useGlobalRoll ? header : fastLds;
+        // LDS budget: beyond 64 KiB per wave (rolling buffers + symbol strings, in the form every class can fall back
+        // to: one wave per region) the class takes the global-memory path
+        const bool absWanted = c.abs;
+        c.geo.useGlobalRoll = 0;
+        setForm(c, false);
+        c.geo.useGlobalRoll = c.ldsBytes + 16 > 64 * 1024;
+        setForm(c, absWanted && !c.geo.useGlobalRoll);  // absolute positions are a form of the LDS rows
         {
             // Expectation emitter, every diagonal of the class within two 64-lane groups: the events are formed inside the
             // traceback (Sweep::tracebackExpect) from three forward diagonals kept in LDS, instead of a second pass over B
@@ -1240,7 +1255,22 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                     if (wt > c.subSlots) c.subSlots = wt;
                     // the forward launch: no candidate ring in its LDS, and with absolute positions few enough registers
                     // for three waves per SIMD -- more waves per CU where that LDS allows them (CPECAN_FWD3=0: never)
-                    c.ldsBytesFwd = c.geo.useGlobalRoll ? c.ldsBytes : c.ldsBytes - sizeof(double) * lds_stage_doubles(geo->emit);
+                    c.ldsBytesFwd = c.geo.useGlobalRoll ? c.ldsBytes : c.ldsBytes - sizeof(double) * lds_stage_doubles(geo->emit, c.abs);
+                    // ... and so does the traceback launch of a five-state class since round 4 (CPECAN_TRACE3=0: never)
+                    const char *t3e = getenv("CPECAN_TRACE3");
+                    if (c.abs && S == 5 && !(t3e && atoi(t3e) == 0) && (160 * 1024) / c.ldsBytes >= 9) {
+                        KernelFn f2 = nullptr, tr3 = nullptr;
+                        pick_split_kernels(c.geo, c.dense, c.abs, &f2, &tr3, false, true);
+                        int p3 = 0;
+                        if (int rc = wavesPerCU(tr3, c.ldsBytes, &p3)) return rc;
+                        if (p3 > perCU) {
+                            c.fnTrace = tr3;
+                            int64_t w3 = (int64_t)p3 * d->numCUs;
+                            if (w3 > nSegClass) w3 = nSegClass;
+                            c.wavesTrace = (int)w3;
+                            if (w3 > c.subSlots) c.subSlots = w3;
+                        }
+                    }
                     const char *f3e = getenv("CPECAN_FWD3");
                     if (c.abs && !(f3e && atoi(f3e) == 0) && (160 * 1024) / c.ldsBytesFwd >= 9) {
                         KernelFn f3 = nullptr, tr = nullptr;
@@ -1258,8 +1288,10 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                     }
                 }
                 c.itemCount = nSegClass;
-            } else {
-                c.abs = false;  // one wave per region: the other form of the rows (its LDS keeps the slack, harmlessly)
+            } else if (c.abs) {
+                // one wave per region: the other form of the rows (a class that went to a team of waves keeps the team's LDS)
+                if (c.threads == CPK_WAVE) setForm(c, false);
+                else c.abs = false;
             }
         }
         if (getenv("CPECAN_TRACE_HOST"))
@@ -1305,7 +1337,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                 if (!c.split) continue;
                 c.split = false;
                 c.fused = false;
-                c.abs = false;
+                if (c.abs) setForm(c, false);
                 c.fn = c.dense ? pick_dense_kernel(c.geo) : pick_kernel(c.geo);
                 c.fnTrace = nullptr;
                 c.subSlots = c.waves;

@@ -381,10 +381,13 @@ __host__ __device__ constexpr int lds_header_doubles(int emit, bool inSweep = fa
 }
 // doubles of LDS behind the rolling rows for the candidate staging rings (16-byte Candidates, 128 per list; none for
 // the forward-only and expectation emitters)
-__host__ __device__ constexpr int lds_stage_doubles(int emit) {
-    return emit == CPECAN_EMIT_MATCH ? 2 * 128 : (emit == CPECAN_EMIT_INDEL ? 3 * 2 * 128 : 0);
-}
 constexpr int kStage = 128;  // LDS staging slots per candidate list (two waves' worth: flushed 64 at a time)
+// ... of the absolute-position traceback: flushed whole at the end of a diagonal once half full -- a diagonal leaves two or
+// three candidates --, and passed by when one group brings more than fit (Sweep::tracebackAbs)
+constexpr int kStageAbs = 32;
+__host__ __device__ constexpr int lds_stage_doubles(int emit, bool abs = false) {
+    return emit == CPECAN_EMIT_MATCH ? 2 * (abs ? kStageAbs : kStage) : (emit == CPECAN_EMIT_INDEL ? 3 * 2 * kStage : 0);
+}
 constexpr int kPrefetch = 3;  // passes (of 64 cells) of F.match prefetched one diagonal ahead in the traceback
 constexpr float kCandMargin = 3.0f;  // log-space slack of the candidate filter (see DESIGN.md "candidate filter")
 

@@ -8,7 +8,10 @@
 // RDBL: a table entry's ringOff counts doubles (the ring of a split region keeps only the states that are read back,
 // cpk_table_gather.inl) instead of cells of S doubles
 // ABS: the rolling rows are indexed by a cell's POSITION (its matrix diagonal, cpk_table_gather.inl "positions") instead of
-// its rank on the anti-diagonal: neighbours sit at constant offsets, out-of-band ones read -inf without a range test
+// its rank on the anti-diagonal: neighbours sit at constant offsets, out-of-band ones read -inf without a range test.
+// The rows are then TWO arrays of S rows (ROWS = S), one per parity of the diagonal, `setStride` doubles apart: S is odd
+// for both models, so a lane stride of S * 8 bytes is as conflict-free as 2S + 1 rows were, without the padding row
+// (round 4: 1.2 KB of LDS per wave at BASELINE config B, part of what the tenth wave per CU needs).
 template <int S, bool FAST, int ROWS = 2 * S + 1, bool COH = false, bool RDBL = false, bool ABS = false>
 struct Sweep {
     const KArgs &a;
@@ -428,25 +431,26 @@ struct Sweep {
         const double *lu;  // the other row set, shifted by d's parity: the neighbour at x-y - 1 is at the cell's own offset,
                            // the one at x-y + 1 R elements further
     };
+    int setStride = 0;  // doubles between the row set of the even and the odd diagonals (S * stride; set by the kernel)
     __device__ __forceinline__ AbsDiag absDiag(int d, const CpkDiag &g, int pLo) const {
         AbsDiag c;
         c.d = d;
         c.xlo = (d + g.xmyL) >> 1;
         c.ownR = (pLo - 1) * R;
         c.W = g.width;
-        c.cur = roll + R + (d & 1) * S;
-        c.lu = roll + R + ((d + 1) & 1) * S + ((d & 1) - 1) * R;
+        c.cur = roll + R + (d & 1) * setStride;
+        c.lu = roll + R + ((d + 1) & 1) * setStride + ((d & 1) - 1) * R;
         return c;
     }
     // every position of every row: -inf (a region's forward sweep and a segment's traceback start from empty rows)
     __device__ void absWipe() {
-        for (int i = lane; i < R * stride; i += CPK_WAVE) roll[i] = NEG_INF;
+        for (int i = lane; i < 2 * setStride; i += CPK_WAVE) roll[i] = NEG_INF;
         roll_fence<false>();
     }
     // Moves the W cells of diagonal dd (first cell at position pOld of its row set) by `delta` positions and sets every
     // other position of that row set to -inf.  W = 0: the diagonal does not exist, the set is wiped.
     __device__ void absMoveRows(int dd, int pOld, int W, int delta) {
-        double *set = roll + (dd & 1) * S;  // position 0
+        double *set = roll + (dd & 1) * setStride;  // position 0
         const int nG = (W + CPK_WAVE - 1) / CPK_WAVE;
         if (delta != 0) {
             for (int i = 0; i < nG; i++) {  // memmove order: towards higher positions from the top group down
@@ -1017,16 +1021,15 @@ struct Sweep {
     __device__ void tracebackAbs(const CpkSegment &sg, const double *endPrior, double *dbgFb, int (&nCand)[NL]) {
         const int J = sg.nRefresh;
         const float logThr = (float)log(m.threshold);
-        int pend[NL], head[NL];
+        // Candidates wait in LDS -- kStageAbs slots per list, filled from slot 0 -- and go to HBM as ONE coalesced store of
+        // everything that waits (round 4: the ring of 128 slots flushed 64 at a time took 2 KB of LDS per wave, this 0.5).
+        int pend[NL];
 #pragma unroll
-        for (int l = 0; l < NL; l++) nCand[l] = pend[l] = head[l] = 0;
-        auto flush = [&](int l, int n) {
-            if (lane < n) {
-                cand[(size_t)l * a.geo.fbCells + nCand[l] + lane] = stage[l * kStage + ((head[l] + lane) & (kStage - 1))];
-            }
-            head[l] = (head[l] + n) & (kStage - 1);
-            pend[l] -= n;
-            nCand[l] += n;
+        for (int l = 0; l < NL; l++) nCand[l] = pend[l] = 0;
+        auto flush = [&](int l) {
+            if (lane < pend[l]) cand[(size_t)l * a.geo.fbCells + nCand[l] + lane] = stage[l * kStageAbs + lane];
+            nCand[l] += pend[l];
+            pend[l] = 0;
         };
         float lastMax = -__builtin_huge_valf();
         double keepFrom = lastMax;  // compared in double: one instruction per group instead of a conversion and a compare
@@ -1060,18 +1063,23 @@ struct Sweep {
                 const bool cell = l == 0 ? (x > 0 && y > 0) : (l == 1 ? x > 0 : y > 0);
                 const bool keep = on && cell && fbv[l] >= keepFrom;
                 const unsigned long long mask = __ballot(keep);
+                const int cnt = __popcll(mask);
+                // what waits goes out at the END of a diagonal (behind the wait for the prefetch, see below); here only
+                // when this group's candidates do not fit behind it (the top diagonal, where every cell is one; a threshold
+                // of zero)
+                const bool direct = pend[l] + cnt > kStageAbs;  // wave-uniform
+                if (direct) flush(l);
                 if (keep) {
                     const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
                     Candidate cd;
                     cd.fb = fbv[l];
                     cd.x = x;
                     cd.y = y;
-                    stage[l * kStage + ((head[l] + pend[l] + rank) & (kStage - 1))] = cd;
+                    if (direct) cand[(size_t)l * a.geo.fbCells + nCand[l] + rank] = cd;  // ... and go straight to HBM then
+                    else stage[l * kStageAbs + pend[l] + rank] = cd;
                 }
-                pend[l] += __popcll(mask);
-                // a full staging half goes out at the END of the diagonal (behind the wait for the prefetch, see below);
-                // here only when the next group's candidates might not fit any more
-                if (pend[l] > kStage - CPK_WAVE) flush(l, CPK_WAVE);
+                if (direct) nCand[l] += cnt;
+                else pend[l] += cnt;
             }
         };
         // a refresh point: per-cell dot products over the states (cell_dotProduct, pairwiseAligner.c:402-408) into cbuf and,
@@ -1102,7 +1110,7 @@ struct Sweep {
             }
 #pragma unroll
             for (int l = 0; l < (CANDS ? NL : 0); l++)
-                if (pend[l] >= CPK_WAVE) flush(l, CPK_WAVE);
+                if (pend[l] >= kStageAbs / 2) flush(l);
         };
         auto dotCell = [&](const AbsDiag &cx, int k, const double (&fRow)[S], double &t) {
             const int kR = cx.ownR + k * R;
@@ -1406,7 +1414,7 @@ struct Sweep {
           }
         }
 #pragma unroll
-        for (int l = 0; l < (CANDS ? NL : 0); l++) flush(l, pend[l]);
+        for (int l = 0; l < (CANDS ? NL : 0); l++) flush(l);
     }
 
     // ---- expectation step (diagonalCalculationExpectations, pairwiseAligner.c:735-746; updateExpectations :418-432).
@@ -2133,7 +2141,8 @@ cpecan_pairhmm_sweep(const KArgs a) {
     const int lane = threadIdx.x;
     const CpkModel &m = *a.model;
     const int stride = a.geo.rollStride;
-    constexpr int R = 2 * S + 1;  // rows of the rolling buffers (Sweep::R)
+    constexpr int R = ABS ? S : 2 * S + 1;  // rows of the rolling buffers (Sweep::R; absolute positions: two arrays of S rows)
+    const int rollDoubles = (ABS ? 2 * S : 2 * S + 1) * stride;
 
     // LDS (doubles): logAdd cubics | emission tables | expectation sums | rolling buffers (FAST) | symbol strings (FAST)
     fill_cubics(lds);
@@ -2152,11 +2161,11 @@ cpecan_pairhmm_sweep(const KArgs a) {
     double likelihood = 0.0;
     constexpr int kHeader = lds_header_doubles(EMIT, INSWEEP);
     double *roll = FAST ? (lds + kHeader) : (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles);
-    Candidate *stageLds = reinterpret_cast<Candidate *>(lds + kHeader + (FAST ? (size_t)(2 * S + 1) * stride : 0));
-    constexpr int kStageDoubles = MODE == kModeForward ? 0 : lds_stage_doubles(EMIT);  // a forward launch stages no candidates
-    uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + kHeader + (size_t)(2 * S + 1) * stride + kStageDoubles);
+    Candidate *stageLds = reinterpret_cast<Candidate *>(lds + kHeader + (FAST ? (size_t)rollDoubles : 0));
+    constexpr int kStageDoubles = MODE == kModeForward ? 0 : lds_stage_doubles(EMIT, ABS);  // a forward launch stages no candidates
+    uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + kHeader + (size_t)rollDoubles + kStageDoubles);
     // every rolling cell starts as -inf; position 0 of each row is never written again (the guard)
-    for (int i = lane; i < (2 * S + 1) * stride; i += CPK_WAVE) roll[i] = NEG_INF;
+    for (int i = lane; i < rollDoubles; i += CPK_WAVE) roll[i] = NEG_INF;
     // expectation step inside the traceback (Sweep::tracebackExpect): three F slots and the window's emission sums behind the strings
     constexpr bool expInSweep = INSWEEP;
     double *frowLds = reinterpret_cast<double *>(seqLds + (a.geo.seqLdsBytes + 15) / 16 * 16);
@@ -2191,14 +2200,15 @@ cpecan_pairhmm_sweep(const KArgs a) {
         const CpkRegion &rg = a.regions[r];
         const int lX = rg.lX, lY = rg.lY, N = lX + lY;
         const uint8_t *gx = a.symbols + rg.seqXOff, *gy = a.symbols + rg.seqYOff;
-        if (FAST) {
+        if (FAST && !ABS) {
             // stage N + bases + N of both strings into LDS, two symbols per byte (per-cell reads come from here)
+            // (absolute positions: the symbols a SEGMENT's diagonals touch, staged per segment below)
             stage_symbols<CPK_WAVE>(seqLds, gx, lX + 2, lane);
             stage_symbols<CPK_WAVE>(seqLds + ((lX + 3) >> 1), gy, lY + 2, lane);
             roll_fence<false>();
         }
         const CpkDiag *table = a.diags + rg.diagOff;
-        Sweep<S, FAST, 2 * S + 1, MODE == kModeFused, MODE != kModeWhole, ABS> sw{a,
+        Sweep<S, FAST, R, MODE == kModeFused, MODE != kModeWhole, ABS> sw{a,
                           a.kc,
                           DiagCache{table, N, 0, lane, 0, 0, 0, 0, ABS ? a.dpos + rg.diagOff : nullptr, 0},
                           FAST ? seqLds : gx,
@@ -2219,6 +2229,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                           N,
                           CpkDiag{},
                           CpkDiag{}};
+        sw.setStride = S * stride;
         if (EMIT == CPECAN_EMIT_EXPECT) {
             // B of a segment's emitted cells (expectations()) or its window records (tracebackExpect())
             sw.bring = a.bring + slot * (size_t)(expInSweep ? (int64_t)a.geo.maxRefresh * sw.kWinDoubles : a.geo.fbCells * S);
@@ -2294,6 +2305,29 @@ cpecan_pairhmm_sweep(const KArgs a) {
             const int siFirst = traceRole ? itemSeg : 0, siEnd = traceRole ? itemSeg + 1 : rg.nSeg;
             for (int si = siFirst; si < siEnd; si++) {
                 const CpkSegment sg = a.segs[rg.segOff + si];
+                if (ABS) {
+                    // Symbol windows (round 4): only the symbols the diagonals of THIS step touch are staged -- the forward
+                    // sweep of diagonals d .. dTop, or the traceback of tbPrev + 1 .. dTop, whose cells also read the symbols
+                    // one past their own (Sweep::bwdCells) -- ~0.7 KB instead of the 2 KB of both whole strings of a 2 kb pair.
+                    // The edges of a band that may run under absolute positions move one x-y step per diagonal
+                    // (CpkRegion::absOk), so the smallest and the largest x and y of a diagonal never decrease with d: the
+                    // window runs from the first cell of the lowest diagonal to the last cell of the highest.  The host sized
+                    // the LDS for the largest window of the class (cpecan_host.c, RegionPlan::winBytes).
+                    const int dLo = traceRole ? sg.tbPrev + 1 : d;
+                    const CpkDiag gl = table[dLo], gh = table[sg.dTop];
+                    const int xLoL = (dLo + gl.xmyL) >> 1, xHiL = xLoL + gl.width - 1;
+                    const int xLoH = (sg.dTop + gh.xmyL) >> 1, xHiH = xLoH + gh.width - 1;
+                    const int x0 = xLoL & ~1, y0 = (dLo - xHiL) & ~1;                 // even: two symbols per byte
+                    const int x1 = xHiH + 1 < lX + 1 ? xHiH + 1 : lX + 1;            // last symbol index read (padded strings:
+                    const int y1 = sg.dTop - xLoH + 1 < lY + 1 ? sg.dTop - xLoH + 1 : lY + 1;  // lX + 2 and lY + 2 entries)
+                    const int nX = x1 - x0 + 1, nY = y1 - y0 + 1;
+                    uint8_t *winY = seqLds + ((nX + 1) >> 1);
+                    stage_symbols<CPK_WAVE>(seqLds, gx + x0, nX, lane);
+                    stage_symbols<CPK_WAVE>(winY, gy + y0, nY, lane);
+                    sw.sxp = seqLds - (x0 >> 1);
+                    sw.syp = winY - (y0 >> 1);
+                    roll_fence<false>();
+                }
                 // Which states of F[d] the traceback will read back: the match row always (posteriors), every state on the
                 // refresh points of the segment that emits d (cell dot products, pairwiseAligner.c:636-653; the schedule is
                 // known up front) and on the two diagonals the forward sweep is resumed from; the indel and expectation
