@@ -144,13 +144,13 @@ def other_configs(names):
     for name in names:
         t0 = time.perf_counter()
         cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "3", "--warmup", "1",
-               "--no-cpu-baseline", "--e2e-batches", "5", "--no-other-configs"]
+               "--no-cpu-baseline", "--e2e-batches", "13" if name == "4" else "5", "--no-other-configs"]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
             line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
             d = json.loads(line)
-            res[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"],
-                         "frac": d["roofline"]["frac"], "value_e2e": d["value_e2e"],
+            res[name] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+                         "frac": d["roofline"]["frac"], "value_e2e": d["value_e2e"], "pipeline_depth": d["e2e"].get("pipeline_depth"),
                          "workload": d["config"]["workload"], "wall_s": time.perf_counter() - t0}
         except Exception as e:  # noqa: BLE001 -- a failed side pass must not lose the headline line
             res[name] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
@@ -167,6 +167,8 @@ def main():
                     help="default: strong when --gpus > 1 (the config's batch dealt out over the ranks)")
     ap.add_argument("--pairs", type=int, default=0, help="override the config's number of pairs (debug)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--anchor-triples", action="store_true",
+                    help="config 4: hand the anchors over as one (x, y, expansion) triple per column instead of as runs")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end (host to host) measurements")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="the default run (config B, one GPU) appends short passes of configs A, 4 and 5 as `other_configs`; skip them")
@@ -245,7 +247,11 @@ def main():
     sm, params, mtype = model_and_params(api, cfg)
     emit = api.EMIT_EXPECT if expect else api.EMIT_MATCH
     problems = workload.config_problems(args.config, mine)
-    prepared, n_prepared, _keep = api.Batch.prepare_problems(problems)  # the C-ABI array a C caller would hold
+    # the C-ABI array a C caller would hold; the realign configuration holds its anchors as runs of matching columns --
+    # what cPecanRealign.c:525-529 makes of a cigar's match operations -- and hands them over as such
+    # (cpecan_batch_add_many_runs; --anchor-triples: one (x, y, expansion) triple per column, as round 3 measured)
+    as_runs = bool(cfg.get("realign")) and not args.anchor_triples
+    prepared, n_prepared, _keep = (api.Batch.prepare_problems_runs if as_runs else api.Batch.prepare_problems)(problems)
 
     def make_batch():
         b = api.Batch(sm, params, emit=emit, device=local_rank)
@@ -374,9 +380,14 @@ def main():
         nb = max(3, nb)
         depth = args.e2e_depth
         if depth < 2:
+            # as many batches in flight as the latency of one batch (pack + plan + upload, copy in, sweep, gather, copy out:
+            # the serial figure above) holds of its longest stage -- the host's share or the sweep -- between two and four,
+            # and no more than fit in half the device's memory
             total_mem = torch.cuda.get_device_properties(local_rank).total_memory
-            host_bound = 2 * e2e["plan_upload_s"] >= e2e["run_download_assemble_s"]
-            depth = 3 if host_bound and 3 * e2e["device_bytes"] < total_mem // 2 else 2
+            stage = max(e2e["plan_upload_s"], kernel_ms * 1e-3, 1e-4)
+            depth = max(2, min(4, int(np.ceil(e2e["serial_s_per_batch"] / stage))))
+            while depth > 2 and depth * e2e["device_bytes"] > total_mem // 2:
+                depth -= 1
         e2e["pipeline_depth"] = depth
         trace = os.environ.get("CPECAN_BENCH_TRACE") == "1"
         barrier()
@@ -452,7 +463,9 @@ def main():
             "higher_is_better": True,
             "scaling": scaling,
             "vs_baseline": None,
-            "dtype": "f64",
+            # the arithmetic the path computes in: fp64 throughout; the expectation emitter's events are 2^(x log2 e) with the
+            # exponent handed to v_exp_f32 as an fp32 value (~1e-7 per event; the sums and the whole DP stay fp64)
+            "dtype": "f64 DP, f32 event exponent" if expect else "f64",
             "data": "synthetic",
             "config": {
                 "workload": "config %s: %d pairs%s, %s, %s, diagonalExpansion=%d, %s, threshold=0.01, traceback 1000/40%s"
@@ -460,7 +473,8 @@ def main():
                                ("%d-%d bp" % (cfg["min_len"], cfg["max_len"])) if cfg.get("realign")
                                else "%d x ~%d bp" % (cfg["length"], cfg["length"]),
                                cfg["model"], cfg["expansion"],
-                               "anchors on every matching column, split at gaps of %d, ragged ends" % cfg["split"]
+                               "anchors on every matching column (given as %s), split at gaps of %d, ragged ends"
+                               % ("runs" if as_runs else "per-column triples", cfg["split"])
                                if cfg.get("realign") else ("anchors every 50 bp" if cfg["anchors"] else "no anchors"),
                                ", expectation emitter%s" % (" + all-reduce of %d counts" % (S * S + S * 16 + 1) if world > 1 else "")
                                if expect else ""),

@@ -70,6 +70,13 @@ class Problem(C.Structure):
                 ("raggedLeft", C.c_int32), ("raggedRight", C.c_int32)]
 
 
+class ProblemRuns(C.Structure):
+    """cpecan_problem_runs: one element of cpecan_batch_add_many_runs (anchors as (x, y, length, expansion) runs)."""
+    _fields_ = [("sX", C.c_char_p), ("lX", C.c_int64), ("sY", C.c_char_p), ("lY", C.c_int64),
+                ("runs", C.POINTER(C.c_int64)), ("nRuns", C.c_int64),
+                ("raggedLeft", C.c_int32), ("raggedRight", C.c_int32)]
+
+
 class Stats(C.Structure):
     _fields_ = [
         ("problems", C.c_int64), ("regions", C.c_int64), ("cells", C.c_int64), ("diagonals", C.c_int64),
@@ -93,6 +100,7 @@ EXPORTS = [
     "cpecan_anchors_from_alignment", "cpecan_batch_set_match_gamma", "cpecan_batch_identity_scores",
     "cpecan_identity_scores", "cpecan_filter_pairs_ordered", "cpecan_batch_add_many",
     "cpecan_filter_to_remove_overlap", "cpecan_cache_trim", "cpecan_ref_cells",
+    "cpecan_batch_add_many_runs", "cpecan_anchor_runs", "cpecan_anchor_runs_from_alignment",
 ]
 OP_MATCH, OP_INDEL_X, OP_INDEL_Y = 0, 1, 2
 POST_REWEIGHT, POST_MEA, POST_LEFT_SHIFT, POST_ORDERED = 1, 2, 4, 8
@@ -156,12 +164,19 @@ def lib():
     L.cpecan_anchors_from_alignment.restype = C.c_int64
     L.cpecan_anchors_from_alignment.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_char_p,
                                                 C.c_int64, C.c_char_p, C.c_int64, i64p]
+    L.cpecan_anchor_runs_from_alignment.argtypes = [i64p, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_char_p,
+                                                    C.c_int64, C.c_char_p, C.c_int64, i64p, C.c_int64]
+    L.cpecan_anchor_runs_from_alignment.restype = C.c_int64
     L.cpecan_batch_set_post.argtypes = [vp, C.c_int, C.c_double]
     L.cpecan_batch_scores.argtypes = [vp, C.c_int64, dp, dp, dp]
     L.cpecan_filter_to_remove_overlap.argtypes = [i64p, C.c_int64, i64p]
     L.cpecan_filter_to_remove_overlap.restype = C.c_int64
     L.cpecan_batch_add_many.argtypes = [vp, C.POINTER(Problem), C.c_int64]
     L.cpecan_batch_add_many.restype = C.c_int64
+    L.cpecan_batch_add_many_runs.argtypes = [vp, C.POINTER(ProblemRuns), C.c_int64]
+    L.cpecan_batch_add_many_runs.restype = C.c_int64
+    L.cpecan_anchor_runs.argtypes = [i64p, C.c_int64, i64p, C.c_int64]
+    L.cpecan_anchor_runs.restype = C.c_int64
     L.cpecan_batch_set_match_gamma.argtypes = [vp, C.c_float]
     L.cpecan_batch_identity_scores.argtypes = [vp, C.c_int64, dp, dp]
     L.cpecan_identity_scores.argtypes = [i32p, C.c_int64, C.c_char_p, C.c_char_p, dp, dp]
@@ -200,6 +215,17 @@ def _anchor_array(anchorPairs):
     if n == 0:
         a = np.zeros((1, 3), dtype=np.int64)
     return a, a.ctypes.data_as(C.POINTER(C.c_int64)), n
+
+
+def anchor_runs(anchorPairs):
+    """cpecan_anchor_runs: the anchors as int64[nRuns, 4] quadruples (x, y, length, expansion)."""
+    a, ptr, n = _anchor_array(anchorPairs)
+    if n == 0:
+        return np.zeros((0, 4), dtype=np.int64)
+    cnt = _check(lib().cpecan_anchor_runs(ptr, n, None, 0), "cpecan_anchor_runs")
+    out = np.zeros((max(1, cnt), 4), dtype=np.int64)
+    _check(lib().cpecan_anchor_runs(ptr, n, out.ctypes.data_as(C.POINTER(C.c_int64)), cnt), "cpecan_anchor_runs")
+    return out[:cnt]
 
 
 # ---- model / parameter constructors, named as in the reference ----
@@ -336,9 +362,34 @@ class Batch:
         return arr, len(problems), keep
 
     def add_prepared(self, arr, n):
-        first = _check(lib().cpecan_batch_add_many(self._h, arr, n), "cpecan_batch_add_many")
+        if isinstance(arr, C.Array) and arr._type_ is ProblemRuns:
+            first = _check(lib().cpecan_batch_add_many_runs(self._h, arr, n), "cpecan_batch_add_many_runs")
+        else:
+            first = _check(lib().cpecan_batch_add_many(self._h, arr, n), "cpecan_batch_add_many")
         self.n += n
         return first
+
+    @staticmethod
+    def prepare_problems_runs(problems):
+        """The run form of the same list (cpecan_problem_runs): the anchors of every problem as (x, y, length, expansion)
+        quadruples, one per run of diagonal neighbours (cpecan_anchor_runs) -- what a realign-style caller holds before it
+        expands the match operations of a cigar into one anchor per column.  Returns (array, n, keepalive)."""
+        problems = list(problems)
+        arr = (ProblemRuns * max(1, len(problems)))()
+        keep = []
+        for i, pr in enumerate(problems):
+            sx, sy = _bytes(pr[0]), _bytes(pr[1])
+            runs = anchor_runs(pr[2] if len(pr) > 2 else ())
+            keep.append((sx, sy, runs))
+            arr[i].sX, arr[i].lX, arr[i].sY, arr[i].lY = sx, len(sx), sy, len(sy)
+            arr[i].runs, arr[i].nRuns = runs.ctypes.data_as(C.POINTER(C.c_int64)), (runs.shape[0] if runs.size else 0)
+            arr[i].raggedLeft = int(pr[3]) if len(pr) > 3 else 0
+            arr[i].raggedRight = int(pr[4]) if len(pr) > 4 else 0
+        return arr, len(problems), keep
+
+    def add_many_runs(self, problems):
+        arr, n, _keep = self.prepare_problems_runs(problems)
+        return self.add_prepared(arr, n)
 
     def add_many(self, problems):
         """problems: iterable of (sX, sY, anchorPairs[, raggedLeft, raggedRight]); cut, converted and copied in parallel
@@ -577,6 +628,21 @@ def convertPairwiseForwardStrandAlignmentToAnchorPairs(ops, start1, start2, trim
                                             sx, len(sx) if sx else 0, sy, len(sy) if sy else 0,
                                             out.ctypes.data_as(C.POINTER(C.c_int64)))
     _check(n, "cpecan_anchors_from_alignment")
+    return out[:n].copy()
+
+
+def anchor_runs_from_alignment(ops, start1, start2, trim, expansion, seqX=None, seqY=None):
+    """cpecan_anchor_runs_from_alignment: the anchors of convertPairwiseForwardStrandAlignmentToAnchorPairs (+ exact-match
+    filter) as runs, int64[nRuns, 4] (x, y, length, expansion), without the per-column list in between."""
+    o = np.ascontiguousarray(np.asarray(ops, dtype=np.int64).reshape(-1, 2))
+    sx = _bytes(seqX) if seqX is not None else None
+    sy = _bytes(seqY) if seqY is not None else None
+    args = (o.ctypes.data_as(C.POINTER(C.c_int64)), len(o), start1, start2, trim, expansion, sx, len(sx) if sx else 0, sy,
+            len(sy) if sy else 0)
+    n = _check(lib().cpecan_anchor_runs_from_alignment(*args, None, 0), "cpecan_anchor_runs_from_alignment")
+    out = np.zeros((max(n, 1), 4), dtype=np.int64)
+    _check(lib().cpecan_anchor_runs_from_alignment(*args, out.ctypes.data_as(C.POINTER(C.c_int64)), n),
+           "cpecan_anchor_runs_from_alignment")
     return out[:n].copy()
 
 

@@ -492,6 +492,60 @@ int64_t cpecan_anchors_from_alignment(const int64_t *ops, int64_t nOps, int64_t 
     return n;
 }
 
+/* The same anchors as runs (cpecan_batch_add_many_runs): the kept columns of a match operation that follow each other
+ * on a matrix diagonal -- a mismatched column or the end of the operation ends a run -- as (x, y, length, expansion). */
+int64_t cpecan_anchor_runs_from_alignment(const int64_t *ops, int64_t nOps, int64_t start1, int64_t start2, int64_t trim,
+                                          int64_t expansion, const char *sX, int64_t lX, const char *sY, int64_t lY,
+                                          int64_t *runs, int64_t cap) {
+    if (nOps < 0 || (nOps > 0 && !ops) || trim < 0 || cap < 0 || (cap > 0 && !runs)) return CPECAN_EINVAL;
+    const int filter = sX && sY;
+    int64_t x = start1, y = start2, n = 0, rx = 0, ry = 0, len = 0; /* the open run: (rx, ry) .. len columns, len == 0: none */
+    for (int64_t i = 0; i < nOps; i++) {
+        const int64_t type = ops[2 * i], opLen = ops[2 * i + 1];
+        if (opLen < 0 || type < CPECAN_OP_MATCH || type > CPECAN_OP_INDEL_Y) return CPECAN_EINVAL;
+        if (type == CPECAN_OP_MATCH) {
+            for (int64_t l = trim; l < opLen - trim; l++) {
+                const int64_t ax = x + l, ay = y + l;
+                if (filter) {
+                    if (ax < 0 || ay < 0 || ax >= lX || ay >= lY) return CPECAN_EINVAL;
+                    int cx = (unsigned char)sX[ax], cy = (unsigned char)sY[ay];
+                    cx -= (cx >= 'a' && cx <= 'z') ? 'a' - 'A' : 0;
+                    cy -= (cy >= 'a' && cy <= 'z') ? 'a' - 'A' : 0;
+                    if (cx != cy || cx == 'N') continue;
+                }
+                if (len > 0 && ax == rx + len && ay == ry + len) {
+                    len++;
+                    continue;
+                }
+                if (len > 0) {
+                    if (n < cap) {
+                        runs[4 * n] = rx;
+                        runs[4 * n + 1] = ry;
+                        runs[4 * n + 2] = len;
+                        runs[4 * n + 3] = expansion;
+                    }
+                    n++;
+                }
+                rx = ax;
+                ry = ay;
+                len = 1;
+            }
+        }
+        if (type != CPECAN_OP_INDEL_Y) x += opLen;
+        if (type != CPECAN_OP_INDEL_X) y += opLen;
+    }
+    if (len > 0) {
+        if (n < cap) {
+            runs[4 * n] = rx;
+            runs[4 * n + 1] = ry;
+            runs[4 * n + 2] = len;
+            runs[4 * n + 3] = expansion;
+        }
+        n++;
+    }
+    return n;
+}
+
 /* filterToRemoveOverlap (impl/pairwiseAligner.c:1095-1135): one backward and one forward pass over the sorted pairs */
 int64_t cpecan_filter_to_remove_overlap(const int64_t *pairs, int64_t n, int64_t *out) {
     if (n < 0 || (n > 0 && (!pairs || !out))) return CPECAN_EINVAL;
@@ -670,9 +724,46 @@ typedef struct {
     int64_t nRects, symbolBytes, nAnchorsKept;
 } AddCount;
 
+/* One problem of an add call: its anchors as triples (x, y, expansion), one per anchor, or -- `runs` -- as quadruples
+ * (x, y, length, expansion), one per run of diagonal neighbours (cpecan_batch_add_many_runs). */
+typedef struct {
+    const char *sX;
+    int64_t lX;
+    const char *sY;
+    int64_t lY;
+    const int64_t *anchors;
+    int64_t nAnchors; /* entries: anchors or runs */
+    int32_t raggedLeft, raggedRight;
+    int runs;
+} ProblemView;
+
+/* getSplitPoints over runs: between two anchors of a run the gap is empty (0 x 0 cells), so only the gaps in front of a
+ * run and behind the last one can be cut -- the same rectangles as cpecan_split_points on the expanded anchors. */
+static int64_t split_points_runs(const int64_t *runs, int64_t nRuns, int64_t lX, int64_t lY, int64_t maxMatrixSize,
+                                 int raggedLeft, int raggedRight, int64_t *out) {
+    SplitState s = {0, 0, out, 0, maxMatrixSize, (int64_t)sqrt((double)maxMatrixSize)};
+    int64_t fromX = 0, fromY = 0;
+    for (int64_t i = 0; i < nRuns; i++) {
+        const int64_t ax = runs[4 * i], ay = runs[4 * i + 1], len = runs[4 * i + 2];
+        if (ax < fromX || ay < fromY || len < 1 || ax + len > lX || ay + len > lY) return CPECAN_EINVAL;
+        cut_if_large(&s, fromX, fromY, ax, ay, raggedLeft && i == 0);
+        fromX = ax + len;
+        fromY = ay + len;
+    }
+    const int cutAtEnd = cut_if_large(&s, fromX, fromY, lX, lY, raggedLeft && nRuns == 0);
+    if (!cutAtEnd || !raggedRight) {
+        int64_t *r = out + 4 * s.count++;
+        r[0] = s.x1;
+        r[1] = s.y1;
+        r[2] = lX;
+        r[3] = lY;
+    }
+    return s.count;
+}
+
 /* The split rectangles of one problem (getSplitPoints semantics, pairwiseAligner.c:1230-1271) into *rects, grown as
  * needed.  Returns their number or < 0. */
-static int64_t problem_rects(const cpecan_batch *b, const cpecan_problem *it, int64_t **rects, int64_t *cap) {
+static int64_t problem_rects(const cpecan_batch *b, const ProblemView *it, int64_t **rects, int64_t *cap) {
     if (4 * (it->nAnchors + 2) > *cap) { /* the caller's scratch: plain heap memory, freed with free() */
         const int64_t c = 8 * (it->nAnchors + 2);
         int64_t *q = realloc(*rects, sizeof(int64_t) * (size_t)c);
@@ -687,15 +778,29 @@ static int64_t problem_rects(const cpecan_batch *b, const cpecan_problem *it, in
         (*rects)[3] = it->lY;
         return 1;
     }
+    if (it->runs)
+        return split_points_runs(it->anchors, it->nAnchors, it->lX, it->lY, b->params.splitMatrixBiggerThanThis, it->raggedLeft,
+                                 it->raggedRight, *rects);
     return cpecan_split_points(it->anchors, it->nAnchors, it->lX, it->lY, b->params.splitMatrixBiggerThanThis, it->raggedLeft,
                                it->raggedRight, *rects);
 }
 
-static int problem_valid(const cpecan_problem *it) {
+static int problem_valid(const ProblemView *it) {
     if (it->lX < 0 || it->lY < 0 || it->nAnchors < 0 || (it->lX > 0 && !it->sX) || (it->lY > 0 && !it->sY) ||
         (it->nAnchors > 0 && !it->anchors))
         return 0;
     if (it->lX + it->lY >= (int64_t)1 << 30) return 0;
+    if (it->runs) { /* strictly increasing from the last anchor of one run to the first of the next */
+        int64_t px = -1, py = -1;
+        for (int64_t i = 0; i < it->nAnchors; i++) {
+            const int64_t x = it->anchors[4 * i], y = it->anchors[4 * i + 1], len = it->anchors[4 * i + 2];
+            if (len < 1 || x <= px || y <= py || x + len > it->lX || y + len > it->lY) return 0;
+            if (it->anchors[4 * i + 3] < INT32_MIN || it->anchors[4 * i + 3] > INT32_MAX) return 0;
+            px = x + len - 1;
+            py = y + len - 1;
+        }
+        return 1;
+    }
     /* anchors must be strictly increasing in both coordinates (pairwiseAligner.c:159-164) */
     for (int64_t i = 0; i < it->nAnchors; i++) {
         const int64_t x = it->anchors[3 * i], y = it->anchors[3 * i + 1];
@@ -706,7 +811,20 @@ static int problem_valid(const cpecan_problem *it) {
     return 1;
 }
 
-int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *items, int64_t n) {
+/* problem i of an add call in either form (the two public structs differ in what their anchor arrays hold) */
+static ProblemView view_of(const void *items, int runs, int64_t i) {
+    ProblemView v;
+    if (runs) {
+        const cpecan_problem_runs *p = (const cpecan_problem_runs *)items + i;
+        v = (ProblemView){p->sX, p->lX, p->sY, p->lY, p->runs, p->nRuns, p->raggedLeft, p->raggedRight, 1};
+    } else {
+        const cpecan_problem *p = (const cpecan_problem *)items + i;
+        v = (ProblemView){p->sX, p->lX, p->sY, p->lY, p->anchors, p->nAnchors, p->raggedLeft, p->raggedRight, 0};
+    }
+    return v;
+}
+
+static int64_t add_many(cpecan_batch *b, const void *items, int runs, int64_t n) {
     if (dl_busy(b)) return CPECAN_ESTATE;
     if (!b || b->frozen) return CPECAN_ESTATE;
     if (n < 0 || (n > 0 && !items)) return CPECAN_EINVAL;
@@ -726,7 +844,7 @@ int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *items, int6
         int64_t *rects = NULL, cap = 0;
 #pragma omp for schedule(dynamic, 32)
         for (int64_t i = 0; i < n; i++) {
-            const cpecan_problem *it = &items[i];
+            const ProblemView view = view_of(items, runs, i), *it = &view;
             int64_t nRects = problem_valid(it) ? problem_rects(b, it, &rects, &cap) : CPECAN_EINVAL;
             if (nRects < 0) {
 #pragma omp critical(cpk_add)
@@ -738,9 +856,15 @@ int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *items, int6
                 continue;
             }
             int64_t sym = 0, kept = 0;
+            int64_t at = 0; /* entries (anchors or runs) handed to rectangles so far; a rectangle ends inside a gap, never inside a run */
             for (int64_t k = 0; k < nRects; k++) {
                 sym += (rects[4 * k + 2] - rects[4 * k]) + (rects[4 * k + 3] - rects[4 * k + 1]) + 4; /* N + bases + N, twice */
-                while (kept < it->nAnchors && it->anchors[3 * kept] + it->anchors[3 * kept + 1] < rects[4 * k + 2] + rects[4 * k + 3]) kept++;
+                if (it->runs) {
+                    for (; at < it->nAnchors && it->anchors[4 * at] + it->anchors[4 * at + 1] < rects[4 * k + 2] + rects[4 * k + 3]; at++)
+                        kept += it->anchors[4 * at + 2];
+                } else {
+                    while (kept < it->nAnchors && it->anchors[3 * kept] + it->anchors[3 * kept + 1] < rects[4 * k + 2] + rects[4 * k + 3]) kept++;
+                }
             }
             cnt[i].nRects = nRects;
             cnt[i].symbolBytes = sym;
@@ -763,7 +887,8 @@ int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *items, int6
         nRegions += cnt[i].nRects;
         nSymbols += cnt[i].symbolBytes;
         nAnchorVals += b->anchorStride * cnt[i].nAnchorsKept;
-        nChars += items[i].lX + items[i].lY;
+        const ProblemView view = view_of(items, runs, i);
+        nChars += view.lX + view.lY;
     }
     if (grow((void **)&b->problems, &b->capProblems, b->nProblems + n, sizeof(HostProblem)) ||
         grow((void **)&b->regions, &b->capRegions, nRegions, sizeof(HostRegion)) ||
@@ -781,7 +906,7 @@ int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *items, int6
         int64_t *rects = NULL, cap = 0;
 #pragma omp for schedule(dynamic, 32)
         for (int64_t i = 0; i < n; i++) {
-            const cpecan_problem *it = &items[i];
+            const ProblemView view = view_of(items, runs, i), *it = &view;
             const int64_t nRects = problem_rects(b, it, &rects, &cap);
             if (nRects != cnt[i].nRects) { /* only an allocation failure can change the answer */
 #pragma omp atomic write
@@ -816,6 +941,29 @@ int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *items, int6
                 r->seqYOff = symAt;
                 symAt = put_symbols(b->symbols, symAt, it->sY + y1, r->lY);
                 r->anchorOff = anchorAt / b->anchorStride;
+                if (it->runs) { /* a run becomes its anchors: the batch's own 8 (12) bytes each, never the API's 24 */
+                    for (; next < it->nAnchors && it->anchors[4 * next] + it->anchors[4 * next + 1] < x2 + y2; next++) {
+                        const int32_t rx = (int32_t)(it->anchors[4 * next] - x1), ry = (int32_t)(it->anchors[4 * next + 1] - y1);
+                        const int64_t len = it->anchors[4 * next + 2];
+                        int32_t *a = b->anchors + anchorAt;
+                        if (b->anchorStride == 3) {
+                            const int32_t e = (int32_t)it->anchors[4 * next + 3];
+                            for (int64_t q = 0; q < len; q++, a += 3) {
+                                a[0] = rx + (int32_t)q;
+                                a[1] = ry + (int32_t)q;
+                                a[2] = e;
+                            }
+                        } else {
+                            for (int64_t q = 0; q < len; q++, a += 2) {
+                                a[0] = rx + (int32_t)q;
+                                a[1] = ry + (int32_t)q;
+                            }
+                        }
+                        anchorAt += b->anchorStride * len;
+                        r->nAnchors += len;
+                    }
+                    continue;
+                }
                 while (next < it->nAnchors && it->anchors[3 * next] + it->anchors[3 * next + 1] < x2 + y2) {
                     int32_t *a = b->anchors + anchorAt;
                     a[0] = (int32_t)(it->anchors[3 * next] - x1);
@@ -838,6 +986,29 @@ int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *items, int6
     b->nAnchorVals = nAnchorVals;
     b->nChars = nChars;
     return firstProblem;
+}
+
+int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *items, int64_t n) { return add_many(b, items, 0, n); }
+int64_t cpecan_batch_add_many_runs(cpecan_batch *b, const cpecan_problem_runs *items, int64_t n) { return add_many(b, items, 1, n); }
+
+int64_t cpecan_anchor_runs(const int64_t *anchors, int64_t nAnchors, int64_t *out, int64_t cap) {
+    if (nAnchors < 0 || cap < 0 || (nAnchors > 0 && !anchors) || (cap > 0 && !out)) return CPECAN_EINVAL;
+    int64_t n = 0;
+    for (int64_t i = 0; i < nAnchors;) {
+        int64_t len = 1;
+        while (i + len < nAnchors && anchors[3 * (i + len)] == anchors[3 * i] + len && anchors[3 * (i + len) + 1] == anchors[3 * i + 1] + len &&
+               anchors[3 * (i + len) + 2] == anchors[3 * i + 2])
+            len++;
+        if (n < cap) {
+            out[4 * n] = anchors[3 * i];
+            out[4 * n + 1] = anchors[3 * i + 1];
+            out[4 * n + 2] = len;
+            out[4 * n + 3] = anchors[3 * i + 2];
+        }
+        n++;
+        i += len;
+    }
+    return n;
 }
 
 int64_t cpecan_batch_add(cpecan_batch *b, const char *sX, int64_t lX, const char *sY, int64_t lY,
@@ -932,6 +1103,8 @@ int cpecan_batch_upload(cpecan_batch *b) {
         goto fail1;
     }
     const int dynamic = b->emit == CPECAN_EMIT_FORWARD ? 0 : p->dynamicAnchorExpansion; /* :894: forward uses the static band */
+    const char *fwEnv = getenv("CPECAN_FAST_WALK");
+    const int fastWalk = !(fwEnv && atoi(fwEnv) == 0);
     int64_t badRegion = -1;
 #pragma omp parallel num_threads(cpk_host_threads())
     {
@@ -952,6 +1125,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
             keys[i].index = i;
             if (!histOff) continue;
             CpkBandIter it;
+            memset(&it, 0, sizeof it);
             int bad = cpk_band_init(&it, b->anchors + (int64_t)b->anchorStride * r->anchorOff, b->anchorStride, r->nAnchors, r->lX, r->lY,
                                     p->diagonalExpansion, dynamic);
             CpkSegment *sg = segs + segStart[i];
@@ -964,7 +1138,70 @@ int cpecan_batch_upload(cpecan_batch *b) {
             int64_t winXlo = 0, winYlo = 0; /* smallest x and y of diagonal tracedBackTo + 1 (symbol windows, RegionPlan::winBytes) */
             int smooth = !dynamic;
             const int64_t minBetween = p->minDiagsBetweenTraceBack, narrow = p->diagonalExpansion * 2 + 1;
+            /* Runs of diagonal neighbours among the anchors (realign-style input: one anchor per matching column) are walked
+             * in closed form.  Between two anchors (X, Y) and (X + 1, Y + 1) of a run, away from the matrix edges, the band
+             * holds exactly two diagonals: x-y in [X-Y-E-1, X-Y+E+1] (E + 2 cells) and [X-Y-E, X-Y+E] (E + 1 cells) -- both
+             * "narrow" for E >= 2 (<= 2E + 1) and both edges one x-y step apart from their neighbours'.  So a stretch of s such
+             * intervals adds s (2E + 3) cells and nothing else, unless a traceback point may fall into it or behind it within the
+             * K diagonals whose offsets the schedule looks back at: those diagonals are walked one by one.
+             * (BASELINE config 4: 1.25e8 diagonals at ~14 cycles each were 31 ms of every batch on 16 threads.)  CPECAN_FAST_WALK=0
+             * walks every diagonal (tests compare the two). */
+            const cpk_anchor_t *ra = b->anchors + (int64_t)b->anchorStride * r->anchorOff;
+            const int64_t E = p->diagonalExpansion, hE = E / 2;
+            const int fastOk = fastWalk && !dynamic && E >= 2 && b->anchorStride == 2;
             for (int64_t d = 0; d <= N && !bad; d++, slot = slot + 1 == K ? 0 : slot + 1) {
+                if (fastOk && it.used >= 2 && d == it.pX + it.pY + 1 && it.qX == it.pX + 1 && it.qY == it.pY + 1) {
+                    /* in the interval (A_j -> A_j+1) of a run, j = used - 2, about to emit its first diagonal */
+                    const int64_t j = it.used - 2;
+                    int64_t sMax = (tracedBackTo + minBetween - (K + 1) - d) / 2; /* every skipped diagonal stays K + 1 below the next traceback point */
+                    sMax = imin(sMax, imin(r->lX - hE - it.pX, r->lY - hE - it.pY)); /* the last interval's rectangle inside the matrix */
+                    if (it.pX - hE < 0 || it.pY - hE < 0) sMax = 0;                  /* ... and the first one's */
+                    sMax = imin(sMax, (N - 2 - d) / 2);
+                    int64_t sRun = 0; /* intervals of the run from here: anchors j .. j + sRun are diagonal neighbours */
+                    while (sRun < sMax && j + sRun + 1 < r->nAnchors && ra[2 * (j + sRun + 1)] == ra[2 * (j + sRun)] + 1 &&
+                           ra[2 * (j + sRun + 1) + 1] == ra[2 * (j + sRun) + 1] + 1)
+                        sRun++;
+                    if (sRun >= 2) {
+                        const int64_t add = sRun * (2 * E + 3);
+                        if (cells + add >= (int64_t)1 << 31) {
+                            bad = 1;
+                            break;
+                        }
+                        const int64_t xmy0 = it.pX - it.pY;
+                        if (d > 0) { /* the step into the stretch: from the diagonal before to its first one */
+                            const int64_t dl = (xmy0 - E - 1) - prevLo, dh = (xmy0 + E + 1) - prevHi;
+                            smooth &= (dl == 1 || dl == -1) && (dh == 1 || dh == -1);
+                        }
+                        cells += add;
+                        maxW = E + 2 > maxW ? E + 2 : maxW;
+                        prevLo = xmy0 - E; /* the stretch's last diagonal: the second one of an interval */
+                        prevHi = xmy0 + E;
+                        /* the iterator as it stands behind anchor j + sRun's own diagonal */
+                        const int64_t jn = j + sRun;
+                        it.pX = (int64_t)ra[2 * jn] + 1;
+                        it.pY = (int64_t)ra[2 * jn + 1] + 1;
+                        it.used = jn + 1;
+                        it.qX = r->lX;
+                        it.qY = r->lY;
+                        if (it.used < it.n) {
+                            it.qX = (int64_t)ra[2 * it.used] + 1;
+                            it.qY = (int64_t)ra[2 * it.used + 1] + 1;
+                            it.used++;
+                            if (it.qX <= it.pX || it.qY <= it.pY || it.qX > it.lX || it.qY > it.lY) {
+                                bad = 1;
+                                break;
+                            }
+                        }
+                        it.qSum = it.qX + it.qY;
+                        it.xLo = cpk_clamp(it.pX - hE, it.lX);
+                        it.yHi = cpk_clamp(it.qY + hE, it.lY);
+                        it.xHi = cpk_clamp(it.qX + hE, it.lX);
+                        it.yLo = cpk_clamp(it.pY - hE, it.lY);
+                        d += 2 * sRun - 1; /* the loop's own step makes it 2 sRun */
+                        slot = (slot + 2 * sRun - 1) % K;
+                        continue;
+                    }
+                }
                 int64_t lo, hi;
                 if (cpk_band_next(&it, d, &lo, &hi)) {
                     bad = 1;
@@ -1009,6 +1246,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
                 const int64_t tfSlot = tf % K; /* once per segment */
                 const int64_t fbCells = histOff[tfSlot] + histW[tfSlot] - offAfter;
                 pl->fbMax = imax(pl->fbMax, fbCells);
+                sg->emitCells = (int32_t)fbCells;
                 {
                     /* the symbols the segment's diagonals tbPrev + 1 .. d touch, the kernel's arithmetic (cpk_sweep.inl,
                      * "Symbol windows"): from the even index at or below the smallest x (y) to one past the largest */
@@ -1086,7 +1324,33 @@ int cpecan_batch_upload(cpecan_batch *b) {
         }
     }
     const double tU2 = now_ms();
-    qsort(keys, (size_t)b->nRegions, sizeof(CostKey), by_cost_desc);
+    /* (class, cells descending, index): the keys stand in index order, so a STABLE sort by (class, -cells) is the order
+     * by_cost_desc defines -- three counting passes of 12 bits instead of qsort's n log n comparator calls (4.3 ms of every
+     * config-4 batch on one thread). */
+    {
+        const int64_t n = b->nRegions;
+        CostKey *tmp = malloc(sizeof(CostKey) * (size_t)(n ? n : 1));
+        if (!tmp) {
+            qsort(keys, (size_t)n, sizeof(CostKey), by_cost_desc);
+        } else {
+            CostKey *src = keys, *dst = tmp;
+            for (int pass = 0; pass < 3; pass++) {
+                int64_t count[4097];
+                memset(count, 0, sizeof count);
+                /* sort value: class in the top 4 of 36 bits, then 2^31 - 1 - cells (cells < 2^31): ascending = by_cost_desc */
+#define CPK_SORT_DIGIT(k) ((int)(((((uint64_t)(k).cls) << 32 | (uint64_t)(0x7fffffffll - (k).cells)) >> (12 * pass)) & 0xfff))
+                for (int64_t i = 0; i < n; i++) count[CPK_SORT_DIGIT(src[i]) + 1]++;
+                for (int q = 0; q < 4096; q++) count[q + 1] += count[q];
+                for (int64_t i = 0; i < n; i++) dst[count[CPK_SORT_DIGIT(src[i])]++] = src[i];
+#undef CPK_SORT_DIGIT
+                CostKey *t = src;
+                src = dst;
+                dst = t;
+            }
+            if (src != keys) memcpy(keys, src, sizeof(CostKey) * (size_t)n); /* three passes: the result is in tmp */
+            free(tmp);
+        }
+    }
     const double tU3 = now_ms();
 
     b->devRegions = host_zalloc((size_t)b->nRegions, sizeof(CpkRegion));
@@ -1102,6 +1366,14 @@ int cpecan_batch_upload(cpecan_batch *b) {
     geo.emit = b->emit;
     geo.debug = b->debug;
     int64_t outAt = 0, dbgCells = 0, dbgDiags = 0, totalCells = 0;
+    /* Two passes: what a region's entry holds of its own (the regions are visited in sorted order, i.e. at random in
+     * memory: on one thread this loop was 6-9 ms of every config-4 batch), then the running offsets and the class maxima. */
+    int64_t tooLarge = -1;
+#pragma omp parallel num_threads(cpk_host_threads()) if (b->nRegions >= 4096)
+    {
+    CpkGeometry lg; /* this thread's class counts and maxima */
+    memset(&lg, 0, sizeof lg);
+#pragma omp for schedule(static)
     for (int64_t di = 0; di < b->nRegions; di++) {
         const int64_t hiRegion = keys[di].index;
         HostRegion *r = &b->regions[hiRegion];
@@ -1124,13 +1396,6 @@ int cpecan_batch_upload(cpecan_batch *b) {
         g->absOk = pl->smooth;
         /* ring: diagonals are laid down one after another and never straddle the end of the ring */
         g->ringCap = (int32_t)imin(pl->liveMax + pl->maxW, ((int64_t)1 << 31) - 1);
-        g->dbgCellOff = dbgCells;
-        g->dbgDiagOff = dbgDiags;
-        if (b->debug) {
-            dbgCells += r->cells;
-            dbgDiags += r->lX + r->lY + 1;
-        }
-        totalCells += r->cells;
         g->cells = r->cells;
         g->outCap = (int32_t)default_out_cap(b, r);
         /* every traceback segment gets a part of the region's output slice of its own (used when the segments run as
@@ -1141,39 +1406,74 @@ int cpecan_batch_upload(cpecan_batch *b) {
             int64_t at = 0;
             for (int64_t si = 0; si < pl->nSeg; si++) {
                 int64_t cap = N > 0 ? (int64_t)g->outCap * (sg[si].tbFrom - sg[si].tbPrev) / N + 16 : 1;
-                if (b->params.threshold <= 0.0) cap = r->cells; /* every cell may be emitted */
+                /* every cell may be emitted: the cells of the segment's own emitted diagonals (round 3 gave every segment
+                 * the whole region's cells, nSeg times what the slice can ever hold) */
+                if (b->params.threshold <= 0.0) cap = sg[si].emitCells;
                 sg[si].outOff = (int32_t)at;
                 sg[si].outCap = (int32_t)cap;
                 at += cap;
             }
             if (at > ((int64_t)1 << 31) - 1) {
-                /* segment offsets and the region's slice are 32-bit: threshold <= 0 on a region of more than 2^31 cells x
-                 * segments cannot be laid out (the reference would return a list of that many tuples) */
-                cpk_set_error("a region's output slice exceeds 2^31 triples (%lld): raise the threshold or split the region",
-                              (long long)at);
-                rc = CPECAN_EINVAL;
-                goto fail2;
+#pragma omp critical(cpk_order)
+                if (at > tooLarge) tooLarge = at;
+                continue;
             }
             if (at > g->outCap) g->outCap = (int32_t)at;
         }
-        g->outOff = outAt;
-        outAt += g->outCap;
         if (keys[di].cls < 3) { /* narrow: scratch of the packed kernel's sub-slots */
             const int k = keys[di].cls;
-            geo.nPacked[k]++;
-            geo.pMaxRefresh[k] = pl->refreshMax > geo.pMaxRefresh[k] ? (int32_t)pl->refreshMax : geo.pMaxRefresh[k];
-            geo.pRingCells[k] = imax(geo.pRingCells[k], pl->liveMax + pl->maxW);
-            geo.pFbCells[k] = imax(geo.pFbCells[k], pl->fbMax);
+            lg.nPacked[k]++;
+            lg.pMaxRefresh[k] = pl->refreshMax > lg.pMaxRefresh[k] ? (int32_t)pl->refreshMax : lg.pMaxRefresh[k];
+            lg.pRingCells[k] = imax(lg.pRingCells[k], pl->liveMax + pl->maxW);
+            lg.pFbCells[k] = imax(lg.pFbCells[k], pl->fbMax);
         } else {
             const int k = keys[di].cls - 3;
-            geo.nWide[k]++;
-            geo.wMaxWidth[k] = g->maxWidth > geo.wMaxWidth[k] ? g->maxWidth : geo.wMaxWidth[k];
-            geo.wMaxRefresh[k] = pl->refreshMax > geo.wMaxRefresh[k] ? (int32_t)pl->refreshMax : geo.wMaxRefresh[k];
-            geo.wRingCells[k] = imax(geo.wRingCells[k], pl->liveMax + pl->maxW);
-            geo.wFbCells[k] = imax(geo.wFbCells[k], pl->fbMax);
-            geo.wSeqLdsBytes[k] = (int32_t)imax(geo.wSeqLdsBytes[k], imin((r->lX + 3) / 2 + (r->lY + 3) / 2, (int64_t)1 << 30));
-            geo.wWinLdsBytes[k] = (int32_t)imax(geo.wWinLdsBytes[k], imin(pl->winBytes, (int64_t)1 << 30));
+            lg.nWide[k]++;
+            lg.wMaxWidth[k] = g->maxWidth > lg.wMaxWidth[k] ? g->maxWidth : lg.wMaxWidth[k];
+            lg.wMaxRefresh[k] = pl->refreshMax > lg.wMaxRefresh[k] ? (int32_t)pl->refreshMax : lg.wMaxRefresh[k];
+            lg.wRingCells[k] = imax(lg.wRingCells[k], pl->liveMax + pl->maxW);
+            lg.wFbCells[k] = imax(lg.wFbCells[k], pl->fbMax);
+            lg.wSeqLdsBytes[k] = (int32_t)imax(lg.wSeqLdsBytes[k], imin((r->lX + 3) / 2 + (r->lY + 3) / 2, (int64_t)1 << 30));
+            lg.wWinLdsBytes[k] = (int32_t)imax(lg.wWinLdsBytes[k], imin(pl->winBytes, (int64_t)1 << 30));
         }
+    }
+#pragma omp critical(cpk_order)
+    {
+        for (int k = 0; k < 3; k++) {
+            geo.nPacked[k] += lg.nPacked[k];
+            geo.pMaxRefresh[k] = lg.pMaxRefresh[k] > geo.pMaxRefresh[k] ? lg.pMaxRefresh[k] : geo.pMaxRefresh[k];
+            geo.pRingCells[k] = imax(geo.pRingCells[k], lg.pRingCells[k]);
+            geo.pFbCells[k] = imax(geo.pFbCells[k], lg.pFbCells[k]);
+        }
+        for (int k = 0; k < CPK_WIDE_CLASSES; k++) {
+            geo.nWide[k] += lg.nWide[k];
+            geo.wMaxWidth[k] = lg.wMaxWidth[k] > geo.wMaxWidth[k] ? lg.wMaxWidth[k] : geo.wMaxWidth[k];
+            geo.wMaxRefresh[k] = lg.wMaxRefresh[k] > geo.wMaxRefresh[k] ? lg.wMaxRefresh[k] : geo.wMaxRefresh[k];
+            geo.wRingCells[k] = imax(geo.wRingCells[k], lg.wRingCells[k]);
+            geo.wFbCells[k] = imax(geo.wFbCells[k], lg.wFbCells[k]);
+            geo.wSeqLdsBytes[k] = lg.wSeqLdsBytes[k] > geo.wSeqLdsBytes[k] ? lg.wSeqLdsBytes[k] : geo.wSeqLdsBytes[k];
+            geo.wWinLdsBytes[k] = lg.wWinLdsBytes[k] > geo.wWinLdsBytes[k] ? lg.wWinLdsBytes[k] : geo.wWinLdsBytes[k];
+        }
+    }
+    }
+    if (tooLarge >= 0) {
+        /* segment offsets and the region's slice are 32-bit: threshold <= 0 on a region of more than 2^31 cells x
+         * segments cannot be laid out (the reference would return a list of that many tuples) */
+        cpk_set_error("a region's output slice exceeds 2^31 triples (%lld): raise the threshold or split the region", (long long)tooLarge);
+        rc = CPECAN_EINVAL;
+        goto fail2;
+    }
+    for (int64_t di = 0; di < b->nRegions; di++) { /* the running offsets, in device order */
+        CpkRegion *g = &b->devRegions[di];
+        g->dbgCellOff = dbgCells;
+        g->dbgDiagOff = dbgDiags;
+        if (b->debug) {
+            dbgCells += g->cells;
+            dbgDiags += (int64_t)g->lX + g->lY + 1;
+        }
+        totalCells += g->cells;
+        g->outOff = outAt;
+        outAt += g->outCap;
     }
     for (int k = 0; k < 3; k++)
         if (geo.nPacked[k]) {

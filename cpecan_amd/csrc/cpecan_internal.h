@@ -37,7 +37,7 @@ typedef struct {
     int32_t nRefresh; /* number of total-probability refresh points in the segment */
     int32_t outOff;   /* the segment's own part of the region's output slice (per list), used when the tracebacks of a */
     int32_t outCap;   /* region run as separate queue items (split classes): first triple and capacity */
-    int32_t pad;
+    int32_t emitCells; /* band cells on the emitted diagonals tbPrev+1..tbFrom: no list of the segment can be longer */
 } CpkSegment;
 
 /* One traceback work item of a split class: segment `seg` (index within its region) of device region `region`. */

@@ -10,6 +10,8 @@
 #include "cpecan_realign.h"
 
 #include <ctype.h>
+#include <omp.h>
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -382,10 +384,13 @@ typedef struct {
     int64_t length;
 } SeqEntry;
 
+#define CPK_REALIGN_MAX_DEVICES 64
 struct cpecan_realigner {
     cpecan_model model;
     cpecan_realign_options opt;
     int device;
+    int devices[CPK_REALIGN_MAX_DEVICES]; /* cpecan_realigner_set_devices: the shards of a call, one per entry */
+    int nDevices;                         /* 0 or 1: everything on `device` */
     SeqEntry *seqs; /* open addressing, capacity a power of two */
     int64_t nSeqs, capSeqs;
     char *finalPairsPath, *allPairsPath;
@@ -580,7 +585,7 @@ typedef struct {
     int flip1, flip2;
     int64_t *anchors;   /* every match column (x, y, expansion) */
     int64_t nAnchors;
-    int64_t *filtered;  /* the exact-match ones (:529) */
+    int64_t *filtered;  /* the exact-match ones (:529), as nFiltered runs (x, y, length, expansion) */
     int64_t nFiltered;
 } Item;
 
@@ -619,7 +624,11 @@ static int item_prepare(const cpecan_realigner *r, const cpecan_cigar *pA, Item 
     int64_t matches = 0;
     for (int64_t i = 0; i < pA->nOps; i++)
         if (pA->ops[2 * i] == CPECAN_OP_MATCH) matches += pA->ops[2 * i + 1];
-    it->filtered = malloc(sizeof(int64_t) * 3 * (size_t)(matches ? matches : 1));
+    /* the exact-match anchors (:525-529) as runs of diagonal neighbours: 32 bytes per run instead of 24 per column */
+    it->nFiltered = cpecan_anchor_runs_from_alignment(pA->ops, pA->nOps, 0, 0, r->opt.constraintDiagonalTrim,
+                                                      r->opt.params.diagonalExpansion, it->subX, it->lX, it->subY, it->lY, NULL, 0);
+    if (it->nFiltered < 0) return CPECAN_EINVAL;
+    it->filtered = malloc(sizeof(int64_t) * 4 * (size_t)(it->nFiltered ? it->nFiltered : 1));
     if (!it->filtered) return CPECAN_ENOMEM;
     if (r->opt.rescoreOriginalAlignment) { /* scoreAnchorPairs looks the unfiltered anchors up (:548) */
         it->anchors = malloc(sizeof(int64_t) * 3 * (size_t)(matches ? matches : 1));
@@ -627,9 +636,9 @@ static int item_prepare(const cpecan_realigner *r, const cpecan_cigar *pA, Item 
         it->nAnchors = cpecan_anchors_from_alignment(pA->ops, pA->nOps, 0, 0, r->opt.constraintDiagonalTrim,
                                                      r->opt.params.diagonalExpansion, NULL, 0, NULL, 0, it->anchors);
     }
-    it->nFiltered = cpecan_anchors_from_alignment(pA->ops, pA->nOps, 0, 0, r->opt.constraintDiagonalTrim,
-                                                  r->opt.params.diagonalExpansion, it->subX, it->lX, it->subY, it->lY,
-                                                  it->filtered);
+    it->nFiltered = cpecan_anchor_runs_from_alignment(pA->ops, pA->nOps, 0, 0, r->opt.constraintDiagonalTrim,
+                                                      r->opt.params.diagonalExpansion, it->subX, it->lX, it->subY, it->lY,
+                                                      it->filtered, it->nFiltered);
     if (it->nAnchors < 0 || it->nFiltered < 0) return CPECAN_EINVAL;
     return CPECAN_OK;
 }
@@ -746,15 +755,15 @@ static int prepare_and_add(const cpecan_realigner *r, const cpecan_cigar *in, in
     for (int64_t from = 0; from < n; from += slice) {
         const int64_t to = from + slice < n ? from + slice : n;
         int rc = prepare_range(r, in, from, to, items);
-        cpecan_problem *probs = rc == CPECAN_OK ? malloc(sizeof(cpecan_problem) * (size_t)(to - from)) : NULL;
+        cpecan_problem_runs *probs = rc == CPECAN_OK ? malloc(sizeof(cpecan_problem_runs) * (size_t)(to - from)) : NULL;
         if (rc == CPECAN_OK && !probs) rc = CPECAN_ENOMEM;
         for (int64_t i = from; rc == CPECAN_OK && i < to; i++) {
-            const cpecan_problem p = {items[i].subX, items[i].lX, items[i].subY, items[i].lY, items[i].filtered,
-                                      items[i].nFiltered, 1, 1};
+            const cpecan_problem_runs p = {items[i].subX, items[i].lX, items[i].subY, items[i].lY, items[i].filtered,
+                                           items[i].nFiltered, 1, 1};
             probs[i - from] = p;
         }
         if (rc == CPECAN_OK) {
-            const int64_t first = cpecan_batch_add_many(b, probs, to - from);
+            const int64_t first = cpecan_batch_add_many_runs(b, probs, to - from);
             rc = first < 0 ? (int)first : CPECAN_OK;
         }
         free(probs);
@@ -850,8 +859,7 @@ static int build_output(const cpecan_realigner *r, const cpecan_batch *b, const 
     return rc;
 }
 
-int cpecan_realigner_realign(cpecan_realigner *r, const cpecan_cigar *in, int64_t n, cpecan_cigar **out, int64_t *nOut) {
-    if (!r || (!in && n > 0) || n < 0 || !out || !nOut) return CPECAN_EINVAL;
+static int realign_on_device(const cpecan_realigner *r, const cpecan_cigar *in, int64_t n, cpecan_cigar **out, int64_t *nOut) {
     *out = NULL;
     *nOut = 0;
     const cpecan_realign_options *o = &r->opt;
@@ -914,7 +922,8 @@ int cpecan_realigner_realign(cpecan_realigner *r, const cpecan_cigar *in, int64_
         rc = item_prepare(r, &in[n - 1], it);
         if (rc == CPECAN_OK) rc = cpecan_batch_create(&raw, &r->model, &o->params, CPECAN_EMIT_MATCH, r->device);
         if (rc == CPECAN_OK) {
-            const int64_t idx = cpecan_batch_add(raw, it->subX, it->lX, it->subY, it->lY, it->filtered, it->nFiltered, 1, 1);
+            const cpecan_problem_runs pr = {it->subX, it->lX, it->subY, it->lY, it->filtered, it->nFiltered, 1, 1};
+            const int64_t idx = cpecan_batch_add_many_runs(raw, &pr, 1);
             rc = idx < 0 ? (int)idx : run_batch(raw);
         }
         const int32_t *all = NULL;
@@ -947,8 +956,7 @@ int cpecan_realigner_realign(cpecan_realigner *r, const cpecan_cigar *in, int64_
     return CPECAN_OK;
 }
 
-int cpecan_realigner_expectations(cpecan_realigner *r, const cpecan_cigar *in, int64_t n, cpecan_hmm *acc) {
-    if (!r || (!in && n > 0) || n < 0 || !acc) return CPECAN_EINVAL;
+static int expectations_on_device(const cpecan_realigner *r, const cpecan_cigar *in, int64_t n, cpecan_hmm *acc) {
     if (n == 0) return CPECAN_OK;
     cpecan_batch *b = NULL;
     int rc = cpecan_batch_create(&b, &r->model, &r->opt.params, CPECAN_EMIT_EXPECT, r->device);
@@ -956,7 +964,8 @@ int cpecan_realigner_expectations(cpecan_realigner *r, const cpecan_cigar *in, i
         Item it;
         rc = item_prepare(r, &in[i], &it);
         if (rc == CPECAN_OK) {
-            const int64_t idx = cpecan_batch_add(b, it.subX, it.lX, it.subY, it.lY, it.filtered, it.nFiltered, 1, 1); /* :532 */
+            const cpecan_problem_runs pr = {it.subX, it.lX, it.subY, it.lY, it.filtered, it.nFiltered, 1, 1};
+            const int64_t idx = cpecan_batch_add_many_runs(b, &pr, 1); /* :532 */
             rc = idx < 0 ? (int)idx : CPECAN_OK;
         }
         item_clear(&it);
@@ -964,5 +973,160 @@ int cpecan_realigner_expectations(cpecan_realigner *r, const cpecan_cigar *in, i
     if (rc == CPECAN_OK) rc = run_batch(b);
     if (rc == CPECAN_OK) rc = cpecan_batch_expectations(b, acc);
     cpecan_batch_destroy(b);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * Several GPUs from one process.  The reference fans a realignment out as one
+ * cPecanRealign process per shard of the cigar file and sums the shards' expectation files (cPecanEm.py:168-188); here
+ * the cigars of ONE call are cut into contiguous shards of about equal band cells, shard k runs as its own batch on
+ * devices[k] from a host thread of its own, and the results are joined in input order -- the expectation counts summed on
+ * the host in shard order (106 doubles: no collective needed inside one process).
+ * ---------------------------------------------------------------------------------------------- */
+int cpecan_realign_shard_bounds(const cpecan_cigar *in, int64_t n, int64_t diagonalExpansion, int nShards, int64_t *bounds) {
+    if ((!in && n > 0) || n < 0 || nShards < 1 || !bounds || diagonalExpansion < 0) return CPECAN_EINVAL;
+    /* band cells of a cigar, near enough: diagonals times band width (cpecan_amd/dist.py: cigar_cost) */
+    long double total = 0;
+    for (int64_t i = 0; i < n; i++)
+        total += (long double)(llabs((long long)(in[i].end1 - in[i].start1)) + llabs((long long)(in[i].end2 - in[i].start2)) + 1) *
+                 (long double)(diagonalExpansion + 1);
+    bounds[0] = 0;
+    long double run = 0;
+    int64_t at = 0;
+    for (int k = 1; k < nShards; k++) { /* the first cigar at which the running cost reaches k / nShards of the total */
+        const long double want = total * (long double)k / (long double)nShards;
+        while (at < n && run < want) {
+            run += (long double)(llabs((long long)(in[at].end1 - in[at].start1)) + llabs((long long)(in[at].end2 - in[at].start2)) + 1) *
+                   (long double)(diagonalExpansion + 1);
+            at++;
+        }
+        bounds[k] = at;
+    }
+    bounds[nShards] = n;
+    return CPECAN_OK;
+}
+
+int cpecan_realigner_set_devices(cpecan_realigner *r, const int *devices, int nDevices) {
+    if (!r || nDevices < 0 || nDevices > CPK_REALIGN_MAX_DEVICES || (nDevices > 0 && !devices)) return CPECAN_EINVAL;
+    for (int k = 0; k < nDevices; k++)
+        if (devices[k] < 0) return CPECAN_EINVAL;
+    for (int k = 0; k < nDevices; k++) r->devices[k] = devices[k];
+    r->nDevices = nDevices;
+    if (nDevices > 0) r->device = devices[0];
+    return CPECAN_OK;
+}
+
+typedef struct {
+    cpecan_realigner shard; /* a shallow copy bound to one device: the sequences are shared, read only */
+    const cpecan_cigar *in;
+    int64_t n;
+    int expect;
+    int threads;
+    cpecan_cigar *out;
+    int64_t nOut;
+    cpecan_hmm acc;
+    int rc;
+    char err[512];
+} ShardJob;
+
+static void *shard_main(void *arg) {
+    ShardJob *j = arg;
+    omp_set_num_threads(j->threads); /* this thread's parallel loops: its share of the host's cores */
+    j->rc = j->expect ? expectations_on_device(&j->shard, j->in, j->n, &j->acc)
+                      : realign_on_device(&j->shard, j->in, j->n, &j->out, &j->nOut);
+    if (j->rc != CPECAN_OK) {
+        strncpy(j->err, cpk_last_error(), sizeof j->err - 1);
+        j->err[sizeof j->err - 1] = 0;
+    }
+    return NULL;
+}
+
+/* runs the shards of a call on their devices; jobs[k].out / .acc hold the results */
+static int run_shards(cpecan_realigner *r, const cpecan_cigar *in, int64_t n, int expect, int32_t hmmType, ShardJob *jobs) {
+    const int K = r->nDevices;
+    int64_t bounds[CPK_REALIGN_MAX_DEVICES + 1];
+    int rc = cpecan_realign_shard_bounds(in, n, r->opt.params.diagonalExpansion, K, bounds);
+    if (rc != CPECAN_OK) return rc;
+    int threads = cpk_host_threads() / K;
+    if (threads < 1) threads = 1;
+    pthread_t tid[CPK_REALIGN_MAX_DEVICES];
+    int started = 0;
+    for (int k = 0; k < K; k++) {
+        ShardJob *j = &jobs[k];
+        memset(j, 0, sizeof *j);
+        j->shard = *r;
+        j->shard.device = r->devices[k];
+        j->shard.nDevices = 0;
+        if (bounds[k + 1] != n || bounds[k] == n) /* the posterior files are the LAST cigar's (cPecanRealign.c:541-570) */
+            j->shard.finalPairsPath = j->shard.allPairsPath = NULL;
+        j->in = in + bounds[k];
+        j->n = bounds[k + 1] - bounds[k];
+        j->expect = expect;
+        j->threads = threads;
+        if (expect && (rc = cpecan_hmm_init(&j->acc, hmmType, 0.0)) != CPECAN_OK) break;
+        if (pthread_create(&tid[k], NULL, shard_main, j) != 0) {
+            cpk_set_error("cannot start the thread of shard %d", k);
+            rc = CPECAN_ENOMEM;
+            break;
+        }
+        started++;
+    }
+    for (int k = 0; k < started; k++) pthread_join(tid[k], NULL);
+    for (int k = 0; k < started && rc == CPECAN_OK; k++)
+        if (jobs[k].rc != CPECAN_OK) {
+            rc = jobs[k].rc;
+            cpk_set_error("shard %d (device %d): %s", k, r->devices[k], jobs[k].err);
+        }
+    if (rc != CPECAN_OK)
+        for (int k = 0; k < started; k++) {
+            cpecan_cigars_free(jobs[k].out, jobs[k].nOut);
+            jobs[k].out = NULL;
+            jobs[k].nOut = 0;
+        }
+    return rc;
+}
+
+int cpecan_realigner_realign(cpecan_realigner *r, const cpecan_cigar *in, int64_t n, cpecan_cigar **out, int64_t *nOut) {
+    if (!r || (!in && n > 0) || n < 0 || !out || !nOut) return CPECAN_EINVAL;
+    if (r->nDevices <= 1 || n < 2) return realign_on_device(r, in, n, out, nOut);
+    *out = NULL;
+    *nOut = 0;
+    ShardJob *jobs = malloc(sizeof(ShardJob) * (size_t)r->nDevices);
+    if (!jobs) return CPECAN_ENOMEM;
+    int rc = run_shards(r, in, n, 0, 0, jobs);
+    if (rc == CPECAN_OK) {
+        int64_t total = 0;
+        for (int k = 0; k < r->nDevices; k++) total += jobs[k].nOut;
+        cpecan_cigar *res = malloc(sizeof(cpecan_cigar) * (size_t)(total ? total : 1));
+        if (!res) {
+            rc = CPECAN_ENOMEM;
+            for (int k = 0; k < r->nDevices; k++) cpecan_cigars_free(jobs[k].out, jobs[k].nOut);
+        } else {
+            int64_t at = 0;
+            for (int k = 0; k < r->nDevices; k++) { /* shard order is input order: ownership of the cigars moves to res */
+                if (jobs[k].nOut) memcpy(res + at, jobs[k].out, sizeof(cpecan_cigar) * (size_t)jobs[k].nOut);
+                at += jobs[k].nOut;
+                free(jobs[k].out);
+            }
+            *out = res;
+            *nOut = total;
+        }
+    }
+    free(jobs);
+    return rc;
+}
+
+int cpecan_realigner_expectations(cpecan_realigner *r, const cpecan_cigar *in, int64_t n, cpecan_hmm *acc) {
+    if (!r || (!in && n > 0) || n < 0 || !acc) return CPECAN_EINVAL;
+    if (r->nDevices <= 1 || n < 2) return expectations_on_device(r, in, n, acc);
+    ShardJob *jobs = malloc(sizeof(ShardJob) * (size_t)r->nDevices);
+    if (!jobs) return CPECAN_ENOMEM;
+    int rc = run_shards(r, in, n, 1, acc->type, jobs);
+    for (int k = 0; rc == CPECAN_OK && k < r->nDevices; k++) { /* the sum of cPecanEm.py:184-188, in shard order */
+        for (int i = 0; i < 25; i++) acc->transitions[i] += jobs[k].acc.transitions[i];
+        for (int i = 0; i < 80; i++) acc->emissions[i] += jobs[k].acc.emissions[i];
+        acc->likelihood += jobs[k].acc.likelihood;
+    }
+    free(jobs);
     return rc;
 }

@@ -21,7 +21,33 @@ static void usage(void) {
             "-u --outputPosteriorProbs FILE  -z --outputAllPosteriorProbs FILE  -v --outputExpectations FILE\n"
             "-y --loadHmm FILE  -a --logLevel L (ignored)  -b --batch N (most alignments per GPU batch, default 32768;\n"
             "a batch also closes at 64 Mbp of aligned sequence)\n"
-            "-g --device N  -h --help\n");
+            "-g --device N  -G --devices LIST (e.g. 0-7 or 0,2,3: the cigars of every batch are cut into one shard per\n"
+            "listed device, run side by side from this process and joined in input order; a device may be listed twice)\n"
+            "-h --help\n");
+}
+
+/* "0-3", "0,2,5", "1,1": a device list; returns the count or -1 */
+static int parse_devices(const char *text, int *out, int cap) {
+    int n = 0;
+    for (const char *p = text; *p;) {
+        char *end;
+        const long a = strtol(p, &end, 10);
+        if (end == p || a < 0) return -1;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = strtol(p + 1, &end, 10);
+            if (end == p + 1 || b < a) return -1;
+            p = end;
+        }
+        for (long d = a; d <= b; d++) {
+            if (n >= cap) return -1;
+            out[n++] = (int)d;
+        }
+        if (*p == ',') p++;
+        else if (*p) return -1;
+    }
+    return n;
 }
 
 static int fail(const char *what) {
@@ -35,6 +61,7 @@ int main(int argc, char **argv) {
     cpecan_realign_options_default(&o);
     const char *posteriorFile = NULL, *allPosteriorFile = NULL, *expectationsFile = NULL, *hmmFile = NULL;
     long long batch = 32768, device = 0, v;
+    int devices[64], nDevices = 0;
     const long long batchBases = 64ll << 20; /* a batch also closes here: ~1.5 GB of anchors on the host */
     static struct option longOpts[] = {{"logLevel", required_argument, 0, 'a'},
                                        {"help", no_argument, 0, 'h'},
@@ -56,8 +83,9 @@ int main(int argc, char **argv) {
                                        {"loadHmm", required_argument, 0, 'y'},
                                        {"batch", required_argument, 0, 'b'},
                                        {"device", required_argument, 0, 'g'},
+                                       {"devices", required_argument, 0, 'G'},
                                        {0, 0, 0, 0}};
-    for (int key; (key = getopt_long(argc, argv, "a:hl:o:r:t:s:wxijkmu:v:y:z:L:b:g:", longOpts, NULL)) != -1;) {
+    for (int key; (key = getopt_long(argc, argv, "a:hl:o:r:t:s:wxijkmu:v:y:z:L:b:g:G:", longOpts, NULL)) != -1;) {
         switch (key) {
         case 'a': break;
         case 'h': usage(); return 0;
@@ -79,6 +107,7 @@ int main(int argc, char **argv) {
         case 'y': hmmFile = optarg; break;
         case 'b': if (sscanf(optarg, "%lld", &batch) != 1 || batch < 1) return 1; break;
         case 'g': if (sscanf(optarg, "%lld", &device) != 1) return 1; break;
+        case 'G': if ((nDevices = parse_devices(optarg, devices, 64)) < 1) { usage(); return 1; } device = devices[0]; break;
         default: usage(); return 1;
         }
     }
@@ -93,6 +122,7 @@ int main(int argc, char **argv) {
     if (expectationsFile && cpecan_hmm_init(&expectations, model.type, 0.000000000001) != CPECAN_OK) return fail("hmm"); /* :497 */
     cpecan_realigner *r = NULL;
     if (cpecan_realigner_create(&r, &model, &o, (int)device) != CPECAN_OK) return fail("options");
+    if (nDevices > 1 && cpecan_realigner_set_devices(r, devices, nDevices) != CPECAN_OK) return fail("devices");
     if (optind >= argc) {
         usage();
         return 1;

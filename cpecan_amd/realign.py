@@ -13,6 +13,7 @@ EXPORTS = [
     "cpecan_realign_options_default", "cpecan_realigner_create", "cpecan_realigner_destroy",
     "cpecan_realigner_add_sequence", "cpecan_realigner_read_fasta", "cpecan_realigner_set_posterior_files",
     "cpecan_realigner_realign", "cpecan_realigner_expectations",
+    "cpecan_realigner_set_devices", "cpecan_realign_shard_bounds",
 ]
 
 
@@ -62,6 +63,8 @@ def _lib():
         L.cpecan_realigner_realign.argtypes = [vp, C.POINTER(_Cigar), C.c_int64, C.POINTER(C.POINTER(_Cigar)),
                                                C.POINTER(C.c_int64)]
         L.cpecan_realigner_expectations.argtypes = [vp, C.POINTER(_Cigar), C.c_int64, C.POINTER(api.Hmm)]
+        L.cpecan_realigner_set_devices.argtypes = [vp, C.POINTER(C.c_int), C.c_int]
+        L.cpecan_realign_shard_bounds.argtypes = [C.POINTER(_Cigar), C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_int64)]
         _bound = True
     return L
 
@@ -192,6 +195,11 @@ class Realigner:
             self._h, final_pairs.encode() if final_pairs else None, all_pairs.encode() if all_pairs else None),
             "cpecan_realigner_set_posterior_files")
 
+    def set_devices(self, devices):
+        """The cigars of every later call are cut into one contiguous shard per listed device (cpecan_realigner_set_devices)."""
+        arr = (C.c_int * max(1, len(devices)))(*devices)
+        api._check(_lib().cpecan_realigner_set_devices(self._h, arr, len(devices)), "cpecan_realigner_set_devices")
+
     def _pack(self, cigars):
         keep = []
         arr = (_Cigar * max(1, len(cigars)))(*[c._to_c(keep) for c in cigars])
@@ -212,3 +220,12 @@ class Realigner:
         api._check(_lib().cpecan_realigner_expectations(self._h, arr, len(cigars), C.byref(hmm)),
                    "cpecan_realigner_expectations")
         return hmm
+
+
+def shard_bounds(cigars, n_shards, expansion=4):
+    """cpecan_realign_shard_bounds: the cut points of n_shards contiguous shards of about equal band cells."""
+    keep = []
+    arr = (_Cigar * max(1, len(cigars)))(*[c._to_c(keep) for c in cigars])
+    out = (C.c_int64 * (n_shards + 1))()
+    api._check(_lib().cpecan_realign_shard_bounds(arr, len(cigars), expansion, n_shards, out), "cpecan_realign_shard_bounds")
+    return list(out)

@@ -134,6 +134,12 @@ enum { CPECAN_OP_MATCH = 0, CPECAN_OP_INDEL_X = 1, CPECAN_OP_INDEL_Y = 2 };
 int64_t cpecan_anchors_from_alignment(const int64_t *ops, int64_t nOps, int64_t start1, int64_t start2, int64_t trim,
                                       int64_t expansion, const char *sX, int64_t lX, const char *sY, int64_t lY,
                                       int64_t *anchors);
+/* The same anchors as runs, for cpecan_batch_add_many_runs: the kept columns that follow each other on a matrix diagonal
+ * -- a mismatched column or the end of the operation ends a run -- as quadruples (x, y, length, expansion).  runs receives
+ * at most cap quadruples; returns the number of runs (which may exceed cap), or < 0. */
+int64_t cpecan_anchor_runs_from_alignment(const int64_t *ops, int64_t nOps, int64_t start1, int64_t start2, int64_t trim,
+                                          int64_t expansion, const char *sX, int64_t lX, const char *sY, int64_t lY,
+                                          int64_t *runs, int64_t cap);
 
 /* filterToRemoveOverlap (pairwiseAligner.c:1095-1135), the step between a sorted list of blast / lastz pairs and an
  * anchor list: a pair (x, y, expansion) is kept when every earlier pair is strictly smaller and every later pair strictly
@@ -195,6 +201,27 @@ typedef struct cpecan_problem {
     int32_t raggedLeft, raggedRight;
 } cpecan_problem;
 int64_t cpecan_batch_add_many(cpecan_batch *b, const cpecan_problem *problems, int64_t n);
+
+/* The same with the anchors as RUNS: run (x, y, length, expansion) stands for the `length` anchors (x + i, y + i, expansion),
+ * i = 0 .. length - 1.  This is what the realign flow holds before it makes one anchor per aligned column out of the match
+ * operations of a cigar (convertPairwiseForwardStrandAlignmentToAnchorPairs, pairwiseAligner.c:979-1003) and drops the
+ * mismatched columns (cPecanRealign.c:525-529): a batch of BASELINE config 4 is 1.4 GB of per-column triples and 0.13 GB of
+ * runs.  Runs strictly increase in x and y from one to the next; results are those of cpecan_batch_add_many on the
+ * expanded anchors, bit for bit.  Returns the index of the first problem. */
+typedef struct cpecan_problem_runs {
+    const char *sX;
+    int64_t lX;
+    const char *sY;
+    int64_t lY;
+    const int64_t *runs; /* nRuns quadruples (x, y, length, expansion) */
+    int64_t nRuns;
+    int32_t raggedLeft, raggedRight;
+} cpecan_problem_runs;
+int64_t cpecan_batch_add_many_runs(cpecan_batch *b, const cpecan_problem_runs *problems, int64_t n);
+/* Run-length form of an anchor list: out receives at most cap quadruples; returns the number of runs the list has (which
+ * may exceed cap: nothing beyond cap is written), or < 0.  Consecutive anchors join a run when both coordinates step by
+ * one and the expansion is the same. */
+int64_t cpecan_anchor_runs(const int64_t *anchors, int64_t nAnchors, int64_t *out, int64_t cap);
 
 /* Freezes the batch: builds band tables and traceback schedules on the host, allocates device
  * memory and copies the packed inputs to the GPU. */

@@ -75,6 +75,17 @@ int64_t cpecan_realigner_read_fasta(cpecan_realigner *r, const char *path);
  * cigar's pairs; that is what is written here.  NULL = none. */
 int cpecan_realigner_set_posterior_files(cpecan_realigner *r, const char *finalPairsPath, const char *allPairsPath);
 
+/* Several GPUs from ONE process.  The reference fans a realignment out as one cPecanRealign process per shard
+ * of the cigar file and sums the shards' expectation files (cPecanEm.py:168-188); with a device list the cigars of every
+ * realign / expectations call are cut into nDevices contiguous shards of about equal band cells
+ * (cpecan_realign_shard_bounds), shard k runs as its own batch on devices[k] from a host thread of its own, and the
+ * results are joined in input order -- expectation counts summed on the host in shard order.  A device may be listed more
+ * than once (two shards on one GPU); nDevices 0 or 1: one batch on the device given to cpecan_realigner_create. */
+int cpecan_realigner_set_devices(cpecan_realigner *r, const int *devices, int nDevices);
+/* bounds[0..nShards]: shard k is cigars [bounds[k], bounds[k+1]); a cigar costs (|end1 - start1| + |end2 - start2| + 1) *
+ * (diagonalExpansion + 1), shard k ends at the first cigar where the running cost reaches k / nShards of the total. */
+int cpecan_realign_shard_bounds(const cpecan_cigar *in, int64_t n, int64_t diagonalExpansion, int nShards, int64_t *bounds);
+
 /* The realign loop (cPecanRealign.c:509-600) over n cigars as one batch.  *out: malloc'd array of *nOut cigars in input
  * order (more than n when splitIndelsLongerThanThis cuts some), to be released with cpecan_cigars_free. */
 int cpecan_realigner_realign(cpecan_realigner *r, const cpecan_cigar *in, int64_t n, cpecan_cigar **out, int64_t *nOut);

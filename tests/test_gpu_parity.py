@@ -320,6 +320,88 @@ def test_short_traceback_schedule_and_threshold_zero():
                  threshold=0.0)
 
 
+def test_threshold_zero_five_segments_slice_is_not_multiplied(monkeypatch):
+    """ADVICE r2 item 4 / VERDICT r3 item 8: with threshold <= 0 every cell is emitted.  A segment's part of the output
+    slice is capped by the cells of ITS emitted diagonals (from the band walk), not by the whole region's cells: a 2 kb
+    x 2 kb region of five segments used to ask for five times the triples it can ever fill.  Exact list equality with
+    the oracle (every cell with x, y > 0, once), in both launch forms, and the device bytes stay near one region's."""
+    sx, sy, a = make_pair(3, 1, 2000, 100)
+    kw = dict(diagonalExpansion=100, threshold=0.0)
+    om, op = ob.model(0), ob.params(**kw)
+    want = ob.aligned_pairs(om, sx, sy, a, op, False, False)
+    for form in ("0", "1"):
+        monkeypatch.setenv("CPECAN_SPLIT", form)
+        _, base = _run_batch(0, [(sx, sy, a)], diagonalExpansion=100)  # the default threshold: a slice of 6 (lX + lY) triples
+        got, st = _run_batch(0, [(sx, sy, a)], **kw)
+        assert st.regions == 1 and st.cells == base.cells and len(got[0]) == len(want)
+        assert_pairs_match(got[0], want, threshold=0.0)
+        assert np.array_equal(got[0][:, 1:], np.asarray(want)[:, 1:])  # the same cells in the same order
+        assert len(want) > st.cells - 2 * 4002  # every band cell except those on the two zero edges
+        # the triples (12 B) and their compact copy grow to one slice of `cells` triples each; five-fold slices (round 3)
+        # were 4 * 24 * cells bytes more
+        extra = st.deviceBytes - base.deviceBytes
+        assert extra < 1.25 * 24 * st.cells, (form, extra, st.cells)
+
+
+def test_run_form_anchors_and_closed_form_band_walk(monkeypatch):
+    """VERDICT r3 item 4.  (a) cpecan_batch_add_many_runs takes the anchors as (x, y, length, expansion) runs of diagonal
+    neighbours -- what cPecanRealign.c:525-529 + pairwiseAligner.c:979-1003 make of a cigar's match operations before they
+    are expanded to one anchor per column -- and must give, bit for bit, what cpecan_batch_add_many gives on the expanded
+    anchors.  (b) Planning walks such runs in closed form (cpecan_host.c, "Runs of diagonal neighbours"): with
+    CPECAN_FAST_WALK=0 every diagonal is walked one by one; cell counts, regions, device memory and every list must be
+    the same -- also where traceback points fall inside runs (short schedules), at matrix edges (anchors from column 0), with
+    split rectangles and with expansions 2 to 10.  And the oracle agrees on a sample."""
+    from cpecan_amd import workload
+    cases = []
+    for E, seed in ((4, 11), (2, 12), (10, 13)):
+        probs = workload.make_realign_batch(seed, 48, 60, 2500, expansion=E)
+        cases.append((probs, dict(diagonalExpansion=E, splitMatrixBiggerThanThis=10), True))
+        cases.append((probs[:24], dict(diagonalExpansion=E, splitMatrixBiggerThanThis=10, minDiagsBetweenTraceBack=120,
+                                       traceBackDiagonals=17), True))
+    # identical sequences: ONE run from corner to corner, traceback points deep inside it
+    rng = random.Random(77)
+    same = [(s, s, np.array([(i, i, 6) for i in range(len(s))], dtype=np.int64)) for s in
+            (_rand_seq(rng, n) for n in (1, 2, 3, 40, 1500, 2600))]
+    cases.append((same, dict(diagonalExpansion=6), False))
+    cases.append((same, dict(diagonalExpansion=6, minDiagsBetweenTraceBack=200, traceBackDiagonals=40), False))
+    for probs, kw, ragged in cases:
+        p = api.pairwiseAlignmentBandingParameters_construct(**kw)
+        problems = [(sx, sy, a, ragged, ragged) for sx, sy, a in probs]
+
+        def run(runs):
+            with api.Batch(_sm(0), p) as b:
+                (b.add_many_runs if runs else b.add_many)(problems)
+                b.upload()
+                b.run()
+                b.download()
+                return [b.result(i).copy() for i in range(len(problems))], b.stats()
+
+        monkeypatch.setenv("CPECAN_FAST_WALK", "0")
+        slow, st0 = run(False)
+        monkeypatch.delenv("CPECAN_FAST_WALK")
+        fast, st1 = run(False)
+        from_runs, st2 = run(True)
+        for st in (st1, st2):
+            assert (st.cells, st.regions, st.diagonals, st.pairs, st.deviceBytes) == \
+                   (st0.cells, st0.regions, st0.diagonals, st0.pairs, st0.deviceBytes)
+        for i, (a0, a1, a2) in enumerate(zip(slow, fast, from_runs)):
+            assert np.array_equal(a0, a1), ("closed-form walk", i)
+            assert np.array_equal(a0, a2), ("run form", i)
+        om, op = ob.model(0), ob.params(**kw)
+        for i in range(0, len(problems), max(1, len(problems) // 6)):
+            sx, sy, a, rl, rr = problems[i]
+            assert_pairs_match(from_runs[i], ob.aligned_pairs(om, sx, sy, a, op, rl, rr), threshold=op.threshold)
+    # bad runs are refused like bad anchors
+    with api.Batch(_sm(0), api.pairwiseAlignmentBandingParameters_construct()) as b:
+        for bad in ([(0, 0, 0, 4)], [(0, 0, 5, 4)], [(2, 2, 1, 4), (2, 3, 1, 4)], [(-1, 0, 1, 4)]):
+            arr = (api.ProblemRuns * 1)()
+            runs = np.array(bad, dtype=np.int64)
+            arr[0].sX, arr[0].lX, arr[0].sY, arr[0].lY = b"ACGT", 4, b"ACGT", 4
+            arr[0].runs, arr[0].nRuns = runs.ctypes.data_as(api.C.POINTER(api.C.c_int64)), len(bad)
+            with pytest.raises(api.CpecanError):
+                b.add_prepared(arr, 1)
+
+
 def test_split_by_large_gaps_regions():
     # cPecanRealign-style: tiny split threshold, small expansion, ragged ends (cPecanRealign.c:355-357,537)
     rng = random.Random(41)

@@ -304,6 +304,69 @@ def test_command_line_end_to_end(tmp_path):
     assert bad.returncode != 0 and "no sequence named" in bad.stderr
 
 
+def test_several_devices_from_one_process(tmp_path):
+    """VERDICT r3 item 6 (SURVEY 8e from the C side): cpecan_realigner_set_devices / cpecan_realign --devices deal the cigars
+    of a call over a device list from ONE process -- here two logical shards on device 0, the one GPU of the box.  The
+    realigned cigars are those of a single batch, cigar for cigar, in input order; the expectation counts are the sum over
+    the shards (106 doubles added on the host, cPecanEm.py:184-188).  And the reference's own fan-out -- one process per
+    shard of the cigar file, the shards' expectation files summed -- gives the same file as one run."""
+    from cpecan_amd.realign import shard_bounds
+    exe = os.path.join(ROOT, "cpecan_amd", "cpecan_realign")
+    rng = random.Random(67 + SHIFT)
+    seqs, cigars = _world(rng, n_cigars=90)
+    with _realigner(seqs) as r:
+        want = r.realign(cigars)
+        acc1 = api.hmm_constructEmpty(0.000000000001, api.fiveState)
+        r.expectations(cigars, acc1)
+        for devices in ([0, 0], [0, 0, 0]):
+            r.set_devices(devices)
+            assert r.realign(cigars) == want
+            accN = api.hmm_constructEmpty(0.000000000001, api.fiveState)
+            r.expectations(cigars, accN)
+            # (not to the last bit: a shard is a smaller batch, whose size classes may hand a region to another kernel -- the
+            # packed kernel forms an event as exp(x - total), the sweep kernel against a window reference -- and an event's
+            # exponent is an fp32 value either way: ~1e-7 per event against north_star's 1e-5; measured here 2e-8)
+            np.testing.assert_allclose(list(accN.transitions), list(acc1.transitions), rtol=1e-6)
+            np.testing.assert_allclose(list(accN.emissions), list(acc1.emissions), rtol=1e-6, atol=1e-300)
+            np.testing.assert_allclose(accN.likelihood, acc1.likelihood, rtol=1e-9)
+        r.set_devices([0, 0])
+        assert r.realign(cigars[:1]) == want[:1]  # fewer cigars than shards
+    # the command line
+    fa = tmp_path / "all.fa"
+    with open(fa, "w") as f:
+        for n in sorted(seqs):
+            f.write(">%s\n%s\n" % (n, seqs[n]))
+
+    def run(text, *args):
+        res = subprocess.run([exe, *args, str(fa)], input=text, capture_output=True, text=True, timeout=300)
+        assert res.returncode == 0, res.stderr
+        return [line for line in res.stdout.split("\n") if line]
+
+    text = "".join(c.format() + "\n" for c in cigars)
+    assert run(text, "--devices", "0,0") == [c.format() for c in want]
+    assert run(text, "--devices", "0-0,0", "--batch", "25") == [c.format() for c in want]
+    one, multi = tmp_path / "one.hmm", tmp_path / "multi.hmm"
+    assert run(text, "--outputExpectations", str(one)) == []
+    assert run(text, "--outputExpectations", str(multi), "--devices", "0,0") == []
+    whole, both = api.hmm_loadFromFile(str(one)), api.hmm_loadFromFile(str(multi))
+    np.testing.assert_allclose(list(both.transitions), list(whole.transitions), rtol=1e-6, atol=2e-6)  # %f text
+    np.testing.assert_allclose(list(both.emissions), list(whole.emissions), rtol=1e-6, atol=2e-6)
+    # one process per shard of the file, files summed (cPecanEm.py:168-188); the pseudo count 1e-12 of every file vanishes in %f
+    lo, mid, hi = shard_bounds(cigars, 2)
+    parts = []
+    for k, (a, b) in enumerate(((lo, mid), (mid, hi))):
+        path = tmp_path / ("shard%d.hmm" % k)
+        assert run("".join(c.format() + "\n" for c in cigars[a:b]), "--outputExpectations", str(path)) == []
+        parts.append(api.hmm_loadFromFile(str(path)))
+    summed_t = [x + y for x, y in zip(parts[0].transitions, parts[1].transitions)]
+    summed_e = [x + y for x, y in zip(parts[0].emissions, parts[1].emissions)]
+    np.testing.assert_allclose(summed_t, list(whole.transitions), rtol=1e-6, atol=3e-6)
+    np.testing.assert_allclose(summed_e, list(whole.emissions), rtol=1e-6, atol=3e-6)
+    np.testing.assert_allclose(parts[0].likelihood + parts[1].likelihood, whole.likelihood, rtol=1e-6, atol=3e-6)
+    bad = subprocess.run([exe, "--devices", "0,x", str(fa)], input=text, capture_output=True, text=True, timeout=60)
+    assert bad.returncode != 0
+
+
 def test_degenerate_cigars():
     """Empty alignments, alignments of indels only, a matchGamma nothing reaches, one-base sequences: no pair survives and
     the cigar falls back to the unaligned ends (convertAlignedPairsToPairwiseAlignment's end pair, :56-87)."""

@@ -178,3 +178,64 @@ def test_fasta_reader_and_missing_inputs(tmp_path):
             with pytest.raises(api.CpecanError) as e:
                 r.realign([c])  # no GPU: loud failure, never a CPU path
             assert "no usable HIP device" in str(e.value) or "HIP" in str(e.value)
+
+
+def test_shard_bounds_match_the_python_deal():
+    """cpecan_realign_shard_bounds (the C side's deal of cigars over devices, cpecan_realigner_set_devices) cuts where
+    cpecan_amd.dist.cost_balanced_bounds -- the deal of the torch.distributed path -- cuts: contiguous shards of about
+    equal band cells, in input order (the reference's own fan-out is one process per shard of the file,
+    cPecanEm.py:168-188)."""
+    from cpecan_amd import dist as cdist
+    from cpecan_amd.realign import shard_bounds
+    rng = random.Random(404)
+    for n, world in ((0, 3), (1, 2), (5, 8), (200, 2), (777, 8), (1000, 5)):
+        cigars = []
+        for i in range(n):
+            lx, ly = rng.randrange(1, 5000), rng.randrange(1, 5000)
+            s1, s2 = rng.randrange(0, 1000), rng.randrange(0, 1000)
+            plus1, plus2 = rng.random() < 0.5, rng.random() < 0.5
+            cigars.append(Cigar("a", s1 if plus1 else s1 + lx, s1 + lx if plus1 else s1, plus1,
+                                "b", s2 if plus2 else s2 + ly, s2 + ly if plus2 else s2, plus2, 0.0, []))
+        got = shard_bounds(cigars, world)
+        assert got[0] == 0 and got[-1] == n and all(a <= b for a, b in zip(got, got[1:]))
+        costs = [cdist.cigar_cost(c) for c in cigars]
+        for rank in range(world):
+            lo, hi = cdist.cost_balanced_bounds(costs, rank, world)
+            assert (got[rank], got[rank + 1]) == (lo, hi), (n, world, rank)
+        if n >= 200:  # balanced: no shard is more than one cigar's cost away from its share
+            total, worst = sum(costs), max(costs)
+            for k in range(world):
+                assert abs(sum(costs[got[k]:got[k + 1]]) - total / world) <= 2 * worst
+
+
+def test_anchor_runs_are_the_anchor_list_run_length_coded():
+    """cpecan_anchor_runs_from_alignment (what the realign front end now hands the batch, cpecan_batch_add_many_runs) gives
+    the runs of the list convertPairwiseForwardStrandAlignmentToAnchorPairs + the exact-match filter give
+    (pairwiseAligner.c:979-1003, cPecanRealign.c:277-281, :525-529): expanded again, the same anchors in the same order."""
+    import numpy as np
+    rng = random.Random(808)
+    for trial in range(60):
+        ops = _random_ops(rng, rng.randrange(1, 14))
+        lx = sum(n for t, n in ops if t != IY)
+        ly = sum(n for t, n in ops if t != DX)
+        sx = "".join(rng.choice("ACGTNacgt") for _ in range(lx))
+        # Y: X's bases along the match columns with some substitutions, random bases in its own insertions
+        sy, x = [], 0
+        for t, n in ops:
+            if t == M:
+                sy += [c if rng.random() < 0.8 else rng.choice("ACGT") for c in sx[x:x + n]]
+            elif t == IY:
+                sy += [rng.choice("ACGT") for _ in range(n)]
+            if t != IY:
+                x += n
+        sy = "".join(sy)
+        assert len(sy) == ly
+        for trim in (0, 1, 3):
+            for filt in (False, True):
+                a = api.convertPairwiseForwardStrandAlignmentToAnchorPairs(ops, 0, 0, trim, 4, sx if filt else None, sy if filt else None)
+                runs = api.anchor_runs_from_alignment(ops, 0, 0, trim, 4, sx if filt else None, sy if filt else None)
+                assert np.array_equal(runs, api.anchor_runs(a))
+                back = [(x0 + i, y0 + i, e) for x0, y0, n, e in runs.tolist() for i in range(n)]
+                assert back == [tuple(t) for t in a.tolist()]
+                for (x0, y0, n, e), (x1, y1, n1, e1) in zip(runs.tolist(), runs.tolist()[1:]):
+                    assert (x1, y1) != (x0 + n, y0 + n)  # maximal: two runs never abut on one diagonal

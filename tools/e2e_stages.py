@@ -12,7 +12,9 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else cfg["n_pairs"]
 torch.zeros(1, device="cuda"); torch.cuda.synchronize()
 sm, p, _ = bench.model_and_params(api, cfg)
 probs = workload.config_problems(name, range(n))
-arr, cnt, keep = api.Batch.prepare_problems(probs)
+# E2E_TRIPLES=1: the anchors of the realign configuration as one triple per column (round 3) instead of as runs
+as_runs = bool(cfg.get("realign")) and os.environ.get("E2E_TRIPLES") != "1"
+arr, cnt, keep = (api.Batch.prepare_problems_runs if as_runs else api.Batch.prepare_problems)(probs)
 T = time.perf_counter
 
 
