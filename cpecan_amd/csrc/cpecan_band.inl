@@ -55,16 +55,9 @@ CPK_HD int cpk_band_init(CpkBandIter *it, const cpk_anchor_t *anchors, int strid
     return 0;
 }
 
-/* Diagonal d = 0, 1, ..., lX+lY in order: *xmyL / *xmyR receive its inclusive x-y range.  Returns 0, or -1 when the
- * anchors do not describe a valid band (diagonal_construct would throw, pairwiseAligner.c:31; asserts :159-166). */
-CPK_HD int cpk_band_next(CpkBandIter *it, int64_t d, int64_t *xmyL, int64_t *xmyR) {
-    const int64_t a = it->xLo > d - it->yHi ? it->xLo : d - it->yHi;
-    const int64_t b = it->xHi < d - it->yLo ? it->xHi : d - it->yLo;
-    if (a > b) return -1;
-    *xmyL = 2 * a - d;
-    *xmyR = 2 * b - d;
-    if (it->qSum != d) return 0;
-    /* the anchor's own diagonal has been emitted: move on to the next interval */
+/* The next anchor's own diagonal has been emitted: the iterator moves on to the interval behind it.  Returns 0, or -1
+ * for anchors that do not describe a valid band. */
+CPK_HD int cpk_band_advance(CpkBandIter *it) {
     it->pX = it->qX;
     it->pY = it->qY;
     it->qX = it->lX;
@@ -84,6 +77,28 @@ CPK_HD int cpk_band_next(CpkBandIter *it, int64_t d, int64_t *xmyL, int64_t *xmy
     it->xHi = cpk_clamp(it->qX + it->e / 2, it->lX);
     it->yLo = cpk_clamp(it->pY - it->e / 2, it->lY);
     return 0;
+}
+
+/* Inside a run of diagonal-neighbour anchors -- the interval (X, Y) -> (X + 1, Y + 1), its rectangle clear of the matrix
+ * edges -- the band holds exactly two diagonals: x-y in [X-Y-E-1, X-Y+E+1] (E + 2 cells), then [X-Y-E, X-Y+E] (E + 1
+ * cells); cpk_band_next gives the same (planning and the device's table builder skip its arithmetic there).  True when
+ * the iterator stands in front of the first diagonal d of such an interval. */
+CPK_HD int cpk_band_in_run(const CpkBandIter *it, int64_t d) {
+    const int64_t h = it->e / 2;
+    return !it->dynamic && it->used >= 2 && d == it->pX + it->pY + 1 && it->qX == it->pX + 1 && it->qY == it->pY + 1 &&
+           it->pX - h >= 0 && it->pY - h >= 0 && it->qX + h <= it->lX && it->qY + h <= it->lY;
+}
+
+/* Diagonal d = 0, 1, ..., lX+lY in order: *xmyL / *xmyR receive its inclusive x-y range.  Returns 0, or -1 when the
+ * anchors do not describe a valid band (diagonal_construct would throw, pairwiseAligner.c:31; asserts :159-166). */
+CPK_HD int cpk_band_next(CpkBandIter *it, int64_t d, int64_t *xmyL, int64_t *xmyR) {
+    const int64_t a = it->xLo > d - it->yHi ? it->xLo : d - it->yHi;
+    const int64_t b = it->xHi < d - it->yLo ? it->xHi : d - it->yLo;
+    if (a > b) return -1;
+    *xmyL = 2 * a - d;
+    *xmyR = 2 * b - d;
+    if (it->qSum != d) return 0;
+    return cpk_band_advance(it); /* the anchor's own diagonal has been emitted: move on to the next interval */
 }
 
 #endif

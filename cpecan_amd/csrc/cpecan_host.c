@@ -1150,7 +1150,7 @@ int cpecan_batch_upload(cpecan_batch *b) {
             const int64_t E = p->diagonalExpansion, hE = E / 2;
             const int fastOk = fastWalk && !dynamic && E >= 2 && b->anchorStride == 2;
             for (int64_t d = 0; d <= N && !bad; d++, slot = slot + 1 == K ? 0 : slot + 1) {
-                if (fastOk && it.used >= 2 && d == it.pX + it.pY + 1 && it.qX == it.pX + 1 && it.qY == it.pY + 1) {
+                if (fastOk && cpk_band_in_run(&it, d)) {
                     /* in the interval (A_j -> A_j+1) of a run, j = used - 2, about to emit its first diagonal */
                     const int64_t j = it.used - 2;
                     int64_t sMax = (tracedBackTo + minBetween - (K + 1) - d) / 2; /* every skipped diagonal stays K + 1 below the next traceback point */

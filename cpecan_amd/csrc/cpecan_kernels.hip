@@ -366,10 +366,15 @@ static void *host_alloc_impl(size_t bytes, bool mustPin) {
     if (bytes < kHostPoolMin && !mustPin) return malloc(bytes ? bytes : 1);
     bytes = (bytes + ((size_t)2 << 20) - 1) / ((size_t)2 << 20) * ((size_t)2 << 20);
     {
-        std::lock_guard<std::mutex> lock(g_hostMutex);
+        std::unique_lock<std::mutex> lock(g_hostMutex);
         int best = -1;
+        // a block serves requests of its own size and up to a quarter less (round 4; rounds 1-3: down to half).  The wide
+        // window let the arrays of a batch trade places -- a 480 MB anchor request took the idle 890 MB result block of
+        // another batch, whose next result request then found nothing and mapped a fresh, unpinned block -- so a pipeline
+        // of BASELINE config-4 batches kept meeting blocks in their first life (a pageable 890 MB copy: 200 ms) and their
+        // second (pinning: 180 ms) long after its first batches.
         for (int i = 0; i < (int)g_hostIdle.size(); i++)
-            if (g_hostIdle[i].bytes >= bytes && g_hostIdle[i].bytes <= 2 * bytes + ((size_t)8 << 20) &&
+            if (g_hostIdle[i].bytes >= bytes && g_hostIdle[i].bytes <= bytes + bytes / 4 + ((size_t)8 << 20) &&
                 // kernels store through the HOST pointer of a mustPin block: only hipHostMalloc'ed memory is guaranteed to
                 // map at the same device address; a range pinned later by hipHostRegister is not (no hipHostGetDevicePointer
                 // is ever asked for), so such blocks never serve a mustPin request
@@ -382,8 +387,18 @@ static void *host_alloc_impl(size_t bytes, bool mustPin) {
             g_hostIdle.pop_back();
             g_hostIdleBytes -= b.bytes;
             if (!b.pinned && host_pinning_enabled()) {  // a second life: worth pinning now (its pages are resident)
-                if (hipHostRegister(b.ptr, b.bytes, hipHostRegisterPortable) == hipSuccess) b.pinned = b.registered = true;
+                // (outside the lock: 0.2 ms per MB, and the other threads of a pipeline -- the batches' download helpers,
+                // the caller packing the next batch -- allocate and free all the time; the block is in neither list meanwhile)
+                lock.unlock();
+                const auto t0 = std::chrono::steady_clock::now();
+                const hipError_t e = hipHostRegister(b.ptr, b.bytes, hipHostRegisterPortable);
+                if (e == hipSuccess) b.pinned = b.registered = true;
                 else (void)hipGetLastError();
+                if (trace_alloc() && b.bytes >= ((size_t)64 << 20))
+                    fprintf(stderr, "[cpecan] hipHostRegister %.1f MB: %.3f ms%s\n", b.bytes / 1048576.0,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(),
+                            e == hipSuccess ? "" : " FAILED");
+                lock.lock();
             }
             g_hostLive.push_back(b);
             return b.ptr;
@@ -398,6 +413,7 @@ static void *host_alloc_impl(size_t bytes, bool mustPin) {
         }
     }
     if (!b.ptr && (mustPin || (b.ptr = host_map(bytes)) == nullptr)) return nullptr;
+    if (trace_alloc() && bytes >= ((size_t)64 << 20)) fprintf(stderr, "[cpecan] new host block %.1f MB%s\n", bytes / 1048576.0, mustPin ? " (pinned)" : "");
     std::lock_guard<std::mutex> lock(g_hostMutex);
     g_hostLive.push_back(b);
     return b.ptr;
@@ -706,7 +722,17 @@ static int shell_init(CpkDevice *d, int device) {
     HIP_TRY(hipEventCreate(&d->evB));
     HIP_TRY(hipEventCreate(&d->evUp0));
     HIP_TRY(hipEventCreate(&d->evUp1));
-    HIP_TRY(hipStreamCreateWithFlags(&d->io, hipStreamNonBlocking));
+    {
+        // The batch's own stream (copies, the table build, gather and consumers) has the high priority: its small kernels
+        // then take the wave slots a draining sweep of ANOTHER batch gives back before that sweep's own queued workgroups
+        // do -- the table build of batch k + 1 runs beside the tail of sweep k instead of behind it (CPECAN_IO_PRIORITY=0:
+        // the default priority, as rounds 1-3).
+        int prLow = 0, prHigh = 0;
+        HIP_TRY(hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
+        const char *env = getenv("CPECAN_IO_PRIORITY");
+        if (env && atoi(env) == 0) prHigh = 0;
+        HIP_TRY(hipStreamCreateWithPriority(&d->io, hipStreamNonBlocking, prHigh));
+    }
     // The side streams of a multi-class batch are created when a batch first needs them (cpk_device_run): the runtime
     // maps streams onto a handful of hardware queues (4 by default), and ten idle streams per shell put a batch's sweep
     // into the same hardware queue as another batch's copies -- a pipeline of batches then ran its sweeps ~100 ms late
@@ -1520,11 +1546,12 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         if (nAnchors > 0)
             if (int rc = staged_h2d(d, dAnchors, anchors, sizeof(cpk_anchor_t) * (size_t)anchorStride * (size_t)nAnchors, &stageAt)) return rc;
         if (int rc = staged_h2d(d, d->dSegs, segs, sizeof(CpkSegment) * (size_t)nSegs, &stageAt)) return rc;  // the builder reads the schedule
+        // (the symbols and the model go first: nothing but the table build is then between the last copy and the sweep)
+        if (int rc = staged_h2d(d, d->dSymbols, symbols, (size_t)nSymbolBytes, &stageAt)) return rc;
+        if (int rc = staged_h2d(d, d->dModel, model, sizeof(CpkModel), &stageAt)) return rc;
         hipLaunchKernelGGL(cpecan_build_diag_table, dim3((unsigned)((geo->nRegions + 63) / 64)), dim3(64), 0, io,
                            d->dRegions, geo->nRegions, dAnchors, anchorStride, d->dSegs, geo->nStates, d->dDiags, d->dDiagPos, expansion, dynamic);
         HIP_TRY(hipGetLastError());
-        if (int rc = staged_h2d(d, d->dSymbols, symbols, (size_t)nSymbolBytes, &stageAt)) return rc;
-        if (int rc = staged_h2d(d, d->dModel, model, sizeof(CpkModel), &stageAt)) return rc;
         HIP_TRY(hipEventRecord(d->evUp1, io));
     }
     d->uploadTimed = false;
@@ -1641,7 +1668,18 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
         }
         const bool onCaller = i == nClasses - 1;
         if (!onCaller && !d->sideStream[i]) {
-            HIP_TRY(hipStreamCreateWithFlags(&d->sideStream[i], hipStreamNonBlocking));
+            // A priority of its own: the runtime maps the streams of one priority onto a handful of hardware queues, and a
+            // pipeline of batches has more streams alive than that -- a side stream that shares its hardware queue with
+            // the caller's stream runs its class BEHIND the caller's instead of beside it (BASELINE config 4, two narrow
+            // classes: 45 ms per batch instead of 28 whenever that happened, profiles/r04_config4_pipeline.txt).  The
+            // queues of the high priority hold nothing but these side streams.
+            {
+                int prLow = 0, prHigh = 0;
+                HIP_TRY(hipDeviceGetStreamPriorityRange(&prLow, &prHigh));
+                const char *env = getenv("CPECAN_SIDE_PRIORITY");  // 0: the default priority, as rounds 1-3 (A/B runs)
+                if (env && atoi(env) == 0) prHigh = 0;
+                HIP_TRY(hipStreamCreateWithPriority(&d->sideStream[i], hipStreamNonBlocking, prHigh));
+            }
             HIP_TRY(hipEventCreateWithFlags(&d->sideDone[i], hipEventDisableTiming));
         }
         hipStream_t cs = onCaller ? st : d->sideStream[i];

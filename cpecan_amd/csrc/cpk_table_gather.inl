@@ -73,12 +73,9 @@ __global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *r
     const CpkSegment *sg = segs + rg.segOff;
     int emitSeg = 0, covSeg = 0;
     int emitFrom = rg.nSeg > 0 ? sg[0].tbFrom : 0, covTop = rg.nSeg > 0 ? sg[0].dTop : 0;
-    for (int64_t d = 0; d <= N; d++) {
-        int64_t lo = 0, hi = 0;
-        cpk_band_next(&it, d, &lo, &hi);
-        const int32_t w = (int32_t)((hi - lo) / 2 + 1);
+    auto put = [&](int64_t d, int32_t lo, int32_t w) {
         CpkDiag e;
-        e.xmyL = (int32_t)lo;
+        e.xmyL = lo;
         e.width = w;
         e.cellOff = cells;
         if (rg.split) {
@@ -97,6 +94,70 @@ __global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *r
         }
         table[d] = e;
         cells += w;
+    };
+    const int32_t E = (int32_t)expansion;
+    // The walk is a chain of dependent anchor loads -- every interval of the band starts with the next anchor, and with an
+    // anchor per matching column (realign-style input) that is every other diagonal: ~1 us each, 9 ms for the longest
+    // region of BASELINE config 4, between the sweeps of a pipeline of batches.  So the anchors are requested kAhead
+    // intervals ahead and handed to the iterator from registers.
+    constexpr int kAhead = 8;
+    int32_t ax[kAhead], ay[kAhead];  // anchors it.used .. it.used + kAhead - 1 (clamped to the last one)
+    const cpk_anchor_t *ra = anchors + (size_t)anchorStride * rg.anchorOff;
+    const int64_t nA = rg.nAnchors;
+    const bool queued = !dynamic && anchorStride == 2 && nA > 0;
+    if (queued) {
+#pragma unroll
+        for (int q = 0; q < kAhead; q++) {
+            const int64_t at = q < nA ? q : nA - 1;
+            ax[q] = ra[2 * at];
+            ay[q] = ra[2 * at + 1];
+        }
+    }
+    // cpk_band_advance with the next anchor taken from the queue
+    auto advance = [&]() {
+        if (!queued) return cpk_band_advance(&it);
+        it.pX = it.qX;
+        it.pY = it.qY;
+        it.qX = it.lX;
+        it.qY = it.lY;
+        if (it.used < it.n) {
+            it.qX = (int64_t)ax[0] + 1;
+            it.qY = (int64_t)ay[0] + 1;
+            it.used++;
+#pragma unroll
+            for (int q = 0; q + 1 < kAhead; q++) {
+                ax[q] = ax[q + 1];
+                ay[q] = ay[q + 1];
+            }
+            const int64_t at = it.used + kAhead - 1 < nA ? it.used + kAhead - 1 : nA - 1;
+            ax[kAhead - 1] = ra[2 * at];
+            ay[kAhead - 1] = ra[2 * at + 1];
+        }
+        it.qSum = it.qX + it.qY;
+        const int64_t h = it.e / 2;
+        it.xLo = cpk_clamp(it.pX - h, it.lX);
+        it.yHi = cpk_clamp(it.qY + h, it.lY);
+        it.xHi = cpk_clamp(it.qX + h, it.lX);
+        it.yLo = cpk_clamp(it.pY - h, it.lY);
+        return 0;
+    };
+    for (int64_t d = 0; d <= N;) {
+        // Between two anchors of a run of diagonal neighbours the two diagonals are known without the rectangle arithmetic
+        // (cpk_band_in_run): a region of BASELINE config 4 is such runs nearly everywhere.
+        if (cpk_band_in_run(&it, d)) {
+            const int32_t xmy0 = (int32_t)(it.pX - it.pY);
+            put(d, xmy0 - E - 1, E + 2);
+            put(d + 1, xmy0 - E, E + 1);
+            advance();
+            d += 2;
+            continue;
+        }
+        // cpk_band_next, with the iterator's advance from the queue
+        const int64_t a2 = it.xLo > d - it.yHi ? it.xLo : d - it.yHi;
+        const int64_t b2 = it.xHi < d - it.yLo ? it.xHi : d - it.yLo;
+        put(d, (int32_t)(2 * a2 - d), (int32_t)(b2 - a2 + 1));
+        if (it.qSum == d) advance();
+        d++;
     }
     if (!dpos || dynamic) return;
     // the position chains of the absolute-position sweeps (see above); the entries just written are read back
