@@ -94,7 +94,29 @@ constexpr int kCubicDoubles = 24;  // 5 rows of {c3, c2, c1, c0}, padded
 #else
 constexpr int kCubicDoubles = 64;  // 16 x {c3, c2}, then 16 x {c1 - 1, c0}
 #endif
+#ifndef CPK_LOGADD_OMOD
+#define CPK_LOGADD_OMOD 0
+#endif
+// CPK_LOGADD_OMOD=1 (round 4; built, measured and NOT shipped -- tools/ab_build.sh omod -DCPK_LOGADD_OMOD=1): nine vector
+// instructions per logAdd instead of ten, for 0.7 % at BASELINE config B (forward launch 35.0 -> 35.1 ms, traceback launch
+// 48.2 -> 47.4), 0.9 % at config 5 and 1.5 % at config A (profiles/r04_ab_logadd_omod.txt) -- the forward group lost 12 of
+// its 187 instructions and ran no faster: the sweeps are not bound by the number of vector instructions -- against a
+// floating-point mode that differs from the reference's for every kernel.  How it works:
+// The bucket of a logAdd is floor(2 dc) and the doubling is an instruction of its own (v_add_f64 dc, dc).  v_min_f64 can deliver 2 * min(|x - y|, 7.75) by itself through the VOP3
+// output modifier (mul:2) -- which the hardware honours only with MODE.IEEE = 0 and the f64 denormals flushed
+// (tools/omod_check.hip: ignored otherwise) -- and Horner runs on u = 2 dc with the coefficients scaled by exact powers of
+// two (c3 / 8, c2 / 4, (c1 - 1) / 2, c0): every intermediate is the old one times 1/4, 1/2, 1, bit for bit.  Nine vector
+// instructions per logAdd instead of ten.  What the mode change costs: signalling NaNs are not quieted (there are none),
+// and an f64 result below 2.2e-308 becomes zero -- log-space values never are, and a posterior that small is far below
+// any threshold (floor(p * 1e7) is 0 either way).  Every kernel that calls logadd sets the mode through fill_cubics().
+__device__ __forceinline__ void logadd_fp_mode() {
+#if CPK_LOGADD_OMOD
+    __builtin_amdgcn_s_setreg((0 << 11) | (9 << 6) | 1, 0);  // hwreg(HW_REG_MODE, 9, 1): IEEE off
+    __builtin_amdgcn_s_setreg((1 << 11) | (6 << 6) | 1, 0);  // hwreg(HW_REG_MODE, 6, 2): f64 / f16 denormals flushed
+#endif
+}
 __device__ __forceinline__ void fill_cubics(double *t) {
+    logadd_fp_mode();
     const float c[16] = {-0.009350833524763f, 0.130659527668286f, 0.498799810682272f, 0.693203116424741f,
                          -0.014532321752540f, 0.139942324101744f, 0.495635523139337f, 0.692140569840976f,
                          -0.004605031767994f, 0.063427417320019f, 0.695956496475118f, 0.514272634594009f,
@@ -115,6 +137,7 @@ __device__ __forceinline__ void fill_cubics(double *t) {
         for (int i = 1; i < 16; i++) v = idx == i ? c[i] : v;
         double w = seg >= 4 ? 0.0 : (double)v;
         if (!CPK_LOGADD_EXACT && seg < 4 && coef == 2) w = w - 1.0;  // Q(d) = P(d) - d
+        if (CPK_LOGADD_OMOD) w *= coef == 0 ? 0.125 : (coef == 1 ? 0.25 : (coef == 2 ? 0.5 : 1.0));  // Horner on u = 2 dc
         t[l] = w;
     }
 }
@@ -155,8 +178,20 @@ constexpr double kLogAddClamp = 7.75;  // any value in [7.5, 8): the last bucket
 struct __attribute__((aligned(16))) CubicHalf {
     double a, b;
 };
+#if CPK_LOGADD_OMOD
+// u = 2 * min(|d|, 7.75) in one instruction (see logadd_fp_mode); NaN (-inf - -inf) and +inf give 15.5, the all-zero bucket
+__device__ __forceinline__ double logadd_arg(double d) {
+    double u;
+    asm("v_min_f64 %0, |%1|, %2 mul:2" : "=v"(u) : "v"(d), "s"(kLogAddClamp));
+    return u;
+}
+__device__ __forceinline__ Cubic cubic_fetch(const Cubic *tab, double u) {
+    const unsigned bucket = (unsigned)u;  // v_cvt_u32_f64
+#else
+__device__ __forceinline__ double logadd_arg(double d) { return __builtin_fmin(__builtin_fabs(d), kLogAddClamp); }
 __device__ __forceinline__ Cubic cubic_fetch(const Cubic *tab, double dc) {
     const unsigned bucket = (unsigned)(dc * 2.0);  // v_mul_f64, v_cvt_u32_f64: exact (truncation of an exact product)
+#endif
     const CubicHalf *t = reinterpret_cast<const CubicHalf *>(tab);
     const CubicHalf h = t[bucket], l = t[16 + bucket];
     return Cubic{h.a, h.b, l.a, l.b};
@@ -164,7 +199,7 @@ __device__ __forceinline__ Cubic cubic_fetch(const Cubic *tab, double dc) {
 
 __device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
     const double hi = __builtin_fmax(x, y);
-    const double dc = __builtin_fmin(__builtin_fabs(x - y), kLogAddClamp);
+    const double dc = logadd_arg(x - y);
     const Cubic q = cubic_fetch(tab, dc);
     double r = __builtin_fma(q.c3, dc, q.c2);
     r = __builtin_fma(r, dc, q.c1);
@@ -249,7 +284,7 @@ __device__ __forceinline__ void logadd_n(const Cubic *tab, double (&acc)[N], con
 #pragma unroll
     for (int i = 0; i < N; i++) {
         hi[i] = __builtin_fmax(acc[i], t[i]);
-        dc[i] = __builtin_fmin(__builtin_fabs(acc[i] - t[i]), kLogAddClamp);
+        dc[i] = logadd_arg(acc[i] - t[i]);
     }
 #pragma unroll
     for (int i = 0; i < N; i++) q[i] = cubic_fetch(tab, dc[i]);

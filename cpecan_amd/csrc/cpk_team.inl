@@ -30,6 +30,7 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
     const int stride = a.geo.rollStride;
 
     // LDS (doubles): logAdd cubics | emissions | weights | exchange area | rolling rows | symbol strings
+    logadd_fp_mode();  // (every wave: fill_cubics below sets it for the one wave that fills the table)
     if (wave == 0) {
         fill_cubics(lds);
         fill_weights<S>(lds + kLdsCubics + kLdsEm, m, a.kc, lane);
