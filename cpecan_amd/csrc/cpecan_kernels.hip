@@ -879,8 +879,10 @@ static KernelFn pick_packed_kernel(const CpkGeometry &g, int cls, bool dynamic) 
             case 2: return five ? cpecan_pairhmm_packed<5, 32, (E), (D)> : cpecan_pairhmm_packed<3, 32, (E), (D)>;          \
         }
     CPK_PICK_PACKED(CPECAN_EMIT_MATCH, false)
+    CPK_PICK_PACKED(CPECAN_EMIT_INDEL, false)
     CPK_PICK_PACKED(CPECAN_EMIT_EXPECT, false)
     CPK_PICK_PACKED(CPECAN_EMIT_MATCH, true)  // per-anchor expansions
+    CPK_PICK_PACKED(CPECAN_EMIT_INDEL, true)
     CPK_PICK_PACKED(CPECAN_EMIT_EXPECT, true)
 #undef CPK_PICK_PACKED
     return nullptr;
@@ -899,10 +901,13 @@ static int64_t split_ring_doubles(const CpkRegion &rg, int S) {
     return ((int64_t)rg.cells + (N + 1) + (int64_t)(S - 1) * rg.maxWidth * fullDiags + S + 1) & ~(int64_t)1;
 }
 // dense: the three-state match kernels allocated for three waves per SIMD (cpk_sweep.inl, WPS)
-static KernelFn pick_fused_kernel(const CpkGeometry &g, bool dense, bool abs) {
+static KernelFn pick_fused_kernel(const CpkGeometry &g, bool dense, bool abs, bool three = false) {
     const bool fast = !g.useGlobalRoll;
     if (abs && fast) {
-        if (g.nStates == 5) return cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeFused, CPK_SWEEP_WAVES, true>;
+        // three (round 4): built for three waves per SIMD, for classes whose LDS lets nine or more waves onto a CU
+        if (g.nStates == 5)
+            return three ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeFused, 3, true>
+                         : cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeFused, CPK_SWEEP_WAVES, true>;
         return dense ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeFused, 3, true>
                      : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeFused, CPK_SWEEP_WAVES, true>;
     }
@@ -1083,7 +1088,9 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         c.candEl = c.geo.fbCells;
         c.refEl = c.geo.refreshCells;
         c.totEl = c.geo.maxRefresh;
-        c.bringEl = expect ? c.geo.fbCells * S : 0;
+        // B of a segment's emitted cells: the expectation step's second pass, the indel emitter's list pass (cpk_packed.inl)
+        c.bringEl = (expect || geo->emit == CPECAN_EMIT_INDEL) ? c.geo.fbCells * S : 0;
+        if (geo->emit == CPECAN_EMIT_INDEL) c.candEl = 0;  // no candidates
         d->classes.push_back(c);
     }
     // The LDS of one wave of the class: tables, rolling rows, candidate stage, symbols -- by the form of its sweeps.
@@ -1251,7 +1258,8 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             // the overlap is down to the seam between the two phases, and the launches' plain ring stores win against
             // the one launch's write-through ones (2 kb pairs, band 100: 5000 / 6500 / 8000 pairs -8 / -8 / -2 % for the one
             // launch, 10 000 pairs -- config B -- +1.7 %: 89.3 against 87.6 ms, and 90.2 against 87.3 ms per pipelined batch)
-            const bool oneLaunch = nSegClass * 2 >= n * 7 /* 3.5 segments per region and more */ && n * 2 < slots * 9;
+            // (round 4, both forms at ten waves per CU: 5000 pairs -3 % for the one launch, 7000 pairs +3 %: ~3.25 rounds)
+            const bool oneLaunch = nSegClass * 2 >= n * 7 /* 3.5 segments per region and more */ && n * 4 < slots * 13;
             if (eligible && wanted) {
                 c.split = true;
                 // CPECAN_SPLIT=2 / 1: force the one-launch (kModeFused) / two-launch form
@@ -1264,13 +1272,26 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                     const char *spinEnv = getenv("CPECAN_FUSED_SPIN");
                     c.geo.fusedSpin = spinEnv ? atoi(spinEnv) : (1 << 24);
                     c.fn = pick_fused_kernel(c.geo, c.dense, c.abs);
+                    int64_t slotsF = slots;
+                    {
+                        const char *t3e = getenv("CPECAN_FUSED3");  // 0: never the three-waves-per-SIMD build
+                        if (c.abs && S == 5 && !(t3e && atoi(t3e) == 0) && (160 * 1024) / c.ldsBytes >= 9) {
+                            KernelFn f3 = pick_fused_kernel(c.geo, c.dense, c.abs, true);
+                            int p3 = 0;
+                            if (int rc = wavesPerCU(f3, c.ldsBytes, &p3)) return rc;
+                            if (p3 > perCU) {
+                                c.fn = f3;
+                                slotsF = (int64_t)p3 * d->numCUs;
+                            }
+                        }
+                    }
                     // One CU in eight keeps a wave slot (and its 19 KB of LDS) free: a launch that fills every slot to its
                     // end starves the small kernels of the batch before it -- the list consumers need a few KB of LDS --
                     // until it drains, and a pipeline two batches deep then idles between sweeps (82 ms measured).
                     // ... so the slots are left free when another batch of this process has run on the device and is still
                     // alive; a batch on its own takes them all (config B: 90.3 -> 89.5 ms).
                     const int64_t spare = (d->device >= 0 && d->device < kMaxDevices && g_ranAlive[d->device] > 0) ? d->numCUs / 8 : 0;
-                    const int64_t room = slots - spare > 0 ? slots - spare : slots;
+                    const int64_t room = slotsF - spare > 0 ? slotsF - spare : slotsF;
                     int64_t wt = room < n + nSegClass ? room : n + nSegClass;
                     c.waves = (int)wt;
                     c.subSlots = wt;
@@ -1445,7 +1466,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         if (int rc = dev_alloc(d, &d->dTotals, (size_t)oTot)) return rc;
         if (oGroll > 0)
             if (int rc = dev_alloc(d, &d->dGroll, (size_t)oGroll)) return rc;
-        if (expect)
+        if (oBring > 0)
             if (int rc = dev_alloc(d, &d->dBring, (size_t)oBring)) return rc;
         if (int rc = dev_alloc(d, &d->dExpect, (size_t)(oExpect > 0 ? oExpect : 128))) return rc;
     }

@@ -11,7 +11,7 @@
 // phases -- forward sweep of segment i, traceback of segment i, totals, emission -- each over its own diagonals; a
 // group that has nothing to do in a phase idles (regions are handed out sorted by size, so neighbours are alike).
 // Arithmetic: the sweep kernel's own cell functions (fwdCellsSym / bwdCellsSym), same order, bit-identical results.
-// Match and expectation emitters; symbols are staged per chunk of 64 diagonals into two LDS windows (one byte per symbol).
+// Match, indel and expectation emitters; symbols are staged per chunk of 64 diagonals into two LDS windows (one byte per symbol).
 // ------------------------------------------------------------------------------------------------
 template <int GW>
 __device__ __forceinline__ float group_max_f32(float v) {
@@ -54,6 +54,14 @@ cpecan_pairhmm_packed(const KArgs a) {
     double *wt = lds + kLdsCubics + kLdsEm;
     fill_weights<S>(wt, m, a.kc, lane);
     constexpr bool kExpect = EMIT == CPECAN_EMIT_EXPECT;
+    // Indel emitter (round 4; diagonalCalculationPosteriorProbs, pairwiseAligner.c:691-733): three lists -- match, gapX,
+    // gapY -- of one segment.  Round 3 built it with three candidate lists live in the traceback: 55 spilled registers,
+    // not kept.  Here the traceback parks B of the emitted cells in global memory, as it does for the expectation step,
+    // and a pass of its own behind the totals forms the three posteriors of every emitted cell from the ring and those
+    // values, diagonal by diagonal in the lists' order: no candidates, nothing more alive in the traceback.
+    constexpr bool kIndel = EMIT == CPECAN_EMIT_INDEL;
+    constexpr bool kKeepB = kExpect || kIndel;
+    constexpr int NL = kIndel ? 3 : 1;
     double *eLds = lds + kLdsCubics + kLdsEm + kLdsWeights;  // expectation emitter: emission sums of this wave, four copies
     if (kExpect)
         for (int i = lane; i < kExpectCopies * 80; i += CPK_WAVE) eLds[i] = 0.0;
@@ -76,6 +84,7 @@ cpecan_pairhmm_packed(const KArgs a) {
     using SW = Sweep<S, false>;
     const unsigned long long groupBits = (GW == 64 ? ~0ull : ((1ull << GW) - 1ull)) << (g * GW);
     const unsigned long long belowMe = groupBits & ((1ull << lane) - 1ull);
+    const unsigned long long aboveMe = groupBits & ~((2ull << lane) - 1ull);  // (2 << 63 wraps to 0: nothing above lane 63)
     const float logThr = (float)log(a.kc.threshold);
     const double thr = a.kc.threshold;
 
@@ -96,9 +105,12 @@ cpecan_pairhmm_packed(const KArgs a) {
         Candidate *cand = a.cand + sub * (size_t)a.geo.fbCells;
         double *cbuf = a.cbuf + sub * (size_t)a.geo.refreshCells, *mbuf = a.mbuf + sub * (size_t)a.geo.refreshCells;
         double *totals = a.totals + sub * (size_t)a.geo.maxRefresh;
-        double *bring = kExpect ? a.bring + sub * (size_t)a.geo.fbCells * S : nullptr;  // B of the segment's emitted cells
+        double *bring = kKeepB ? a.bring + sub * (size_t)a.geo.fbCells * S : nullptr;  // B of the segment's emitted cells
         int32_t *out = a.triples + 3 * rg.outOff;
         int count = 0;
+        int countL[NL];  // indel emitter: triples of the region so far, per list
+#pragma unroll
+        for (int l = 0; l < NL; l++) countL[l] = 0;
 
         for (int i = c; i < kRowDoubles; i += GW) rows[i] = NEG_INF;  // position 0 stays the -inf guard
         auto fbuf1 = [&](int d) { return rows + R + (d & 1) * S; };
@@ -261,11 +273,11 @@ cpecan_pairhmm_packed(const KArgs a) {
                 if (pendMj >= 0) mbuf[(size_t)c * J + pendMj] = pendM;
                 if (pendCj >= 0) cbuf[(size_t)c * J + pendCj] = pendC;
                 pendMj = pendCj = -1;
-                if (!kExpect && __ballot(pend >= GW)) {
+                if (!kKeepB && __ballot(pend >= GW)) {
                     if (pend >= GW) flush(GW);
                 }
             };
-            const int bBase = (kExpect && segOn) ? table[sg.tbPrev + 1].cellOff : 0;
+            const int bBase = (kKeepB && segOn) ? table[sg.tbPrev + 1].cellOff : 0;
             int d2 = segOn ? sg.dTop : 0;
             CpkDiag eb{}, ea{};  // entries of d2+1, d2+2
             while (__ballot(segOn && d2 > sg.tbPrev)) {
@@ -370,12 +382,12 @@ cpecan_pairhmm_packed(const KArgs a) {
                         pendM = fbv;
                         pendMj = jrNext;
                     }
-                    if (kExpect && emit && on) {  // kept for the expectation step
+                    if (kKeepB && emit && on) {  // kept for the expectation step / the indel emitter's pass
                         double *bo = bring + (size_t)(e.cellOff - bBase + c) * S;
 #pragma unroll
                         for (int s = 0; s < S; s++) bo[s] = v[0][s];
                     }
-                    if (!kExpect) {
+                    if (!kKeepB) {
                         const float keepFrom = lastMax + logThr - kCandMargin;
                         const bool keep = on && emit && x > 0 && y > 0 && (float)fbv >= keepFrom;
                         const unsigned long long mask = __ballot(keep);
@@ -401,7 +413,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                                 t = logadd(lg, t, rf[s2] + v[0][s2]);
                             pendC = t;
                             pendCj = jr;
-                            if (!kExpect && x > 0 && y > 0) fbf = (float)fbv;
+                            if (!kKeepB && x > 0 && y > 0) fbf = (float)fbv;
                         }
                         const float diagMax = group_max_f32<GW>(fbf);
                         if (refresh) lastMax = fmaxf(diagMax, lastMax - 1.0f);
@@ -415,7 +427,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                 }
             }
             issueStores();
-            if (!kExpect && __ballot(pend > 0)) flush(pend);
+            if (!kKeepB && __ballot(pend > 0)) flush(pend);
             roll_fence<true>();  // candidate / cbuf / mbuf stores of the group's lanes are visible to each other
             // ---------------- totals at the refresh points (:636-653): lane c takes points c, c + GW, ... ----------------
             for (int j0 = 0; __ballot(segOn && j0 + c < J); j0 += GW) {
@@ -534,6 +546,55 @@ cpecan_pairhmm_packed(const KArgs a) {
                         if (act) e2d--;
                     }
                 }
+            } else if (kIndel) {
+                // ---------------- the three lists of the segment (:691-733): every emitted cell, diagonals ascending, x-y
+                // descending inside a diagonal (the reference appends in x-y ascending order and the lists are reversed
+                // on the way out, SURVEY 8b "list order") ----------------
+                if (segOn && c == 0) {
+#pragma unroll
+                    for (int l = 0; l < NL; l++) a.segStarts[(size_t)l * a.nSegsTotal + rg.segOff + si] = countL[l];
+                }
+                int ed = segOn ? sg.tbPrev + 1 : 0;
+                while (__ballot(segOn && ed <= sg.tbFrom)) {
+                    const bool more = segOn && ed <= sg.tbFrom;
+                    const int cnt = more ? (sg.tbFrom - ed + 1 < kPackChunk ? sg.tbFrom - ed + 1 : kPackChunk) : 0;
+                    int x0, y0;
+                    stage_chunk(more, ed, 1, cnt, 0, x0, y0);  // (the table entries; the symbol windows are not read)
+                    for (int i = 0; i < kPackChunk; i++) {
+                        if (!__ballot(i < cnt)) break;
+                        const bool act = i < cnt;
+                        const CpkDiag e = act ? unpack(ebuf[i]) : CpkDiag{0, 1, 0, 0};
+                        const int W = e.width;
+                        const bool on = act && c < W;
+                        const int kc = on ? c : 0;  // every load is unconditional: cell 0 of a valid diagonal
+                        const double total = ld_self(totals + (act ? (sg.tbFrom - ed) / CPK_REFRESH_PERIOD : 0));
+                        const double *fr = ringAt(e);
+                        const double *bo = bring + (size_t)(act ? e.cellOff - bBase + kc : 0) * S;
+                        double fbv[NL];
+#pragma unroll
+                        for (int l = 0; l < NL; l++) fbv[l] = ld_self(fr + SW::ringIdx(W, l, kc)) + ld_self(bo + l);
+                        const int x = ((ed + e.xmyL) >> 1) + kc, y = ed - x;
+#pragma unroll
+                        for (int l = 0; l < NL; l++) {
+                            const bool cell = l == 0 ? (x > 0 && y > 0) : (l == 1 ? x > 0 : y > 0);  // :700, :711, :722
+                            double p = (on && cell) ? exp(fbv[l] - total) : 0.0;
+                            const bool keep = on && cell && p >= thr;
+                            const unsigned long long mask = __ballot(keep);
+                            if (keep) {
+                                if (p > 1.0) p = 1.0;
+                                const int pos = countL[l] + __popcll(mask & aboveMe);
+                                if (pos < rg.outCap) {
+                                    int32_t *o = a.triples + 3 * ((size_t)l * a.outTriplesPerList + rg.outOff + pos);
+                                    o[0] = (int32_t)floor(p * (double)CPECAN_PROB_1);
+                                    o[1] = x - 1;
+                                    o[2] = y - 1;
+                                }
+                            }
+                            countL[l] += __popcll(mask & groupBits);
+                        }
+                        if (act) ed++;
+                    }
+                }
             } else {
             // ---------------- thresholded posteriors from the candidates, walked backwards (:655-689) ----------------
                 if (segOn && c == 0) a.segStarts[rg.segOff + si] = count;
@@ -594,7 +655,14 @@ cpecan_pairhmm_packed(const KArgs a) {
                 }
             }
         }
-        if (have && c == 0) a.outCounts[r] = count;
+        if (have && c == 0) {
+            if (kIndel) {
+#pragma unroll
+                for (int l = 0; l < NL; l++) a.outCounts[(size_t)l * a.geo.nRegions + r] = countL[l];
+            } else {
+                a.outCounts[r] = count;
+            }
+        }
     }
     if (kExpect) {
         // one partial result per wave, as in the sweep kernel: [0,25) transitions [from*S+to], [25,105) emissions, [105] likelihood

@@ -152,8 +152,13 @@ struct Sweep {
 #pragma unroll
         for (int q = 0; q < NC; q++) {
             const int x = c.xlo + k[q], y = c.d - x;
+#ifdef CPK_TIMING_NO_SYMBOLS  // timing experiment (tools/ab_build.sh): symbols from the lane number instead of LDS -- results invalid
+            cX[q] = (x + lane) & 3;
+            cY[q] = (y + 2 * lane) & 3;
+#else
             cX[q] = symX(x);
             cY[q] = symY(y);
+#endif
         }
         fwdCellsSym<NC>(c, cX, cY, kR, v);
     }

@@ -952,6 +952,66 @@ def test_packed_and_sweep_kernels_agree_bit_for_bit(monkeypatch):
             assert a.shape == b.shape and (a == b).all()
 
 
+def test_packed_kernel_indel_emitter(monkeypatch):
+    """the indel emitter (diagonalCalculationPosteriorProbs, pairwiseAligner.c:691-733 -- what
+    getShiftedMEAAlignment :1764-1790 needs) on narrow bands through the packed kernel: the traceback parks B of the emitted
+    cells and a pass behind the totals writes the three lists.  All three group widths, both model families, per-anchor
+    expansions, split rectangles, short schedules, a realign-style sample: list for list what one wave per region gives
+    (CPECAN_PACKED=0) -- bit for bit -- and what the oracle gives."""
+    from cpecan_amd.workload import make_realign_batch
+    rng = random.Random(321)
+    cases = []
+    for mtype, exp in ((0, 2), (2, 6), (1, 14), (3, 26)):
+        probs, raggeds = [], []
+        for _ in range(36):
+            sx = _rand_seq(rng, rng.randrange(1, 500))
+            sy = _evolve(rng, sx) or "C"
+            anchors, x, y = [], -1, -1
+            while True:
+                x += rng.randrange(1, 5)
+                y += rng.randrange(1, 5)
+                if x >= len(sx) or y >= len(sy):
+                    break
+                anchors.append((x, y, exp))
+            probs.append((sx, sy, anchors))
+            raggeds.append((rng.random() > 0.5, rng.random() > 0.5))
+        probs += [("A", "A", []), ("ACGTAC", "", []), ("", "GGT", [])]
+        raggeds += [(False, False), (False, True), (True, True)]
+        cases.append((mtype, probs, raggeds, dict(diagonalExpansion=exp, minDiagsBetweenTraceBack=rng.randrange(40, 200),
+                                                  traceBackDiagonals=rng.randrange(3, 30),
+                                                  splitMatrixBiggerThanThis=rng.choice([10, 50, 10 ** 12]))))
+    sample = make_realign_batch(4, 40, 100, 2500, 4)
+    cases.append((0, sample, [(True, True)] * len(sample), dict(diagonalExpansion=4, splitMatrixBiggerThanThis=10)))
+    dyn = [(sx, sy, [(x, y, 2 * ((x * 7 + y) % 9)) for x, y, _ in a]) for sx, sy, a in cases[0][1]]
+    cases.append((0, dyn, cases[0][2], dict(dynamicAnchorExpansion=1, minDiagsBetweenTraceBack=90, traceBackDiagonals=12)))
+
+    def run(mtype, probs, raggeds, pkw):
+        p = api.pairwiseAlignmentBandingParameters_construct(**pkw)
+        with api.Batch(_sm(mtype), p, emit=api.EMIT_INDEL) as b:
+            for (sx, sy, a), (rl, rr) in zip(probs, raggeds):
+                b.add(sx, sy, a, rl, rr)
+            b.upload()
+            b.run()
+            b.download()
+            return [[b.result(i, which).copy() for which in range(3)] for i in range(len(probs))], b.stats()
+
+    for mtype, probs, raggeds, pkw in cases:
+        monkeypatch.setenv("CPECAN_PACKED", "2")
+        packed, st_p = run(mtype, probs, raggeds, pkw)
+        monkeypatch.setenv("CPECAN_PACKED", "0")
+        sweep, st_s = run(mtype, probs, raggeds, pkw)
+        assert st_p.cells == st_s.cells and st_p.pairs == st_s.pairs
+        om, op = ob.model(mtype), ob.params(**pkw)
+        for i, (got, ref) in enumerate(zip(packed, sweep)):
+            for which in range(3):
+                assert got[which].shape == ref[which].shape and (got[which] == ref[which]).all(), (i, which)
+            if i % 5 == 0:
+                (sx, sy, a), (rl, rr) = probs[i], raggeds[i]
+                want = ob.aligned_pairs_with_indels(om, sx, sy, a, op, rl, rr)
+                for which in range(3):
+                    assert_pairs_match(got[which], want[which], threshold=op.threshold)
+
+
 def test_packed_kernel_degenerate_regions(force_packed):
     """One-base and one-sided problems, anchors on the very first / last base, through the packed kernel."""
     probs = [("A", "A", []), ("A", "ACGT", []), ("ACGTAC", "", []), ("", "GGT", []), ("ACGT", "ACGT", [(0, 0, 2), (3, 3, 2)]),
@@ -1083,7 +1143,7 @@ def test_one_launch_form_keeps_spare_slots_only_beside_a_live_batch(monkeypatch)
     monkeypatch.delenv("CPECAN_SPLIT", raising=False)
     gc.collect()  # batches that earlier tests left to the collector count as alive until they are destroyed
     cus = torch.cuda.get_device_properties(0).multi_processor_count
-    probs = [make_pair(4, i, 2000, 100) for i in range(420)]  # regions + segments > wave slots
+    probs = [make_pair(4, i, 2000, 100) for i in range(460)]  # regions + segments > wave slots (ten per CU since round 4)
     sm = api.stateMachine5_construct()
     p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=100)
     arr, cnt, keep = api.Batch.prepare_problems(probs)
