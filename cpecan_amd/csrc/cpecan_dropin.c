@@ -134,11 +134,58 @@ static double prior_ragged_end(StateMachine *sM, int64_t s) {
     }
     return 0.0;
 }
-static void cell_calculate_stub(StateMachine *sM, double *current, double *lower, double *middle, double *upper, Symbol cX,
-                                Symbol cY, void (*doTransition)(double *, double *, int64_t, int64_t, double, double, void *),
-                                void *extraArgs) {
-    (void)sM; (void)current; (void)lower; (void)middle; (void)upper; (void)cX; (void)cY; (void)doTransition; (void)extraArgs;
-    die("cpecan_hip: cellCalculate is evaluated on the GPU only (use getAlignedPairsUsingAnchors & co.)");
+/* sM->cellCalculate (inc/stateMachine.h:47-50; stateMachine5_cellCalculate impl/stateMachine.c:450-480,
+ * stateMachine3_cellCalculate :689-714): the ordered list of transitions into `current` handed to the CALLER's
+ * doTransition, one call per transition, blocks of absent neighbours skipped.  This is the vtable's contract and holds no
+ * arithmetic of the recurrence -- what a transition does (a logAdd fold forwards or backwards, an expectation update) is
+ * the callback's business; the library's own DP never comes through here (it runs on the GPU, and cell_calculateForward /
+ * Backward below evaluate the reference's two callbacks there).  A symbol outside a, c, g, t emits as n
+ * (emissions_getGapProb / getMatchProb, :351-366). */
+static void cell_calculate_dispatch(StateMachine *sM, double *current, double *lower, double *middle, double *upper, Symbol cX,
+                                    Symbol cY, void (*doTransition)(double *, double *, int64_t, int64_t, double, double, void *),
+                                    void *extraArgs) {
+    const cpecan_model *m = flat_or_die(sM);
+    const int x = (int)cX, y = (int)cY;
+    const int nX = x < 0 || x > 3, nY = y < 0 || y > 3;
+    const double eX = nX ? -1.386294361 : m->emissionGapX[x], eY = nY ? -1.386294361 : m->emissionGapY[y];
+    const double eM = (nX || nY) ? -2.772588722 : m->emissionMatch[x * 4 + y];
+    if (sM->stateNumber == 5) { /* 0 match, 1 shortGapX, 2 shortGapY, 3 longGapX, 4 longGapY */
+        if (lower) {
+            doTransition(lower, current, 0, 1, eX, m->gapShortOpenX, extraArgs);
+            doTransition(lower, current, 1, 1, eX, m->gapShortExtendX, extraArgs);
+            doTransition(lower, current, 0, 3, eX, m->gapLongOpenX, extraArgs);
+            doTransition(lower, current, 3, 3, eX, m->gapLongExtendX, extraArgs);
+        }
+        if (middle) {
+            doTransition(middle, current, 0, 0, eM, m->matchContinue, extraArgs);
+            doTransition(middle, current, 1, 0, eM, m->matchFromShortGapX, extraArgs);
+            doTransition(middle, current, 2, 0, eM, m->matchFromShortGapY, extraArgs);
+            doTransition(middle, current, 3, 0, eM, m->matchFromLongGapX, extraArgs);
+            doTransition(middle, current, 4, 0, eM, m->matchFromLongGapY, extraArgs);
+        }
+        if (upper) {
+            doTransition(upper, current, 0, 2, eY, m->gapShortOpenY, extraArgs);
+            doTransition(upper, current, 2, 2, eY, m->gapShortExtendY, extraArgs);
+            doTransition(upper, current, 0, 4, eY, m->gapLongOpenY, extraArgs);
+            doTransition(upper, current, 4, 4, eY, m->gapLongExtendY, extraArgs);
+        }
+        return;
+    }
+    if (lower) { /* 0 match, 1 gapX, 2 gapY */
+        doTransition(lower, current, 0, 1, eX, m->gapShortOpenX, extraArgs);
+        doTransition(lower, current, 1, 1, eX, m->gapShortExtendX, extraArgs);
+        doTransition(lower, current, 2, 1, eX, m->gapShortSwitchToX, extraArgs);
+    }
+    if (middle) {
+        doTransition(middle, current, 0, 0, eM, m->matchContinue, extraArgs);
+        doTransition(middle, current, 1, 0, eM, m->matchFromShortGapX, extraArgs);
+        doTransition(middle, current, 2, 0, eM, m->matchFromShortGapY, extraArgs);
+    }
+    if (upper) {
+        doTransition(upper, current, 0, 2, eY, m->gapShortOpenY, extraArgs);
+        doTransition(upper, current, 2, 2, eY, m->gapShortExtendY, extraArgs);
+        doTransition(upper, current, 1, 2, eY, m->gapShortSwitchToY, extraArgs);
+    }
 }
 static StateMachine *wrap_model(const cpecan_model *m) {
     OwnStateMachine *o = calloc(1, sizeof *o);
@@ -154,7 +201,7 @@ static StateMachine *wrap_model(const cpecan_model *m) {
     o->model.endStateProb = prior_end;
     o->model.raggedStartStateProb = prior_ragged_start;
     o->model.raggedEndStateProb = prior_ragged_end;
-    o->model.cellCalculate = cell_calculate_stub;
+    o->model.cellCalculate = cell_calculate_dispatch;
     return &o->model;
 }
 StateMachine *stateMachine5_construct(StateMachineType type) {

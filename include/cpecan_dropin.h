@@ -19,9 +19,11 @@
  * 186-237: DpDiagonal, DpMatrix, cell_calculateForward / Backward, cell_dotProduct[2], diagonalCalculationForward /
  * Backward / TotalProbability, the per-diagonal emitters on DpMatrix rows) ARE provided: the containers are host memory
  * with the reference's semantics, their DP arithmetic runs on the GPU (cpecan_ref_cells, one lane, the reference's order
- * of operations -- the library holds no CPU implementation of the recurrences).  sM->cellCalculate itself, which takes an
- * arbitrary per-transition callback, stays a stub that aborts; getPosteriorProbsWithBanding accepts the reference's three
- * emitters (recognised by address, see below) and refuses foreign callbacks.
+ * of operations -- the library holds no CPU implementation of the recurrences).  sM->cellCalculate, which takes an
+ * arbitrary per-transition callback, hands that callback the model's ordered transition list (states, emission and
+ * transition log-probabilities, absent neighbours skipped: impl/stateMachine.c:450-480, :689-714) -- the vtable's contract,
+ * no arithmetic of its own (round 4; it aborted before); getPosteriorProbsWithBanding accepts the reference's three
+ * emitters (recognised by address, see below) and refuses foreign diagonal callbacks.
  */
 #ifndef CPECAN_DROPIN_H_
 #define CPECAN_DROPIN_H_

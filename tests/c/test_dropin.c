@@ -629,6 +629,72 @@ static void test_splitting_wrapper_gpu(void) {
     stateMachine_destruct(sM);
 }
 
+/* sM->cellCalculate (inc/stateMachine.h:47-50): the vtable entry hands the ordered transition list of
+ * stateMachine5_cellCalculate / stateMachine3_cellCalculate (impl/stateMachine.c:450-480, :689-714) to the caller's
+ * callback.  (a) the list itself, recorded: order, states, emission and transition log-probabilities, absent neighbours
+ * skipped; (b) with a forward fold as the callback -- to[t] = logAdd(to[t], from[f] + (eP + tP)), doTransitionForward of
+ * impl/pairwiseAligner.c:382-385 -- the cell equals what cell_calculateForward computes (on the GPU). */
+typedef struct {
+    int n;
+    int64_t from[16], to[16];
+    double eP[16], tP[16];
+    double *src[16];
+} TransitionLog;
+static void record_transition(double *from, double *to, int64_t f, int64_t t, double eP, double tP, void *extra) {
+    TransitionLog *log = extra;
+    (void)to;
+    if (log->n < 16) {
+        log->src[log->n] = from;
+        log->from[log->n] = f;
+        log->to[log->n] = t;
+        log->eP[log->n] = eP;
+        log->tP[log->n] = tP;
+    }
+    log->n++;
+}
+static void fold_forward(double *from, double *to, int64_t f, int64_t t, double eP, double tP, void *extra) {
+    (void)extra;
+    to[t] = logAdd(to[t], from[f] + (eP + tP));
+}
+static void test_cellCalculate_vtable(int gpu) {
+    StateMachine *sM5 = stateMachine5_construct(fiveState), *sM3 = stateMachine3_construct(threeState);
+    double lower[5] = {-1, -2, -3, -4, -5}, middle[5] = {-1.5, -2.5, -3.5, -4.5, -5.5}, upper[5] = {-0.5, -6, -7, -8, -9}, cur[5];
+    TransitionLog log;
+    memset(&log, 0, sizeof log);
+    sM5->cellCalculate(sM5, cur, lower, middle, upper, c, g, record_transition, &log);
+    CHECK(log.n == 13);
+    const int64_t from5[13] = {0, 1, 0, 3, 0, 1, 2, 3, 4, 0, 2, 0, 4}, to5[13] = {1, 1, 3, 3, 0, 0, 0, 0, 0, 2, 2, 4, 4};
+    for (int i = 0; i < 13 && i < log.n; i++) {
+        CHECK(log.from[i] == from5[i] && log.to[i] == to5[i]);
+        CHECK(log.src[i] == (i < 4 ? lower : (i < 9 ? middle : upper)));
+    }
+    CHECK(log.eP[0] == log.eP[3] && log.eP[4] == log.eP[8] && log.eP[9] == log.eP[12] && log.eP[0] != log.eP[4]);
+    memset(&log, 0, sizeof log);
+    sM5->cellCalculate(sM5, cur, NULL, middle, NULL, a, n, record_transition, &log); /* band edge: only the middle block; an N */
+    CHECK(log.n == 5 && log.eP[0] == -2.772588722 && log.src[0] == middle);
+    memset(&log, 0, sizeof log);
+    sM3->cellCalculate(sM3, cur, lower, middle, upper, t, t, record_transition, &log);
+    CHECK(log.n == 9);
+    const int64_t from3[9] = {0, 1, 2, 0, 1, 2, 0, 2, 1}, to3[9] = {1, 1, 1, 0, 0, 0, 2, 2, 2};
+    for (int i = 0; i < 9 && i < log.n; i++) CHECK(log.from[i] == from3[i] && log.to[i] == to3[i]);
+    memset(&log, 0, sizeof log);
+    sM3->cellCalculate(sM3, cur, lower, NULL, upper, n, a, record_transition, &log);
+    CHECK(log.n == 6 && log.eP[0] == -1.386294361); /* gapX emission of an N */
+    if (gpu) {
+        StateMachine *both[2] = {sM5, sM3};
+        for (int k = 0; k < 2; k++) {
+            StateMachine *sM = both[k];
+            double viaCallback[5], viaGpu[5];
+            for (int64_t i = 0; i < sM->stateNumber; i++) viaCallback[i] = viaGpu[i] = LOG_ZERO;
+            sM->cellCalculate(sM, viaCallback, lower, middle, upper, g, t, fold_forward, NULL);
+            cell_calculateForward(sM, viaGpu, lower, middle, upper, g, t, NULL);
+            for (int64_t i = 0; i < sM->stateNumber; i++) CHECK(fabs(viaCallback[i] - viaGpu[i]) < 1e-12);
+        }
+    }
+    stateMachine_destruct(sM5);
+    stateMachine_destruct(sM3);
+}
+
 int main(int argc, char **argv) {
     const int gpu = argc > 1 && strcmp(argv[1], "gpu") == 0;
     test_bands();
@@ -643,6 +709,7 @@ int main(int argc, char **argv) {
     test_diagonal_logadd_dynamic_band_hmm_json();
     test_dp_containers();
     test_list_helpers();
+    test_cellCalculate_vtable(gpu);
     if (gpu) test_known_answers_gpu();
     if (gpu) test_getPosteriorProbsWithBanding_gpu();
     if (gpu) test_consumers_gpu();

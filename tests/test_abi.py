@@ -354,3 +354,37 @@ def test_hmm_loadFromFile_reads_the_reference_trained_hmm_text():
     om = ob.model_from_hmm(oh)
     for x in range(4):
         assert abs(m.emissionGapX[x] - om.gapXEm[x]) < 1e-15 and abs(m.emissionGapY[x] - om.gapYEm[x]) < 1e-15
+
+
+def test_planning_is_the_same_for_runs_triples_and_both_band_walks(monkeypatch):
+    """Host planning needs no GPU (cpecan_batch_upload plans, then fails for want of a device here): the band cells,
+    regions and diagonals of a batch are the same whether the anchors come as runs (cpecan_batch_add_many_runs) or as one
+    triple per column, and whether planning walks the runs of diagonal-neighbour anchors in closed form or every diagonal
+    (CPECAN_FAST_WALK=0) -- expansions 2 to 10, default and short traceback schedules, split rectangles, anchors from the
+    first column on.  (On the GPU box tests/test_gpu_parity.py compares the lists as well; tools/asan_cpu.sh runs this under
+    AddressSanitizer.)"""
+    import random
+    from cpecan_amd import workload
+    if api.device_count() > 0:
+        pytest.skip("a GPU is present: the upload succeeds (covered by the GPU tests)")
+    rng = random.Random(5)
+    for E, seed, kw in ((4, 21, {}), (2, 22, dict(minDiagsBetweenTraceBack=150, traceBackDiagonals=21)),
+                        (10, 23, dict(minDiagsBetweenTraceBack=64, traceBackDiagonals=40)), (6, 24, dict(splitMatrixBiggerThanThis=10 ** 12))):
+        probs = workload.make_realign_batch(seed, 120, 30, 4000, expansion=E)
+        same = "".join(rng.choice("ACGT") for _ in range(3000))
+        probs.append((same, same, np.array([(i, i, E) for i in range(len(same))], dtype=np.int64)))
+        problems = [(sx, sy, a, True, True) for sx, sy, a in probs]
+        pkw = dict(diagonalExpansion=E, splitMatrixBiggerThanThis=10)
+        pkw.update(kw)
+        p = api.pairwiseAlignmentBandingParameters_construct(**pkw)
+        seen = set()
+        for runs in (False, True):
+            for walk in ("0", "1"):
+                monkeypatch.setenv("CPECAN_FAST_WALK", walk)
+                with api.Batch(api.stateMachine5_construct(), p) as b:
+                    (b.add_many_runs if runs else b.add_many)(problems)
+                    with pytest.raises(api.CpecanError):
+                        b.upload()
+                    st = b.stats()
+                    seen.add((st.problems, st.regions, st.cells, st.diagonals))
+        assert len(seen) == 1 and next(iter(seen))[2] > 0, seen
