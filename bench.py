@@ -462,8 +462,9 @@ def main():
             "algorithmic_bytes_per_cell": bytes_per_cell, "kernel_ms": kernel_ms,
             # what the counters say moves: far fewer bytes than the algorithmic figure, so HBM is NOT what limits it
             "measured_hbm_gbs": (traffic["hbm_bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9) if traffic else None,
-            "limiter": "per-wave dependency chains at 2 waves/SIMD, then the LDS array and fp64 VALU issue "
-                       "(DESIGN.md section 5); HBM traffic is ~1/3 of the algorithmic bytes",
+            "limiter": "per-wave dependency chains (four logAdds deep per cell, an LDS round trip in each) at the 2-2.5 waves "
+                       "per SIMD the rolling rows in LDS allow, then the LDS array and fp64 VALU issue (DESIGN.md section 5); "
+                       "HBM traffic is ~1/3 of the algorithmic bytes",
         }
         if compute:
             # vector-instruction ceiling: VALU instructions per 64-cell group (PMC) x issue cycles measured per class
