@@ -1570,9 +1570,24 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         // (the symbols and the model go first: nothing but the table build is then between the last copy and the sweep)
         if (int rc = staged_h2d(d, d->dSymbols, symbols, (size_t)nSymbolBytes, &stageAt)) return rc;
         if (int rc = staged_h2d(d, d->dModel, model, sizeof(CpkModel), &stageAt)) return rc;
-        hipLaunchKernelGGL(cpecan_build_diag_table, dim3((unsigned)((geo->nRegions + 63) / 64)), dim3(64), 0, io,
-                           d->dRegions, geo->nRegions, dAnchors, anchorStride, d->dSegs, geo->nStates, d->dDiags, d->dDiagPos, expansion, dynamic);
-        HIP_TRY(hipGetLastError());
+        // the regions of split classes: one wave per region (cpk_table_gather.inl); every other region: one thread
+        // (CPECAN_TABLE_WAVE=0: one thread for all, as rounds 1-3 -- tests compare the two)
+        const char *twEnv = getenv("CPECAN_TABLE_WAVE");
+        const bool tableWave = !(twEnv && atoi(twEnv) == 0);
+        int64_t nSplitRegions = 0;
+        for (const LaunchClass &c : d->classes)
+            if (c.split && tableWave) {
+                hipLaunchKernelGGL(cpecan_build_diag_table_wave, dim3((unsigned)c.regionCount), dim3(64), 0, io, d->dRegions, c.regionBase,
+                                   dAnchors, anchorStride, d->dSegs, geo->nStates, d->dDiags, d->dDiagPos, expansion, dynamic);
+                HIP_TRY(hipGetLastError());
+                nSplitRegions += c.regionCount;
+            }
+        if (nSplitRegions < geo->nRegions) {
+            hipLaunchKernelGGL(cpecan_build_diag_table, dim3((unsigned)((geo->nRegions + 63) / 64)), dim3(64), 0, io,
+                               d->dRegions, geo->nRegions, dAnchors, anchorStride, d->dSegs, geo->nStates, d->dDiags, d->dDiagPos, expansion,
+                               dynamic, tableWave ? 1 : 0);
+            HIP_TRY(hipGetLastError());
+        }
         HIP_TRY(hipEventRecord(d->evUp1, io));
     }
     d->uploadTimed = false;

@@ -57,10 +57,12 @@ __device__ __forceinline__ int abs_chain_step(int lo, int hi, int lo1, int hi1, 
 }
 
 __global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *regions, int nRegions, const cpk_anchor_t *anchors, int anchorStride,
-                                                              const CpkSegment *segs, int S, CpkDiag *diags, int32_t *dpos, int64_t expansion, int dynamic) {
+                                                              const CpkSegment *segs, int S, CpkDiag *diags, int32_t *dpos, int64_t expansion, int dynamic,
+                                                              int skipSplit) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nRegions) return;
     const CpkRegion rg = regions[i];
+    if (rg.split && skipSplit) return;  // its table is cpecan_build_diag_table_wave's (one wave per region, below)
     CpkDiag *table = diags + rg.diagOff;
     const int64_t N = (int64_t)rg.lX + rg.lY;
     CpkBandIter it;
@@ -177,6 +179,142 @@ __global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *r
             const int lo = table[d].xmyL, hi = lo + 2 * (table[d].width - 1);
             const int v = abs_chain_step(lo, hi, lo1, hi1, lo2, hi2, N - d >= 2 ? 2 : (int)(N - d), P, B);
             pt[d] = (pt[d] & 0xffff) | (v << 16);
+            lo2 = lo1; hi2 = hi1; lo1 = lo; hi1 = hi;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same table for the regions of a SPLIT class, one WAVE per region (round 4).  One thread per region is a chain of
+// ~N dependent iterations -- 7-9 ms for a 2 kb pair's 4001 diagonals and its two position chains whatever the batch, and
+// ~160 waves on a 256-CU chip: it was the longest stage of a 1250-pair batch's pipeline next to its 12.6 ms sweep, the whole
+// of config A's gap between kernel and end-to-end rate, and a third of a single call's latency.  A split region's ring
+// never wraps, so everything the table holds is a prefix sum or a local property:
+//   * lane l takes the diagonals [l * chunk, (l + 1) * chunk); it finds the band's interval at its first diagonal by a
+//     binary search over the anchors' x + y (strictly increasing) and sets the iterator there;
+//   * pass A sums its chunk's cells and ring doubles, a wave scan gives every lane its offsets, pass B walks the chunk again
+//     and writes the entries;
+//   * the position chains (see above) re-base -- forget everything -- at every `danger` diagonal, and whether a diagonal is
+//     one depends on it and its two neighbours only: a lane scans back (forward chain) or ahead (backward chain) from its
+//     chunk to the nearest one, runs the chain from there without writing, and writes from its chunk's first diagonal on.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool abs_danger(int lo, int hi, int lo1, int hi1, int lo2, int hi2, int have) {
+    if (have == 0) return true;
+    const int dl = lo - lo1, dh = hi - hi1;
+    bool danger = (dl != 1 && dl != -1) || (dh != 1 && dh != -1);
+    if (have >= 2) danger = danger || (lo < lo1 && lo1 > lo2) || (hi > hi1 && hi1 < hi2);
+    return danger;
+}
+
+__global__ void __launch_bounds__(64) cpecan_build_diag_table_wave(const CpkRegion *regions, int regionBase, const cpk_anchor_t *anchors,
+                                                                   int anchorStride, const CpkSegment *segs, int S, CpkDiag *diags,
+                                                                   int32_t *dpos, int64_t expansion, int dynamic) {
+    const int lane = threadIdx.x;
+    const CpkRegion rg = regions[regionBase + blockIdx.x];
+    CpkDiag *table = diags + rg.diagOff;
+    const int N = rg.lX + rg.lY, nD = N + 1;
+    const int chunk = (nD + CPK_WAVE - 1) / CPK_WAVE;
+    const int d0 = lane * chunk < nD ? lane * chunk : nD, d1 = d0 + chunk < nD ? d0 + chunk : nD;
+    const cpk_anchor_t *ra = anchors + (size_t)anchorStride * rg.anchorOff;
+    const int nA = rg.nAnchors;
+    CpkBandIter it;
+    cpk_band_init(&it, ra, anchorStride, nA, rg.lX, rg.lY, expansion, dynamic);
+    if (d0 > 0 && d0 < nD) {
+        // the interval of diagonal d0: (p -> q), q the first anchor whose own diagonal (x + y + 2 in matrix coordinates) is
+        // not below d0, p the anchor before it (the virtual ones (0, 0) / (lX, lY) at either end)
+        int loI = 0, hiI = nA;  // first index with sum >= d0 lies in [loI, hiI]
+        while (loI < hiI) {
+            const int mid = (loI + hiI) >> 1;
+            if (ra[(size_t)anchorStride * mid] + ra[(size_t)anchorStride * mid + 1] + 2 < d0) loI = mid + 1;
+            else hiI = mid;
+        }
+        const int j = loI;
+        it.pX = j > 0 ? (int64_t)ra[(size_t)anchorStride * (j - 1)] + 1 : 0;
+        it.pY = j > 0 ? (int64_t)ra[(size_t)anchorStride * (j - 1) + 1] + 1 : 0;
+        it.qX = j < nA ? (int64_t)ra[(size_t)anchorStride * j] + 1 : rg.lX;
+        it.qY = j < nA ? (int64_t)ra[(size_t)anchorStride * j + 1] + 1 : rg.lY;
+        it.used = j < nA ? j + 1 : nA;
+        if (dynamic) it.e = j < nA ? ra[(size_t)anchorStride * j + 2] : (nA > 0 ? ra[(size_t)anchorStride * (nA - 1) + 2] : 0);
+        it.qSum = it.qX + it.qY;
+        const int64_t h = it.e / 2;
+        it.xLo = cpk_clamp(it.pX - h, it.lX);
+        it.yHi = cpk_clamp(it.qY + h, it.lY);
+        it.xHi = cpk_clamp(it.qX + h, it.lX);
+        it.yLo = cpk_clamp(it.pY - h, it.lY);
+    }
+    // the segments in force at d0 (the serial builder's emitSeg / covSeg)
+    const CpkSegment *sg = segs + rg.segOff;
+    int emitSeg = 0, covSeg = 0;
+    while (emitSeg + 1 < rg.nSeg && d0 > sg[emitSeg].tbFrom) emitSeg++;
+    while (covSeg + 1 < rg.nSeg && d0 > sg[covSeg].dTop) covSeg++;
+    const CpkBandIter it0 = it;
+    const int emitSeg0 = emitSeg, covSeg0 = covSeg;
+    int32_t cells = 0, pos = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        it = it0;
+        emitSeg = emitSeg0;
+        covSeg = covSeg0;
+        int emitFrom = rg.nSeg > 0 ? sg[emitSeg].tbFrom : 0, covTop = rg.nSeg > 0 ? sg[covSeg].dTop : 0;
+        for (int d = d0; d < d1; d++) {
+            int64_t lo = 0, hi = 0;
+            cpk_band_next(&it, d, &lo, &hi);
+            const int32_t w = (int32_t)((hi - lo) / 2 + 1);
+            while (d > emitFrom && emitSeg + 1 < rg.nSeg) emitFrom = sg[++emitSeg].tbFrom;
+            while (d > covTop && covSeg + 1 < rg.nSeg) covTop = sg[++covSeg].dTop;
+            const bool all = d == 0 || (emitFrom - d) % CPK_REFRESH_PERIOD == 0 || d >= covTop - 1;
+            const int32_t we = (w + 1) & ~1;
+            if (pass == 1) table[d] = CpkDiag{(int32_t)lo, w, pos, cells};
+            cells += w;
+            pos += all ? we + w * (S - 1) : we;
+        }
+        if (pass == 0) {  // exclusive scan of the chunks' sums: where this lane's chunk starts
+            int32_t incC = cells, incP = pos;
+#pragma unroll
+            for (int off = 1; off < CPK_WAVE; off <<= 1) {
+                const int32_t tc = __shfl_up(incC, off), tp = __shfl_up(incP, off);
+                if (lane >= off) {
+                    incC += tc;
+                    incP += tp;
+                }
+            }
+            cells = incC - cells;
+            pos = incP - pos;
+        }
+    }
+    if (!dpos || dynamic) return;
+    __syncthreads();  // (one wave: every lane's entries are written and visible)
+    int32_t *pt = dpos + rg.diagOff;
+    const int P = rg.maxWidth + kAbsSlack;
+    auto loOf = [&](int d) { return table[d].xmyL; };
+    auto hiOf = [&](int d) { return table[d].xmyL + 2 * (table[d].width - 1); };
+    if (d0 < d1) {
+        // forward chain: from the nearest danger diagonal at or below d0
+        int s0 = d0;
+        for (; s0 > 0; s0--) {
+            const int have = s0 >= 2 ? 2 : s0;
+            if (abs_danger(loOf(s0), hiOf(s0), loOf(s0 - 1), hiOf(s0 - 1), have >= 2 ? loOf(s0 - 2) : 0, have >= 2 ? hiOf(s0 - 2) : 0, have)) break;
+        }
+        int B = 0;
+        int lo1 = s0 >= 1 ? loOf(s0 - 1) : 0, hi1 = s0 >= 1 ? hiOf(s0 - 1) : 0, lo2 = s0 >= 2 ? loOf(s0 - 2) : 0, hi2 = s0 >= 2 ? hiOf(s0 - 2) : 0;
+        for (int d = s0; d < d1; d++) {
+            const int lo = loOf(d), hi = hiOf(d);
+            const int v = abs_chain_step(lo, hi, lo1, hi1, lo2, hi2, d >= 2 ? 2 : d, P, B);
+            if (d >= d0) pt[d] = v;
+            lo2 = lo1; hi2 = hi1; lo1 = lo; hi1 = hi;
+        }
+        // backward chain (descending diagonals): from the nearest danger diagonal at or above the chunk's last one
+        int s1 = d1 - 1;
+        for (; s1 < N; s1++) {
+            const int have = N - s1 >= 2 ? 2 : N - s1;
+            if (abs_danger(loOf(s1), hiOf(s1), loOf(s1 + 1), hiOf(s1 + 1), have >= 2 ? loOf(s1 + 2) : 0, have >= 2 ? hiOf(s1 + 2) : 0, have)) break;
+        }
+        B = 0;
+        lo1 = s1 + 1 <= N ? loOf(s1 + 1) : 0; hi1 = s1 + 1 <= N ? hiOf(s1 + 1) : 0;
+        lo2 = s1 + 2 <= N ? loOf(s1 + 2) : 0; hi2 = s1 + 2 <= N ? hiOf(s1 + 2) : 0;
+        for (int d = s1; d >= d0; d--) {
+            const int lo = loOf(d), hi = hiOf(d);
+            const int v = abs_chain_step(lo, hi, lo1, hi1, lo2, hi2, N - d >= 2 ? 2 : N - d, P, B);
+            if (d < d1) pt[d] = (pt[d] & 0xffff) | (v << 16);
             lo2 = lo1; hi2 = hi1; lo1 = lo; hi1 = hi;
         }
     }

@@ -1245,6 +1245,41 @@ def test_pipelined_batches_equal_unpipelined_ones():
                 assert np.array_equal(a, b), (name, "job", k, "problem", i, len(a), len(b))
 
 
+def test_table_built_by_a_wave_per_region_equals_the_serial_one(monkeypatch):
+    """Round 4: the per-diagonal table (and the position chains of the absolute-position sweeps) of a split class's regions
+    is built by one WAVE per region -- every lane a chunk of the diagonals: band iterator set by a binary search over the
+    anchors, offsets by a wave scan, position chains replayed from the nearest re-base point -- instead of one thread
+    (CPECAN_TABLE_WAVE=0).  Same lists, bit for bit, in both split forms: fixed expansions (absolute positions), per-anchor
+    expansions (rank-indexed rows), no anchors at all, regions shorter than a wave has lanes, split rectangles."""
+    rng = random.Random(4040)
+    cases = []
+    cases.append((0, [make_pair(3, i, 2000, 100) for i in range(5)] + [make_pair(2, i, 700, 30) for i in range(5)], None,
+                  dict(diagonalExpansion=100)))
+    cases.append((2, [make_pair(2, i, 1000, 50) for i in range(10)], None, dict(diagonalExpansion=50)))
+    fz, rg = _fuzz_problems(rng, 40, 20)
+    cases.append((0, fz, rg, dict(diagonalExpansion=20, minDiagsBetweenTraceBack=60, traceBackDiagonals=7, splitMatrixBiggerThanThis=900)))
+    fz2, rg2 = _fuzz_problems(rng, 30, 12)
+    dyn = [(sx, sy, [(x, y, 2 * ((3 * x + y) % 11)) for x, y, *_ in a]) for sx, sy, a in fz2]
+    cases.append((0, dyn, rg2, dict(dynamicAnchorExpansion=1, minDiagsBetweenTraceBack=80, traceBackDiagonals=9)))
+    cases.append((2, [("ACGTTGCA" * 40, "ACGTTGCA" * 41, ()), ("A", "C", ()), ("ACGT", "", ()), ("AC" * 30, "AC" * 29, [(5, 5, 4)])], None,
+                  dict(diagonalExpansion=4, minDiagsBetweenTraceBack=50, traceBackDiagonals=3)))
+    for mtype, problems, raggeds, pkw in cases:
+        for form in ("1", "2"):
+            monkeypatch.setenv("CPECAN_SPLIT", form)
+            monkeypatch.setenv("CPECAN_TABLE_WAVE", "0")
+            serial, st0 = _run_batch(mtype, problems, raggeds, **pkw)
+            monkeypatch.delenv("CPECAN_TABLE_WAVE")
+            wave, st1 = _run_batch(mtype, problems, raggeds, **pkw)
+            assert (st1.cells, st1.pairs, st1.launchForm) == (st0.cells, st0.pairs, st0.launchForm)
+            for i, (a, b) in enumerate(zip(wave, serial)):
+                assert np.array_equal(a, b), (form, i)
+        om, op = ob.model(mtype), ob.params(**pkw)
+        for i in range(0, len(problems), 4):
+            sx, sy, a = problems[i]
+            rl, rr = raggeds[i] if raggeds else (False, False)
+            assert_pairs_match(wave[i], ob.aligned_pairs(om, sx, sy, a, op, rl, rr), threshold=op.threshold)
+
+
 def test_one_launch_form_times_out_into_two_launches(monkeypatch):
     """an item of the one-launch form that gives up waiting for its region's forward values (here: after a
     single poll, CPECAN_FUSED_SPIN=1) is reported by the launch, and the download runs the class again as two launches
