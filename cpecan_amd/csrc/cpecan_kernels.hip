@@ -1099,7 +1099,9 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     auto setForm = [&](LaunchClass &cc, bool abs) {
         cc.abs = abs;
         cc.geo.rollStride = cc.geo.maxWidth + (abs ? kAbsSlack : 1);
-        cc.geo.seqLdsBytes = abs ? geo->wWinLdsBytes[cc.k] : geo->wSeqLdsBytes[cc.k];
+        const char *winEnv = getenv("CPECAN_ABS_WINDOWS");  // 0: the absolute-position sweeps stage whole strings (diagnostics, tests)
+        cc.geo.reserved0 = (abs && winEnv && atoi(winEnv) == 0) ? 1 : 0;
+        cc.geo.seqLdsBytes = (abs && !cc.geo.reserved0) ? geo->wWinLdsBytes[cc.k] : geo->wSeqLdsBytes[cc.k];
         cc.geo.rollDoubles = (int64_t)(abs ? 2 * S : 2 * S + 1) * cc.geo.rollStride;
         const size_t header = sizeof(double) * (lds_header_doubles(geo->emit) + lds_stage_doubles(geo->emit, abs));
         cc.ldsBytes = cc.geo.useGlobalRoll ? header
@@ -1165,8 +1167,12 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         int perCU = 0;
         // Bands of several hundred cells: a team of kTeamWaves waves per region (cpk_team.inl) instead of one wave
         constexpr int kTeamWaves = 4;
-        const size_t teamLds = sizeof(double) * ((size_t)team_header_doubles() + (size_t)3 * S * c.geo.rollStride) +
-                               (size_t)((c.geo.seqLdsBytes + 15) / 16 * 16);
+        // (the team kernel stages both whole strings and keeps 3 S rows of maxWidth + 1 positions, whatever form of the
+        // rows the class would take with one wave per region: NOT c.geo.seqLdsBytes / rollStride, which setForm() above
+        // may have set to the symbol windows and slack of the absolute-position sweeps)
+        const int teamStride = c.geo.maxWidth + 1;
+        const size_t teamLds = sizeof(double) * ((size_t)team_header_doubles() + (size_t)3 * S * teamStride) +
+                               (size_t)((geo->wSeqLdsBytes[k] + 15) / 16 * 16);
         // A class goes to teams where one wave per region is down to three waves per CU or fewer (measured: at four per
         // CU, ~400-cell bands, the single wave still wins by 13 %; at three, ~450 cells, the team wins by 30 %), or on
         // the global-memory variant.  CPECAN_TEAM=<cells> (tests, diagnostics): from that band width instead; 0: never.
@@ -1183,6 +1189,11 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                           : (big ? cpecan_pairhmm_team<3, 2 * kTeamWaves> : cpecan_pairhmm_team<3, kTeamWaves>);
             c.threads = CPK_WAVE * kTeamWaves * (big ? 2 : 1);
             c.geo.useGlobalRoll = 0;
+            c.abs = false;
+            c.geo.reserved0 = 0;
+            c.geo.rollStride = teamStride;
+            c.geo.seqLdsBytes = geo->wSeqLdsBytes[k];
+            c.geo.rollDoubles = (int64_t)(2 * S + 1) * c.geo.rollStride;
             c.ldsBytes = teamLds;
             c.grollEl = 0;
             hipFuncAttributes attr;

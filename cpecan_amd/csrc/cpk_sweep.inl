@@ -2205,7 +2205,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
         const CpkRegion &rg = a.regions[r];
         const int lX = rg.lX, lY = rg.lY, N = lX + lY;
         const uint8_t *gx = a.symbols + rg.seqXOff, *gy = a.symbols + rg.seqYOff;
-        if (FAST && !ABS) {
+        if (FAST && (!ABS || a.geo.reserved0)) {  // (reserved0: CPECAN_ABS_WINDOWS=0, whole strings for the absolute-position sweeps too)
             // stage N + bases + N of both strings into LDS, two symbols per byte (per-cell reads come from here)
             // (absolute positions: the symbols a SEGMENT's diagonals touch, staged per segment below)
             stage_symbols<CPK_WAVE>(seqLds, gx, lX + 2, lane);
@@ -2310,7 +2310,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
             const int siFirst = traceRole ? itemSeg : 0, siEnd = traceRole ? itemSeg + 1 : rg.nSeg;
             for (int si = siFirst; si < siEnd; si++) {
                 const CpkSegment sg = a.segs[rg.segOff + si];
-                if (ABS) {
+                if (ABS && !a.geo.reserved0) {
                     // Symbol windows (round 4): only the symbols the diagonals of THIS step touch are staged -- the forward
                     // sweep of diagonals d .. dTop, or the traceback of tbPrev + 1 .. dTop, whose cells also read the symbols
                     // one past their own (Sweep::bwdCells) -- ~0.7 KB instead of the 2 KB of both whole strings of a 2 kb pair.

@@ -1473,6 +1473,11 @@ def test_split_classes_equal_whole_region_waves(monkeypatch):
     cases.append((0, fz, dict(diagonalExpansion=20, minDiagsBetweenTraceBack=60, traceBackDiagonals=7, splitMatrixBiggerThanThis=900)))
     cases.append((0, [make_pair(7, i, 700, 20) for i in range(4)] + [("", "", ()), ("ACGT", "", ())],
                   dict(diagonalExpansion=20, minDiagsBetweenTraceBack=90, traceBackDiagonals=10, threshold=0.0)))
+    # sparse anchors under a wide expansion: diagonals of > 256 cells, a class that goes to a TEAM of waves although its
+    # regions would qualify for the absolute-position sweeps (round 4: the team's LDS was then sized for the symbol
+    # windows of those sweeps while the team stages whole strings -- tools/soak_forms.py seed 41 round 33)
+    cases.append((0, [make_pair(41, i, L, 100, anchor_every=400) for i, L in enumerate((1500, 2200, 900, 1800))],
+                  dict(diagonalExpansion=100, threshold=0.0)))
     for mtype, problems, pkw in cases:
         monkeypatch.setenv("CPECAN_SPLIT", "0")
         whole, st0 = _run_batch(mtype, problems, **pkw)
