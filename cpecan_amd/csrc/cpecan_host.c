@@ -1322,8 +1322,11 @@ int cpecan_batch_upload(cpecan_batch *b) {
             const int64_t w = plan[i].maxW;
             const size_t lds = sizeof(double) * (size_t)(544 + 768 + (2 * S + 1) * (w + 1)) +
                                (size_t)((b->regions[i].lX + 3) / 2 + (b->regions[i].lY + 3) / 2) + 16;
-            static const int64_t edge[CPK_WIDE_CLASSES - 2] = {128, 192, 256, 384, 512};
-            int k = 0;
+            static const int64_t edge[CPK_WIDE_CLASSES - 2] = {64, 128, 192, 256, 384, 512};
+            /* up to 64 cells: a class of its own for the expectation emitter only -- its in-sweep kernel has a build unrolled
+             * for one 64-lane group per diagonal (BASELINE config 5: 99 % of the regions); the other emitters' kernels loop
+             * over groups and gain nothing from another launch */
+            int k = b->emit == CPECAN_EMIT_EXPECT ? 0 : 1;
             while (k < CPK_WIDE_CLASSES - 2 && w > edge[k]) k++; /* CPK_WIDE_CLASSES - 2: wider, but its LDS still fits */
             keys[i].cls = 3 + (lds > 64 * 1024 ? CPK_WIDE_CLASSES - 1 : k);
         }

@@ -84,7 +84,7 @@ typedef struct {
     double threshold;
 } CpkModel;
 
-#define CPK_WIDE_CLASSES 7
+#define CPK_WIDE_CLASSES 8
 /* Per-launch geometry computed on the host. */
 typedef struct {
     int32_t nRegions;

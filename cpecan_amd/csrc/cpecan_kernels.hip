@@ -83,7 +83,7 @@ extern "C" const char *cpk_last_error(void) { return g_err; }
 // host side of the HIP TU: memory, launch, timing
 // ------------------------------------------------------------------------------------------------
 using KernelFn = void (*)(const KArgs);
-constexpr int kMaxClasses = CPK_WIDE_CLASSES + 3;
+constexpr int kMaxClasses = CPK_WIDE_CLASSES + 6;  // wide classes + three packed ones, each of which may run as a split and a whole part
 
 // One kernel launch of a run: the regions [regionBase, regionBase + regionCount) of the device order, which share one
 // size class, with LDS, occupancy and per-wave scratch sized for the largest of THEM.
@@ -887,6 +887,21 @@ static KernelFn pick_packed_kernel(const CpkGeometry &g, int cls, bool dynamic) 
 #undef CPK_PICK_PACKED
     return nullptr;
 }
+// the two kernels of a split packed class (match emitter, fixed expansion; cpk_packed.inl, MODE)
+static void pick_packed_split_kernels(const CpkGeometry &g, int cls, KernelFn *fwd, KernelFn *trace) {
+    const bool five = g.nStates == 5;
+#define CPK_PICK_PACKED_SPLIT(GW)                                                                                                \
+    {                                                                                                                            \
+        *fwd = five ? cpecan_pairhmm_packed<5, GW, CPECAN_EMIT_MATCH, false, kModeForward> : cpecan_pairhmm_packed<3, GW, CPECAN_EMIT_MATCH, false, kModeForward>; \
+        *trace = five ? cpecan_pairhmm_packed<5, GW, CPECAN_EMIT_MATCH, false, kModeTrace> : cpecan_pairhmm_packed<3, GW, CPECAN_EMIT_MATCH, false, kModeTrace>;   \
+    }
+    switch (cls) {
+        case 0: CPK_PICK_PACKED_SPLIT(8) break;
+        case 1: CPK_PICK_PACKED_SPLIT(16) break;
+        default: CPK_PICK_PACKED_SPLIT(32) break;
+    }
+#undef CPK_PICK_PACKED_SPLIT
+}
 
 // the two kernels of a split class (match emitter)
 // Doubles of the ring a split region keeps its forward values in.  The match emitter stores the match row of every
@@ -956,9 +971,12 @@ static KernelFn pick_dense_kernel(const CpkGeometry &g) {  // one wave per regio
 
 static KernelFn pick_kernel(const CpkGeometry &g) {
     const bool fast = !g.useGlobalRoll;  // second template argument = FAST (LDS rolling buffers + LDS symbol strings)
+    if (g.emit == CPECAN_EMIT_EXPECT && fast && g.expInSweep == 1)  // no diagonal wider than one 64-lane group
+        return g.nStates == 5 ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, false, 1>
+                              : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, false, 1>;
     if (g.emit == CPECAN_EMIT_EXPECT && fast && g.expInSweep)
-        return g.nStates == 5 ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, false, true>
-                              : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, false, true>;
+        return g.nStates == 5 ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, false, 2>
+                              : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, false, 2>;
 #define CPK_PICK(E)                                                                                          \
     if (g.emit == (E)) {                                                                                     \
         if (g.nStates == 5) return fast ? cpecan_pairhmm_sweep<5, true, (E)> : cpecan_pairhmm_sweep<5, false, (E)>; \
@@ -1056,6 +1074,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     const int nCandLists = geo->emit == CPECAN_EMIT_INDEL ? 3 : 1;
     const bool expect = geo->emit == CPECAN_EMIT_EXPECT;
     int regionAt = 0;
+    std::vector<LaunchClass> packedSplit, packedWhole;
     for (int k = 0; k < 3; k++) {  // narrow regions come first in the device order: the packed kernel, 64 / GW to a wave
         if (geo->nPacked[k] <= 0) continue;
         LaunchClass c;
@@ -1076,14 +1095,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                      (size_t)G * pack_group_bytes(S, GW);
         int perCU = 0;
         if (int rc = wavesPerCU(c.fn, c.ldsBytes, &perCU)) return rc;
-        int64_t waves = (int64_t)perCU * d->numCUs;
-        const int64_t wavesNeeded = (geo->nPacked[k] + G - 1) / G;
-        if (waves > wavesNeeded) waves = wavesNeeded;
-        c.waves = (int)waves;
-        c.subSlots = waves * G;
-        c.regionBase = regionAt;
-        c.regionCount = geo->nPacked[k];
-        regionAt += geo->nPacked[k];
+        const int64_t slots = (int64_t)perCU * d->numCUs;
         c.ringEl = c.geo.ringCells * S;
         c.candEl = c.geo.fbCells;
         c.refEl = c.geo.refreshCells;
@@ -1091,8 +1103,68 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         // B of a segment's emitted cells: the expectation step's second pass, the indel emitter's list pass (cpk_packed.inl)
         c.bringEl = (expect || geo->emit == CPECAN_EMIT_INDEL) ? c.geo.fbCells * S : 0;
         if (geo->emit == CPECAN_EMIT_INDEL) c.candEl = 0;  // no candidates
-        d->classes.push_back(c);
+        // Split (round 4, cpk_packed.inl "MODE"): forward sweeps into rings of the regions' own, then one queue item per
+        // (region, traceback segment).  Worth it where ONE group's walk through the longest region -- its forward and its
+        // backward steps, one after the other -- is what a launch of whole regions waits for: a realign-style batch of
+        // 100-5000 bp alignments took 20 ms with 6 000 pairs and 29 with 50 000 (profiles/r04_config4_chain_bound.txt).
+        // Then the LONG regions of the class -- the device order is longest first -- become a split class of their own,
+        // launched first: their forward chains (half the steps) run beside the whole-region waves of the shorter ones, and
+        // their tracebacks, side by side, behind.  Long: more than half the diagonals of the longest, so that the whole
+        // regions' chains (2 N steps) are no longer than the longest forward chain.  CPECAN_PACKED_SPLIT=1 / 0 (tests, A/B
+        // runs): every region of every packed class / none; CPECAN_PACKED_SPLIT_FROM=<diagonals>: regions longer than that.
+        const int64_t base = regionAt, n = geo->nPacked[k];
+        regionAt += geo->nPacked[k];
+        int64_t cut = 0;  // the first `cut` regions of the class run split
+        {
+            int64_t stepsAll = 0, nMax = 0;
+            int32_t segMax = 0;
+            for (int64_t di = base; di < base + n; di++) {
+                const int64_t N = (int64_t)regions[di].lX + regions[di].lY;
+                segMax = regions[di].nSeg > segMax ? regions[di].nSeg : segMax;
+                stepsAll += 2 * N;
+                nMax = N > nMax ? N : nMax;
+            }
+            const char *env = getenv("CPECAN_PACKED_SPLIT"), *fromEnv = getenv("CPECAN_PACKED_SPLIT_FROM");
+            const bool eligible = geo->emit == CPECAN_EMIT_MATCH && !dynamic && !geo->debug;
+            // (the steps of a wave if the class's steps were dealt out evenly over every wave slot of the chip)
+            const int64_t balanced = stepsAll / (G * slots) + 1;
+            if (eligible && env && atoi(env) != 0) cut = n;
+            else if (eligible && !(env && atoi(env) == 0) && (fromEnv || (segMax >= 3 && 2 * nMax * 2 >= balanced * 3))) {
+                const int64_t from = fromEnv ? atoll(fromEnv) : nMax / 2;
+                for (int64_t di = base; di < base + n; di++)  // (ordered by cells, not by diagonals: up to the last long one)
+                    if ((int64_t)regions[di].lX + regions[di].lY > from) cut = di - base + 1;
+            }
+        }
+        for (int part = 0; part < 2; part++) {
+            const int64_t pBase = part == 0 ? base : base + cut, pCount = part == 0 ? cut : n - cut;
+            if (pCount <= 0) continue;
+            LaunchClass cc = c;
+            cc.regionBase = (int)pBase;
+            cc.regionCount = (int)pCount;
+            int64_t waves = (pCount + G - 1) / G;
+            if (waves > slots) waves = slots;
+            cc.waves = (int)waves;
+            cc.subSlots = waves * G;
+            if (part == 0) {
+                int64_t nSegPart = 0;
+                for (int64_t di = pBase; di < pBase + pCount; di++) nSegPart += regions[di].nSeg;
+                cc.split = true;
+                pick_packed_split_kernels(cc.geo, k, &cc.fn, &cc.fnTrace);
+                int64_t wt = (nSegPart + G - 1) / G;
+                if (wt > slots) wt = slots;
+                cc.wavesTrace = (int)wt;
+                if (wt * G > cc.subSlots) cc.subSlots = wt * G;
+                cc.itemCount = nSegPart;
+            }
+            if (getenv("CPECAN_TRACE_HOST"))
+                fprintf(stderr, "cpecan packed class %d: %d regions in groups of %d lanes, LDS %zu B, waves %d / %d, %s\n", k, cc.regionCount, GW,
+                        cc.ldsBytes, cc.waves, cc.wavesTrace, cc.split ? "two launches" : "whole regions");
+            (part == 0 ? packedSplit : packedWhole).push_back(cc);
+        }
     }
+    // the split parts first: their forward chains are the longest thing in the batch and start before anything else
+    for (const LaunchClass &cc : packedSplit) d->classes.push_back(cc);
+    for (const LaunchClass &cc : packedWhole) d->classes.push_back(cc);
     // The LDS of one wave of the class: tables, rolling rows, candidate stage, symbols -- by the form of its sweeps.
     // Absolute positions (cpk_sweep.inl): two arrays of S rows with a few positions of slack, a stage of 64
     // candidates, and the symbols of one traceback segment at a time instead of both whole strings.
@@ -1150,6 +1222,10 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             // the traceback whatever the LDS costs.
             const char *env = getenv("CPECAN_EXP_INSWEEP");
             c.geo.expInSweep = expect && !c.geo.useGlobalRoll && c.geo.maxWidth <= 2 * CPK_WAVE /* Sweep::kExpGroups */ && !(env && atoi(env) == 0);
+            // 1: the build unrolled for ONE group per diagonal (classes up to 64 cells -- the host gives the expectation
+            // emitter a size class of its own there, cpecan_host.c); 2: for two.  CPECAN_EXP_ONE_GROUP=0: always the latter.
+            const char *oneEnv = getenv("CPECAN_EXP_ONE_GROUP");
+            if (c.geo.expInSweep) c.geo.expInSweep = (c.geo.maxWidth <= CPK_WAVE && !(oneEnv && atoi(oneEnv) == 0)) ? 1 : 2;
             if (c.geo.expInSweep) {
                 const size_t with = c.ldsBytes + sizeof(double) * (size_t)3 * (c.geo.maxWidth + 1) * S + sizeof(double) * kExpectWinCopies * 80 -
                                     sizeof(double) * (size_t)(lds_header_doubles(geo->emit) - lds_header_doubles(geo->emit, true));
@@ -1395,13 +1471,18 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                 if (!c.split) continue;
                 c.split = false;
                 c.fused = false;
-                if (c.abs) setForm(c, false);
-                c.fn = c.dense ? pick_dense_kernel(c.geo) : pick_kernel(c.geo);
                 c.fnTrace = nullptr;
-                c.subSlots = c.waves;
                 c.itemCount = 0;
                 c.ringTotal = 0;
                 c.ringEl = c.geo.ringCells * S;
+                if (c.packed) {
+                    c.fn = pick_packed_kernel(c.geo, c.k, false);
+                    c.subSlots = (int64_t)c.waves * (CPK_WAVE / (8 << c.k));
+                    continue;
+                }
+                if (c.abs) setForm(c, false);
+                c.fn = c.dense ? pick_dense_kernel(c.geo) : pick_kernel(c.geo);
+                c.subSlots = c.waves;
             }
         };
         planSplit();

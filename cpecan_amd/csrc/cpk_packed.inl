@@ -36,9 +36,21 @@ __host__ __device__ constexpr int pack_group_bytes(int S, int gw) {  // a multip
 // an anchor brings a larger expansion, so the symbols a chunk of 64 diagonals needs do not start at its first diagonal's:
 // the windows start at the minimum over the chunk's diagonals, and a cell outside a window (a chunk whose band wanders
 // further than the window holds: never with a fixed expansion) reads its symbol from global memory.
-template <int S, int GW, int EMIT, bool DYN = false>  // EMIT: CPECAN_EMIT_MATCH or CPECAN_EMIT_EXPECT
+// MODE (round 4, match emitter): kModeWhole -- a group takes a region through its forward sweep and its tracebacks, segment
+// by segment, over a ring of the group's own; kModeForward / kModeTrace -- a SPLIT class (cf. cpecan_pairhmm_sweep): the
+// first launch sweeps every region forward into a ring of the region's own (never wraps; the layout of the sweep kernel's
+// split regions: the match row of every diagonal, every state only where a traceback reads it back), the second takes
+// one queue item per (region, traceback segment), longest first, G items to a wave.  Why: a realign-style batch holds
+// regions of 100 to 10 000 diagonals, and ONE group walking a 10 000-diagonal region through 10 000 forward and 10 400
+// backward steps is 20 ms whatever else the chip does -- BASELINE config 4 took 20.2 ms with 6 000 pairs and 29.3 with
+// 50 000 (profiles/r04_config4_chain_bound.txt).  Split, the chain is the forward steps alone and the tracebacks of a
+// long region run side by side.
+template <int S, int GW, int EMIT, bool DYN = false, int MODE = kModeWhole>  // EMIT: CPECAN_EMIT_MATCH, _INDEL or _EXPECT
 __global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(CPK_PACKED_WAVES, CPK_PACKED_WAVES)))
 cpecan_pairhmm_packed(const KArgs a) {
+    static_assert(MODE == kModeWhole || MODE == kModeForward || MODE == kModeTrace, "packed kernel: whole regions, or the two launches of a split class");
+    static_assert(MODE == kModeWhole || (EMIT == CPECAN_EMIT_MATCH && !DYN), "split classes: match emitter, fixed expansion");
+    constexpr bool kSplit = MODE != kModeWhole;
     constexpr int G = CPK_WAVE / GW;
     constexpr int R = 2 * S + 1;
     constexpr int kRowDoubles = R * (GW + 1);
@@ -79,9 +91,10 @@ cpecan_pairhmm_packed(const KArgs a) {
     __syncthreads();
 
     // the cell functions only need the tables; every position-dependent input is passed per call
-    Sweep<S, false> sw{a, a.kc, DiagCache{nullptr, 0, 0, lane, 0, 0, 0, 0}, nullptr, nullptr, rows, lds + kLdsCubics, wt, lg,
-                       nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, GW + 1, lane, lane * R, 0, CpkDiag{}, CpkDiag{}};
-    using SW = Sweep<S, false>;
+    // (RDBL = kSplit: a split region's ring counts doubles and pads the match row, Sweep::ringIdx)
+    using SW = Sweep<S, false, 2 * S + 1, false, kSplit>;
+    SW sw{a, a.kc, DiagCache{nullptr, 0, 0, lane, 0, 0, 0, 0}, nullptr, nullptr, rows, lds + kLdsCubics, wt, lg,
+          nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, GW + 1, lane, lane * R, 0, CpkDiag{}, CpkDiag{}};
     const unsigned long long groupBits = (GW == 64 ? ~0ull : ((1ull << GW) - 1ull)) << (g * GW);
     const unsigned long long belowMe = groupBits & ((1ull << lane) - 1ull);
     const unsigned long long aboveMe = groupBits & ~((2ull << lane) - 1ull);  // (2 << 63 wraps to 0: nothing above lane 63)
@@ -93,15 +106,17 @@ cpecan_pairhmm_packed(const KArgs a) {
         const int tk = __builtin_amdgcn_readfirstlane((int)ticket);
         if (tk >= a.regionCount) break;
         const bool have = tk + g < a.regionCount;
-        const int r = a.regionBase + (have ? tk + g : tk);
+        // kModeTrace: the queue holds (region, segment) items, longest first (a.regionCount of them); else regions
+        const int itemSeg = MODE == kModeTrace ? a.items[have ? tk + g : tk].seg : 0;
+        const int r = MODE == kModeTrace ? a.items[have ? tk + g : tk].region : a.regionBase + (have ? tk + g : tk);
         const CpkRegion rg = a.regions[r];
         const int N = have ? rg.lX + rg.lY : 0;
-        const int nSeg = (have && N > 0) ? rg.nSeg : 0;
+        const int nSeg = (have && N > 0) ? (MODE == kModeTrace ? 1 : rg.nSeg) : 0;
         const CpkDiag *table = a.diags + rg.diagOff;
-        const CpkSegment *segs = a.segs + rg.segOff;
+        const CpkSegment *segs = a.segs + rg.segOff + itemSeg;
         const uint8_t *gx = a.symbols + rg.seqXOff, *gy = a.symbols + rg.seqYOff;  // padded: index p = base p-1, N at both ends
         const size_t sub = (size_t)blockIdx.x * G + g;  // scratch sub-slot of this group
-        double *ring = a.ring + sub * (size_t)a.geo.ringCells * S;
+        double *ring = kSplit ? a.ring + (size_t)rg.ringBase : a.ring + sub * (size_t)a.geo.ringCells * S;
         Candidate *cand = a.cand + sub * (size_t)a.geo.fbCells;
         double *cbuf = a.cbuf + sub * (size_t)a.geo.refreshCells, *mbuf = a.mbuf + sub * (size_t)a.geo.refreshCells;
         double *totals = a.totals + sub * (size_t)a.geo.maxRefresh;
@@ -116,7 +131,7 @@ cpecan_pairhmm_packed(const KArgs a) {
         auto fbuf1 = [&](int d) { return rows + R + (d & 1) * S; };
         auto bM1 = [&](int d) { return rows + R + (d + 3) % 3; };
         auto bG1 = [&](int d) { return rows + R + 2 + (d & 1) * (S - 1); };
-        auto ringAt = [&](const CpkDiag &e) { return ring + (size_t)e.ringOff * S; };
+        auto ringAt = [&](const CpkDiag &e) { return ring + (size_t)e.ringOff * (kSplit ? 1 : S); };
         auto unpack = [](const int4 &t) { return CpkDiag{t.x, t.y, t.z, t.w}; };
         // the symbol of padded position p of X / Y for a cell of the staged chunk (windows from x0 / y0)
         auto symAtX = [&](int p, int x0) -> int {
@@ -193,23 +208,27 @@ cpecan_pairhmm_packed(const KArgs a) {
         };
 
         CpkDiag e1{}, e2{};  // entries of d-1 and d-2 of the forward sweep
-        if (nSeg > 0) {
+        if (nSeg > 0 && MODE != kModeTrace) {
             const int4 t0 = *reinterpret_cast<const int4 *>(table);
             e1 = e2 = unpack(t0);
             const double *startPrior = rg.raggedLeft ? m.raggedStart : m.start;
             if (c < S) {  // diagonal 0: the single cell (0,0) holds the start prior (pairwiseAligner.c:776-777)
                 fbuf1(0)[c] = startPrior[c];
-                ringAt(e1)[c] = startPrior[c];
+                ringAt(e1)[SW::ringIdx(1, c, 0)] = startPrior[c];
             }
         }
         int d = 1;
+        // split classes: which states of F[d] go to the ring -- the table builder's rule (cpk_table_gather.inl, `all`; the
+        // forward loop of cpecan_pairhmm_sweep): every state on the refresh diagonals of the segment that EMITS d (the
+        // first with tbFrom >= d) and on the two diagonals below the top of the segment that covers d; else the match row
+        int emitSeg = 0, emitFrom = (kSplit && nSeg > 0) ? segs[0].tbFrom : 0;
         const int maxSeg = wave_max_i32(nSeg);
         for (int si = 0; si < maxSeg; si++) {
             const bool segOn = si < nSeg;
             CpkSegment sg{};
             if (segOn) sg = segs[si];
             // ---------------- forward sweep up to dTop (pairwiseAligner.c:609-629) ----------------
-            while (__ballot(segOn && d <= sg.dTop)) {
+            while (MODE != kModeTrace && __ballot(segOn && d <= sg.dTop)) {
                 const bool more = segOn && d <= sg.dTop;
                 const int cnt = more ? (sg.dTop - d + 1 < kPackChunk ? sg.dTop - d + 1 : kPackChunk) : 0;
                 int x0, y0;
@@ -234,13 +253,21 @@ cpecan_pairhmm_packed(const KArgs a) {
                     const int kR[1] = {c * R};
                     double v[1][S];
                     sw.template fwdCellsSym<1>(fc, cX, cY, kR, v);
+                    bool all = true;
+                    if (kSplit && act) {
+                        while (d > emitFrom && emitSeg + 1 < nSeg) emitFrom = segs[++emitSeg].tbFrom;
+                        all = (emitFrom - d) % CPK_REFRESH_PERIOD == 0 || d >= sg.dTop - 1;
+                    }
                     if (on) {
                         double *cur = fbuf1(d);
                         double *o = ringAt(e);
 #pragma unroll
                         for (int s = 0; s < S; s++) cur[s + c * R] = v[0][s];
+                        o[SW::ringIdx(W, 0, c)] = v[0][0];
+                        if (all) {
 #pragma unroll
-                        for (int s = 0; s < S; s++) o[SW::ringIdx(W, s, c)] = v[0][s];
+                            for (int s = 1; s < S; s++) o[SW::ringIdx(W, s, c)] = v[0][s];
+                        }
                     }
                     if (act) {
                         e2 = e1;
@@ -249,6 +276,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                     }
                 }
             }
+            if (MODE == kModeForward) continue;  // the tracebacks of a split class are the items of the next launch
             // ---------------- traceback of the segment (pairwiseAligner.c:796-862) ----------------
             const double *endPrior = (segOn && sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
             double ep[S];
@@ -597,7 +625,10 @@ cpecan_pairhmm_packed(const KArgs a) {
                 }
             } else {
             // ---------------- thresholded posteriors from the candidates, walked backwards (:655-689) ----------------
-                if (segOn && c == 0) a.segStarts[rg.segOff + si] = count;
+                // (kModeTrace: the segment's own part of the region's slice -- the other segments are other items')
+                int32_t *outSeg = MODE == kModeTrace ? out + 3 * (size_t)sg.outOff : out;
+                const int outCap = MODE == kModeTrace ? sg.outCap : rg.outCap;
+                if (segOn && c == 0) a.segStarts[rg.segOff + itemSeg + si] = MODE == kModeTrace ? sg.outOff : count;
                 // kEmitU candidates per lane and pass: their loads (candidate, then the total of its diagonal) are in flight
                 // together -- one candidate per lane was two dependent global round trips for every GW pairs
                 constexpr int kEmitU = 4;
@@ -630,18 +661,19 @@ cpecan_pairhmm_packed(const KArgs a) {
                         if (keep) {
                             if (p > 1.0) p = 1.0;
                             const int pos = count + __popcll(mask & belowMe);
-                            if (pos < rg.outCap) {
-                                out[3 * (size_t)pos + 0] = (int32_t)floor(p * (double)CPECAN_PROB_1);
-                                out[3 * (size_t)pos + 1] = x - 1;
-                                out[3 * (size_t)pos + 2] = y - 1;
+                            if (pos < outCap) {
+                                outSeg[3 * (size_t)pos + 0] = (int32_t)floor(p * (double)CPECAN_PROB_1);
+                                outSeg[3 * (size_t)pos + 1] = x - 1;
+                                outSeg[3 * (size_t)pos + 2] = y - 1;
                             }
                         }
                         count += __popcll(mask & groupBits);
                     }
                 }
+                if (MODE == kModeTrace && segOn && c == 0) a.segCounts[rg.segOff + itemSeg + si] = count;
             }
             // ---------------- the traceback used the rolling buffers: restore F[dTop-1], F[dTop] ----------------
-            if (segOn && !sg.atEnd) {
+            if (MODE == kModeWhole && segOn && !sg.atEnd) {
 #pragma unroll
                 for (int back = 1; back >= 0; back--) {
                     const int dd = sg.dTop - back;
@@ -655,7 +687,7 @@ cpecan_pairhmm_packed(const KArgs a) {
                 }
             }
         }
-        if (have && c == 0) {
+        if (MODE == kModeWhole && have && c == 0) {
             if (kIndel) {
 #pragma unroll
                 for (int l = 0; l < NL; l++) a.outCounts[(size_t)l * a.geo.nRegions + r] = countL[l];

@@ -12,7 +12,8 @@
 // The rows are then TWO arrays of S rows (ROWS = S), one per parity of the diagonal, `setStride` doubles apart: S is odd
 // for both models, so a lane stride of S * 8 bytes is as conflict-free as 2S + 1 rows were, without the padding row
 // (round 4: 1.2 KB of LDS per wave at BASELINE config B, part of what the tenth wave per CU needs).
-template <int S, bool FAST, int ROWS = 2 * S + 1, bool COH = false, bool RDBL = false, bool ABS = false>
+// XG: 64-lane groups per diagonal tracebackExpect() is unrolled for (1: no diagonal of the class is wider than a wave)
+template <int S, bool FAST, int ROWS = 2 * S + 1, bool COH = false, bool RDBL = false, bool ABS = false, int XG = 2>
 struct Sweep {
     const KArgs &a;
     const KConsts &m;  // kernarg-resident constants
@@ -1659,7 +1660,7 @@ struct Sweep {
     static constexpr int kWinDoubles = 96;  // a window's record: kNT transition sums | [13] ref | [14] diagonals | [16, 96) emission sums
 
     static constexpr int kWinCopies = kExpectWinCopies;  // LDS copies of the window's emission sums (lane & 1)
-    static constexpr int kExpGroups = 2;  // 64-lane groups per diagonal tracebackExpect() is unrolled for (class: <= 128 cells)
+    static constexpr int kExpGroups = XG;  // 64-lane groups per diagonal tracebackExpect() is unrolled for (class: <= 64 / <= 128 cells)
     __device__ void tracebackExpect(const CpkSegment &sg, const double *endPrior, double *dbgFb) {
         const int J = sg.nRefresh;
         const int FS = (a.geo.maxWidth + 1) * S;  // doubles per F slot
@@ -2137,7 +2138,8 @@ constexpr int kModeWhole = 0, kModeForward = 1, kModeTrace = 2, kModeFused = 3;
 #endif
 // INSWEEP: expectation emitter, every diagonal of the class within one 64-lane group: the events are formed inside the
 // traceback (Sweep::tracebackExpect / scaleWindows) instead of in a second pass (Sweep::expectations)
-template <int S, bool FAST, int EMIT, int MODE = kModeWhole, int WPS = CPK_SWEEP_WAVES, bool ABS = false, bool INSWEEP = false>
+// (INSWEEP = 1: a class without a diagonal wider than 64 cells -- one group per diagonal, nothing kept for a second)
+template <int S, bool FAST, int EMIT, int MODE = kModeWhole, int WPS = CPK_SWEEP_WAVES, bool ABS = false, int INSWEEP = 0>
 __global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 cpecan_pairhmm_sweep(const KArgs a) {
     static_assert(!ABS || (FAST && MODE != kModeWhole && EMIT == CPECAN_EMIT_MATCH), "absolute positions: split classes of the match emitter");
@@ -2156,7 +2158,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
     double *wt = lds + kLdsCubics + kLdsEm;
     fill_weights<S>(wt, m, a.kc, lane);
     double *eLds = lds + kLdsCubics + kLdsEm + kLdsWeights;  // emission-expectation sums of this wave (expectation emitter)
-    constexpr int kECopies = lds_expect_copies(INSWEEP);
+    constexpr int kECopies = lds_expect_copies(INSWEEP != 0);
     if (EMIT == CPECAN_EMIT_EXPECT)
         for (int i = lane; i < kECopies * 80; i += CPK_WAVE) eLds[i] = 0.0;
     constexpr int kNT = S == 5 ? 13 : 9;
@@ -2164,7 +2166,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
 #pragma unroll
     for (int i = 0; i < kNT; i++) tAcc[i] = 0.0;
     double likelihood = 0.0;
-    constexpr int kHeader = lds_header_doubles(EMIT, INSWEEP);
+    constexpr int kHeader = lds_header_doubles(EMIT, INSWEEP != 0);
     double *roll = FAST ? (lds + kHeader) : (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles);
     Candidate *stageLds = reinterpret_cast<Candidate *>(lds + kHeader + (FAST ? (size_t)rollDoubles : 0));
     constexpr int kStageDoubles = MODE == kModeForward ? 0 : lds_stage_doubles(EMIT, ABS);  // a forward launch stages no candidates
@@ -2172,7 +2174,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
     // every rolling cell starts as -inf; position 0 of each row is never written again (the guard)
     for (int i = lane; i < rollDoubles; i += CPK_WAVE) roll[i] = NEG_INF;
     // expectation step inside the traceback (Sweep::tracebackExpect): three F slots and the window's emission sums behind the strings
-    constexpr bool expInSweep = INSWEEP;
+    constexpr bool expInSweep = INSWEEP != 0;
     double *frowLds = reinterpret_cast<double *>(seqLds + (a.geo.seqLdsBytes + 15) / 16 * 16);
     double *eWinLds = reinterpret_cast<double *>(frowLds + 3 * (a.geo.maxWidth + 1) * S);
     if (expInSweep) {
@@ -2213,7 +2215,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
             roll_fence<false>();
         }
         const CpkDiag *table = a.diags + rg.diagOff;
-        Sweep<S, FAST, R, MODE == kModeFused, MODE != kModeWhole, ABS> sw{a,
+        Sweep<S, FAST, R, MODE == kModeFused, MODE != kModeWhole, ABS, INSWEEP == 1 ? 1 : 2> sw{a,
                           a.kc,
                           DiagCache{table, N, 0, lane, 0, 0, 0, 0, ABS ? a.dpos + rg.diagOff : nullptr, 0},
                           FAST ? seqLds : gx,
@@ -2387,7 +2389,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
                 int nCand[NL];
                 if constexpr (ABS) sw.template tracebackAbs<NL, true>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
-                else if constexpr (INSWEEP) sw.tracebackExpect(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr);
+                else if constexpr (INSWEEP != 0) sw.tracebackExpect(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr);
                 else sw.template traceback<NL, EMIT != CPECAN_EMIT_EXPECT>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
                 roll_fence<true>();  // candidate / cbuf / mbuf stores of all lanes are complete before they are re-read
                 sw.foldTotals(sg, table);
@@ -2396,7 +2398,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                         a.dbgTotals[rg.dbgDiagOff + d2] = ld_self(sw.totals + (sg.tbFrom - d2) / CPK_REFRESH_PERIOD);
                 }
                 if (EMIT == CPECAN_EMIT_EXPECT) {
-                    if constexpr (INSWEEP) sw.scaleWindows(sg, tAcc, eLds, likelihood);
+                    if constexpr (INSWEEP != 0) sw.scaleWindows(sg, tAcc, eLds, likelihood);
                     else sw.expectations(sg, tAcc, eLds, likelihood);
                 }
 #pragma unroll

@@ -952,6 +952,66 @@ def test_packed_and_sweep_kernels_agree_bit_for_bit(monkeypatch):
             assert a.shape == b.shape and (a == b).all()
 
 
+def test_packed_split_classes_equal_whole_regions(monkeypatch):
+    """Round 4: a packed class as two launches (cpk_packed.inl MODE: every forward sweep into a ring of the region's own,
+    then one queue item per region and traceback segment, G items to a wave).  Forced on and off (CPECAN_PACKED_SPLIT) over
+    all three group widths and both model families -- random anchors with several short traceback segments per region,
+    ragged ends, split rectangles, a realign-style sample whose long alignments have a dozen segments, a threshold of zero
+    (the per-segment slices overflow and the batch re-runs), wide regions riding along -- the lists must be identical
+    triple for triple, and equal to the oracle's."""
+    from cpecan_amd.workload import make_realign_batch
+    rng = random.Random(2024)
+    cases = []
+    for mtype, exp in ((0, 2), (2, 6), (1, 14), (3, 26)):
+        probs, raggeds = [], []
+        for _ in range(40):
+            sx = _rand_seq(rng, rng.randrange(1, 900))
+            sy = _evolve(rng, sx) or "C"
+            anchors, x, y = [], -1, -1
+            while True:
+                x += rng.randrange(1, 5)
+                y += rng.randrange(1, 5)
+                if x >= len(sx) or y >= len(sy):
+                    break
+                anchors.append((x, y, exp))
+            probs.append((sx, sy, anchors))
+            raggeds.append((rng.random() > 0.5, rng.random() > 0.5))
+        probs += [(_rand_seq(rng, 120), _rand_seq(rng, 130), [])] * 2  # wide: the sweep kernel, beside the packed classes
+        raggeds += [(False, False)] * 2
+        tbd = rng.randrange(5, 40)
+        cases.append((mtype, probs, raggeds, dict(diagonalExpansion=exp, minDiagsBetweenTraceBack=tbd + rng.randrange(20, 200),
+                                                   traceBackDiagonals=tbd, splitMatrixBiggerThanThis=rng.choice([10, 50, 10 ** 12]))))
+    realign = make_realign_batch(4, 60, 100, 5000, 4)
+    cases.append((0, realign, [(True, True)] * len(realign), dict(diagonalExpansion=4, splitMatrixBiggerThanThis=10,
+                                                                  minDiagsBetweenTraceBack=1000, traceBackDiagonals=40)))
+    cases.append((2, realign[:20], [(True, False)] * 20, dict(diagonalExpansion=4, threshold=0.0, minDiagsBetweenTraceBack=300,
+                                                              traceBackDiagonals=20)))
+    monkeypatch.setenv("CPECAN_PACKED", "2")
+    for mtype, probs, raggeds, kw in cases:
+        monkeypatch.setenv("CPECAN_PACKED_SPLIT", "0")
+        whole, st0 = _run_batch(mtype, probs, raggeds, **kw)
+        monkeypatch.setenv("CPECAN_PACKED_SPLIT", "1")
+        split, st1 = _run_batch(mtype, probs, raggeds, **kw)
+        assert st1.cells == st0.cells and st1.regions == st0.regions
+        for a, b in zip(split, whole):
+            assert a.shape == b.shape and (a == b).all()
+        om, op = ob.model(mtype), ob.params(**kw)
+        for i in range(0, len(probs), 7):
+            sx, sy, an = probs[i]
+            rl, rr = raggeds[i]
+            assert_pairs_match(split[i], ob.aligned_pairs(om, sx, sy, an, op, rl, rr), threshold=op.threshold)
+    # the default choice: a batch whose longest region is what a launch of whole regions waits for goes split by itself
+    monkeypatch.delenv("CPECAN_PACKED_SPLIT")
+    monkeypatch.delenv("CPECAN_PACKED")
+    big = make_realign_batch(4, 400, 100, 5000, 4)
+    kw = dict(diagonalExpansion=4, splitMatrixBiggerThanThis=10, minDiagsBetweenTraceBack=1000, traceBackDiagonals=40)
+    auto, st2 = _run_batch(0, big, [(True, True)] * len(big), **kw)
+    monkeypatch.setenv("CPECAN_PACKED_SPLIT", "0")
+    ref, st3 = _run_batch(0, big, [(True, True)] * len(big), **kw)
+    for a, b in zip(auto, ref):
+        assert a.shape == b.shape and (a == b).all()
+
+
 def test_packed_kernel_indel_emitter(monkeypatch):
     """the indel emitter (diagonalCalculationPosteriorProbs, pairwiseAligner.c:691-733 -- what
     getShiftedMEAAlignment :1764-1790 needs) on narrow bands through the packed kernel: the traceback parks B of the emitted
