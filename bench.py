@@ -386,6 +386,11 @@ def main():
             total_mem = torch.cuda.get_device_properties(local_rank).total_memory
             stage = max(e2e["plan_upload_s"], kernel_ms * 1e-3, 1e-4)
             depth = max(2, min(4, int(np.ceil(e2e["serial_s_per_batch"] / stage))))
+            if e2e["plan_upload_s"] > kernel_ms * 1e-3:
+                # host-bound (config 4): in the pipeline a batch's latency is longer than the serial figure -- its gather and
+                # its copy out queue behind the next batches' sweeps and copies -- and two more batches in flight cover that
+                # (steady 36-42 ms per batch at four, 32-34 at six: profiles/r04_config4_chain_bound.txt)
+                depth = min(6, depth + 2)
             while depth > 2 and depth * e2e["device_bytes"] > total_mem // 2:
                 depth -= 1
         e2e["pipeline_depth"] = depth

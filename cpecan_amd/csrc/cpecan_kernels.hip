@@ -1128,8 +1128,13 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             const bool eligible = geo->emit == CPECAN_EMIT_MATCH && !dynamic && !geo->debug;
             // (the steps of a wave if the class's steps were dealt out evenly over every wave slot of the chip)
             const int64_t balanced = stepsAll / (G * slots) + 1;
+            // ... and only for a batch that has the device to itself: with other batches of the process in flight (a
+            // pipeline) their waves fill the slots a chain leaves idle, and the split form -- rings of whole regions in HBM
+            // instead of a cache-resident ring per group, six launches instead of two -- costs throughput: config 4 end to end,
+            // four batches in flight, 35-37 ms per batch with whole regions against 43 split (profiles/r04_config4_chain_bound.txt)
+            const bool lone = !(d->device >= 0 && d->device < kMaxDevices && g_ranAlive[d->device] > 0);
             if (eligible && env && atoi(env) != 0) cut = n;
-            else if (eligible && !(env && atoi(env) == 0) && (fromEnv || (segMax >= 3 && 2 * nMax * 2 >= balanced * 3))) {
+            else if (eligible && !(env && atoi(env) == 0) && (fromEnv || (lone && segMax >= 3 && 2 * nMax * 2 >= balanced * 3))) {
                 const int64_t from = fromEnv ? atoll(fromEnv) : nMax / 2;
                 for (int64_t di = base; di < base + n; di++)  // (ordered by cells, not by diagonals: up to the last long one)
                     if ((int64_t)regions[di].lX + regions[di].lY > from) cut = di - base + 1;
