@@ -217,9 +217,10 @@ __device__ __forceinline__ double logadd(const Cubic *tab, double x, double y) {
 // and so does NaN (-inf - -inf: a window reference or total of -inf, e.g. a zero-probability region under a loaded HMM
 // with -inf transitions): fmax returns its non-NaN operand, one instruction -- a NaN here would poison the sums of the
 // whole batch, whose per-wave partials are added up on the host.
-__device__ __forceinline__ double exp_1e7(double x) {
-    return (double)__builtin_amdgcn_exp2f((float)__builtin_fmax(x * 1.4426950408889634 /* log2(e) */, -200.0));
+__device__ __forceinline__ float exp_1e7f(double x) {
+    return __builtin_amdgcn_exp2f((float)__builtin_fmax(x * 1.4426950408889634 /* log2(e) */, -200.0));
 }
+__device__ __forceinline__ double exp_1e7(double x) { return (double)exp_1e7f(x); }
 
 // Packs the nSym one-byte symbols at src into LDS, two to a byte (low nibble = even index; a missing partner reads as
 // N), with LANES threads.  The loads of a batch go out together and are clamped instead of predicated: as a loop of
@@ -317,6 +318,23 @@ __device__ __forceinline__ float wave_max_f32(float v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
     return v;
+}
+
+// Sum of v over the 64 lanes, in every lane: an inclusive scan inside the rows of 16 lanes (row_shr), the rows joined with
+// row_bcast:15 / :31 -- six v_add_f32 with a DPP operand and one v_readlane, no LDS (six rounds of __shfl_xor are twelve
+// ds_bpermute_b32 and their waits for a double).  The order of the additions is fixed (lane order within pairs, quads, ...).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_or_zero_f32(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, ROW_MASK, 0xf, true));
+}
+__device__ __forceinline__ float wave_sum_f32(float v) {
+    v += dpp_or_zero_f32<0x111, 0xf>(v);  // row_shr:1
+    v += dpp_or_zero_f32<0x112, 0xf>(v);  // row_shr:2
+    v += dpp_or_zero_f32<0x114, 0xf>(v);  // row_shr:4
+    v += dpp_or_zero_f32<0x118, 0xf>(v);  // row_shr:8: lane 15 of every row holds the row's sum
+    v += dpp_or_zero_f32<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v += dpp_or_zero_f32<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3: lane 63 holds the total
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 template <bool GLOBAL_ROLL>

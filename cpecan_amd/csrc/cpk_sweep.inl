@@ -1707,9 +1707,13 @@ struct Sweep {
         loadF(g1, fN);
         storeF(pF1, g1.width, fN);
         loadF(g2, fN);  // F[dTop-2]: stored at the top of the first diagonal
-        double tW[kNT];  // this lane's transition sums of the current window
+        // This lane's transition sums of the current window -- at most ten diagonals, one cell each -- in fp32, as the events
+        // themselves are (exp_1e7f: v_exp_f32); the window's sums over the lanes are fp32 too (wave_sum_f32), the windows of a
+        // segment and everything above them fp64.  (Round 4: fp64 sums were 13 conversions per cell and, per window, 13 x 6
+        // rounds of two ds_bpermute each.)
+        float tW[kNT];
 #pragma unroll
-        for (int i = 0; i < kNT; i++) tW[i] = 0.0;
+        for (int i = 0; i < kNT; i++) tW[i] = 0.0f;
         double ref = 0.0;  // the window's provisional normaliser (set on its refresh diagonal, before its first event)
         int jw = 0, nWin = 0;  // the window's index (= its refresh point's) and its diagonals so far
         // Global stores wait a diagonal in registers and go out at the top of the next one, in front of its F request: the
@@ -1866,11 +1870,11 @@ struct Sweep {
                     const double refL = on ? ref : __builtin_huge_val();
 #pragma unroll
                     for (int s = 0; s < S; s++) vr[s] = v[q][s] - refL;
-                    double eAcc[S];  // this cell's events summed per target state: one LDS atomic per state, not per event
+                    float eAcc[S];  // this cell's events summed per target state: one LDS atomic per state, not per event
 #pragma unroll
-                    for (int s = 0; s < S; s++) eAcc[s] = 0.0;
+                    for (int s = 0; s < S; s++) eAcc[s] = 0.0f;
                     auto event = [&](int ti, double from, int to, double w) {
-                        const double p = exp_1e7(from + w + vr[to]);
+                        const float p = exp_1e7f(from + w + vr[to]);
                         tW[ti] += p;
                         eAcc[to] += p;
                     };
@@ -1910,7 +1914,7 @@ struct Sweep {
                     if (on && cX < CPK_SYM_N && cY < CPK_SYM_N) {  // emissions are counted for ACGT x ACGT cells only (:429)
                         double *copy = eWin + (lane & (kWinCopies - 1)) * 80 + cX * 4 + cY;
 #pragma unroll
-                        for (int s = 0; s < S; s++) atomicAdd(&copy[s * 16], eAcc[s]);
+                        for (int s = 0; s < S; s++) atomicAdd(&copy[s * 16], (double)eAcc[s]);
                     }
                 }
                 nWin++;
@@ -1919,11 +1923,9 @@ struct Sweep {
                     double mine = lane == kNT ? ref : (double)nWin;  // [13] = ref, [14] = diagonals, [15] unused
 #pragma unroll
                     for (int i = 0; i < kNT; i++) {
-                        double t = tW[i];
-#pragma unroll
-                        for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off);
-                        if (lane == i) mine = t;
-                        tW[i] = 0.0;
+                        const float t = wave_sum_f32(tW[i]);
+                        if (lane == i) mine = (double)t;
+                        tW[i] = 0.0f;
                     }
                     pendRec[0] = mine;
                     roll_fence<false>();
