@@ -2135,6 +2135,9 @@ constexpr int kModeWhole = 0, kModeForward = 1, kModeTrace = 2, kModeFused = 3;
 // handful of spills) three fit, and a queue that long runs 9-34 % faster with them (cpk_device_upload).
 // ABS: the sweeps of a split class over absolute positions (Sweep::forwardStreamAbs / tracebackAbs): match emitter, LDS rows,
 // fixed expansion (KArgs::dpos holds the positions)
+#ifndef CPK_FUSED_PRIO
+#define CPK_FUSED_PRIO 0
+#endif
 #ifndef CPK_INSWEEP_PLAIN_FWD
 #define CPK_INSWEEP_PLAIN_FWD 1  // bands this narrow have no whole group in front of a tail: the plain per-diagonal forward (1.2 % faster, config 5)
 #endif
@@ -2203,6 +2206,15 @@ cpecan_pairhmm_sweep(const KArgs a) {
         const bool traceRole = MODE == kModeTrace || (MODE == kModeFused && tk >= a.regionCount);  // wave-uniform
         const bool forwardRole = MODE == kModeForward || (MODE == kModeFused && !traceRole);
         const int ti = MODE == kModeFused ? tk - a.regionCount : tk;
+#if CPK_FUSED_PRIO
+        // One launch, regions and items in one queue: the forward sweep of a region is the chain everything else of the
+        // region waits for, so its wave goes ahead of the item waves that share its SIMD (s_setprio: the arbiter picks the
+        // highest-priority wave that can issue).
+        if (MODE == kModeFused) {
+            if (forwardRole) __builtin_amdgcn_s_setprio(CPK_FUSED_PRIO);
+            else __builtin_amdgcn_s_setprio(0);
+        }
+#endif
         const int r = traceRole ? a.items[ti].region : a.regionBase + tk;
         const int itemSeg = traceRole ? a.items[ti].seg : 0;
 
