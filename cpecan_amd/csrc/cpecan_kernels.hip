@@ -104,11 +104,6 @@ struct LaunchClass {
     bool dense = false;  // three-state match kernels allocated for three waves per SIMD (WPS = 3)
     bool fused = false;  // split, as ONE launch (kModeFused): regions and their traceback items in one queue
     bool abs = false;    // split, with the sweeps over absolute positions (cpk_sweep.inl "Absolute-position sweeps")
-    // split, absolute positions, launch 1 = forward sweeps AND the backward sweeps of the segments side by side
-    // (kModeBack), launch 2 = items that read both back (kModeCombine): a second ring per region and a row per item
-    bool bidir = false;
-    int64_t backOff = 0, stradOff = 0;  // ... in doubles from the class's ring pointer
-    int32_t stradStride = 0;
     KernelFn fnTrace = nullptr;
     int wavesTrace = 0;
     int64_t itemBase = 0, itemCount = 0;  // its items in dItems
@@ -920,18 +915,6 @@ static int64_t split_ring_doubles(const CpkRegion &rg, int S) {
     // + one double of padding per diagonal (match rows start and end on even doubles); an even total keeps the next region's ring aligned
     return ((int64_t)rg.cells + (N + 1) + (int64_t)(S - 1) * rg.maxWidth * fullDiags + S + 1) & ~(int64_t)1;
 }
-// the two kernels of a class that runs its forward and backward sweeps side by side (absolute positions, LDS rows)
-static void pick_bidir_kernels(const CpkGeometry &g, bool three, KernelFn *back, KernelFn *combine) {
-    if (g.nStates == 5) {
-        *back = three ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeBack, 3, true> : cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeBack, CPK_SWEEP_WAVES, true>;
-        *combine = three ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeCombine, 3, true>
-                         : cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_MATCH, kModeCombine, CPK_SWEEP_WAVES, true>;
-    } else {
-        *back = three ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeBack, 3, true> : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeBack, CPK_SWEEP_WAVES, true>;
-        *combine = three ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeCombine, 3, true>
-                         : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeCombine, CPK_SWEEP_WAVES, true>;
-    }
-}
 // dense: the three-state match kernels allocated for three waves per SIMD (cpk_sweep.inl, WPS)
 static KernelFn pick_fused_kernel(const CpkGeometry &g, bool dense, bool abs, bool three = false) {
     const bool fast = !g.useGlobalRoll;
@@ -1444,42 +1427,6 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                     }
                 }
                 c.itemCount = nSegClass;
-                {
-                    // Forward and backward sweeps side by side (cpk_sweep.inl, kModeBack / kModeCombine).  CPECAN_BIDIR=1 / 0
-                    // (tests, A/B runs): always / never for a two-launch class under absolute positions.
-                    const char *bdEnv = getenv("CPECAN_BIDIR");
-                    const bool bdWanted = bdEnv ? atoi(bdEnv) != 0 : false;
-                    if (!c.fused && c.abs && !c.geo.useGlobalRoll && bdWanted) {
-                        c.bidir = true;
-                        pick_bidir_kernels(c.geo, false, &c.fn, &c.fnTrace);
-                        int pB = 0, pC = 0;
-                        if (int rc = wavesPerCU(c.fn, c.ldsBytes, &pB)) return rc;
-                        if (int rc = wavesPerCU(c.fnTrace, c.ldsBytes, &pC)) return rc;
-                        if ((160 * 1024) / c.ldsBytes >= 9) {  // the builds for three waves per SIMD where the LDS lets them pay
-                            KernelFn b3 = nullptr, c3 = nullptr;
-                            pick_bidir_kernels(c.geo, true, &b3, &c3);
-                            int p3 = 0;
-                            if (int rc = wavesPerCU(b3, c.ldsBytes, &p3)) return rc;
-                            if (p3 > pB) {
-                                c.fn = b3;
-                                pB = p3;
-                            }
-                            if (int rc = wavesPerCU(c3, c.ldsBytes, &p3)) return rc;
-                            if (p3 > pC) {
-                                c.fnTrace = c3;
-                                pC = p3;
-                            }
-                        }
-                        int64_t wb = (int64_t)pB * d->numCUs, wc = (int64_t)pC * d->numCUs;
-                        if (wb > n + nSegClass) wb = n + nSegClass;
-                        if (wc > nSegClass) wc = nSegClass;
-                        c.waves = (int)wb;
-                        c.wavesTrace = (int)wc;
-                        c.subSlots = wb > wc ? wb : wc;
-                        c.ldsBytesFwd = 0;  // launch 1 runs tracebacks too: the whole LDS
-                        c.stradStride = (c.geo.maxWidth + 2) & ~1;
-                    }
-                }
             } else if (c.abs) {
                 // one wave per region: the other form of the rows (a class that went to a team of waves keeps the team's LDS)
                 if (c.threads == CPK_WAVE) setForm(c, false);
@@ -1487,10 +1434,9 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             }
         }
         if (getenv("CPECAN_TRACE_HOST"))
-            fprintf(stderr, "cpecan class %d: %d regions, widest diagonal %d, LDS %zu B (forward launch %zu B), waves %d / %d, %s%s%s%s%s\n", k,
+            fprintf(stderr, "cpecan class %d: %d regions, widest diagonal %d, LDS %zu B (forward launch %zu B), waves %d / %d, %s%s%s%s\n", k,
                     c.regionCount, c.geo.maxWidth, c.ldsBytes, c.ldsBytesFwd, c.waves, c.wavesTrace,
                     c.split ? (c.fused ? "one launch" : "two launches") : "one wave per region", c.abs ? ", absolute positions" : "",
-                    c.bidir ? ", forward and backward sweeps side by side" : "",
                     c.dense ? ", three waves per SIMD" : "", c.geo.expInSweep ? ", expectation events inside the traceback" : "");
         c.ringEl = c.geo.ringCells * S;
         c.candEl = c.geo.fbCells * nCandLists;
@@ -1522,13 +1468,6 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                 if (!c.split) continue;
                 c.ringTotal = 0;
                 for (int64_t di = c.regionBase; di < c.regionBase + c.regionCount; di++) c.ringTotal += split_ring_doubles(regions[di], S);
-                if (c.bidir) {
-                    // ... a second ring per region for the backward values, then a row per item (64 doubles in front of the
-                    // rows and 256 behind: the streamed prefetch reads that far beside a row, Sweep::tracebackAbs)
-                    c.backOff = c.ringTotal;
-                    c.stradOff = 2 * c.ringTotal + 64;
-                    c.ringTotal = c.stradOff + c.itemCount * c.stradStride + 256;
-                }
                 c.ringEl = 0;
             }
         };
@@ -1537,7 +1476,6 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                 if (!c.split) continue;
                 c.split = false;
                 c.fused = false;
-                c.bidir = false;
                 c.fnTrace = nullptr;
                 c.itemCount = 0;
                 c.ringTotal = 0;
@@ -1857,13 +1795,10 @@ extern "C" int cpk_device_run(CpkDevice *d, void *stream) {
         p.bring = d->dBring ? d->dBring + c.oBring : nullptr;
         p.expectOut = d->dExpect + c.oExpect;
         p.queue = d->dQueue + i;
-        if (c.fused || c.bidir) {
+        if (c.fused) {
             p.items = d->dItems + c.itemBase;
             p.itemCount = (int32_t)c.itemCount;
         }
-        p.backOff = c.backOff;
-        p.stradOff = c.stradOff;
-        p.stradStride = c.stradStride;
         const bool onCaller = i == nClasses - 1;
         if (!onCaller && !d->sideStream[i]) {
             // A priority of its own: the runtime maps the streams of one priority onto a handful of hardware queues, and a

@@ -41,10 +41,6 @@ struct KArgs {
     int *progress;       // [nRegions + 1] kModeFused: segments of a region whose forward values are complete; last word: error flag
     int32_t itemCount;   // kModeFused: items behind the regionCount regions of the queue
     const CpkItem *items;  // (region, segment) queue of a split class's traceback launch
-    // kModeBack / kModeCombine: where, in doubles from `ring`, the class keeps the regions' rings of backward values (a
-    // region's at backOff + its ringBase) and the items' rows for B.match of diagonal tbFrom + 1 (item i's at stradOff + i * stradStride)
-    int64_t backOff, stradOff;
-    int32_t stradStride;
     int32_t *triples;    // [nLists][outTriplesPerList*3]
     int64_t outTriplesPerList;
     int64_t nSegsTotal;

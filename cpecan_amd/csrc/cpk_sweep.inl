@@ -433,7 +433,6 @@ struct Sweep {
         int xlo;           // x of its first cell
         int ownR;          // (position of its first cell - 1) * R: element offset of cell 0 from a row pointer at position 1
         int W;
-        int ringOff;       // its offset in the region's ring (the second ring of backward values has the same layout)
         double *cur;       // row set of d's parity, position 1: the diagonal's values go there, over those of d -+ 2
         const double *lu;  // the other row set, shifted by d's parity: the neighbour at x-y - 1 is at the cell's own offset,
                            // the one at x-y + 1 R elements further
@@ -445,7 +444,6 @@ struct Sweep {
         c.xlo = (d + g.xmyL) >> 1;
         c.ownR = (pLo - 1) * R;
         c.W = g.width;
-        c.ringOff = g.ringOff;
         c.cur = roll + R + (d & 1) * setStride;
         c.lu = roll + R + ((d + 1) & 1) * setStride + ((d & 1) - 1) * R;
         return c;
@@ -1025,19 +1023,7 @@ struct Sweep {
     // diagonal it joins are of the same kind (both emitted or both not), so a group has no per-lane flags; the prefetch
     // of the next diagonal's F rows is three loads off one per-lane address (lanes outside the row read neighbouring ring
     // words, which the ring's padding makes legal, and ignore them).
-    // PART (round 4): the backward sweep of a segment needs nothing of the forward sweep -- B[dTop] is the end prior -- so a
-    // class whose launches are single chains (fewer regions than wave slots: one wave walks 2 N forward diagonals, then one
-    // wave per segment walks its backward diagonals) can run both at once.  kPartBack: the backward values only, into a
-    // second ring of the region (`bback`: the forward ring's layout -- the match row of every emitted diagonal, every state
-    // on the refresh diagonals; a diagonal is emitted by exactly one segment, so the items of a region never write the same
-    // words) and, for the match row of the diagonal above the segment's first refresh point (tbFrom + 1: emitted by the
-    // NEXT segment with other values), a row of the item's own (`strad`).  kPartCombine, once both sweeps are done: the same
-    // walk over the same groups, with B read back instead of computed -- posterior candidates, the two series of the totals.
-    // kPartAll: both in one (every other launch form).
-    static constexpr int kPartAll = 0, kPartBack = 1, kPartCombine = 2;
-    double *bback = nullptr;  // kPartBack / kPartCombine: the region's ring of backward values
-    double *strad = nullptr;  //   ... and the item's row for B.match of diagonal tbFrom + 1
-    template <int NL, bool CANDS, int PART = 0>
+    template <int NL, bool CANDS>
     __device__ void tracebackAbs(const CpkSegment &sg, const double *endPrior, double *dbgFb, int (&nCand)[NL]) {
         const int J = sg.nRefresh;
         const float logThr = (float)log(m.threshold);
@@ -1053,7 +1039,7 @@ struct Sweep {
         };
         float lastMax = -__builtin_huge_valf();
         double keepFrom = lastMax;  // compared in double: one instruction per group instead of a conversion and a compare
-        if (PART != kPartCombine) absWipe();  // nothing above the top diagonal exists: its neighbours read -inf
+        absWipe();  // nothing above the top diagonal exists: its neighbours read -inf
         // F rows of the emitted states, lane <-> cell k = q * 64 - off + lane of group q; unclamped (see above)
         double fmCur[NL][kPrefetch];
         auto loadRows = [&](const CpkDiag &gd, int offd, double (&dst)[NL][kPrefetch]) {
@@ -1070,12 +1056,6 @@ struct Sweep {
 #pragma unroll
             for (int q = 0; q < kPrefetch; q++) dst[0][q] = ringLd(src + q * CPK_WAVE);
 #endif
-        };
-        // kPartCombine: B.match of the same cells, from the region's second ring -- or, for diagonal tbFrom + 1, the item's row
-        auto loadRowsB = [&](const CpkDiag &gd, int offd, int d, double (&dst)[kPrefetch]) {
-            const double *src = (d > sg.tbFrom ? strad : bback + gd.ringOff) + (lane - offd);
-#pragma unroll
-            for (int q = 0; q < kPrefetch; q++) dst[q] = ringLd(src + q * CPK_WAVE);
         };
         // posterior candidates of one group of an emitted diagonal: fb = F + B of the NL emitted states
         auto emitCells = [&](int d, int x, bool on, const double (&f0)[NL], const double (&v)[S], int dbgAt) {
@@ -1138,21 +1118,19 @@ struct Sweep {
             for (int l = 0; l < (CANDS ? NL : 0); l++)
                 if (pend[l] >= kStageAbs / 2) flush(l);
         };
-        // (B of the cell: the rolling rows, or -- kPartCombine -- bRow, read back from the second ring)
-        auto dotCell = [&](const AbsDiag &cx, int k, const double (&fRow)[S], const double (&bRow)[S], double &t) {
+        auto dotCell = [&](const AbsDiag &cx, int k, const double (&fRow)[S], double &t) {
             const int kR = cx.ownR + k * R;
-            t = fRow[0] + (PART == kPartCombine ? bRow[0] : cx.cur[kR]);
+            t = fRow[0] + cx.cur[kR];
             const int x = cx.xlo + k, y = cx.d - x;
             const float fbf = (x > 0 && y > 0) ? (float)t : -__builtin_huge_valf();
 #pragma unroll
-            for (int s2 = 1; s2 < S; s2++) t = logadd(lg, t, fRow[s2] + (PART == kPartCombine ? bRow[s2] : cx.cur[s2 + kR]));
+            for (int s2 = 1; s2 < S; s2++) t = logadd(lg, t, fRow[s2] + cx.cur[s2 + kR]);
             return fbf;
         };
         auto refreshDots = [&](const AbsDiag &cx, const CpkDiag &g, int off, int jr, const double (&fm)[NL][kPrefetch],
-                               const double (&rfC)[S][kPrefetch], const double (&rbC)[S][kPrefetch], bool bIsPrior) {
+                               const double (&rfC)[S][kPrefetch]) {
             const int W = g.width;
             const double *fsrc = ringAt(g);
-            const double *bsrc = PART == kPartCombine ? bback + g.ringOff : nullptr;
             float diagMax = -__builtin_huge_valf();
 #pragma unroll
             for (int q = 0; q < kPrefetch; q++) {
@@ -1160,13 +1138,10 @@ struct Sweep {
                 float fbf = -__builtin_huge_valf();
                 if (q * CPK_WAVE - off < W) {  // wave-uniform
                     if ((unsigned)k < (unsigned)W) {
-                        double fRow[S], bRow[S];
+                        double fRow[S];
 #pragma unroll
-                        for (int s2 = 0; s2 < S; s2++) {
-                            fRow[s2] = s2 < NL ? fm[s2][q] : rfC[s2][q];
-                            bRow[s2] = rbC[s2][q];
-                        }
-                        fbf = dotCell(cx, k, fRow, bRow, pendC[q]);
+                        for (int s2 = 0; s2 < S; s2++) fRow[s2] = s2 < NL ? fm[s2][q] : rfC[s2][q];
+                        fbf = dotCell(cx, k, fRow, pendC[q]);
                     }
                     if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
                 }
@@ -1175,14 +1150,11 @@ struct Sweep {
                 const int k = kb + lane;
                 float fbf = -__builtin_huge_valf();
                 if (k < W) {
-                    double fRow[S], bRow[S];
+                    double fRow[S];
 #pragma unroll
-                    for (int s2 = 0; s2 < S; s2++) {
-                        fRow[s2] = ringLd(fsrc + ringIdx(W, s2, k));
-                        bRow[s2] = PART != kPartCombine ? 0.0 : (bIsPrior ? rbC[s2][0] : ringLd(bsrc + ringIdx(W, s2, k)));
-                    }
+                    for (int s2 = 0; s2 < S; s2++) fRow[s2] = ringLd(fsrc + ringIdx(W, s2, k));
                     double tk;
-                    fbf = dotCell(cx, k, fRow, bRow, tk);
+                    fbf = dotCell(cx, k, fRow, tk);
                     cbuf[(size_t)k * J + jr] = tk;
                 }
                 if (CANDS) diagMax = fmaxf(diagMax, wave_max_f32(fbf));
@@ -1204,30 +1176,6 @@ struct Sweep {
                 for (int s2 = NL; s2 < S; s2++) rfC[s2][q] = (unsigned)k < (unsigned)g.width ? ringLd(fsrc + ringIdx(g.width, s2, k)) : 0.0;
             }
         };
-        // kPartCombine: every state of B on a refresh diagonal (the match row rides in the prefetch: bm)
-        auto loadRefreshRowsB = [&](const CpkDiag &g, int off, const double (&bm)[kPrefetch], double (&rbC)[S][kPrefetch]) {
-            const double *bsrc = bback + g.ringOff;
-#pragma unroll
-            for (int q = 0; q < kPrefetch; q++) {
-                const int k = q * CPK_WAVE - off + lane;
-                rbC[0][q] = bm[q];
-#pragma unroll
-                for (int s2 = 1; s2 < S; s2++) rbC[s2][q] = (unsigned)k < (unsigned)g.width ? ringLd(bsrc + ringIdx(g.width, s2, k)) : 0.0;
-            }
-        };
-        // kPartBack: the cell's backward values into the second ring / the item's row (flags and offsets per lane in a shared group)
-        auto storeB = [&](int ringOffL, int WL, int k, bool on, bool stM, bool stAll, bool stStrad, const double (&v)[S]) {
-            if (!on) return;
-            if (stM) {
-                double *o = bback + ringOffL;
-                o[ringIdx(WL, 0, k)] = v[0];
-                if (stAll) {
-#pragma unroll
-                    for (int st = 1; st < S; st++) o[ringIdx(WL, st, k)] = v[st];
-                }
-            }
-            if (stStrad) strad[k] = v[0];
-        };
 
         // ---- the top diagonal: every cell gets the end-state prior (pairwiseAligner.c:798-799); nothing is read
         CpkDiag g = dc.get(sg.dTop, true);
@@ -1246,13 +1194,11 @@ struct Sweep {
             for (int kb = 0; kb < W; kb += CPK_WAVE) {
                 const int k0 = kb + lane;
                 const bool on = k0 < W;
-                if (on && PART != kPartCombine) {
+                if (on) {
 #pragma unroll
                     for (int st = 0; st < S; st++) cx.cur[st + cx.ownR + k0 * R] = ep[st];
                 }
-                if (PART == kPartBack) {
-                    storeB(g.ringOff, W, k0, on, emit, untilRefresh == 0, feedsTop && !emit, ep);
-                } else if (emit || feedsTop) {
+                if (emit || feedsTop) {
                     double f0[NL];
 #pragma unroll
                     for (int l = 0; l < NL; l++) f0[l] = ringLd(fsrc + ringIdx(W, l, on ? k0 : W - 1));
@@ -1262,20 +1208,16 @@ struct Sweep {
             }
             roll_fence<false>();
             if (untilRefresh == 0) {
-                if (PART != kPartBack) {
-                    double fm[NL][kPrefetch], rfC[S][kPrefetch], rbC[S][kPrefetch];
+                double fm[NL][kPrefetch], rfC[S][kPrefetch];
 #pragma unroll
-                    for (int q = 0; q < kPrefetch; q++) {
-                        const int k = q * CPK_WAVE + lane;
+                for (int q = 0; q < kPrefetch; q++) {
+                    const int k = q * CPK_WAVE + lane;
 #pragma unroll
-                        for (int l = 0; l < NL; l++) fm[l][q] = ringLd(fsrc + ringIdx(W, l, k < W ? k : W - 1));
-#pragma unroll
-                        for (int st = 0; st < S; st++) rbC[st][q] = ep[st];  // B of the top diagonal is the end prior
-                    }
-                    loadRefreshRows(g, 0, rfC);
-                    refreshDots(cx, g, 0, jr, fm, rfC, rbC, true);
-                    issueStores();
+                    for (int l = 0; l < NL; l++) fm[l][q] = ringLd(fsrc + ringIdx(W, l, k < W ? k : W - 1));
                 }
+                loadRefreshRows(g, 0, rfC);
+                refreshDots(cx, g, 0, jr, fm, rfC);
+                issueStores();
                 untilRefresh = CPK_REFRESH_PERIOD - 1;
                 jr++;
             } else {
@@ -1283,126 +1225,12 @@ struct Sweep {
             }
         }
 
-        if constexpr (PART == kPartCombine) {
-            // ---- kPartCombine: no diagonal depends on the one above it, so the rows of kAhead diagonals are requested
-            // together -- a wave that walked them one by one, a row requested a diagonal ahead, waited a memory round trip
-            // per diagonal with nothing to compute meanwhile (config A: 1.38 ms for the 1040 diagonals of a segment).  No
-            // cells wait for the next diagonal here (off = 0 throughout): groups cost next to nothing.  Visit order, candidate
-            // bound and the two series are those of the loop below.
-            constexpr int kAhead = 4;
-            int d2 = sg.dTop - 1;
-            if (d2 > sg.tbFrom + 1) {  // nothing to do between the top diagonal and tbFrom + 1 (neither emitted nor part of a series)
-                untilRefresh -= d2 - (sg.tbFrom + 1);  // = 1: the next diagonal is the one above the first refresh point
-                d2 = sg.tbFrom + 1;
-            }
-            while (d2 > sg.tbPrev) {
-                const int lo = d2 - (CPK_WAVE - 1) > sg.tbPrev + 1 ? d2 - (CPK_WAVE - 1) : sg.tbPrev + 1;
-                dc.load(d2 - (CPK_WAVE - 1));  // table entries of d2 - 63 .. d2
-                while (d2 >= lo) {
-                    CpkDiag gg[kAhead];
-                    double fB[kAhead][NL][kPrefetch], bB[kAhead][kPrefetch];
-#pragma unroll
-                    for (int j = 0; j < kAhead; j++) {
-                        const int dd = d2 - j >= lo ? d2 - j : d2;  // past the chunk: this block's first diagonal again (never used)
-                        gg[j] = dc.at(dd - dc.base);
-                        loadRows(gg[j], 0, fB[j]);
-                        loadRowsB(gg[j], 0, dd, bB[j]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < kAhead; j++) {
-                        const int dd = d2 - j;
-                        if (dd < lo) break;  // wave-uniform
-                        const CpkDiag gd = gg[j];
-                        const int W = gd.width;
-                        const bool emit = dd <= sg.tbFrom;
-                        const bool refresh = untilRefresh == 0;
-                        const bool feeds = untilRefresh == 1 && dd - 1 > sg.tbPrev;
-#pragma unroll
-                        for (int q = 0; q < kPrefetch; q++) {
-#pragma unroll
-                            for (int l = 0; l < NL; l++) asm volatile("" : "+v"(fB[j][l][q]));
-                            asm volatile("" : "+v"(bB[j][q]));
-                        }
-                        AbsDiag cx{};
-                        cx.d = dd;
-                        cx.xlo = (dd + gd.xmyL) >> 1;
-                        cx.W = W;
-                        cx.ringOff = gd.ringOff;
-                        if (emit) {
-#pragma unroll
-                            for (int q = 0; q < kPrefetch; q++) {
-                                if (q * CPK_WAVE < W) {  // wave-uniform
-                                    const int k0 = q * CPK_WAVE + lane;
-                                    const bool on = k0 < W;
-                                    double f0[NL], v[S];
-#pragma unroll
-                                    for (int l = 0; l < NL; l++) f0[l] = fB[j][l][q];
-                                    v[0] = bB[j][q];
-#pragma unroll
-                                    for (int st = 1; st < S; st++) v[st] = 0.0;
-                                    emitCells(dd, cx.xlo + (on ? k0 : W - 1), on, f0, v, gd.cellOff + (on ? k0 : W - 1));
-                                }
-                            }
-                            for (int kb = kPrefetch * CPK_WAVE; kb < W; kb += CPK_WAVE) {  // diagonals wider than the prefetch
-                                const int k0 = kb + lane;
-                                const bool on = k0 < W;
-                                double f0[NL], v[S];
-#pragma unroll
-                                for (int l = 0; l < NL; l++) f0[l] = ringLd(ringAt(gd) + ringIdx(W, l, on ? k0 : W - 1));
-                                v[0] = ringLd((dd > sg.tbFrom ? strad : bback + gd.ringOff) + (on ? k0 : W - 1));
-#pragma unroll
-                                for (int st = 1; st < S; st++) v[st] = 0.0;
-                                emitCells(dd, cx.xlo + (on ? k0 : W - 1), on, f0, v, gd.cellOff + (on ? k0 : W - 1));
-                            }
-                        }
-                        if (feeds) {
-#pragma unroll
-                            for (int q = 0; q < kPrefetch; q++) {
-                                const int k = q * CPK_WAVE + lane;
-                                pendM[q] = k < W ? fB[j][0][q] + bB[j][q] : 0.0;
-                            }
-                            pendMW = W;
-                            pendMOff = 0;
-                            pendMj = jr;
-                            const double *fsrc = ringAt(gd), *bsrc = dd > sg.tbFrom ? strad : bback + gd.ringOff;
-                            for (int kb = kPrefetch * CPK_WAVE; kb < W; kb += CPK_WAVE) {
-                                const int k = kb + lane;
-                                if (k < W) mbuf[(size_t)k * J + jr] = ringLd(fsrc + ringIdx(W, 0, k)) + ringLd(bsrc + k);
-                            }
-                        }
-                        if (refresh) {
-                            double rfC[S][kPrefetch], rbC[S][kPrefetch];
-                            loadRefreshRows(gd, 0, rfC);
-                            loadRefreshRowsB(gd, 0, bB[j], rbC);
-                            refreshDots(cx, gd, 0, jr, fB[j], rfC, rbC, false);
-                        }
-                        issueStores();
-                        if (refresh) {
-                            untilRefresh = CPK_REFRESH_PERIOD - 1;
-                            jr++;
-                        } else {
-                            untilRefresh--;
-                        }
-                    }
-                    d2 = d2 - kAhead >= lo ? d2 - kAhead : lo - 1;
-                }
-            }
-#pragma unroll
-            for (int l = 0; l < (CANDS ? NL : 0); l++) flush(l);
-            return;
-        }
         // ---- the diagonals below it
-        // kPartCombine has nothing to do between the top diagonal and tbFrom + 1 (neither emitted nor part of a series)
-        int dStart = sg.dTop - 1;
-        if (PART == kPartCombine && dStart > sg.tbFrom + 1) {
-            untilRefresh -= dStart - (sg.tbFrom + 1);  // = 1: the next diagonal is the one above the first refresh point
-            dStart = sg.tbFrom + 1;
-        }
         int posb = gpos & 0x7fff, posa = 0;  // positions of the first cells of d2 + 1 and d2 + 2 under the base in force
-        g = dStart >= 0 ? dc.get(dStart, true) : CpkDiag{};
-        gpos = dStart >= 0 ? dc.posGet(dStart, true) >> 16 : 0;
-        CpkDiag gnext = dStart >= 1 ? dc.get(dStart - 1, true) : CpkDiag{};
-        int gnpos = dStart >= 1 ? dc.posGet(dStart - 1, true) >> 16 : 0;
+        g = sg.dTop >= 1 ? dc.get(sg.dTop - 1, true) : CpkDiag{};
+        gpos = sg.dTop >= 1 ? dc.posGet(sg.dTop - 1, true) >> 16 : 0;
+        CpkDiag gnext = sg.dTop >= 2 ? dc.get(sg.dTop - 2, true) : CpkDiag{};
+        int gnpos = sg.dTop >= 2 ? dc.posGet(sg.dTop - 2, true) >> 16 : 0;
         int off = 0;         // lane of the current diagonal's cell 0 in its first group
         bool carry = false;  // lanes [0, off) of that group hold the last cells of the diagonal above:
         AbsDiag tl{};        //   its context,
@@ -1410,23 +1238,12 @@ struct Sweep {
         double fTail[NL];    //   and its F values
 #pragma unroll
         for (int l = 0; l < NL; l++) fTail[l] = 0.0;
-        double bmCur[kPrefetch], bTail = 0.0;  // kPartCombine: B.match of the same cells
+        loadRows(g, 0, fmCur);
 #pragma unroll
-        for (int q = 0; q < kPrefetch; q++) bmCur[q] = 0.0;
-        if (PART != kPartBack) {
-            loadRows(g, 0, fmCur);
-            if (PART == kPartCombine && dStart > sg.tbPrev) loadRowsB(g, 0, dStart, bmCur);
+        for (int l = 0; l < NL; l++)
 #pragma unroll
-            for (int l = 0; l < NL; l++)
-#pragma unroll
-                for (int q = 0; q < kPrefetch; q++) asm volatile("" : "+v"(fmCur[l][q]));
-        } else {
-#pragma unroll
-            for (int l = 0; l < NL; l++)
-#pragma unroll
-                for (int q = 0; q < kPrefetch; q++) fmCur[l][q] = 0.0;
-        }
-        for (int d2 = dStart; d2 > sg.tbPrev;) {
+            for (int q = 0; q < kPrefetch; q++) asm volatile("" : "+v"(fmCur[l][q]));
+        for (int d2 = sg.dTop - 1; d2 > sg.tbPrev;) {
           dc.load(d2 - 2 - (CPK_WAVE - 1));  // the chunk of table entries that ends at d2 - 2
           for (int ci = CPK_WAVE - 1; ci >= 0 && d2 > sg.tbPrev; ci--, d2--) {
             const int W = g.width;
@@ -1436,7 +1253,7 @@ struct Sweep {
             // diagonal above a refresh point writes that series (see traceback above)
             const bool feeds = untilRefresh == 1 && d2 - 1 > sg.tbPrev;
             const int pLo = gpos & 0x7fff;
-            if (PART != kPartCombine && (gpos & 0x8000)) {  // rare; never with cells of the diagonal above waiting (carryNext below)
+            if (gpos & 0x8000) {  // rare; never with cells of the diagonal above waiting (carryNext below)
                 const bool have2 = d2 + 2 <= sg.dTop;
                 const CpkDiag gb = dc.table[d2 + 1], ga = dc.table[have2 ? d2 + 2 : d2 + 1];  // (not kept in registers: once per rectangle)
                 const int delta = absRebase(d2, g, pLo, -1, gb, posb, true, ga, posa, have2);
@@ -1455,20 +1272,17 @@ struct Sweep {
                 carryNext = (gnpos & 0x7fff) + bN + ((d2 - 1) & 1) - 1 < pLo + qT * CPK_WAVE - off;
             }
             const int offNext = carryNext ? r : 0;
-            double fmNext[NL][kPrefetch], bmNext[kPrefetch];
-            if (PART != kPartBack) loadRows(gnext, offNext, fmNext);  // one diagonal of arithmetic covers the round trip
-            if (PART == kPartCombine && d2 - 1 > sg.tbPrev) loadRowsB(gnext, offNext, d2 - 1, bmNext);
+            double fmNext[NL][kPrefetch];
+            loadRows(gnext, offNext, fmNext);  // one diagonal of arithmetic covers the round trip
             const CpkDiag gnext2 = dc.at(ci);
             const int gnpos2 = dc.posAt(ci) >> 16;
-            double rfC[S][kPrefetch], rbC[S][kPrefetch];  // a refresh point reads every state of F[d2]: requested here, used behind the groups
+            double rfC[S][kPrefetch];  // a refresh point reads every state of F[d2]: requested here, used behind the groups
 #ifndef CPK_TIMING_NO_PASSES
-            if (refresh && PART != kPartBack) loadRefreshRows(g, off, rfC);
-            if (refresh && PART == kPartCombine) loadRefreshRowsB(g, off, bmCur, rbC);
+            if (refresh) loadRefreshRows(g, off, rfC);
 #endif
             // One group of 64 cells: lane by lane cell k0 of diagonal t (wave-uniform except in the shared group); lanes that
             // are not `on` compute a cell of their diagonal all the same and store nothing.
-            auto group = [&](const AbsDiag &t, int k0, int kR0, bool on, const double (&f0)[NL], int tCellOff, double b0, bool stAll,
-                             bool stStrad) {
+            auto group = [&](const AbsDiag &t, int k0, int kR0, bool on, const double (&f0)[NL], int tCellOff) {
 #ifdef CPK_TIMING_TRACE_REPEAT  // timing experiment: every traceback group computed this many times (0: not at all)
               for (int rep = 0; rep < CPK_TIMING_TRACE_REPEAT; rep++) {
 #endif
@@ -1484,20 +1298,10 @@ struct Sweep {
                 const int kk[1] = {k0};
                 const int kkR[1] = {kR0};
                 double v[1][S];
-                if (PART == kPartCombine) {
-                    v[0][0] = b0;  // (the other states are read on refresh diagonals only: refreshDots)
+                bwdCells<1>(c, kk, kkR, v);
+                if (on) {
 #pragma unroll
-                    for (int st = 1; st < S; st++) v[0][st] = 0.0;
-                } else {
-                    bwdCells<1>(c, kk, kkR, v);
-                    if (on) {
-#pragma unroll
-                        for (int st = 0; st < S; st++) t.cur[st + kR0] = v[0][st];
-                    }
-                }
-                if (PART == kPartBack) {
-                    storeB(t.ringOff, t.W, k0, on, emit, stAll, stStrad, v[0]);
-                    return;
+                    for (int st = 0; st < S; st++) t.cur[st + kR0] = v[0][st];
                 }
 #ifdef CPK_TIMING_TRACE_NO_EMIT
                 if (emit && a.geo.maxWidth < 0) emitCells(t.d, t.xlo + k0, on, f0, v[0], tCellOff + k0);
@@ -1517,8 +1321,7 @@ struct Sweep {
                 mx.d = inA ? tl.d : cx.d;
                 mx.xlo = inA ? tl.xlo : cx.xlo;
                 mx.ownR = 0;
-                mx.W = inA ? tl.W : cx.W;
-                mx.ringOff = inA ? tl.ringOff : cx.ringOff;
+                mx.W = 0;
                 mx.cur = inA ? tl.cur : cx.cur;
                 mx.lu = inA ? tl.lu : cx.lu;
                 // lanes past the end of a narrow diagonal compute its first cell
@@ -1527,8 +1330,7 @@ struct Sweep {
                 double f0[NL];
 #pragma unroll
                 for (int l = 0; l < NL; l++) f0[l] = inA ? fTail[l] : fmCur[l][0];
-                // (the diagonal a waiting tail belongs to is neither a refresh point nor the diagonal above one: carryNext)
-                group(mx, k0, kR0, on, f0, inA ? tlCellOff : g.cellOff, inA ? bTail : bmCur[0], !inA && refresh, !inA && feeds && !emit);
+                group(mx, k0, kR0, on, f0, inA ? tlCellOff : g.cellOff);
                 q0 = 1;
             }
             // this diagonal's own groups; its last cells wait for the next diagonal when they may (carryNext)
@@ -1542,8 +1344,7 @@ struct Sweep {
                     const int kb = q * CPK_WAVE - off;
                     const int k0 = kb + lane;
                     const bool on = k0 < W;
-                    group(cx, on ? k0 : W - 1, on ? cx.ownR + kb * R + laneR : cx.ownR + (W - 1) * R, on, f0, g.cellOff, bmCur[q], refresh,
-                          feeds && !emit);
+                    group(cx, on ? k0 : W - 1, on ? cx.ownR + kb * R + laneR : cx.ownR + (W - 1) * R, on, f0, g.cellOff);
                 }
             }
             for (int q = kPrefetch; q < nNow; q++) {  // diagonals wider than the prefetch load F on the spot
@@ -1552,22 +1353,20 @@ struct Sweep {
                 const bool on = k0 < W;
                 double f0[NL];
 #pragma unroll
-                for (int l = 0; l < NL; l++) f0[l] = PART == kPartBack ? 0.0 : ringLd(ringAt(g) + ringIdx(W, l, on ? k0 : W - 1));
-                const double b0 = PART != kPartCombine ? 0.0 : ringLd((d2 > sg.tbFrom ? strad : bback + g.ringOff) + (on ? k0 : W - 1));
-                group(cx, on ? k0 : W - 1, on ? cx.ownR + kb * R + laneR : cx.ownR + (W - 1) * R, on, f0, g.cellOff, b0, refresh,
-                      feeds && !emit);
+                for (int l = 0; l < NL; l++) f0[l] = ringLd(ringAt(g) + ringIdx(W, l, on ? k0 : W - 1));
+                group(cx, on ? k0 : W - 1, on ? cx.ownR + kb * R + laneR : cx.ownR + (W - 1) * R, on, f0, g.cellOff);
             }
 #ifdef CPK_TIMING_NO_PASSES  // timing experiment: neither the straddle series nor the dot products
             if ((feeds || refresh) && a.geo.maxWidth < 0) {
 #else
-            if ((feeds || refresh) && PART != kPartBack) {  // one diagonal in five: all its cells are done (no tail waits), a pass of its own follows
+            if (feeds || refresh) {  // one diagonal in five: all its cells are done (no tail waits), a pass of its own follows
 #endif
                 roll_fence<false>();
                 if (feeds) {  // F.m of the cells from the prefetched registers, B.m from the rows
 #pragma unroll
                     for (int q = 0; q < kPrefetch; q++) {
                         const int k = q * CPK_WAVE - off + lane;
-                        pendM[q] = (unsigned)k < (unsigned)W ? fmCur[0][q] + (PART == kPartCombine ? bmCur[q] : cx.cur[cx.ownR + k * R]) : 0.0;
+                        pendM[q] = (unsigned)k < (unsigned)W ? fmCur[0][q] + cx.cur[cx.ownR + k * R] : 0.0;
                     }
                     pendMW = W;
                     pendMOff = off;
@@ -1575,12 +1374,10 @@ struct Sweep {
                     const double *fsrc = ringAt(g);
                     for (int kb = kPrefetch * CPK_WAVE - off; kb < W; kb += CPK_WAVE) {
                         const int k = kb + lane;
-                        if (k < W)
-                            mbuf[(size_t)k * J + jr] = ringLd(fsrc + ringIdx(W, 0, k)) +
-                                                       (PART == kPartCombine ? ringLd((d2 > sg.tbFrom ? strad : bback + g.ringOff) + k) : cx.cur[cx.ownR + k * R]);
+                        if (k < W) mbuf[(size_t)k * J + jr] = ringLd(fsrc + ringIdx(W, 0, k)) + cx.cur[cx.ownR + k * R];
                     }
                 }
-                if (refresh) refreshDots(cx, g, off, jr, fmCur, rfC, rbC, false);
+                if (refresh) refreshDots(cx, g, off, jr, fmCur, rfC);
             }
             // the cells that wait: their context and their F values (group qT of this diagonal's prefetched rows)
             if (carryNext) {
@@ -1594,12 +1391,6 @@ struct Sweep {
                     for (int q = kPrefetch - 2; q >= 1; q--) f = qT == q ? fmCur[l][q] : f;
                     fTail[l] = f;
                 }
-                if (PART == kPartCombine) {
-                    double bt = bmCur[kPrefetch - 1];
-#pragma unroll
-                    for (int q = kPrefetch - 2; q >= 1; q--) bt = qT == q ? bmCur[q] : bt;
-                    bTail = bt;
-                }
             }
             carry = carryNext;
             off = offNext;
@@ -1612,22 +1403,13 @@ struct Sweep {
             gnpos = gnpos2;
             // The empty asm consumes the prefetched registers HERE, one whole diagonal after their loads were issued and
             // before the next prefetch goes out (left to itself hipcc waits at the first use, behind the next prefetch).
-            if (PART != kPartBack) {
 #pragma unroll
-                for (int l = 0; l < NL; l++)
-#pragma unroll
-                    for (int q = 0; q < kPrefetch; q++) {
-                        asm volatile("" : "+v"(fmNext[l][q]));
-                        fmCur[l][q] = fmNext[l][q];
-                    }
-            }
-            if (PART == kPartCombine && d2 - 1 > sg.tbPrev) {
+            for (int l = 0; l < NL; l++)
 #pragma unroll
                 for (int q = 0; q < kPrefetch; q++) {
-                    asm volatile("" : "+v"(bmNext[q]));
-                    bmCur[q] = bmNext[q];
+                    asm volatile("" : "+v"(fmNext[l][q]));
+                    fmCur[l][q] = fmNext[l][q];
                 }
-            }
             issueStores();
             if (refresh) {
                 untilRefresh = CPK_REFRESH_PERIOD - 1;
@@ -2341,10 +2123,6 @@ constexpr int kEmitForward = 3;
 //                 or done: no deadlock whatever the number of resident waves.  The tracebacks of a region's first
 //                 segments then run beside the forward sweeps of the class instead of behind the slowest of them.
 constexpr int kModeWhole = 0, kModeForward = 1, kModeTrace = 2, kModeFused = 3;
-// kModeBack / kModeCombine (round 4, absolute positions): the regions' forward sweeps AND, side by side in the same launch,
-// the backward sweeps of their segments (Sweep::tracebackAbs, kPartBack -- the backward sweep needs nothing of the forward
-// one), then a launch of items that read both back and emit (kPartCombine).  For classes whose launches are single chains.
-constexpr int kModeBack = 4, kModeCombine = 5;
 // kModeFused hands the forward ring from wave to wave inside one launch with sc1 (device-scope write-through / read-through)
 // accesses and a flag behind an acknowledged-stores wait: the hand-off MI355X_MICROARCH.md lists for gfx942 / gfx950, outside
 // what the HIP memory model promises in general.  This translation unit is gfx950 code; refuse anything else.
@@ -2370,7 +2148,6 @@ template <int S, bool FAST, int EMIT, int MODE = kModeWhole, int WPS = CPK_SWEEP
 __global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 cpecan_pairhmm_sweep(const KArgs a) {
     static_assert(!ABS || (FAST && MODE != kModeWhole && EMIT == CPECAN_EMIT_MATCH), "absolute positions: split classes of the match emitter");
-    static_assert((MODE != kModeBack && MODE != kModeCombine) || ABS, "forward and backward sweeps side by side: absolute positions only");
     static_assert(!INSWEEP || (FAST && MODE == kModeWhole && EMIT == CPECAN_EMIT_EXPECT), "in-sweep events: expectation emitter, LDS rows");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
@@ -2398,7 +2175,6 @@ cpecan_pairhmm_sweep(const KArgs a) {
     double *roll = FAST ? (lds + kHeader) : (a.groll + (size_t)blockIdx.x * a.geo.rollDoubles);
     Candidate *stageLds = reinterpret_cast<Candidate *>(lds + kHeader + (FAST ? (size_t)rollDoubles : 0));
     constexpr int kStageDoubles = MODE == kModeForward ? 0 : lds_stage_doubles(EMIT, ABS);  // a forward launch stages no candidates
-    constexpr bool kQueueHasItems = MODE == kModeFused || MODE == kModeBack;  // regions, then (region, segment) items in ONE queue
     uint8_t *seqLds = reinterpret_cast<uint8_t *>(lds + kHeader + (size_t)rollDoubles + kStageDoubles);
     // every rolling cell starts as -inf; position 0 of each row is never written again (the guard)
     for (int i = lane; i < rollDoubles; i += CPK_WAVE) roll[i] = NEG_INF;
@@ -2425,18 +2201,11 @@ cpecan_pairhmm_sweep(const KArgs a) {
         const unsigned int ticket = atomicAdd(a.queue, lane == 0 ? 1u : 0u);
 #endif
         const int tk = __builtin_amdgcn_readfirstlane((int)ticket);
-        if (tk >= a.regionCount + (kQueueHasItems ? a.itemCount : 0)) break;
-        // kModeTrace / kModeCombine: the queue holds (region, segment) items, longest first; kModeFused / kModeBack: regions,
-        // then items; else regions
-        const bool traceRole = MODE == kModeTrace || MODE == kModeCombine || (kQueueHasItems && tk >= a.regionCount);  // wave-uniform
-        const bool forwardRole = MODE == kModeForward || (kQueueHasItems && !traceRole);
-        const int ti = kQueueHasItems ? tk - a.regionCount : tk;
-        // kModeBack: the forward sweep of a region is the longest chain of the launch (2 N diagonals against a segment's ~1000)
-        // and shares its SIMD with item waves: it goes first
-        if (MODE == kModeBack) {
-            if (forwardRole) __builtin_amdgcn_s_setprio(3);
-            else __builtin_amdgcn_s_setprio(0);
-        }
+        if (tk >= a.regionCount + (MODE == kModeFused ? a.itemCount : 0)) break;
+        // kModeTrace: the queue holds (region, segment) items, longest first; kModeFused: regions, then items; else regions
+        const bool traceRole = MODE == kModeTrace || (MODE == kModeFused && tk >= a.regionCount);  // wave-uniform
+        const bool forwardRole = MODE == kModeForward || (MODE == kModeFused && !traceRole);
+        const int ti = MODE == kModeFused ? tk - a.regionCount : tk;
 #if CPK_FUSED_PRIO
         // One launch, regions and items in one queue: the forward sweep of a region is the chain everything else of the
         // region waits for, so its wave goes ahead of the item waves that share its SIMD (s_setprio: the arbiter picks the
@@ -2482,11 +2251,6 @@ cpecan_pairhmm_sweep(const KArgs a) {
                           CpkDiag{},
                           CpkDiag{}};
         sw.setStride = S * stride;
-        if (MODE == kModeBack || MODE == kModeCombine) {
-            // the region's second ring and the item's own row (cpk_device_upload lays them out behind the class's rings)
-            sw.bback = a.ring + a.backOff + (size_t)rg.ringBase;
-            sw.strad = a.ring + a.stradOff + (size_t)(traceRole ? ti : 0) * (size_t)a.stradStride;
-        }
         if (EMIT == CPECAN_EMIT_EXPECT) {
             // B of a segment's emitted cells (expectations()) or its window records (tracebackExpect())
             sw.bring = a.bring + slot * (size_t)(expInSweep ? (int64_t)a.geo.maxRefresh * sw.kWinDoubles : a.geo.fbCells * S);
@@ -2562,7 +2326,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
             const int siFirst = traceRole ? itemSeg : 0, siEnd = traceRole ? itemSeg + 1 : rg.nSeg;
             for (int si = siFirst; si < siEnd; si++) {
                 const CpkSegment sg = a.segs[rg.segOff + si];
-                if (ABS && !a.geo.reserved0 && MODE != kModeCombine) {
+                if (ABS && !a.geo.reserved0) {
                     // Symbol windows (round 4): only the symbols the diagonals of THIS step touch are staged -- the forward
                     // sweep of diagonals d .. dTop, or the traceback of tbPrev + 1 .. dTop, whose cells also read the symbols
                     // one past their own (Sweep::bwdCells) -- ~0.7 KB instead of the 2 KB of both whole strings of a 2 kb pair.
@@ -2638,12 +2402,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
 #endif
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
                 int nCand[NL];
-                if constexpr (MODE == kModeBack) {
-                    sw.template tracebackAbs<NL, false, sw.kPartBack>(sg, endPrior, nullptr, nCand);
-                    continue;  // what is left of the item is the next launch's (kModeCombine)
-                } else if constexpr (MODE == kModeCombine)
-                    sw.template tracebackAbs<NL, true, sw.kPartCombine>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
-                else if constexpr (ABS) sw.template tracebackAbs<NL, true>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
+                if constexpr (ABS) sw.template tracebackAbs<NL, true>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
                 else if constexpr (INSWEEP != 0) sw.tracebackExpect(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr);
                 else sw.template traceback<NL, EMIT != CPECAN_EMIT_EXPECT>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
                 roll_fence<true>();  // candidate / cbuf / mbuf stores of all lanes are complete before they are re-read

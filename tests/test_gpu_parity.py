@@ -1117,7 +1117,7 @@ def test_packed_kernel_expectations(force_packed, mtype):
 
 
 # ---- per-cell log-space values: sharper than any posterior (they see every logAdd of both sweeps) ----
-@pytest.mark.parametrize("form", ["whole", "split_abs", "fused_abs", "split_dense_rows", "bidir_abs"])
+@pytest.mark.parametrize("form", ["whole", "split_abs", "fused_abs", "split_dense_rows"])
 @pytest.mark.parametrize("case", ["tiny5", "tiny3", "full200", "A_1kb", "B_2kb", "short_tracebacks", "asym_ragged"])
 def test_cell_values_and_totals_match_oracle(case, form, monkeypatch):
     """F.match + B.match of every emitted cell and the total probability used on every emitted diagonal (the debug
@@ -1128,10 +1128,8 @@ def test_cell_values_and_totals_match_oracle(case, form, monkeypatch):
     from parity import LOG_TOL
     if form != "whole" and case in ("tiny5", "tiny3", "full200"):
         pytest.skip("single-segment problems run one wave per region")
-    monkeypatch.setenv("CPECAN_SPLIT", {"whole": "0", "split_abs": "1", "fused_abs": "2", "split_dense_rows": "1", "bidir_abs": "1"}[form])
+    monkeypatch.setenv("CPECAN_SPLIT", {"whole": "0", "split_abs": "1", "fused_abs": "2", "split_dense_rows": "1"}[form])
     monkeypatch.setenv("CPECAN_ABS", "0" if form == "split_dense_rows" else "1")
-    # bidir_abs (round 4): forward and backward sweeps side by side in one launch, an emitting launch behind them
-    monkeypatch.setenv("CPECAN_BIDIR", "1" if form == "bidir_abs" else "0")
     rl = rr = False
     if case == "tiny5":
         mtype, (sx, sy, a), pkw = 0, ("AGCG", "AGTTCG", ()), dict(threshold=0.2)
@@ -1554,13 +1552,6 @@ def test_split_classes_equal_whole_region_waves(monkeypatch):
         monkeypatch.delenv("CPECAN_ABS")
         assert st3.cells == st0.cells
         for a, b in zip(ranked, whole):
-            assert np.array_equal(a, b)
-        # ... with the backward sweeps of the segments beside the forward sweeps and an emitting launch behind both
-        monkeypatch.setenv("CPECAN_BIDIR", "1")
-        bidir, st4 = _run_batch(mtype, problems, **pkw)
-        monkeypatch.delenv("CPECAN_BIDIR")
-        assert st4.cells == st0.cells
-        for a, b in zip(bidir, whole):
             assert np.array_equal(a, b)
         # ... and as ONE launch (CPECAN_SPLIT=2: regions and their traceback items in one queue, an item waits for its
         # region's forward wave to pass its segment)
