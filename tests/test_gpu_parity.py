@@ -1000,6 +1000,21 @@ def test_packed_split_classes_equal_whole_regions(monkeypatch):
             sx, sy, an = probs[i]
             rl, rr = raggeds[i]
             assert_pairs_match(split[i], ob.aligned_pairs(om, sx, sy, an, op, rl, rr), threshold=op.threshold)
+    # rings of whole regions are given up first when they do not fit the share of the device they may take: the split parts
+    # fall back to whole regions (two launches of the whole-region kernel over the two parts of the class)
+    mtype, probs, raggeds, kw = cases[4]
+    monkeypatch.setenv("CPECAN_PACKED_SPLIT_FROM", "1500")
+    monkeypatch.delenv("CPECAN_PACKED_SPLIT")
+    monkeypatch.setenv("CPECAN_SPLIT_BUDGET_FRAC", "1e-7")
+    back, st5 = _run_batch(mtype, probs, raggeds, **kw)
+    monkeypatch.delenv("CPECAN_SPLIT_BUDGET_FRAC")
+    cut, st6 = _run_batch(mtype, probs, raggeds, **kw)
+    monkeypatch.setenv("CPECAN_PACKED_SPLIT", "0")
+    ref5, _ = _run_batch(mtype, probs, raggeds, **kw)
+    assert st5.deviceBytes < st6.deviceBytes
+    for a, b, c in zip(back, cut, ref5):
+        assert a.shape == c.shape and (a == c).all() and b.shape == c.shape and (b == c).all()
+    monkeypatch.delenv("CPECAN_PACKED_SPLIT_FROM")
     # the default choice: a batch whose longest region is what a launch of whole regions waits for goes split by itself
     monkeypatch.delenv("CPECAN_PACKED_SPLIT")
     monkeypatch.delenv("CPECAN_PACKED")
