@@ -969,15 +969,8 @@ static KernelFn pick_dense_kernel(const CpkGeometry &g) {  // one wave per regio
     return !g.useGlobalRoll ? cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_MATCH, kModeWhole, 3> : cpecan_pairhmm_sweep<3, false, CPECAN_EMIT_MATCH, kModeWhole, 3>;
 }
 
-static KernelFn pick_kernel(const CpkGeometry &g, bool expAbs = false) {
+static KernelFn pick_kernel(const CpkGeometry &g) {
     const bool fast = !g.useGlobalRoll;  // second template argument = FAST (LDS rolling buffers + LDS symbol strings)
-    if (g.emit == CPECAN_EMIT_EXPECT && fast && g.expInSweep && expAbs) {  // ... with the rows by absolute position
-        if (g.expInSweep == 1)
-            return g.nStates == 5 ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, true, 1>
-                                  : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, true, 1>;
-        return g.nStates == 5 ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, true, 2>
-                              : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, true, 2>;
-    }
     if (g.emit == CPECAN_EMIT_EXPECT && fast && g.expInSweep == 1)  // no diagonal wider than one 64-lane group
         return g.nStates == 5 ? cpecan_pairhmm_sweep<5, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, false, 1>
                               : cpecan_pairhmm_sweep<3, true, CPECAN_EMIT_EXPECT, kModeWhole, CPK_SWEEP_WAVES, false, 1>;
@@ -1180,13 +1173,11 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     // The LDS of one wave of the class: tables, rolling rows, candidate stage, symbols -- by the form of its sweeps.
     // Absolute positions (cpk_sweep.inl): two arrays of S rows with a few positions of slack, a stage of 64
     // candidates, and the symbols of one traceback segment at a time instead of both whole strings.
-    auto setForm = [&](LaunchClass &cc, bool abs, bool wholeStrings = false) {
+    auto setForm = [&](LaunchClass &cc, bool abs) {
         cc.abs = abs;
         cc.geo.rollStride = cc.geo.maxWidth + (abs ? kAbsSlack : 1);
         const char *winEnv = getenv("CPECAN_ABS_WINDOWS");  // 0: the absolute-position sweeps stage whole strings (diagnostics, tests)
-        // (a whole-region wave under absolute positions -- the expectation emitter, below -- walks the region's forward
-        // diagonals and its tracebacks in turn: whole strings)
-        cc.geo.reserved0 = (abs && (wholeStrings || (winEnv && atoi(winEnv) == 0))) ? 1 : 0;
+        cc.geo.reserved0 = (abs && winEnv && atoi(winEnv) == 0) ? 1 : 0;
         cc.geo.seqLdsBytes = (abs && !cc.geo.reserved0) ? geo->wWinLdsBytes[cc.k] : geo->wSeqLdsBytes[cc.k];
         cc.geo.rollDoubles = (int64_t)(abs ? 2 * S : 2 * S + 1) * cc.geo.rollStride;
         const size_t header = sizeof(double) * (lds_header_doubles(geo->emit) + lds_stage_doubles(geo->emit, abs));
@@ -1209,15 +1200,11 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         // rolling rows by absolute position (cpk_sweep.inl): the rows need a few positions of slack.
         // CPECAN_ABS=0: never (A/B runs, tests of the other form).
         int64_t nSegClass = 0;
-        bool absOk = (geo->emit == CPECAN_EMIT_MATCH || expect) && !dynamic;
+        bool absOk = geo->emit == CPECAN_EMIT_MATCH && !dynamic;
         for (int64_t di = regionAt; di < regionAt + geo->nWide[k]; di++) {
             nSegClass += regions[di].nSeg;
             absOk = absOk && regions[di].absOk;
         }
-        // Expectation emitter with its events inside the traceback (below): the rolling rows by absolute position too --
-        // forward and backward cells without neighbour shifts and range tests (round 4).  CPECAN_EXP_ABS=0: by rank.
-        const char *expAbsEnv = getenv("CPECAN_EXP_ABS");
-        const bool expAbsWanted = expect && absOk && !geo->debug && !(expAbsEnv && atoi(expAbsEnv) == 0);
         {
             const char *env = getenv("CPECAN_SPLIT"), *absEnv = getenv("CPECAN_ABS");
             const bool splitLikely = geo->emit == CPECAN_EMIT_MATCH && (!geo->debug || env) && nSegClass > 0 &&
@@ -1232,7 +1219,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         c.geo.useGlobalRoll = 0;
         setForm(c, false);
         c.geo.useGlobalRoll = c.ldsBytes + 16 > 64 * 1024;
-        setForm(c, (absWanted || expAbsWanted) && !c.geo.useGlobalRoll, expAbsWanted);  // absolute positions are a form of the LDS rows
+        setForm(c, absWanted && !c.geo.useGlobalRoll);  // absolute positions are a form of the LDS rows
         {
             // Expectation emitter, every diagonal of the class within two 64-lane groups: the events are formed inside the
             // traceback (Sweep::tracebackExpect) from three forward diagonals kept in LDS, instead of a second pass over B
@@ -1252,10 +1239,8 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                 if (with <= 160 * 1024 / 8 || (env && atoi(env) >= 2)) c.ldsBytes = with;
                 else c.geo.expInSweep = 0;
             }
-            if (expAbsWanted && c.abs && !c.geo.expInSweep) setForm(c, false);  // the second-pass form indexes its rows by rank
         }
-        const bool expAbs = expect && c.abs;
-        c.fn = pick_kernel(c.geo, expAbs);
+        c.fn = pick_kernel(c.geo);
         if (!c.fn) {
             cpk_set_error("no kernel for emitter %d", geo->emit);
             return CPECAN_EINVAL;
@@ -1442,7 +1427,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                     }
                 }
                 c.itemCount = nSegClass;
-            } else if (c.abs && !expAbs) {
+            } else if (c.abs) {
                 // one wave per region: the other form of the rows (a class that went to a team of waves keeps the team's LDS)
                 if (c.threads == CPK_WAVE) setForm(c, false);
                 else c.abs = false;

@@ -568,7 +568,6 @@ struct Sweep {
         atail.has = false;
     }
     // pos: the diagonal's entry of KArgs::dpos, forward half (position of its first cell | base-moves flag << 15)
-    template <bool PLAIN = false>
     __device__ void forwardStreamAbs(int d, const CpkDiag &g, int pos, int ringStates) {
         const int W = g.width;
         const int pLo = pos & 0x7fff;
@@ -582,12 +581,6 @@ struct Sweep {
         const AbsDiag c = absDiag(d, g, pLo);
         double *out = ringAt(g);
         int lo = 0;
-        if (PLAIN) {  // diagonals of about one group: nothing to stream (the expectation emitter's narrow classes)
-            for (; lo < W; lo += CPK_WAVE) absFwdGroup(c, out, ringStates, lo, W);
-            apos2 = apos1;
-            apos1 = pLo;
-            return;
-        }
 #if defined(CPK_ABS_FWD_FORM) && CPK_ABS_FWD_FORM > 0
         // timing experiments (tools/ab_build.sh): no streaming; FORM 2: pairs of groups in lock-step (two cells per lane).
         // Measured (profiles/r03_forward_what_bounds_it.txt, r03_ab_forward_pairs_under_subscribed.txt): the pairs are 6 %
@@ -673,22 +666,6 @@ struct Sweep {
             }
         }
         roll_fence<!FAST>();
-    }
-
-    // ... under absolute positions (whole-region waves of the expectation emitter, round 4): the rows were wiped
-    // (absWipe) and F[d] goes back to the position its first cell had when the forward sweep left it (apos1 / apos2)
-    __device__ void reloadForwardAbs(const CpkDiag &g, int d, int pos) {
-        const int W = g.width;
-        double *cur = roll + R + (d & 1) * setStride + (pos - 1) * R;
-        const double *src = ringAt(g);
-        for (int kb = 0; kb < W; kb += CPK_WAVE) {
-            const int k = kb + lane;
-            if (k < W) {
-#pragma unroll
-                for (int s = 0; s < S; s++) cur[s + k * R] = ld_self(src + ringIdx(W, s, k));
-            }
-        }
-        roll_fence<false>();
     }
 
     struct BwdCtx {
@@ -1720,17 +1697,6 @@ struct Sweep {
         CpkDiag g = dc.get(sg.dTop, true);
         CpkDiag g1 = dc.get(sg.dTop >= 1 ? sg.dTop - 1 : 0, true);
         CpkDiag g2 = dc.get(sg.dTop >= 2 ? sg.dTop - 2 : 0, true);
-        // ABS (round 4): the B rows by absolute position, as in tracebackAbs -- the three neighbours of a cell at constant
-        // offsets, no shifts and no range tests (the F slots of the events stay indexed by rank: they are a structure of
-        // their own).  gp .. gp2: the positions of d2, d2-1, d2-2 (backward half of KArgs::dpos); posb / posa: first-cell
-        // positions of d2+1 / d2+2 under the base in force.
-        int gp = 0, gp1 = 0, gp2 = 0, posb = 0, posa = 0;
-        if (ABS) {
-            gp = dc.posGet(sg.dTop, true) >> 16;
-            gp1 = dc.posGet(sg.dTop >= 1 ? sg.dTop - 1 : 0, true) >> 16;
-            gp2 = dc.posGet(sg.dTop >= 2 ? sg.dTop - 2 : 0, true) >> 16;
-            absWipe();  // nothing above the top diagonal exists: its neighbours read -inf
-        }
         double fN[kExpGroups][S];
 #pragma unroll
         for (int q = 0; q < kExpGroups; q++)
@@ -1797,37 +1763,18 @@ struct Sweep {
             storeF(pF2, g2.width, fN);
             issueStores();
             const CpkDiag g3 = dc.at(ci);  // entry of d2-3 (of diagonal 0 below it: never used then)
-            const int gp3 = ABS ? dc.posAt(ci) >> 16 : 0;
             loadF(g3, fN);
             double *curM = pM0, *curG = bG1(d2);
             const int xlo = (d2 + g.xmyL) >> 1;
             BwdCtx c;
             c.d2 = d2;
             c.xlo = xlo;
-            AbsDiag cx{};
-            const int pLo = gp & 0x7fff;
-            if (ABS) {
-                if (!seeded && (gp & 0x8000)) {  // rare: once per rectangle of the band
-                    const bool have2 = d2 + 2 <= sg.dTop;
-                    const int delta = absRebase(d2, g, pLo, -1, gb, posb, true, ga, posa, have2);
-                    posb += delta;
-                    posa += delta;
-                }
-                cx = absDiag(d2, g, pLo);
-                c.dbR = 0;
-                c.wBR = 0;
-                c.daR = 0;
-                c.wAR = 0;
-                c.pb = cx.lu;
-                c.pa = cx.cur;
-            } else {
-                c.dbR = ((g.xmyL - 1 - gb.xmyL) >> 1) * R;
-                c.wBR = gb.width * R;
-                c.daR = ((g.xmyL - ga.xmyL) >> 1) * R;
-                c.wAR = d2 + 2 <= sg.dTop ? ga.width * R : 0;
-                c.pb = bG1(d2 + 1);
-                c.pa = pM2;
-            }
+            c.dbR = ((g.xmyL - 1 - gb.xmyL) >> 1) * R;
+            c.wBR = gb.width * R;
+            c.daR = ((g.xmyL - ga.xmyL) >> 1) * R;
+            c.wAR = d2 + 2 <= sg.dTop ? ga.width * R : 0;
+            c.pb = bG1(d2 + 1);
+            c.pa = pM2;
             // backward cells of the diagonal, a group of 64 at a time; v stays in registers for the events
             double v[kExpGroups][S];
 #pragma unroll
@@ -1840,21 +1787,16 @@ struct Sweep {
                         for (int s = 0; s < S; s++) v[q][s] = ep[s];  // (pairwiseAligner.c:798-799)
                     } else {
                         const int kk[1] = {on ? k0 : W - 1};
-                        const int kkR[1] = {(ABS ? cx.ownR : 0) + (on ? k0 * R : (W - 1) * R)};
+                        const int kkR[1] = {on ? k0 * R : (W - 1) * R};
                         double vv[1][S];
                         bwdCells<1>(c, kk, kkR, vv);
 #pragma unroll
                         for (int s = 0; s < S; s++) v[q][s] = vv[0][s];
                     }
                     if (on) {
-                        if (ABS) {
+                        curM[k0 * R] = v[q][0];
 #pragma unroll
-                            for (int s = 0; s < S; s++) cx.cur[s + cx.ownR + k0 * R] = v[q][s];
-                        } else {
-                            curM[k0 * R] = v[q][0];
-#pragma unroll
-                            for (int s = 1; s < S; s++) curG[s + k0 * R] = v[q][s];
-                        }
+                        for (int s = 1; s < S; s++) curG[s + k0 * R] = v[q][s];
                     }
                 }
             }
@@ -2011,13 +1953,6 @@ struct Sweep {
             g = g1;
             g1 = g2;
             g2 = g3;
-            if (ABS) {
-                posa = posb;
-                posb = pLo;
-                gp = gp1;
-                gp1 = gp2;
-                gp2 = gp3;
-            }
             double *t = pF0;
             pF0 = pF1;
             pF1 = pF2;
@@ -2212,8 +2147,7 @@ constexpr int kModeWhole = 0, kModeForward = 1, kModeTrace = 2, kModeFused = 3;
 template <int S, bool FAST, int EMIT, int MODE = kModeWhole, int WPS = CPK_SWEEP_WAVES, bool ABS = false, int INSWEEP = 0>
 __global__ void __launch_bounds__(CPK_WAVE) __attribute__((amdgpu_waves_per_eu(WPS, WPS)))
 cpecan_pairhmm_sweep(const KArgs a) {
-    static_assert(!ABS || (FAST && ((MODE != kModeWhole && EMIT == CPECAN_EMIT_MATCH) || (MODE == kModeWhole && INSWEEP != 0))),
-                  "absolute positions: split classes of the match emitter, or the expectation emitter with its events inside the traceback");
+    static_assert(!ABS || (FAST && MODE != kModeWhole && EMIT == CPECAN_EMIT_MATCH), "absolute positions: split classes of the match emitter");
     static_assert(!INSWEEP || (FAST && MODE == kModeWhole && EMIT == CPECAN_EMIT_EXPECT), "in-sweep events: expectation emitter, LDS rows");
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x;
@@ -2430,7 +2364,7 @@ cpecan_pairhmm_sweep(const KArgs a) {
                         }
                         const bool all = EMIT != CPECAN_EMIT_MATCH || toRefresh == 0 || d >= sg.dTop - 1;
                         toRefresh = toRefresh == 0 ? CPK_REFRESH_PERIOD - 1 : toRefresh - 1;
-                        if (ABS) sw.template forwardStreamAbs<INSWEEP != 0 && CPK_INSWEEP_PLAIN_FWD>(d, sw.dc.at(d - sw.dc.base), sw.dc.posAt(d - sw.dc.base), all ? S : 1);
+                        if (ABS) sw.forwardStreamAbs(d, sw.dc.at(d - sw.dc.base), sw.dc.posAt(d - sw.dc.base), all ? S : 1);
                         else if (FAST && !(INSWEEP && CPK_INSWEEP_PLAIN_FWD)) sw.forwardStream(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
                         else sw.forward(d, sw.dc.at(d - sw.dc.base), all ? S : 1);
                     }
@@ -2468,8 +2402,8 @@ cpecan_pairhmm_sweep(const KArgs a) {
 #endif
                 const double *endPrior = (sg.atEnd && rg.raggedRight) ? m.raggedEnd : m.end;
                 int nCand[NL];
-                if constexpr (INSWEEP != 0) sw.tracebackExpect(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr);
-                else if constexpr (ABS) sw.template tracebackAbs<NL, true>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
+                if constexpr (ABS) sw.template tracebackAbs<NL, true>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
+                else if constexpr (INSWEEP != 0) sw.tracebackExpect(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr);
                 else sw.template traceback<NL, EMIT != CPECAN_EMIT_EXPECT>(sg, endPrior, (a.geo.debug & 1) ? a.dbgFb + rg.dbgCellOff : nullptr, nCand);
                 roll_fence<true>();  // candidate / cbuf / mbuf stores of all lanes are complete before they are re-read
                 sw.foldTotals(sg, table);
@@ -2503,14 +2437,8 @@ cpecan_pairhmm_sweep(const KArgs a) {
                     // the traceback reused the rolling buffers: restore F[dTop-1], F[dTop] for the forward sweep
                     const CpkDiag gTopM1 = sw.dc.get(sg.dTop - 1, false);
                     const CpkDiag gTop = sw.dc.get(sg.dTop, false);
-                    if constexpr (ABS) {
-                        sw.absWipe();
-                        sw.reloadForwardAbs(gTopM1, sg.dTop - 1, sw.apos2);
-                        sw.reloadForwardAbs(gTop, sg.dTop, sw.apos1);
-                    } else {
-                        sw.reloadForward(gTopM1, sg.dTop - 1);
-                        sw.reloadForward(gTop, sg.dTop);
-                    }
+                    sw.reloadForward(gTopM1, sg.dTop - 1);
+                    sw.reloadForward(gTop, sg.dTop);
                     sw.f2 = gTopM1;
                     sw.f1 = gTop;
                 }
