@@ -1264,8 +1264,12 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                                     : (c.geo.maxWidth > 256 && (soloPerCU <= 3 || c.geo.useGlobalRoll));
         // one workgroup per CU is all the LDS allows from ~660 cells: then eight waves share the region
         const bool big = 2 * teamLds > 160 * 1024;
-        if (wanted && geo->emit == CPECAN_EMIT_MATCH && !geo->debug &&
+        if (wanted && (geo->emit == CPECAN_EMIT_MATCH || geo->emit == CPECAN_EMIT_INDEL) && !geo->debug &&
             c.geo.maxWidth <= CPK_WAVE * kTeamWaves * (big ? 2 : 1) * kTeamGroups && teamLds <= 160 * 1024) {
+            if (geo->emit == CPECAN_EMIT_INDEL)  // (round 4: the three lists of the indel emitter from the team as well)
+                c.fn = S == 5 ? (big ? cpecan_pairhmm_team<5, 2 * kTeamWaves, CPECAN_EMIT_INDEL> : cpecan_pairhmm_team<5, kTeamWaves, CPECAN_EMIT_INDEL>)
+                              : (big ? cpecan_pairhmm_team<3, 2 * kTeamWaves, CPECAN_EMIT_INDEL> : cpecan_pairhmm_team<3, kTeamWaves, CPECAN_EMIT_INDEL>);
+            else
             c.fn = S == 5 ? (big ? cpecan_pairhmm_team<5, 2 * kTeamWaves> : cpecan_pairhmm_team<5, kTeamWaves>)
                           : (big ? cpecan_pairhmm_team<3, 2 * kTeamWaves> : cpecan_pairhmm_team<3, kTeamWaves>);
             c.threads = CPK_WAVE * kTeamWaves * (big ? 2 : 1);
@@ -1436,7 +1440,8 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         if (getenv("CPECAN_TRACE_HOST"))
             fprintf(stderr, "cpecan class %d: %d regions, widest diagonal %d, LDS %zu B (forward launch %zu B), waves %d / %d, %s%s%s%s\n", k,
                     c.regionCount, c.geo.maxWidth, c.ldsBytes, c.ldsBytesFwd, c.waves, c.wavesTrace,
-                    c.split ? (c.fused ? "one launch" : "two launches") : "one wave per region", c.abs ? ", absolute positions" : "",
+                    c.split ? (c.fused ? "one launch" : "two launches") : (c.threads > CPK_WAVE ? "a team of waves per region" : "one wave per region"),
+                    c.abs ? ", absolute positions" : "",
                     c.dense ? ", three waves per SIMD" : "", c.geo.expInSweep ? ", expectation events inside the traceback" : "");
         c.ringEl = c.geo.ringCells * S;
         c.candEl = c.geo.fbCells * nCandLists;

@@ -16,12 +16,17 @@
 //   * the candidate bound (lastMax) is the maximum over the waves' maxima on refresh diagonals, exchanged the same way;
 //   * F rows are read from the forward ring where they are used (the other waves of the team cover the latency).
 constexpr int kTeamGroups = 3;  // 64-cell groups a wave handles per diagonal at most: bands up to 64 * T * kTeamGroups cells
-constexpr int kTeamXchg = 32;   // doubles of LDS for the exchange area (counts, maxima, the region ticket)
+constexpr int kTeamXchg = 48;   // doubles of LDS for the exchange area (counts per list, maxima, the region ticket)
 
 __host__ __device__ constexpr int team_header_doubles() { return kLdsCubics + kLdsEm + kLdsWeights + kTeamXchg; }
 
-template <int S, int T>
+// EMIT (round 4): CPECAN_EMIT_MATCH, or CPECAN_EMIT_INDEL -- the three lists of diagonalCalculationPosteriorProbs
+// (pairwiseAligner.c:691-733: match, gapX, gapY; what getShiftedMEAAlignment needs): every state of every forward diagonal
+// goes to the ring, a wave keeps the candidates of three lists per diagonal and the waves exchange three counts.
+template <int S, int T, int EMIT = CPECAN_EMIT_MATCH>
 __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a) {
+    static_assert(EMIT == CPECAN_EMIT_MATCH || EMIT == CPECAN_EMIT_INDEL, "team kernel: match or match + indel lists");
+    constexpr int NL = EMIT == CPECAN_EMIT_INDEL ? 3 : 1;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int R = 3 * S;
     using SweepT = Sweep<S, true, R>;
@@ -39,7 +44,7 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
     double *em = lds + kLdsCubics;
     double *wt = lds + kLdsCubics + kLdsEm;
     int *xi = reinterpret_cast<int *>(lds + kLdsCubics + kLdsEm + kLdsWeights);  // [0]: ticket, [8 + parity * T + w]: counts
-    float *xf = reinterpret_cast<float *>(xi + 8 + 2 * T);                   // [parity * T + w]: maxima
+    float *xf = reinterpret_cast<float *>(xi + 8 + 2 * NL * T);              // [parity * T + w]: maxima (counts: [8 + (parity * NL + l) * T + w])
     double *roll = lds + team_header_doubles();
     uint8_t *seqLds = reinterpret_cast<uint8_t *>(roll + (size_t)R * stride);
     for (int i = tid; i < R * stride; i += CPK_WAVE * T) roll[i] = NEG_INF;  // position 0 of every row stays the guard
@@ -78,7 +83,7 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                   wt,
                   lg,
                   a.ring + slot * (size_t)a.geo.ringCells * S,
-                  a.cand + slot * (size_t)a.geo.fbCells,
+                  a.cand + slot * (size_t)a.geo.fbCells * NL,
                   nullptr,
                   a.cbuf + slot * (size_t)a.geo.refreshCells,
                   a.mbuf + slot * (size_t)a.geo.refreshCells,
@@ -90,7 +95,9 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                   CpkDiag{},
                   CpkDiag{}};
         __syncthreads();  // symbols staged
-        int count = 0;
+        int count[NL];
+#pragma unroll
+        for (int l = 0; l < NL; l++) count[l] = 0;
 #ifdef CPK_DIAGNOSTICS
         if (a.geo.debug & 4) {  // diagnostic build (CPECAN_DEBUG_SKIP=4): regions are fetched and staged, nothing is computed
             if (tid == 0) a.outCounts[r] = 0;
@@ -124,7 +131,7 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                     const int dEnd = d + CPK_WAVE - 1 < sg.dTop ? d + CPK_WAVE - 1 : sg.dTop;
                     for (; d <= dEnd; d++) {
                         while (d > emitFrom) emitFrom = a.segs[rg.segOff + ++emitSeg].tbFrom;
-                        const bool all = (emitFrom - d) % CPK_REFRESH_PERIOD == 0 || d >= sg.dTop - 1;
+                        const bool all = EMIT != CPECAN_EMIT_MATCH || (emitFrom - d) % CPK_REFRESH_PERIOD == 0 || d >= sg.dTop - 1;
                         const CpkDiag g = sw.dc.at(d - sw.dc.base);
                         const int W = g.width;
                         typename SweepT::FwdCtx c;
@@ -171,12 +178,14 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                 for (int s = 0; s < S; s++) ep[s] = endPrior[s];
                 const int J = sg.nRefresh;
                 float lastMax = -__builtin_huge_valf();
-                int nCand = 0;
+                int nCand[NL];
+#pragma unroll
+                for (int l = 0; l < NL; l++) nCand[l] = 0;
                 int untilRefresh = sg.dTop - sg.tbFrom, jr = 0;
                 CpkDiag gb{}, ga{};
                 CpkDiag g = sw.dc.get(sg.dTop, true);
                 // F.match of this wave's cells, one diagonal ahead of its use (the ring is in HBM): group gi of the range
-                auto loadF = [&](const CpkDiag &gd, double (&dst)[kTeamGroups]) {
+                auto loadF = [&](const CpkDiag &gd, double (&dst)[NL][kTeamGroups]) {
                     int flo, fhi;
                     range(gd.width, flo, fhi);
                     const double *src = sw.ringAt(gd);
@@ -184,10 +193,11 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                     for (int gi = 0; gi < kTeamGroups; gi++) {
                         int k = flo + gi * CPK_WAVE + lane;
                         k = k < gd.width ? k : gd.width - 1;
-                        dst[gi] = ld_self(src + SweepT::ringIdx(gd.width, 0, k > 0 ? k : 0));
+#pragma unroll
+                        for (int l = 0; l < NL; l++) dst[l][gi] = ld_self(src + SweepT::ringIdx(gd.width, l, k > 0 ? k : 0));
                     }
                 };
-                double fCur[kTeamGroups];
+                double fCur[NL][kTeamGroups];
                 loadF(g, fCur);
                 for (int d2 = sg.dTop; d2 > sg.tbPrev;) {
                     sw.dc.load(d2 - 1 - (CPK_WAVE - 1));  // entries of the 64 diagonals ending at d2-1
@@ -198,7 +208,7 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                         const bool refresh = untilRefresh == 0;
                         const bool feeds = untilRefresh == 1 && d2 - 1 > sg.tbPrev;
                         const CpkDiag gnext = sw.dc.at(ci);  // entry of d2-1 (of diagonal 0 when d2 < 1: not used then)
-                        double fNext[kTeamGroups];
+                        double fNext[NL][kTeamGroups];
                         loadF(gnext, fNext);
                         double *curM = sw.bM1(d2), *curG = sw.bG1(d2);
                         const double *fsrc = sw.ringAt(g);
@@ -216,10 +226,12 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                         int lo, hi;
                         range(W, lo, hi);
                         // this wave's candidates of the diagonal wait in registers for the other waves' counts
-                        double pfb[kTeamGroups];
+                        double pfb[NL][kTeamGroups];
                         int px[kTeamGroups];
-                        unsigned long long pmask[kTeamGroups];
-                        int myCount = 0;
+                        unsigned long long pmask[NL][kTeamGroups];
+                        int myCount[NL];
+#pragma unroll
+                        for (int l = 0; l < NL; l++) myCount[l] = 0;
                         float myMax = -__builtin_huge_valf();
                         // refresh diagonals need the other states of F as well (cell dot products): their loads go out
                         // here, ahead of the diagonal's arithmetic
@@ -235,8 +247,11 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                         }
 #pragma unroll
                         for (int gi = 0; gi < kTeamGroups; gi++) {
-                            pmask[gi] = 0;
-                            pfb[gi] = 0.0;
+#pragma unroll
+                            for (int l = 0; l < NL; l++) {
+                                pmask[l][gi] = 0;
+                                pfb[l][gi] = 0.0;
+                            }
                             px[gi] = 0;
                             const int kb = lo + gi * CPK_WAVE;
                             if (kb < hi) {  // wave-uniform
@@ -260,15 +275,21 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                                 }
                                 const int x = xlo + kc, y = d2 - x;
                                 if (emit || feeds) {
-                                    const double f0 = fCur[gi];
+                                    const double f0 = fCur[0][gi];
                                     const double fb = f0 + v[0][0];
                                     if (feeds && on) sw.mbuf[(size_t)k0 * J + jr] = fb;  // series of the refresh point below (:647)
                                     if (emit) {
-                                        const bool keep = on && x > 0 && y > 0 && (float)fb >= keepFrom;
-                                        pmask[gi] = __ballot(keep);
-                                        pfb[gi] = fb;
                                         px[gi] = x;
-                                        myCount += __popcll(pmask[gi]);
+#pragma unroll
+                                        for (int l = 0; l < NL; l++) {
+                                            // match cells need x > 0 and y > 0, gapX cells x > 0, gapY cells y > 0 (:700, :711, :722)
+                                            const bool cell = l == 0 ? (x > 0 && y > 0) : (l == 1 ? x > 0 : y > 0);
+                                            const double fbl = l == 0 ? fb : fCur[l][gi] + v[0][l];
+                                            const bool keep = on && cell && (float)fbl >= keepFrom;
+                                            pmask[l][gi] = __ballot(keep);
+                                            pfb[l][gi] = fbl;
+                                            myCount[l] += __popcll(pmask[l][gi]);
+                                        }
                                         if (refresh) {
                                             // cell dot product over the states (pairwiseAligner.c:402-408) and this wave's
                                             // share of the diagonal's largest F.m + B.m
@@ -290,37 +311,42 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                         // ---- the waves meet: the diagonal is complete, counts and maxima are exchanged ----
                         const int par = d2 & 1;
                         if (lane == 0) {
-                            xi[8 + par * T + wave] = myCount;
+#pragma unroll
+                            for (int l = 0; l < NL; l++) xi[8 + (par * NL + l) * T + wave] = myCount[l];
                             xf[par * T + wave] = myMax;
                         }
                         __syncthreads();
-                        int before = 0, total = 0;
                         float dmax = -__builtin_huge_valf();
 #pragma unroll
-                        for (int w = 0; w < T; w++) {
-                            const int cw = xi[8 + par * T + w];
-                            before += w < wave ? cw : 0;
-                            total += cw;
-                            dmax = fmaxf(dmax, xf[par * T + w]);
-                        }
-                        if (emit) {
-                            int at = nCand + before;
+                        for (int w = 0; w < T; w++) dmax = fmaxf(dmax, xf[par * T + w]);
 #pragma unroll
-                            for (int gi = 0; gi < kTeamGroups; gi++) {
-                                const unsigned long long mk = pmask[gi];
-                                if (mk) {  // wave-uniform
-                                    if ((mk >> lane) & 1ull) {
-                                        const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
-                                        Candidate cd;
-                                        cd.fb = pfb[gi];
-                                        cd.x = px[gi];
-                                        cd.y = d2 - px[gi];
-                                        sw.cand[at + rank] = cd;
-                                    }
-                                    at += __popcll(mk);
-                                }
+                        for (int l = 0; l < NL; l++) {
+                            int before = 0, total = 0;
+#pragma unroll
+                            for (int w = 0; w < T; w++) {
+                                const int cw = xi[8 + (par * NL + l) * T + w];
+                                before += w < wave ? cw : 0;
+                                total += cw;
                             }
-                            nCand += total;
+                            if (emit) {
+                                int at = nCand[l] + before;
+#pragma unroll
+                                for (int gi = 0; gi < kTeamGroups; gi++) {
+                                    const unsigned long long mk = pmask[l][gi];
+                                    if (mk) {  // wave-uniform
+                                        if ((mk >> lane) & 1ull) {
+                                            const int rank = __builtin_amdgcn_mbcnt_hi((unsigned)(mk >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mk, 0));
+                                            Candidate cd;
+                                            cd.fb = pfb[l][gi];
+                                            cd.x = px[gi];
+                                            cd.y = d2 - px[gi];
+                                            sw.cand[(size_t)l * a.geo.fbCells + at + rank] = cd;
+                                        }
+                                        at += __popcll(mk);
+                                    }
+                                }
+                                nCand[l] += total;
+                            }
                         }
                         if (refresh) lastMax = fmaxf(dmax, lastMax - 1.0f);
                         ga = gb;
@@ -328,8 +354,11 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                         g = gnext;
 #pragma unroll
                         for (int gi = 0; gi < kTeamGroups; gi++) {
-                            asm volatile("" : "+v"(fNext[gi]));  // waited for here, a diagonal after the loads were issued
-                            fCur[gi] = fNext[gi];
+#pragma unroll
+                            for (int l = 0; l < NL; l++) {
+                                asm volatile("" : "+v"(fNext[l][gi]));  // waited for here, a diagonal after the loads were issued
+                                fCur[l][gi] = fNext[l][gi];
+                            }
                         }
                         if (refresh) {
                             untilRefresh = CPK_REFRESH_PERIOD - 1;
@@ -344,8 +373,12 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                 // wave 0 folds the totals and emits while the others already put the forward rows back
                 if (wave == 0) {
                     sw.template foldTotals<true>(sg, table);
-                    if (lane == 0) a.segStarts[(size_t)rg.segOff + si] = count;
-                    count = sw.emitMatches(sg, sw.cand, nCand, a.triples + 3 * (size_t)rg.outOff, rg.outCap, count);
+#pragma unroll
+                    for (int l = 0; l < NL; l++) {
+                        if (lane == 0) a.segStarts[(size_t)l * a.nSegsTotal + rg.segOff + si] = count[l];
+                        count[l] = sw.emitMatches(sg, sw.cand + (size_t)l * a.geo.fbCells, nCand[l],
+                                                  a.triples + 3 * ((size_t)l * a.outTriplesPerList + rg.outOff), rg.outCap, count[l]);
+                    }
                 }
                 if (!sg.atEnd) {
                     // the traceback reused the rows: put F[dTop-1] and F[dTop] back for the forward sweep
@@ -369,7 +402,9 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                 __syncthreads();
             }
         }
-        if (tid == 0) a.outCounts[r] = count;
+#pragma unroll
+        for (int l = 0; l < NL; l++)
+            if (tid == 0) a.outCounts[(size_t)l * a.geo.nRegions + r] = count[l];
         // count lives in wave 0 only: tid 0 is lane 0 of wave 0
     }
 }

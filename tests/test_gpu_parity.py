@@ -561,6 +561,30 @@ def test_indel_emitter_matches_oracle(mtype):
     _check_indels(mtype, sx, sy, a, diagonalExpansion=30)  # multi-segment
 
 
+@pytest.mark.parametrize("mtype", [0, 2])
+def test_indel_emitter_on_the_team_kernel(mtype, monkeypatch):
+    """Round 4: the three lists of the indel emitter (pairwiseAligner.c:691-733) from the team of waves that wide bands go
+    to -- an unanchored 500 x 500 pair (501 cells: four waves) and, five-state, 900 x 900 (eight waves) by the library's own
+    choice, and a multi-segment band of ~157 cells forced onto the team (CPECAN_TEAM=100): each equal to the oracle's lists
+    and, list for list, to what one wave per region gives (CPECAN_TEAM=0)."""
+    cases = [(make_pair(36, 0, 500, 0)[:2] + ((),), dict(diagonalExpansion=40), None)]
+    if mtype == 0:
+        cases.append((make_pair(34, 0, 900, 0)[:2] + ((),), dict(diagonalExpansion=40), None))
+    cases.append((make_pair(3, 5, 1500, 100), dict(diagonalExpansion=100), "100"))
+    for (sx, sy, a), pkw, team in cases:
+        if team:
+            monkeypatch.setenv("CPECAN_TEAM", team)
+        else:
+            monkeypatch.delenv("CPECAN_TEAM", raising=False)
+        teamed = _check_indels(mtype, sx, sy, a, True, False, **pkw)
+        monkeypatch.setenv("CPECAN_TEAM", "0")
+        solo = api.getAlignedPairsWithIndelsUsingAnchors(_sm(mtype), sx, sy, a, api.pairwiseAlignmentBandingParameters_construct(**pkw),
+                                                         True, False)
+        for t, o in zip(teamed, solo):
+            assert np.array_equal(t, o)
+    monkeypatch.delenv("CPECAN_TEAM", raising=False)
+
+
 def test_indel_emitter_match_list_equals_match_emitter():
     sx, sy, a = make_pair(9, 1, 500, 20)
     p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=20)
