@@ -32,6 +32,12 @@ typedef struct {
     int64_t xLo, xHi, yLo, yHi;
     int64_t e;              /* expansion in force */
     int dynamic;
+    /* The anchors as RUNS of diagonal neighbours (round 4; the host's planning of realign-style batches, whose anchors
+     * arrive as runs and are expanded to one anchor per column on the device only): `runs` holds (x, y, length, -) per run,
+     * anchor number `used` is anchor `ro` of run `ri`; qRi / qRo: where the anchor now in (qX, qY) sits.  NULL: `anchors`. */
+    const int32_t *runs;
+    int64_t nRuns, ri, qRi;
+    int32_t ro, qRo;
 } CpkBandIter;
 
 CPK_HD int64_t cpk_clamp(int64_t v, int64_t hi) { return v < 0 ? 0 : (v > hi ? hi : v); }
@@ -52,7 +58,19 @@ CPK_HD int cpk_band_init(CpkBandIter *it, const cpk_anchor_t *anchors, int strid
     it->xLo = it->xHi = it->yLo = it->yHi = 0;
     it->e = dynamic ? 0 : expansion;
     it->dynamic = dynamic;
+    it->runs = 0;
+    it->nRuns = it->ri = it->qRi = 0;
+    it->ro = it->qRo = 0;
     return 0;
+}
+
+/* The same over runs (fixed expansion only): n = the number of ANCHORS the runs stand for. */
+CPK_HD int cpk_band_init_runs(CpkBandIter *it, const int32_t *runs, int64_t nRuns, int64_t n, int64_t lX, int64_t lY,
+                              int64_t expansion) {
+    const int rc = cpk_band_init(it, 0, 2, n, lX, lY, expansion, 0);
+    it->runs = runs;
+    it->nRuns = nRuns;
+    return rc;
 }
 
 /* The next anchor's own diagonal has been emitted: the iterator moves on to the interval behind it.  Returns 0, or -1
@@ -63,10 +81,22 @@ CPK_HD int cpk_band_advance(CpkBandIter *it) {
     it->qX = it->lX;
     it->qY = it->lY;
     if (it->used < it->n) {
-        const cpk_anchor_t *q = it->anchors + (int64_t)it->stride * it->used;
-        it->qX = (int64_t)q[0] + 1;
-        it->qY = (int64_t)q[1] + 1;
-        if (it->dynamic) it->e = q[2]; /* stride 3 whenever dynamic */
+        if (it->runs) {
+            const int32_t *q = it->runs + 4 * it->ri;
+            it->qX = (int64_t)q[0] + it->ro + 1;
+            it->qY = (int64_t)q[1] + it->ro + 1;
+            it->qRi = it->ri;
+            it->qRo = it->ro;
+            if (++it->ro >= q[2]) {
+                it->ro = 0;
+                it->ri++;
+            }
+        } else {
+            const cpk_anchor_t *q = it->anchors + (int64_t)it->stride * it->used;
+            it->qX = (int64_t)q[0] + 1;
+            it->qY = (int64_t)q[1] + 1;
+            if (it->dynamic) it->e = q[2]; /* stride 3 whenever dynamic */
+        }
         it->used++;
         if (it->qX <= it->pX || it->qY <= it->pY || it->qX > it->lX || it->qY > it->lY || it->e < 0 || it->e % 2 != 0)
             return -1;

@@ -389,6 +389,7 @@ typedef struct {
     int64_t lX, lY;
     int64_t seqXOff, seqYOff; /* into the symbol blob */
     int64_t anchorOff, nAnchors;
+    int64_t runOff, nRuns; /* its runs in cpecan_batch.runs (a batch that keeps its anchors as runs) */
     int raggedLeft, raggedRight;
     /* filled by upload */
     int64_t cells;
@@ -418,6 +419,14 @@ struct cpecan_batch {
     int32_t *anchors; /* cpk_anchor_t: anchorStride values per anchor, coordinates relative to the region */
     int anchorStride; /* 2: (x, y); 3: (x, y, expansion) for per-anchor expansions */
     int64_t nAnchorVals, capAnchorVals;
+    /* Round 4: a batch of fixed expansion whose first problems arrive as runs (cpecan_batch_add_many_runs) KEEPS them as runs
+     * -- (x, y, length, index of the run's first anchor among the batch's anchors) -- and never holds one anchor per column
+     * on the host: planning walks the runs (cpk_band_init_runs) and the device expands them in front of its table builder.
+     * BASELINE config 4: 6e7 anchors, 0.5 GB written by every add and read again by every band walk.  runForm: -1 not
+     * decided yet, 0 anchors, 1 runs.  nAnchorVals still counts the expanded anchors. */
+    int32_t *runs;
+    int64_t nRunVals, capRunVals;
+    int runForm;
     /* frozen state */
     CpkRegion *devRegions; /* cost-sorted */
     int64_t *devToHost;    /* devRegions[i] describes regions[devToHost[i]] */
@@ -641,6 +650,7 @@ int cpecan_batch_create(cpecan_batch **out, const cpecan_model *model, const cpe
     b->dev = NULL;
     b->nLists = emit == CPECAN_EMIT_INDEL ? 3 : 1;
     b->anchorStride = params->dynamicAnchorExpansion ? 3 : 2;
+    b->runForm = -1;
     b->postMatchGamma = 0.85f; /* cPecanRealign.c:355 */
     *out = b;
     return CPECAN_OK;
@@ -667,6 +677,7 @@ void cpecan_batch_destroy(cpecan_batch *b) {
     cpk_host_free(b->regions);
     cpk_host_free(b->symbols);
     cpk_host_free(b->anchors);
+    cpk_host_free(b->runs);
     cpk_host_free(b->devRegions);
     cpk_host_free(b->devToHost);
     cpk_host_free(b->segs);
@@ -721,7 +732,7 @@ static int64_t put_symbols(uint8_t *dst, int64_t at, const char *s, int64_t l) {
 
 /* What one problem adds to the batch's arrays; filled by the counting pass of cpecan_batch_add_many. */
 typedef struct {
-    int64_t nRects, symbolBytes, nAnchorsKept;
+    int64_t nRects, symbolBytes, nAnchorsKept, nRunsKept;
 } AddCount;
 
 /* One problem of an add call: its anchors as triples (x, y, expansion), one per anchor, or -- `runs` -- as quadruples
@@ -829,6 +840,11 @@ static int64_t add_many(cpecan_batch *b, const void *items, int runs, int64_t n)
     if (!b || b->frozen) return CPECAN_ESTATE;
     if (n < 0 || (n > 0 && !items)) return CPECAN_EINVAL;
     if (n == 0) return b->nProblems;
+    if (b->runForm < 0) { /* decided by the batch's first problems.  CPECAN_KEEP_RUNS=0: one anchor per column on the host, as rounds 1-3 */
+        const char *env = getenv("CPECAN_KEEP_RUNS");
+        b->runForm = (runs && b->anchorStride == 2 && !(env && atoi(env) == 0)) ? 1 : 0;
+    }
+    const int keepRuns = b->runForm == 1;
     AddCount *cnt = malloc(sizeof(AddCount) * (size_t)n);
     int64_t *offs = malloc(sizeof(int64_t) * 4 * (size_t)n); /* first region, symbol byte, anchor triple, char of each */
     if (!cnt || !offs) {
@@ -852,7 +868,7 @@ static int64_t add_many(cpecan_batch *b, const void *items, int runs, int64_t n)
                     firstBad = i;
                     bad = nRects == CPECAN_ENOMEM ? CPECAN_ENOMEM : CPECAN_EINVAL;
                 }
-                cnt[i].nRects = cnt[i].symbolBytes = cnt[i].nAnchorsKept = 0;
+                cnt[i].nRects = cnt[i].symbolBytes = cnt[i].nAnchorsKept = cnt[i].nRunsKept = 0;
                 continue;
             }
             int64_t sym = 0, kept = 0;
@@ -869,6 +885,8 @@ static int64_t add_many(cpecan_batch *b, const void *items, int runs, int64_t n)
             cnt[i].nRects = nRects;
             cnt[i].symbolBytes = sym;
             cnt[i].nAnchorsKept = kept;
+            /* a batch that keeps runs: the problem's runs as they are, or -- anchors given one by one -- a run of one each */
+            cnt[i].nRunsKept = it->runs ? at : kept;
         }
         free(rects);
     }
@@ -878,12 +896,22 @@ static int64_t add_many(cpecan_batch *b, const void *items, int runs, int64_t n)
         if (bad == CPECAN_EINVAL) cpk_set_error("problem %lld of the call: bad lengths or anchors", (long long)firstBad);
         return bad;
     }
-    int64_t nRegions = b->nRegions, nSymbols = b->nSymbols, nAnchorVals = b->nAnchorVals, nChars = b->nChars;
+    int64_t nRegions = b->nRegions, nSymbols = b->nSymbols, nAnchorVals = b->nAnchorVals, nChars = b->nChars, nRunVals = b->nRunVals;
+    int64_t *runAt = keepRuns ? malloc(sizeof(int64_t) * (size_t)n) : NULL; /* first run value of each problem */
+    if (keepRuns && !runAt) {
+        free(cnt);
+        free(offs);
+        return CPECAN_ENOMEM;
+    }
     for (int64_t i = 0; i < n; i++) {
         offs[4 * i] = nRegions;
         offs[4 * i + 1] = nSymbols;
         offs[4 * i + 2] = nAnchorVals;
         offs[4 * i + 3] = nChars;
+        if (keepRuns) {
+            runAt[i] = nRunVals;
+            nRunVals += 4 * cnt[i].nRunsKept;
+        }
         nRegions += cnt[i].nRects;
         nSymbols += cnt[i].symbolBytes;
         nAnchorVals += b->anchorStride * cnt[i].nAnchorsKept;
@@ -892,10 +920,13 @@ static int64_t add_many(cpecan_batch *b, const void *items, int runs, int64_t n)
     }
     if (grow((void **)&b->problems, &b->capProblems, b->nProblems + n, sizeof(HostProblem)) ||
         grow((void **)&b->regions, &b->capRegions, nRegions, sizeof(HostRegion)) ||
-        grow((void **)&b->anchors, &b->capAnchorVals, nAnchorVals, sizeof(int32_t)) ||
-        grow((void **)&b->symbols, &b->capSymbols, nSymbols, 1) || grow((void **)&b->chars, &b->capChars, nChars + 1, 1)) {
+        (keepRuns ? grow((void **)&b->runs, &b->capRunVals, nRunVals, sizeof(int32_t))
+                  : grow((void **)&b->anchors, &b->capAnchorVals, nAnchorVals, sizeof(int32_t))) ||
+        grow((void **)&b->symbols, &b->capSymbols, nSymbols, 1) || grow((void **)&b->chars, &b->capChars, nChars + 1, 1) ||
+        (keepRuns && nAnchorVals / 2 >= ((int64_t)1 << 31))) { /* (a run's first anchor is a 32-bit index) */
         free(cnt);
         free(offs);
+        free(runAt);
         return CPECAN_ENOMEM;
     }
     /* pass 2: every problem writes its own slices */
@@ -925,6 +956,7 @@ static int64_t add_many(cpecan_batch *b, const void *items, int runs, int64_t n)
             pr->charY = pr->charX + it->lX;
             for (int64_t k = 0; k < it->lY; k++) ch[it->lX + k] = g_upperOf[(unsigned char)it->sY[k]];
             int64_t next = 0, symAt = offs[4 * i + 1], anchorAt = offs[4 * i + 2]; /* anchors go to regions in order, :1296-1308 */
+            int64_t runValAt = keepRuns ? runAt[i] : 0;
             for (int64_t k = 0; k < nRects; k++) {
                 const int64_t x1 = rects[4 * k], y1 = rects[4 * k + 1], x2 = rects[4 * k + 2], y2 = rects[4 * k + 3];
                 HostRegion *r = &b->regions[offs[4 * i] + k];
@@ -941,6 +973,25 @@ static int64_t add_many(cpecan_batch *b, const void *items, int runs, int64_t n)
                 r->seqYOff = symAt;
                 symAt = put_symbols(b->symbols, symAt, it->sY + y1, r->lY);
                 r->anchorOff = anchorAt / b->anchorStride;
+                if (keepRuns) { /* the runs stay runs: 16 bytes each, whatever their length */
+                    r->runOff = runValAt / 4;
+                    for (; next < it->nAnchors; next++) {
+                        const int64_t ax = it->runs ? it->anchors[4 * next] : it->anchors[3 * next];
+                        const int64_t ay = it->runs ? it->anchors[4 * next + 1] : it->anchors[3 * next + 1];
+                        if (ax + ay >= x2 + y2) break;
+                        const int64_t len = it->runs ? it->anchors[4 * next + 2] : 1;
+                        int32_t *q = b->runs + runValAt;
+                        q[0] = (int32_t)(ax - x1);
+                        q[1] = (int32_t)(ay - y1);
+                        q[2] = (int32_t)len;
+                        q[3] = (int32_t)(anchorAt / 2); /* its first anchor among the batch's (expanded on the device) */
+                        runValAt += 4;
+                        anchorAt += 2 * len;
+                        r->nAnchors += len;
+                        r->nRuns++;
+                    }
+                    continue;
+                }
                 if (it->runs) { /* a run becomes its anchors: the batch's own 8 (12) bytes each, never the API's 24 */
                     for (; next < it->nAnchors && it->anchors[4 * next] + it->anchors[4 * next + 1] < x2 + y2; next++) {
                         const int32_t rx = (int32_t)(it->anchors[4 * next] - x1), ry = (int32_t)(it->anchors[4 * next + 1] - y1);
@@ -979,11 +1030,13 @@ static int64_t add_many(cpecan_batch *b, const void *items, int runs, int64_t n)
     }
     free(cnt);
     free(offs);
+    free(runAt);
     if (oom) return CPECAN_ENOMEM;
     b->nProblems += n;
     b->nRegions = nRegions;
     b->nSymbols = nSymbols;
     b->nAnchorVals = nAnchorVals;
+    b->nRunVals = nRunVals;
     b->nChars = nChars;
     return firstProblem;
 }
@@ -1126,8 +1179,10 @@ int cpecan_batch_upload(cpecan_batch *b) {
             if (!histOff) continue;
             CpkBandIter it;
             memset(&it, 0, sizeof it);
-            int bad = cpk_band_init(&it, b->anchors + (int64_t)b->anchorStride * r->anchorOff, b->anchorStride, r->nAnchors, r->lX, r->lY,
-                                    p->diagonalExpansion, dynamic);
+            const int keepRuns = b->runForm == 1;
+            int bad = keepRuns ? cpk_band_init_runs(&it, b->runs + 4 * r->runOff, r->nRuns, r->nAnchors, r->lX, r->lY, p->diagonalExpansion)
+                               : cpk_band_init(&it, b->anchors + (int64_t)b->anchorStride * r->anchorOff, b->anchorStride, r->nAnchors,
+                                               r->lX, r->lY, p->diagonalExpansion, dynamic);
             CpkSegment *sg = segs + segStart[i];
             int64_t cells = 0, tracedBackTo = 0;
             int64_t offTracedBackTo = 0; /* cells before diagonal tracedBackTo */
@@ -1146,9 +1201,9 @@ int cpecan_batch_upload(cpecan_batch *b) {
              * K diagonals whose offsets the schedule looks back at: those diagonals are walked one by one.
              * (BASELINE config 4: 1.25e8 diagonals at ~14 cycles each were 31 ms of every batch on 16 threads.)  CPECAN_FAST_WALK=0
              * walks every diagonal (tests compare the two). */
-            const cpk_anchor_t *ra = b->anchors + (int64_t)b->anchorStride * r->anchorOff;
+            const cpk_anchor_t *ra = keepRuns ? NULL : b->anchors + (int64_t)b->anchorStride * r->anchorOff;
             const int64_t E = p->diagonalExpansion, hE = E / 2;
-            const int fastOk = fastWalk && !dynamic && E >= 2 && b->anchorStride == 2;
+            const int fastOk = fastWalk && !dynamic && E >= 2 && b->anchorStride == 2;  /* (runs are kept for stride 2 only) */
             for (int64_t d = 0; d <= N && !bad; d++, slot = slot + 1 == K ? 0 : slot + 1) {
                 if (fastOk && cpk_band_in_run(&it, d)) {
                     /* in the interval (A_j -> A_j+1) of a run, j = used - 2, about to emit its first diagonal */
@@ -1158,9 +1213,17 @@ int cpecan_batch_upload(cpecan_batch *b) {
                     if (it.pX - hE < 0 || it.pY - hE < 0) sMax = 0;                  /* ... and the first one's */
                     sMax = imin(sMax, (N - 2 - d) / 2);
                     int64_t sRun = 0; /* intervals of the run from here: anchors j .. j + sRun are diagonal neighbours */
-                    while (sRun < sMax && j + sRun + 1 < r->nAnchors && ra[2 * (j + sRun + 1)] == ra[2 * (j + sRun)] + 1 &&
-                           ra[2 * (j + sRun + 1) + 1] == ra[2 * (j + sRun) + 1] + 1)
-                        sRun++;
+                    if (keepRuns) {
+                        /* anchor j + 1 is the one in (qX, qY): anchor qRo of run qRi, with length - 1 - qRo neighbours behind it
+                         * in its run (a run that happens to continue in the next one starts a stretch of its own there) */
+                        sRun = 1 + (int64_t)b->runs[4 * (r->runOff + it.qRi) + 2] - 1 - it.qRo;
+                        sRun = sRun < sMax ? sRun : sMax;
+                        sRun = sRun < 0 ? 0 : sRun;
+                    } else {
+                        while (sRun < sMax && j + sRun + 1 < r->nAnchors && ra[2 * (j + sRun + 1)] == ra[2 * (j + sRun)] + 1 &&
+                               ra[2 * (j + sRun + 1) + 1] == ra[2 * (j + sRun) + 1] + 1)
+                            sRun++;
+                    }
                     if (sRun >= 2) {
                         const int64_t add = sRun * (2 * E + 3);
                         if (cells + add >= (int64_t)1 << 31) {
@@ -1178,14 +1241,38 @@ int cpecan_batch_upload(cpecan_batch *b) {
                         prevHi = xmy0 + E;
                         /* the iterator as it stands behind anchor j + sRun's own diagonal */
                         const int64_t jn = j + sRun;
-                        it.pX = (int64_t)ra[2 * jn] + 1;
-                        it.pY = (int64_t)ra[2 * jn + 1] + 1;
+                        if (keepRuns) {
+                            /* anchor jn = anchor j + 1 moved sRun - 1 steps along its run; the cursor goes to the anchor behind it */
+                            it.pX = it.qX + (sRun - 1);
+                            it.pY = it.qY + (sRun - 1);
+                            it.ri = it.qRi;
+                            it.ro = it.qRo + (int32_t)sRun;
+                            if (it.ro >= b->runs[4 * (r->runOff + it.ri) + 2]) {
+                                it.ro = 0;
+                                it.ri++;
+                            }
+                        } else {
+                            it.pX = (int64_t)ra[2 * jn] + 1;
+                            it.pY = (int64_t)ra[2 * jn + 1] + 1;
+                        }
                         it.used = jn + 1;
                         it.qX = r->lX;
                         it.qY = r->lY;
                         if (it.used < it.n) {
-                            it.qX = (int64_t)ra[2 * it.used] + 1;
-                            it.qY = (int64_t)ra[2 * it.used + 1] + 1;
+                            if (keepRuns) {
+                                const int32_t *q = b->runs + 4 * (r->runOff + it.ri);
+                                it.qX = (int64_t)q[0] + it.ro + 1;
+                                it.qY = (int64_t)q[1] + it.ro + 1;
+                                it.qRi = it.ri;
+                                it.qRo = it.ro;
+                                if (++it.ro >= q[2]) {
+                                    it.ro = 0;
+                                    it.ri++;
+                                }
+                            } else {
+                                it.qX = (int64_t)ra[2 * it.used] + 1;
+                                it.qY = (int64_t)ra[2 * it.used + 1] + 1;
+                            }
                             it.used++;
                             if (it.qX <= it.pX || it.qY <= it.pY || it.qX > it.lX || it.qY > it.lY) {
                                 bad = 1;
@@ -1523,7 +1610,8 @@ int cpecan_batch_upload(cpecan_batch *b) {
         rc = cpk_device_create(&b->dev, b->device); /* fails with CPECAN_ENODEVICE when there is no GPU */
         if (rc != CPECAN_OK) goto fail2;
     }
-    rc = cpk_device_upload(b->dev, &geo, &km, b->devRegions, b->anchors, b->anchorStride, b->nAnchorVals / b->anchorStride, totalDiags,
+    rc = cpk_device_upload(b->dev, &geo, &km, b->devRegions, b->runForm == 1 ? NULL : b->anchors, b->anchorStride,
+                           b->nAnchorVals / b->anchorStride, b->runForm == 1 ? b->runs : NULL, b->runForm == 1 ? b->nRunVals / 4 : 0, totalDiags,
                            p->diagonalExpansion, dynamic, segs, nSegs, b->symbols, b->nSymbols, b->outTriples, b->nLists,
                            b->dbgCells, b->dbgDiags, &b->stats.h2dMs);
     if (rc != CPECAN_OK) goto fail2;

@@ -158,7 +158,9 @@ void cpk_device_destroy(CpkDevice *dev);
 /* The per-diagonal table (nDiags entries) is built on the device from the anchors (cpecan_band.inl). */
 /* Regions of a class that is split (see CpkItem) get ringCap / ringBase / split set here, in the caller's array. */
 int cpk_device_upload(CpkDevice *dev, const CpkGeometry *geo, const CpkModel *model, CpkRegion *regions,
-                      const int32_t *anchors /* cpk_anchor_t, cpecan_band.inl */, int anchorStride, int64_t nAnchors, int64_t nDiags,
+                      const int32_t *anchors /* cpk_anchor_t, cpecan_band.inl */, int anchorStride, int64_t nAnchors,
+                      const int32_t *runs /* or: (x, y, length, first anchor) per run, expanded on the device; anchors NULL */, int64_t nRuns,
+                      int64_t nDiags,
                       int64_t expansion, int dynamic,
                       const CpkSegment *segs, int64_t nSegs, const uint8_t *symbols, int64_t nSymbolBytes,
                       int64_t outTriplesPerList, int nLists, int64_t dbgCells, int64_t dbgDiags, double *h2dMs);

@@ -1024,7 +1024,8 @@ static int stage_reserve(CpkDevice *d, size_t bytes) {
 }
 
 extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const CpkModel *model, CpkRegion *regions,
-                                 const cpk_anchor_t *anchors, int anchorStride, int64_t nAnchors, int64_t nDiags, int64_t expansion, int dynamic,
+                                 const cpk_anchor_t *anchors, int anchorStride, int64_t nAnchors, const int32_t *runs, int64_t nRuns,
+                                 int64_t nDiags, int64_t expansion, int dynamic,
                                  const CpkSegment *segs, int64_t nSegs, const uint8_t *symbols, int64_t nSymbolBytes,
                                  int64_t outTriplesPerList, int nLists, int64_t dbgCells, int64_t dbgDiags,
                                  double *h2dMs) {
@@ -1650,10 +1651,12 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
     // staging buffer; cpk_device_run makes the sweep wait for evUp1.  (The host goes on planning the next batch while
     // the copy engine works: 19 ms per config-4 batch.)  The anchor block stays with the batch until it is destroyed.
     size_t stageAt = 0;
-    const size_t anchorBytes = sizeof(cpk_anchor_t) * (size_t)anchorStride * (size_t)(nAnchors > 0 ? nAnchors : 1);
+    // (anchors as runs: 16 bytes per run cross the bus and cpecan_expand_runs writes the anchors the table builders read)
+    const size_t anchorBytes = runs ? sizeof(int32_t) * 4 * (size_t)(nRuns > 0 ? nRuns : 1)
+                                    : sizeof(cpk_anchor_t) * (size_t)anchorStride * (size_t)(nAnchors > 0 ? nAnchors : 1);
     {
         auto staged = [](const void *p, size_t bytes) { return (bytes > kStageMaxCopy || host_is_pinned(p, bytes)) ? (size_t)0 : bytes + 256; };
-        if (int rc = stage_reserve(d, staged(regions, sizeof(CpkRegion) * (size_t)geo->nRegions) + staged(anchors, anchorBytes) +
+        if (int rc = stage_reserve(d, staged(regions, sizeof(CpkRegion) * (size_t)geo->nRegions) + staged(runs ? (const void *)runs : (const void *)anchors, anchorBytes) +
                                       staged(segs, sizeof(CpkSegment) * (size_t)nSegs) + staged(symbols, (size_t)nSymbolBytes) +
                                       sizeof(CpkModel) + sizeof(CpkItem) * items.size() + 8 * 256))
             return rc;
@@ -1666,7 +1669,15 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         // anchors -> per-diagonal table, on the device (the anchors are only needed for this)
         cpk_anchor_t *dAnchors = nullptr;
         if (int rc = dev_alloc(d, &dAnchors, (size_t)anchorStride * (size_t)(nAnchors > 0 ? nAnchors : 1))) return rc;
-        if (nAnchors > 0)
+        if (runs && nRuns > 0) {
+            int32_t *dRuns = nullptr;
+            if (int rc = dev_alloc(d, &dRuns, (size_t)4 * (size_t)nRuns)) return rc;
+            if (int rc = staged_h2d(d, dRuns, runs, sizeof(int32_t) * 4 * (size_t)nRuns, &stageAt)) return rc;
+            const int64_t blocks = (nRuns + 255) / 256;
+            hipLaunchKernelGGL(cpecan_expand_runs, dim3((unsigned)(blocks < 65535 * 16 ? blocks : 65535 * 16)), dim3(256), 0, io,
+                               reinterpret_cast<const int4 *>(dRuns), nRuns, dAnchors);
+            HIP_TRY(hipGetLastError());
+        } else if (nAnchors > 0)
             if (int rc = staged_h2d(d, dAnchors, anchors, sizeof(cpk_anchor_t) * (size_t)anchorStride * (size_t)nAnchors, &stageAt)) return rc;
         if (int rc = staged_h2d(d, d->dSegs, segs, sizeof(CpkSegment) * (size_t)nSegs, &stageAt)) return rc;  // the builder reads the schedule
         // (the symbols and the model go first: nothing but the table build is then between the last copy and the sweep)

@@ -56,6 +56,16 @@ __device__ __forceinline__ int abs_chain_step(int lo, int hi, int lo1, int hi1, 
     return ((lo - B) >> 1) | (flag << 15);
 }
 
+// Anchors handed over as runs of diagonal neighbours (round 4: a realign-style batch keeps its runs on the host, 16 bytes each
+// instead of 8 per column): run (x, y, length, first) becomes the anchors first .. first + length - 1 the builders below read.
+__global__ void __launch_bounds__(256) cpecan_expand_runs(const int4 *runs, int64_t nRuns, cpk_anchor_t *anchors) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nRuns; i += (int64_t)gridDim.x * blockDim.x) {
+        const int4 r = runs[i];
+        int2 *out = reinterpret_cast<int2 *>(anchors) + (size_t)(unsigned)r.w;
+        for (int q = 0; q < r.z; q++) out[q] = int2{r.x + q, r.y + q};
+    }
+}
+
 __global__ void __launch_bounds__(64) cpecan_build_diag_table(const CpkRegion *regions, int nRegions, const cpk_anchor_t *anchors, int anchorStride,
                                                               const CpkSegment *segs, int S, CpkDiag *diags, int32_t *dpos, int64_t expansion, int dynamic,
                                                               int skipSplit) {

@@ -382,8 +382,16 @@ def test_run_form_anchors_and_closed_form_band_walk(monkeypatch):
         fast, st1 = run(False)
         from_runs, st2 = run(True)
         for st in (st1, st2):
-            assert (st.cells, st.regions, st.diagonals, st.pairs, st.deviceBytes) == \
-                   (st0.cells, st0.regions, st0.diagonals, st0.pairs, st0.deviceBytes)
+            assert (st.cells, st.regions, st.diagonals, st.pairs) == (st0.cells, st0.regions, st0.diagonals, st0.pairs)
+        # (a batch that got runs keeps them as runs and expands them on the device: 16 bytes per run beside the anchors)
+        assert st1.deviceBytes == st0.deviceBytes and st0.deviceBytes <= st2.deviceBytes <= st0.deviceBytes + 16 * st0.cells
+        # ... unless told to expand them on the host as rounds 1-3 did (CPECAN_KEEP_RUNS=0): the same lists
+        monkeypatch.setenv("CPECAN_KEEP_RUNS", "0")
+        expanded, st3 = run(True)
+        monkeypatch.delenv("CPECAN_KEEP_RUNS")
+        assert st3.deviceBytes == st0.deviceBytes
+        for a0, a3 in zip(slow, expanded):
+            assert np.array_equal(a0, a3)
         for i, (a0, a1, a2) in enumerate(zip(slow, fast, from_runs)):
             assert np.array_equal(a0, a1), ("closed-form walk", i)
             assert np.array_equal(a0, a2), ("run form", i)
