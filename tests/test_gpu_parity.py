@@ -392,6 +392,22 @@ def test_run_form_anchors_and_closed_form_band_walk(monkeypatch):
         assert st3.deviceBytes == st0.deviceBytes
         for a0, a3 in zip(slow, expanded):
             assert np.array_equal(a0, a3)
+        # one batch, both forms: the form of the first problems decides what the batch keeps -- runs first: the anchors that
+        # come one by one behind them become runs of one; anchors first: the runs behind them are expanded on the host
+        half = len(problems) // 2
+        for runs_first in (True, False):
+            with api.Batch(_sm(0), p) as b:
+                if runs_first:
+                    b.add_many_runs(problems[:half])
+                    b.add_many(problems[half:])
+                else:
+                    b.add_many(problems[:half])
+                    b.add_many_runs(problems[half:])
+                b.upload()
+                b.run()
+                b.download()
+                for i in range(len(problems)):
+                    assert np.array_equal(slow[i], b.result(i)), ("mixed forms", runs_first, i)
         for i, (a0, a1, a2) in enumerate(zip(slow, fast, from_runs)):
             assert np.array_equal(a0, a1), ("closed-form walk", i)
             assert np.array_equal(a0, a2), ("run form", i)
