@@ -1253,7 +1253,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
         // rows the class would take with one wave per region: NOT c.geo.seqLdsBytes / rollStride, which setForm() above
         // may have set to the symbol windows and slack of the absolute-position sweeps)
         const int teamStride = c.geo.maxWidth + 1;
-        const size_t teamLds = sizeof(double) * ((size_t)team_header_doubles() + (size_t)3 * S * teamStride) +
+        const size_t teamLds = sizeof(double) * ((size_t)team_header_doubles(expect) + (size_t)3 * S * teamStride) +
                                (size_t)((geo->wSeqLdsBytes[k] + 15) / 16 * 16);
         // A class goes to teams where one wave per region is down to three waves per CU or fewer (measured: at four per
         // CU, ~400-cell bands, the single wave still wins by 13 %; at three, ~450 cells, the team wins by 30 %), or on
@@ -1265,9 +1265,12 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
                                     : (c.geo.maxWidth > 256 && (soloPerCU <= 3 || c.geo.useGlobalRoll));
         // one workgroup per CU is all the LDS allows from ~660 cells: then eight waves share the region
         const bool big = 2 * teamLds > 160 * 1024;
-        if (wanted && (geo->emit == CPECAN_EMIT_MATCH || geo->emit == CPECAN_EMIT_INDEL) && !geo->debug &&
+        if (wanted && (geo->emit == CPECAN_EMIT_MATCH || geo->emit == CPECAN_EMIT_INDEL || expect) && !geo->debug &&
             c.geo.maxWidth <= CPK_WAVE * kTeamWaves * (big ? 2 : 1) * kTeamGroups && teamLds <= 160 * 1024) {
-            if (geo->emit == CPECAN_EMIT_INDEL)  // (round 4: the three lists of the indel emitter from the team as well)
+            if (expect)  // (round 4: the expectation emitter -- its second pass shared by the team's waves)
+                c.fn = S == 5 ? (big ? cpecan_pairhmm_team<5, 2 * kTeamWaves, CPECAN_EMIT_EXPECT> : cpecan_pairhmm_team<5, kTeamWaves, CPECAN_EMIT_EXPECT>)
+                              : (big ? cpecan_pairhmm_team<3, 2 * kTeamWaves, CPECAN_EMIT_EXPECT> : cpecan_pairhmm_team<3, kTeamWaves, CPECAN_EMIT_EXPECT>);
+            else if (geo->emit == CPECAN_EMIT_INDEL)  // (round 4: the three lists of the indel emitter from the team as well)
                 c.fn = S == 5 ? (big ? cpecan_pairhmm_team<5, 2 * kTeamWaves, CPECAN_EMIT_INDEL> : cpecan_pairhmm_team<5, kTeamWaves, CPECAN_EMIT_INDEL>)
                               : (big ? cpecan_pairhmm_team<3, 2 * kTeamWaves, CPECAN_EMIT_INDEL> : cpecan_pairhmm_team<3, kTeamWaves, CPECAN_EMIT_INDEL>);
             else
@@ -1554,7 +1557,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             oTot += c.subSlots * c.totEl;
             oBring += c.subSlots * c.bringEl;
             oGroll += c.subSlots * c.grollEl;
-            oExpect += (int64_t)c.waves * 128;
+            oExpect += (int64_t)c.waves * (c.threads / CPK_WAVE) * 128;  // a partial result per wave
             d->totalWaves += (c.split && c.wavesTrace > c.waves ? c.wavesTrace : c.waves) * (c.threads / CPK_WAVE);
             if (c.ldsBytes > 64 * 1024) {
                 HIP_TRY(hipFuncSetAttribute((const void *)c.fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.ldsBytes));

@@ -1457,6 +1457,8 @@ struct Sweep {
         unsigned x, y;
     };
 
+    // expStride / expPhase (the team kernel): this wave takes the items whose number is expPhase modulo expStride
+    int expStride = 1, expPhase = 0;
     __device__ void expectations(const CpkSegment &sg, double (&tAcc)[kNT], double *eLds, double &likelihood) {
         const int bBase = dc.table[sg.tbPrev + 1].cellOff;
         // kDepth items are in flight: the loads of an item (16 values per cell) are issued kDepth - 1 items before its
@@ -1520,6 +1522,13 @@ struct Sweep {
                 curValid = false;
             }
             return it;
+        };
+        int itemNo = 0;
+        auto next_mine = [&]() {  // the next item that is this wave's (every item with one wave per region)
+            for (;;) {
+                const ExpItem it = next_item();
+                if (!it.valid || expStride == 1 || itemNo++ % expStride == expPhase) return it;
+            }
         };
         auto issue = [&](const ExpItem &it, ExpLoads &L) {
             const bool inA = lane < it.nA;
@@ -1620,7 +1629,7 @@ struct Sweep {
         ExpLoads L[kDepth];
 #pragma unroll
         for (int j = 0; j < kDepth; j++) {
-            const ExpItem it = next_item();
+            const ExpItem it = next_mine();
             valid[j] = it.valid;
             issue(it, L[j]);
         }
@@ -1637,7 +1646,7 @@ struct Sweep {
                 }
                 asm volatile("" : "+v"(L[j].total));
                 events(L[j]);
-                const ExpItem it = next_item();  // the item behind the youngest one in flight
+                const ExpItem it = next_mine();  // the item behind the youngest one in flight
                 valid[j] = it.valid;
                 issue(it, L[j]);
             }

@@ -1,4 +1,4 @@
-// cpk_team.inl -- the team sweep kernel: T waves of one workgroup share one wide DP region (match emitter, LDS rows).
+// cpk_team.inl -- the team sweep kernel: T waves of one workgroup share one wide DP region (match, indel and expectation emitters; LDS rows).
 // Part of the single HIP translation unit cpecan_kernels.hip (included there, after cpk_sweep.inl); not compiled on its own.
 //
 // A band of a few hundred cells per diagonal needs tens of KB of LDS for its rolling rows: with one wave per region a CU
@@ -18,15 +18,22 @@
 constexpr int kTeamGroups = 3;  // 64-cell groups a wave handles per diagonal at most: bands up to 64 * T * kTeamGroups cells
 constexpr int kTeamXchg = 48;   // doubles of LDS for the exchange area (counts per list, maxima, the region ticket)
 
-__host__ __device__ constexpr int team_header_doubles() { return kLdsCubics + kLdsEm + kLdsWeights + kTeamXchg; }
+// (expect: the workgroup's emission sums of the expectation emitter, kExpectCopies copies of 80, behind the exchange area)
+__host__ __device__ constexpr int team_header_doubles(bool expect = false) {
+    return kLdsCubics + kLdsEm + kLdsWeights + kTeamXchg + (expect ? kExpectCopies * 80 : 0);
+}
 
 // EMIT (round 4): CPECAN_EMIT_MATCH, or CPECAN_EMIT_INDEL -- the three lists of diagonalCalculationPosteriorProbs
 // (pairwiseAligner.c:691-733: match, gapX, gapY; what getShiftedMEAAlignment needs): every state of every forward diagonal
 // goes to the ring, a wave keeps the candidates of three lists per diagonal and the waves exchange three counts.
 template <int S, int T, int EMIT = CPECAN_EMIT_MATCH>
 __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a) {
-    static_assert(EMIT == CPECAN_EMIT_MATCH || EMIT == CPECAN_EMIT_INDEL, "team kernel: match or match + indel lists");
+    // ... or CPECAN_EMIT_EXPECT: the traceback parks B of the emitted cells (`bring`, the layout Sweep::traceback writes),
+    // wave 0 folds the totals, and the T waves share the second pass (Sweep::expectations: every T-th item of 64 cells each),
+    // every wave with transition sums of its own, the emission sums of the workgroup in LDS.
+    static_assert(EMIT == CPECAN_EMIT_MATCH || EMIT == CPECAN_EMIT_INDEL || EMIT == CPECAN_EMIT_EXPECT, "team kernel: match, match + indel lists, expectations");
     constexpr int NL = EMIT == CPECAN_EMIT_INDEL ? 3 : 1;
+    constexpr bool kExpect = EMIT == CPECAN_EMIT_EXPECT;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     constexpr int R = 3 * S;
     using SweepT = Sweep<S, true, R>;
@@ -45,9 +52,17 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
     double *wt = lds + kLdsCubics + kLdsEm;
     int *xi = reinterpret_cast<int *>(lds + kLdsCubics + kLdsEm + kLdsWeights);  // [0]: ticket, [8 + parity * T + w]: counts
     float *xf = reinterpret_cast<float *>(xi + 8 + 2 * NL * T);              // [parity * T + w]: maxima (counts: [8 + (parity * NL + l) * T + w])
-    double *roll = lds + team_header_doubles();
+    double *eLds = lds + team_header_doubles();  // (expectation emitter only)
+    double *roll = lds + team_header_doubles(kExpect);
     uint8_t *seqLds = reinterpret_cast<uint8_t *>(roll + (size_t)R * stride);
     for (int i = tid; i < R * stride; i += CPK_WAVE * T) roll[i] = NEG_INF;  // position 0 of every row stays the guard
+    if (kExpect)
+        for (int i = tid; i < kExpectCopies * 80; i += CPK_WAVE * T) eLds[i] = 0.0;
+    constexpr int kNT = S == 5 ? 13 : 9;
+    double tAcc[kNT];  // this wave's transition sums (expectation emitter), one per transition in list order
+#pragma unroll
+    for (int i = 0; i < kNT; i++) tAcc[i] = 0.0;
+    double likelihood = 0.0;
     __syncthreads();
 
     // forward diagonal d (d >= -1), state s of cell k: frow(d)[s + k * R]
@@ -94,6 +109,11 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                   N,
                   CpkDiag{},
                   CpkDiag{}};
+        if (kExpect) {
+            sw.bring = a.bring + slot * (size_t)a.geo.fbCells * S;  // B of a segment's emitted cells
+            sw.expStride = T;  // the second pass: this wave takes every T-th item
+            sw.expPhase = wave;
+        }
         __syncthreads();  // symbols staged
         int count[NL];
 #pragma unroll
@@ -184,6 +204,7 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                 int untilRefresh = sg.dTop - sg.tbFrom, jr = 0;
                 CpkDiag gb{}, ga{};
                 CpkDiag g = sw.dc.get(sg.dTop, true);
+                const int bBase = kExpect ? table[sg.tbPrev + 1].cellOff : 0;
                 // F.match of this wave's cells, one diagonal ahead of its use (the ring is in HBM): group gi of the range
                 auto loadF = [&](const CpkDiag &gd, double (&dst)[NL][kTeamGroups]) {
                     int flo, fhi;
@@ -274,6 +295,12 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                                     for (int s = 1; s < S; s++) curG[s + kR0] = v[0][s];
                                 }
                                 const int x = xlo + kc, y = d2 - x;
+                                if (kExpect && emit && on) {  // kept for the second pass, per group of gN cells, state-major
+                                    const int gN = W - kb < CPK_WAVE ? W - kb : CPK_WAVE;
+                                    double *bo = sw.bring + (size_t)(g.cellOff - bBase + kb) * S + lane;
+#pragma unroll
+                                    for (int s = 0; s < S; s++) bo[s * gN] = v[0][s];
+                                }
                                 if (emit || feeds) {
                                     const double f0 = fCur[0][gi];
                                     const double fb = f0 + v[0][0];
@@ -285,7 +312,7 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                                             // match cells need x > 0 and y > 0, gapX cells x > 0, gapY cells y > 0 (:700, :711, :722)
                                             const bool cell = l == 0 ? (x > 0 && y > 0) : (l == 1 ? x > 0 : y > 0);
                                             const double fbl = l == 0 ? fb : fCur[l][gi] + v[0][l];
-                                            const bool keep = on && cell && (float)fbl >= keepFrom;
+                                            const bool keep = !kExpect && on && cell && (float)fbl >= keepFrom;
                                             pmask[l][gi] = __ballot(keep);
                                             pfb[l][gi] = fbl;
                                             myCount[l] += __popcll(pmask[l][gi]);
@@ -374,7 +401,7 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                 if (wave == 0) {
                     sw.template foldTotals<true>(sg, table);
 #pragma unroll
-                    for (int l = 0; l < NL; l++) {
+                    for (int l = 0; l < (kExpect ? 0 : NL); l++) {
                         if (lane == 0) a.segStarts[(size_t)l * a.nSegsTotal + rg.segOff + si] = count[l];
                         count[l] = sw.emitMatches(sg, sw.cand + (size_t)l * a.geo.fbCells, nCand[l],
                                                   a.triples + 3 * ((size_t)l * a.outTriplesPerList + rg.outOff), rg.outCap, count[l]);
@@ -399,6 +426,11 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
                     f2 = gTopM1;
                     f1 = gTop;
                 }
+                if (kExpect) {
+                    __threadfence_block();
+                    __syncthreads();  // the totals are written
+                    sw.expectations(sg, tAcc, eLds, likelihood);
+                }
                 __syncthreads();
             }
         }
@@ -406,5 +438,35 @@ __global__ void __launch_bounds__(CPK_WAVE *T) cpecan_pairhmm_team(const KArgs a
         for (int l = 0; l < NL; l++)
             if (tid == 0) a.outCounts[(size_t)l * a.geo.nRegions + r] = count[l];
         // count lives in wave 0 only: tid 0 is lane 0 of wave 0
+    }
+    if (kExpect) {
+        // one partial result per WAVE (cpecan_pairhmm_sweep writes one per workgroup of one wave): [0,25) transitions
+        // [from*S+to], [25,105) emissions -- the workgroup's, by wave 0 -- [105] likelihood
+        __syncthreads();
+        double *dst = a.expectOut + ((size_t)blockIdx.x * T + wave) * 128;
+        constexpr int kFrom5[13] = {0, 1, 0, 3, 0, 1, 2, 3, 4, 0, 2, 0, 4}, kTo5[13] = {1, 1, 3, 3, 0, 0, 0, 0, 0, 2, 2, 4, 4};
+        constexpr int kFrom3[9] = {0, 1, 2, 0, 1, 2, 0, 2, 1}, kTo3[9] = {1, 1, 1, 0, 0, 0, 2, 2, 2};
+        for (int i = lane; i < 106; i += CPK_WAVE) dst[i] = 0.0;
+        __threadfence_block();
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < kNT; i++) {
+            double v = tAcc[i];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+            const int idx = S == 5 ? kFrom5[i] * 5 + kTo5[i] : kFrom3[i] * 3 + kTo3[i];
+            if (lane == 0) dst[idx] = v;
+        }
+        if (wave == 0) {
+            for (int i = lane; i < 80; i += CPK_WAVE) {
+                double e = 0.0;
+                for (int k = 0; k < kExpectCopies; k++) e += eLds[k * 80 + i];
+                dst[25 + i] = e;
+            }
+        }
+        double v = likelihood;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) dst[105] = v;
     }
 }

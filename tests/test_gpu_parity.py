@@ -609,6 +609,47 @@ def test_indel_emitter_on_the_team_kernel(mtype, monkeypatch):
     monkeypatch.delenv("CPECAN_TEAM", raising=False)
 
 
+@pytest.mark.parametrize("mtype", [0, 3])
+def test_expectation_emitter_on_the_team_kernel(mtype, monkeypatch):
+    """Round 4: expectations from the team of waves wide bands go to -- the traceback parks B of the emitted cells, wave 0
+    folds the totals, the waves share the second pass.  Unanchored 500 x 500 (a team of four) and 900 x 900 pairs (eight; the
+    five-state model by the library's own choice) and a multi-segment band forced onto the team (CPECAN_TEAM=100), several
+    regions per launch: counts and likelihood within 1e-5 of the oracle's and within 1e-9 of one wave per region's
+    (CPECAN_TEAM=0; the order of the sums differs)."""
+    cases = [([make_pair(36, i, 500, 0)[:2] + ((),) for i in range(3)] + [make_pair(34, 0, 900, 0)[:2] + ((),)], dict(diagonalExpansion=40), None),
+             ([make_pair(3, 5 + i, 1500, 100) for i in range(3)], dict(diagonalExpansion=100), "100")]
+    for probs, pkw, team in cases:
+        p = api.pairwiseAlignmentBandingParameters_construct(**pkw)
+        accs = []
+        for env in (team, "0"):
+            if env is None:
+                monkeypatch.delenv("CPECAN_TEAM", raising=False)
+            else:
+                monkeypatch.setenv("CPECAN_TEAM", env)
+            acc = api.hmm_constructEmpty(0.0, mtype)
+            with api.Batch(_sm(mtype), p, emit=api.EMIT_EXPECT) as b:
+                for sx, sy, a in probs:
+                    b.add(sx, sy, a, True, False)
+                b.upload()
+                b.run()
+                b.download()
+                b.expectations(acc)
+            accs.append(acc)
+        oacc = ob.hmm(mtype, 0.0)
+        om, op = ob.model(mtype), ob.params(**pkw)
+        for sx, sy, a in probs:
+            ob.expectations(om, oacc, sx, sy, a, op, True, False)
+        S = accs[0].stateNumber
+        for acc, rtol in ((accs[0], 1e-5), (accs[1], 1e-5)):
+            np.testing.assert_allclose(list(acc.transitions)[:S * S], list(oacc.T)[:S * S], rtol=rtol)
+            np.testing.assert_allclose(list(acc.emissions)[:S * 16], list(oacc.E)[:S * 16], rtol=rtol, atol=1e-12)
+            np.testing.assert_allclose(acc.likelihood, oacc.likelihood, rtol=1e-9)
+        np.testing.assert_allclose(list(accs[0].transitions)[:S * S], list(accs[1].transitions)[:S * S], rtol=1e-9)
+        np.testing.assert_allclose(list(accs[0].emissions)[:S * 16], list(accs[1].emissions)[:S * 16], rtol=1e-9, atol=1e-15)
+        np.testing.assert_allclose(accs[0].likelihood, accs[1].likelihood, rtol=1e-12)
+    monkeypatch.delenv("CPECAN_TEAM", raising=False)
+
+
 def test_indel_emitter_match_list_equals_match_emitter():
     sx, sy, a = make_pair(9, 1, 500, 20)
     p = api.pairwiseAlignmentBandingParameters_construct(diagonalExpansion=20)
