@@ -1280,6 +1280,7 @@ extern "C" int cpk_device_upload(CpkDevice *d, const CpkGeometry *geo, const Cpk
             c.geo.useGlobalRoll = 0;
             c.abs = false;
             c.geo.reserved0 = 0;
+            c.geo.expInSweep = 0;  // (the team's expectation emitter is the second pass: B of the emitted cells in `bring`)
             c.geo.rollStride = teamStride;
             c.geo.seqLdsBytes = geo->wSeqLdsBytes[k];
             c.geo.rollDoubles = (int64_t)(2 * S + 1) * c.geo.rollStride;

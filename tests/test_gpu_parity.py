@@ -617,7 +617,11 @@ def test_expectation_emitter_on_the_team_kernel(mtype, monkeypatch):
     regions per launch: counts and likelihood within 1e-5 of the oracle's and within 1e-9 of one wave per region's
     (CPECAN_TEAM=0; the order of the sums differs)."""
     cases = [([make_pair(36, i, 500, 0)[:2] + ((),) for i in range(3)] + [make_pair(34, 0, 900, 0)[:2] + ((),)], dict(diagonalExpansion=40), None),
-             ([make_pair(3, 5 + i, 1500, 100) for i in range(3)], dict(diagonalExpansion=100), "100")]
+             ([make_pair(3, 5 + i, 1500, 100) for i in range(3)], dict(diagonalExpansion=100), "100"),
+             # a class narrow enough for the events inside the traceback (<= 128 cells), forced onto the team: the team's
+             # second pass needs B of the emitted cells, not the window records (tools/soak_emitters.py, seed 5 round 0)
+             ([make_pair(8, i, 700, 60, anchor_every=150) for i in range(5)],
+              dict(diagonalExpansion=60, traceBackDiagonals=12, minDiagsBetweenTraceBack=300), "100")]
     for probs, pkw, team in cases:
         p = api.pairwiseAlignmentBandingParameters_construct(**pkw)
         accs = []
