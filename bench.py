@@ -144,7 +144,7 @@ def other_configs(names):
     for name in names:
         t0 = time.perf_counter()
         cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--steps", "3", "--warmup", "1",
-               "--no-cpu-baseline", "--e2e-batches", "13" if name == "4" else "5", "--no-other-configs"]
+               "--no-cpu-baseline", "--e2e-batches", "25" if name == "4" else "5", "--no-other-configs"]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
             line = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")][-1]
